@@ -1,0 +1,517 @@
+"""CPU oracle for the GOLF hot path (TEST INFRASTRUCTURE — NOT PRODUCT CODE).
+
+Plain numpy float64 restatements of the reference algorithm for the path named by
+BASELINE.json ``north_star``: time-varying LPC synthesis filter + glottal-flow source.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package ``golf_amd`` never does.
+
+Pinning status
+--------------
+* The reference's *glue* (padding, unfold, window, OLA, normaliser, truncation, table blend,
+  grid construction, ctrl transforms) is pinned: ``oracle/make_fixtures.py`` imports the
+  reference's own ``models/*.py`` in the build container and commits its outputs under
+  ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function here against them.
+* The third-party arithmetic the reference calls is NOT vendored in /root/reference and not
+  installable here: ``torchlpc.sample_wise_lpc`` (unpinned, requirements.txt:19),
+  ``torchaudio.functional.lfilter`` (>=2.0.0, requirements.txt:5), ``kazane.Decimate``
+  (unpinned, requirements.txt:9).  Their published difference equations are restated below
+  (``sample_wise_lpc``, ``lfilter_allpole``); scipy.signal.lfilter is used as an independent
+  witness for the LTI case.  The reference repo holds no golden vector for them
+   => for those three kernels: **parity unpinned** by reference tests.
+  ``kazane.Decimate`` taps are unknown => the decimator takes its taps as an input.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+__all__ = [
+    "linear_upsample",
+    "sample_wise_lpc",
+    "ltv_allpole_ss_forward",
+    "ltv_allpole_ss_backward",
+    "lfilter_allpole",
+    "hann_window_periodic",
+    "lti_frames_ola_forward",
+    "ltv_inverse_filter",
+    "rc2lpc",
+    "logits2biquads",
+    "biquads2lpc",
+    "lf_table_v2",
+    "lf_pulse_v1",
+    "build_glottal_table",
+    "wavetable_generate",
+    "indexed_glottal_forward",
+    "decimate_fir",
+    "default_decimation_taps",
+    "source_filter_ss",
+]
+
+
+# --------------------------------------------------------------------------------------
+# a-3  frame -> sample linear upsampling
+# --------------------------------------------------------------------------------------
+def linear_upsample(z: np.ndarray, hop: int, axis: int = 1) -> np.ndarray:
+    """models/utils.py:538-544 (F.interpolate linear, align_corners=True) as used by
+    AudioTensor.reduce_hop_length (models/utils.py:171-191).
+
+    out[n] = z[f]*(1-w) + z[f+1]*w, f = n // hop, w = (n % hop)/hop, length (F-1)*hop+1.
+    """
+    z = np.asarray(z, dtype=np.float64)
+    z = np.moveaxis(z, axis, -1)
+    F = z.shape[-1]
+    if hop == 1 or F == 1:
+        return np.moveaxis(z.copy(), -1, axis)
+    n = np.arange((F - 1) * hop + 1)
+    f = np.minimum(n // hop, F - 2)
+    w = (n - f * hop) / hop
+    out = z[..., f] * (1.0 - w) + z[..., f + 1] * w
+    return np.moveaxis(out, -1, axis)
+
+
+# --------------------------------------------------------------------------------------
+# a-1  sample-wise LTV all-pole (torchlpc.sample_wise_lpc restated) + fused module forward
+# --------------------------------------------------------------------------------------
+def sample_wise_lpc(x: np.ndarray, A: np.ndarray, zi: np.ndarray | None = None) -> np.ndarray:
+    """torchlpc.sample_wise_lpc (third-party, call site models/filters.py:112):
+    y[b,t] = x[b,t] - sum_{i=0}^{M-1} A[b,t,i] * y[b,t-1-i], zero initial state.
+    x (B,T), A (B,T,M).  zi (B,M) optional: zi[:,i] = y[-1-i].
+    """
+    x = np.asarray(x, dtype=np.float64)
+    A = np.asarray(A, dtype=np.float64)
+    B, T = x.shape
+    M = A.shape[2]
+    ypad = np.zeros((B, T + M), dtype=np.float64)
+    if zi is not None:
+        ypad[:, :M] = np.asarray(zi, dtype=np.float64)[:, ::-1]
+    for t in range(T):
+        # window ypad[:, t:t+M] = y[t-M .. t-1]; reversed => y[t-1-i]
+        hist = ypad[:, t : t + M][:, ::-1]
+        ypad[:, t + M] = x[:, t] - np.einsum("bi,bi->b", A[:, t, :], hist)
+    return ypad[:, M:]
+
+
+def ltv_allpole_ss_forward(ex, gain, a, hop: int) -> np.ndarray:
+    """LTVMinimumPhaseFilterPrecise.forward, models/filters.py:99-113.
+
+    ex (B,Tx) hop 1, gain (B,F) hop ``hop``, a (B,F,M) hop ``hop``.
+    x = ex * up(gain) (AudioTensor broadcasting truncates to the shorter, utils.py:230-232),
+    A = up(a)[:, :len(x)], y = sample_wise_lpc(x, A).  Output length min(Tx, (F-1)*hop+1).
+    """
+    ex = np.asarray(ex, dtype=np.float64)
+    G = linear_upsample(gain, hop, axis=1)
+    T = min(ex.shape[1], G.shape[1])
+    x = ex[:, :T] * G[:, :T]
+    A = linear_upsample(a, hop, axis=1)[:, :T]
+    return sample_wise_lpc(x, A)
+
+
+def _upsample_adjoint(v: np.ndarray, hop: int, F: int) -> np.ndarray:
+    """Adjoint of linear_upsample along axis 1: v (B,T,...) -> (B,F,...)."""
+    B, T = v.shape[:2]
+    out = np.zeros((B, F) + v.shape[2:], dtype=np.float64)
+    if hop == 1 or F == 1:
+        out[:, :T] = v
+        return out
+    n = np.arange(T)
+    f = np.minimum(n // hop, F - 2)
+    w = (n - f * hop) / hop
+    wshape = (1, T) + (1,) * (v.ndim - 2)
+    np.add.at(out, (slice(None), f), v * (1.0 - w).reshape(wshape))
+    np.add.at(out, (slice(None), f + 1), v * w.reshape(wshape))
+    return out
+
+
+def ltv_allpole_ss_backward(gy, ex, gain, a, hop: int):
+    """Closed-form gradient of ltv_allpole_ss_forward (what torchlpc's
+    autograd Function + autograd through F.interpolate compute in the reference).
+
+    g[t] = gy[t] - sum_i A[t+1+i, i] * g[t+1+i]          (reverse-time recursion)
+    d/d ex[t]   = g[t] * G[t]
+    d/d gain[f] = up^T(g * ex)[f]
+    d/d a[f,i]  = up^T(-g[t] * y[t-1-i])[f,i]
+    Returns (g_ex (B,Tx), g_gain (B,F), g_a (B,F,M)); g_ex is zero beyond the output length.
+    """
+    gy = np.asarray(gy, dtype=np.float64)
+    ex = np.asarray(ex, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    B, F, M = a.shape
+    G = linear_upsample(gain, hop, axis=1)
+    T = min(ex.shape[1], G.shape[1])
+    G = G[:, :T]
+    A = linear_upsample(a, hop, axis=1)[:, :T]
+    x = ex[:, :T] * G
+    y = sample_wise_lpc(x, A)
+    gpad = np.zeros((B, T + M), dtype=np.float64)  # gpad[:, t] = g[t], zeros beyond T
+    for t in range(T - 1, -1, -1):
+        acc = gy[:, t].copy()
+        for i in range(M):
+            tt = t + 1 + i
+            if tt < T:
+                acc -= A[:, tt, i] * gpad[:, tt]
+        gpad[:, t] = acc
+    g = gpad[:, :T]
+    g_ex = np.zeros_like(ex)
+    g_ex[:, :T] = g * G
+    g_gain = _upsample_adjoint(g * ex[:, :T], hop, F)
+    ypad = np.concatenate([np.zeros((B, M)), y], axis=1)  # ypad[:, M+t] = y[t]
+    gA = np.empty((B, T, M), dtype=np.float64)
+    for i in range(M):
+        gA[:, :, i] = -g * ypad[:, M - 1 - i : M - 1 - i + T]
+    g_a = _upsample_adjoint(gA, hop, F)
+    return g_ex, g_gain, g_a
+
+
+# --------------------------------------------------------------------------------------
+# a-4  frame-wise LTI all-pole + windowed overlap-add (GOLF-ff)
+# --------------------------------------------------------------------------------------
+def lfilter_allpole(x: np.ndarray, a: np.ndarray) -> np.ndarray:
+    """torchaudio.functional.lfilter(x, [1,a], [1,0..], clamp=False) per row, as called by
+    lpc_synthesis (models/lpc.py:11-16) with gains == 1:
+    y[r,t] = x[r,t] - sum_i a[r,i] * y[r,t-1-i], zero state.  x (R,W), a (R,M)."""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    R, W = x.shape
+    M = a.shape[1]
+    ypad = np.zeros((R, W + M), dtype=np.float64)
+    for t in range(W):
+        hist = ypad[:, t : t + M][:, ::-1]
+        ypad[:, t + M] = x[:, t] - np.einsum("ri,ri->r", a, hist)
+    return ypad[:, M:]
+
+
+def hann_window_periodic(W: int) -> np.ndarray:
+    """torch.hann_window(W) (periodic=True default) — get_window_fn("hanning"),
+    models/utils.py:417-419."""
+    n = np.arange(W)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / W)
+
+
+def lti_frames_ola_forward(ex, gain, a, hop: int, window: np.ndarray, centred: bool = True):
+    """LTVMinimumPhaseFilter.forward, models/filters.py:131-184.
+
+    frames of zero-padded x = ex*up(gain); per-frame LTI all-pole from zero state
+    (lpc_synthesis, models/lpc.py:11-16); windowed OLA through conv_transpose1d with a
+    diag(window) kernel, stride hop, padding W//2, normalised by the OLA of ones
+    (filters.py:169-180).  centred=False drops the first hop//2 input samples and
+    reflect-pads the output (filters.py:147,181-182).
+    Returns (y, norm)."""
+    ex = np.asarray(ex, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    W = window.shape[0]
+    assert W >= 2 * hop
+    pad = W // 2
+    G = linear_upsample(gain, hop, axis=1)
+    e = ex if centred else ex[:, hop // 2 :]
+    T = min(e.shape[1], G.shape[1])
+    x = e[:, :T] * G[:, :T]
+    B = x.shape[0]
+    xp = np.concatenate([np.zeros((B, pad)), x, np.zeros((B, pad))], axis=1)
+    nfr = (xp.shape[1] - W) // hop + 1
+    assert nfr <= a.shape[1]
+    frames = np.stack([xp[:, f * hop : f * hop + W] for f in range(nfr)], axis=1)  # (B,nfr,W)
+    filt = lfilter_allpole(frames.reshape(B * nfr, W), a[:, :nfr].reshape(B * nfr, -1)).reshape(
+        B, nfr, W
+    )
+    # conv_transpose1d(stride=hop, padding=pad): full length (nfr-1)*hop + W, then trim pad each side
+    full = (nfr - 1) * hop + W
+    acc = np.zeros((B, full))
+    norm = np.zeros(full)
+    for f in range(nfr):
+        acc[:, f * hop : f * hop + W] += filt[:, f] * window
+        norm[f * hop : f * hop + W] += window
+    acc = acc[:, pad : full - pad]
+    norm = norm[pad : full - pad]
+    y = acc / norm
+    if not centred:
+        k = hop // 2
+        y = np.concatenate([y[:, 1 : k + 1][:, ::-1], y], axis=1)  # F.pad reflect (left)
+    return y, norm
+
+
+# --------------------------------------------------------------------------------------
+# a-5  inverse (analysis) filter
+# --------------------------------------------------------------------------------------
+def ltv_inverse_filter(y, a, hop: int) -> np.ndarray:
+    """LTVMinimumPhaseFilter.reverse, models/filters.py:186-195 + fir_filt utils.py:433-441:
+    e[t] = y[t] + sum_i A[t,i] * y[t-1-i] with sample-rate A = up(a)."""
+    y = np.asarray(y, dtype=np.float64)
+    A = linear_upsample(a, hop, axis=1)
+    T = min(y.shape[1], A.shape[1])
+    y = y[:, :T]
+    A = A[:, :T]
+    B, _, M = A.shape
+    ypad = np.concatenate([np.zeros((B, M)), y], axis=1)
+    e = y.copy()
+    for i in range(M):
+        e += A[:, :, i] * ypad[:, M - 1 - i : M - 1 - i + T]
+    return e
+
+
+# --------------------------------------------------------------------------------------
+# a-2  control transforms
+# --------------------------------------------------------------------------------------
+def rc2lpc(rc: np.ndarray) -> np.ndarray:
+    """models/utils.py:581-593 — Levinson step-up; returns a_1..a_M."""
+    rc = np.asarray(rc, dtype=np.float64)
+    order = rc.shape[-1]
+    if order == 1:
+        return rc
+    cur = np.concatenate([np.ones_like(rc[..., :1]), rc[..., :1]], axis=-1)
+    for n in range(1, order):
+        prev = np.concatenate([cur, np.zeros_like(rc[..., :1])], axis=-1)
+        cur = prev + rc[..., n : n + 1] * prev[..., ::-1]
+    return cur[..., 1:]
+
+
+def logits2biquads(logits: np.ndarray, rep_type: str, max_abs_pole: float = 0.99) -> np.ndarray:
+    """models/utils.py:487-525 get_logits2biquads; logits (...,2) -> (...,3) = [1,a1,a2]."""
+    l = np.asarray(logits, dtype=np.float64)
+    assert l.shape[-1] == 2
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    if rep_type == "coef":
+        a1 = np.tanh(l[..., 0]) * max_abs_pole * 2
+        a1a = np.abs(a1)
+        a2 = 0.5 * ((2 - a1a) * np.tanh(l[..., 1]) * max_abs_pole + a1a)
+    elif rep_type == "conj":
+        mag = sig(l[..., 0]) * max_abs_pole
+        cos = np.tanh(l[..., 1])
+        a1 = -2 * mag * cos
+        a2 = mag**2
+    elif rep_type == "real":
+        z1 = np.tanh(l[..., 0]) * max_abs_pole
+        z2 = np.tanh(l[..., 1]) * max_abs_pole
+        a1 = -z1 - z2
+        a2 = z1 * z2
+    else:
+        raise ValueError(rep_type)
+    return np.stack([np.ones_like(a1), a1, a2], axis=-1)
+
+
+def biquads2lpc(biquads: np.ndarray) -> np.ndarray:
+    """models/utils.py:480-484 (+coeff_product :444-460): multiply K second-order sections
+    (...,K,3) out to direct form and drop the leading 1 -> (...,2K)."""
+    bq = np.asarray(biquads, dtype=np.float64)
+    lead = bq.shape[:-2]
+    K = bq.shape[-2]
+    flat = bq.reshape(-1, K, 3)
+    out = np.empty((flat.shape[0], 2 * K + 1))
+    for r in range(flat.shape[0]):
+        p = np.array([1.0])
+        for k in range(K):
+            p = np.convolve(p, flat[r, k])
+        out[r] = p
+    return out.reshape(*lead, 2 * K + 1)[..., 1:]
+
+
+# --------------------------------------------------------------------------------------
+# a-7  LF glottal-flow derivative tables
+# --------------------------------------------------------------------------------------
+def lf_table_v2(Rd: np.ndarray, points: int = 1024) -> np.ndarray:
+    """get_transformed_lf_v2, models/utils.py:363-400 (closed-form LF from R_d)."""
+    Rd = np.asarray(Rd, dtype=np.float64).reshape(-1, 1)
+    Ra = -0.01 + 0.048 * Rd
+    Rk = 0.224 + 0.118 * Rd
+    Rg = (Rk / 4) * (0.5 + 1.2 * Rk) / (0.11 * Rd - Ra * (0.5 + 1.2 * Rk))
+    Ta = Ra
+    Tp = 1 / (2 * Rg)
+    Te = Tp + Tp * Rk
+    epsilon = 1 / Ta
+    shift = np.exp(-epsilon * (1 - Te))
+    delta = 1 - shift
+    rhs = (1 / epsilon) * (shift - 1) + (1 - Te) * shift
+    rhs = rhs / delta
+    lower = -(Te - Tp) / 2 + rhs
+    upper = -lower
+    omega = np.pi / Tp
+    s = np.sin(omega * Te)
+    y = -np.pi * s * upper / (Tp * 2)
+    z = np.log(y)
+    alpha = z / (Tp / 2 - Te)
+    EO = -1 / (s * np.exp(alpha * Te))
+    # torch.linspace(0,1,points+1)[:-1] is computed in float32 in the reference
+    t = np.linspace(0.0, 1.0, points + 1)[None, :-1]
+    before = EO * np.exp(alpha * t) * np.sin(omega * t)
+    after = (-np.exp(-epsilon * (t - Te)) + shift) / delta
+    out = np.where(t < Te, before, after)
+    return out.squeeze() if out.shape[0] == 1 else out
+
+
+def lf_pulse_v1(R_d: float = 0.3, T_0: float = 5.0, n_iter_eps: int = 5, n_iter_a: int = 100,
+                points: int = 1000) -> np.ndarray:
+    """get_transformed_lf, models/utils.py:308-360 (Newton iterations for eps and a)."""
+    R_ap = 0.048 * R_d - 0.01
+    R_kp = 0.118 * R_d + 0.224
+    R_gp = 0.25 * R_kp * (0.5 + 1.2 * R_kp) / (0.11 * R_d - R_ap * (0.5 + 1.2 * R_kp))
+    T_a = R_ap * T_0
+    T_p = 0.5 * T_0 / R_gp
+    T_e = T_p * (R_kp + 1)
+    T_b = T_0 - T_e
+    omega_g = math.pi / T_p
+    E_e = 1
+    a = 1
+    eps = 1
+    for _ in range(n_iter_eps):
+        f_eps = eps * T_a + math.expm1(-eps * T_b)
+        f_eps_grad = T_a - T_b * math.exp(-eps * T_b)
+        eps = abs(eps - f_eps / f_eps_grad)
+    E_0 = 0.0
+    for _ in range(n_iter_a):
+        E_0 = -E_e * math.exp(-a * T_e) / math.sin(omega_g * T_e)
+        A_o = E_0 * math.exp(a * T_e) / math.sqrt(omega_g**2 + a**2) * math.sin(
+            omega_g * T_e - math.atan(omega_g / a)
+        ) + E_0 * omega_g / (omega_g**2 + a**2)
+        A_r = -E_e / (eps**2 * T_a) * (1 - math.exp(-eps * T_b) * (1 + eps * T_b))
+        f_a = A_o + A_r
+        f_a_grad = (1 - 2 * a * A_r / E_e) * math.sin(omega_g * T_e) - omega_g * T_e * math.exp(
+            -a * T_e
+        )
+        a = a - f_a / f_a_grad
+    t = np.linspace(0.0, T_0, points + 1)[:-1]
+    before_t = t[t < T_e]
+    after_t = t[t >= T_e]
+    before = E_0 * np.exp(a * before_t) * np.sin(omega_g * before_t)
+    after = -E_e / eps / T_a * (np.exp(-eps * (after_t - T_e)) - math.exp(-eps * T_b))
+    return np.concatenate([before, after])
+
+
+def build_glottal_table(table_size=100, table_type="derivative", normalize_method="constant_power",
+                        align_peak=True, min_R_d=0.3, max_R_d=2.7, lf_v2=False, **lf_kwargs):
+    """GlottalFlowTable.__init__, models/synth.py:59-120.  Returns (R_d_values, table)."""
+    Rd = np.exp(np.linspace(math.log(min_R_d), math.log(max_R_d), table_size))
+    if lf_v2:
+        table = lf_table_v2(Rd, **lf_kwargs)
+    else:
+        table = np.stack([lf_pulse_v1(R_d=float(r), **lf_kwargs) for r in Rd])
+    table = np.array(table, dtype=np.float64)
+    if table_type == "flow":
+        table = np.cumsum(table, axis=1)
+    elif table_type != "derivative":
+        raise ValueError(table_type)
+    if align_peak:
+        peak = table.argmin(axis=1) if table_type == "derivative" else table.argmax(axis=1)
+        target = int(peak.max())
+        for i in range(table.shape[0]):
+            table[i] = np.roll(table[i], target - int(peak[i]))
+    if normalize_method == "constant_power":
+        table = table / np.linalg.norm(table, axis=1, keepdims=True) * math.sqrt(table.shape[1])
+    elif normalize_method == "peak":
+        if table_type == "flow":
+            table = table / table.max(axis=1, keepdims=True)
+    elif normalize_method is not None:
+        raise ValueError(normalize_method)
+    return Rd, table
+
+
+# --------------------------------------------------------------------------------------
+# a-9 / a-8  wavetable lookup and the indexed glottal oscillator
+# --------------------------------------------------------------------------------------
+def wavetable_generate(wrapped_phase: np.ndarray, tables: np.ndarray, hop_t: int) -> np.ndarray:
+    """GlottalFlowTable.generate, models/synth.py:124-177 (grid_sample bilinear,
+    align_corners=True) — SURVEY.md App. A-4.
+    wrapped_phase (B,N) in [0,1); tables (B,K,L) at hop ``hop_t``."""
+    ph = np.asarray(wrapped_phase, dtype=np.float64)
+    tb = np.asarray(tables, dtype=np.float64)
+    B, N = ph.shape
+    L = tb.shape[2]
+    blocks = (N + hop_t - 1) // hop_t
+    if tb.shape[1] < blocks + 1:
+        reps = blocks + 1 - tb.shape[1]
+        tb = np.concatenate([tb, np.repeat(tb[:, -1:], reps, axis=1)], axis=1)
+    else:
+        tb = tb[:, : blocks + 1]
+    tb = np.concatenate([tb, tb[:, :, :1]], axis=2)  # wrap column
+    c = ph * L
+    c0 = np.floor(c).astype(np.int64)
+    c0 = np.clip(c0, 0, L - 1)
+    cf = c - c0
+    r = np.arange(N) / hop_t
+    r0 = np.minimum(np.floor(r).astype(np.int64), blocks - 1) if blocks > 0 else np.zeros(N, np.int64)
+    rf = r - r0
+    bi = np.arange(B)[:, None]
+    r0b = np.broadcast_to(r0[None, :], (B, N))
+    top = tb[bi, r0b, c0] * (1 - cf) + tb[bi, r0b, c0 + 1] * cf
+    bot = tb[bi, r0b + 1, c0] * (1 - cf) + tb[bi, r0b + 1, c0 + 1] * cf
+    return top * (1 - rf[None, :]) + bot * rf[None, :]
+
+
+def indexed_glottal_forward(phase, phase_hop: int, weight, weight_hop: int, table,
+                            oversampling: int = 1, equal_energy: bool = False,
+                            phase_offset=None, decim_taps=None):
+    """IndexedGlottalFlowTable.forward, models/synth.py:213-263.
+
+    phase (B,Tp) per-sample phase increment (cycles/sample) at hop ``phase_hop``;
+    weight (B,Fw) table_select_weight in [0,1] at hop ``weight_hop``; table (n_tab,L).
+    Returns dict(instant_phase, pre (the signal handed to the decimator), out).
+    ``out`` = pre when oversampling == 1, else decimate_fir(pre, decim_taps, oversampling)
+    (None if no taps given: kazane's taps are unknown, parity is asserted on ``pre``)."""
+    phase = np.asarray(phase, dtype=np.float64)
+    weight = np.asarray(weight, dtype=np.float64)
+    table = np.asarray(table, dtype=np.float64)
+    n_tab, L = table.shape
+    idx_raw = weight * (n_tab - 1)
+    i0 = np.clip(np.trunc(idx_raw).astype(np.int64), 0, n_tab - 2)
+    p = (idx_raw - i0)[..., None]
+    interp_tables = table[i0] * (1 - p) + table[i0 + 1] * p  # (B,Fw,L)
+    hop_t = weight_hop
+    if oversampling > 1:
+        hop_t = weight_hop * oversampling
+        phase = phase / oversampling
+        phase_hop = phase_hop * oversampling
+    up = linear_upsample(phase, phase_hop, axis=1)
+    inst = np.cumsum(up, axis=1)
+    if phase_offset is not None:
+        inst = inst + phase_offset
+    wrapped = inst % 1.0
+    y = wavetable_generate(wrapped, interp_tables, hop_t)
+    if equal_energy:
+        y = y / np.sqrt(up)
+    out = y
+    if oversampling > 1:
+        out = decimate_fir(y, decim_taps, oversampling) if decim_taps is not None else None
+    return {"instant_phase": inst, "pre": y, "out": out}
+
+
+def default_decimation_taps(q: int, zeros: int = 16, rolloff: float = 0.945) -> np.ndarray:
+    """Own windowed-sinc design standing in for kazane.Decimate(q) (third-party, absent,
+    unpinned — SURVEY.md §8c): K = 2*zeros*q+1 taps, cutoff rolloff/(2q), Hann window,
+    unity DC gain.  Parity for the decimator is unpinned; the taps are an *input* of both
+    the oracle and the HIP kernel so kazane's real kernel can be dropped in."""
+    n = np.arange(-zeros * q, zeros * q + 1, dtype=np.float64)
+    h = np.sinc(n * rolloff / q) * (0.5 + 0.5 * np.cos(np.pi * n / (zeros * q + 1)))
+    return h / h.sum()
+
+
+def decimate_fir(x: np.ndarray, taps: np.ndarray, q: int) -> np.ndarray:
+    """Strided FIR: out[m] = sum_k taps[k] * x[m*q + k - (K-1)/2], zero padding,
+    out length (N-1)//q + 1  (conv1d stride q, padding (K-1)/2; correlation, as F.conv1d)."""
+    x = np.asarray(x, dtype=np.float64)
+    taps = np.asarray(taps, dtype=np.float64)
+    K = taps.shape[0]
+    assert K % 2 == 1
+    half = (K - 1) // 2
+    B, N = x.shape
+    n_out = (N - 1) // q + 1
+    xp = np.concatenate([np.zeros((B, half)), x, np.zeros((B, half + q))], axis=1)
+    out = np.zeros((B, n_out))
+    for k in range(K):
+        out += taps[k] * xp[:, k : k + (n_out - 1) * q + 1 : q]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a-13  composition (SourceFilterSynth with PassThrough noise/room filters)
+# --------------------------------------------------------------------------------------
+def source_filter_ss(phase, phase_hop, weight, weight_hop, table, noise, gain, a, hop,
+                     oversampling=1, equal_energy=False, decim_taps=None):
+    """models/sf.py:35-64 with noise_filter = room_filter = PassThrough,
+    subtract_harmonics=False, voicing=None, injected noise:
+    src = osc + noise ; y = LTVMinimumPhaseFilterPrecise(src, gain, a)."""
+    osc = indexed_glottal_forward(phase, phase_hop, weight, weight_hop, table, oversampling,
+                                  equal_energy, None, decim_taps)["out"]
+    T = min(osc.shape[1], np.asarray(noise).shape[1])
+    src = osc[:, :T] + np.asarray(noise, dtype=np.float64)[:, :T]
+    return src, ltv_allpole_ss_forward(src, gain, a, hop)

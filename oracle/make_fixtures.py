@@ -1,0 +1,379 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN glue code (TEST INFRASTRUCTURE).
+
+Runs ONLY in the build container (needs /root/reference; the GPU box never has it).  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_fixtures.py
+
+What is the reference's code and what is restated
+-------------------------------------------------
+/root/reference/models/{utils,ctrl,lpc,synth,noise,filters,sf}.py are imported verbatim.  Their
+third-party imports are absent from this image, so ``sys.modules`` stubs
+provide them:
+
+* ``models.audiotensor.AudioTensor``      := the reference's own ``models.utils.LegacyAudioTensor``
+  (the submodule directory is empty; .gitmodules:4-6).
+* ``torchlpc.sample_wise_lpc``            := explicit float64 torch loop of its difference equation
+  (autograd-able, so reference gradients are captured too).
+* ``torchaudio.functional.lfilter``       := scipy.signal.lfilter per row (float64, independent witness).
+* ``kazane.Decimate``                     := recorder: stores its input (the pre-decimation signal),
+  returns x[..., ::q].  kazane's taps are unknown => decimation parity is unpinned.
+* ``torch_fftconv``, ``diffsptk``, ``torchaudio.transforms``, ``pyworld`` := inert placeholders
+  (only needed so that ``import models.filters`` succeeds; never on the measured path).
+
+Every array written is an input or an output of reference code — no reference source text.
+"""
+import hashlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+import scipy.signal
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- stubs
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def sample_wise_lpc(x, a):
+    B, T = x.shape
+    M = a.shape[2]
+    hist = [x.new_zeros(B) for _ in range(M)]  # hist[i] = y[t-1-i]
+    ys = []
+    for t in range(T):
+        acc = x[:, t]
+        for i in range(M):
+            acc = acc - a[:, t, i] * hist[i]
+        ys.append(acc)
+        hist = [acc] + hist[:-1]
+    return torch.stack(ys, 1)
+
+
+def lfilter(x, a_coeffs, b_coeffs, clamp=True, batching=True):
+    xn = x.detach().double().numpy()
+    an = a_coeffs.detach().double().numpy()
+    bn = b_coeffs.detach().double().numpy()
+    out = np.stack([scipy.signal.lfilter(bn[r], an[r], xn[r]) for r in range(xn.shape[0])])
+    return torch.from_numpy(out).to(x.dtype)
+
+
+class _Dummy(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+class Decimate(nn.Module):
+    last_input = None
+
+    def __init__(self, q=2, *a, **k):
+        super().__init__()
+        self.q = q
+        self.register_buffer("kernel", torch.ones(1, 1, 1))  # must be a buffer (synth.py:209-211)
+
+    def forward(self, x):
+        Decimate.last_input = x.detach().clone()
+        return x[..., :: self.q]
+
+
+_mod("pyworld", dio=lambda *a, **k: None)
+_mod("torchlpc", sample_wise_lpc=sample_wise_lpc)
+_mod("torchaudio")
+_mod("torchaudio.functional", lfilter=lfilter, melscale_fbanks=lambda *a, **k: None)
+_mod("torchaudio.transforms", Spectrogram=_Dummy, InverseSpectrogram=_Dummy)
+_mod("torch_fftconv")
+_mod("torch_fftconv.functional", fft_conv1d=torch.nn.functional.conv1d)
+_mod("diffsptk", MLSA=_Dummy, MelCepstralAnalysis=_Dummy, MelGeneralizedCepstrumToSpectrum=_Dummy,
+     PQMF=_Dummy, IPQMF=_Dummy)
+_mod("diffsptk.functional", lsp2lpc=lambda *a, **k: None)
+_mod("kazane", Decimate=Decimate)
+
+sys.path.insert(0, REF)
+import models.utils as ru  # noqa: E402
+
+_mod("models.audiotensor", AudioTensor=ru.LegacyAudioTensor)
+import models.ctrl as rctrl  # noqa: E402,F401
+import models.filters as rf  # noqa: E402
+import models.noise as rn  # noqa: E402
+import models.sf as rsf  # noqa: E402
+import models.synth as rs  # noqa: E402
+
+AT = ru.LegacyAudioTensor
+torch.manual_seed(2434)
+rng = np.random.default_rng(2434)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    arrs = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"wrote {name}.npz:", {k: v.shape for k, v in arrs.items()})
+
+
+def smooth_lpc(B, F, M, scale=0.5, step=0.02):
+    """SURVEY §8d smooth random-walk logits -> stable, slowly varying direct-form a."""
+    base = rng.normal(0, scale, (B, 1, M))
+    walk = np.cumsum(rng.normal(0, step, (B, F, M)), axis=1)
+    logits = torch.from_numpy((base + walk).astype(np.float32)).double()
+    return logits, ru.rc2lpc(torch.tanh(logits))
+
+
+# ----------------------------------------------------------------------------- g1 rc2lpc
+rc = torch.tanh(torch.from_numpy(rng.normal(0, 1, (2, 3, 22)).astype(np.float32)).double())
+save("g1_rc2lpc", rc=rc, lpc=ru.rc2lpc(rc), rc1=rc[..., :1], lpc1=ru.rc2lpc(rc[..., :1]))
+
+# ----------------------------------------------------------------------------- g2 biquads
+logits = torch.from_numpy(rng.normal(0, 1.5, (2, 3, 11, 2)).astype(np.float32)).double()
+d = {"logits": logits}
+for t in ("coef", "conj", "real"):
+    bq = ru.get_logits2biquads(t)(logits)  # default max_abs_pole 0.99 (biquads.py:10)
+    d["bq_" + t] = bq
+    d["lpc_" + t] = ru.biquads2lpc(bq)
+bq = ru.get_logits2biquads("coef", 0.9)(logits)
+d["bq_coef_09"] = bq
+save("g2_biquads", **d)
+
+# ----------------------------------------------------------------------------- g3 LF tables
+Rd = torch.exp(torch.linspace(np.log(0.3), np.log(2.7), 100))
+v2 = ru.get_transformed_lf_v2(Rd, points=2048)
+v1_rows = {f"v1_row{r}": ru.get_transformed_lf(R_d=Rd[r], points=2048) for r in (0, 49, 99)}
+osc_v2 = rs.IndexedGlottalFlowTable(table_size=100, table_type="derivative", normalize_method="constant_power",
+                                    align_peak=True, lf_v2=True, points=2048)
+osc_v1 = rs.IndexedGlottalFlowTable(table_size=100, table_type="derivative", normalize_method="constant_power",
+                                    align_peak=True, lf_v2=False, T_0=5.0, n_iter_eps=5, n_iter_a=100, points=2048)
+osc_flow = rs.IndexedGlottalFlowTable(table_size=12, table_type="flow", normalize_method="peak",
+                                      align_peak=True, lf_v2=True, points=256)
+osc_none = rs.IndexedGlottalFlowTable(table_size=12, table_type="derivative", normalize_method=None,
+                                      align_peak=False, lf_v2=False, points=256)
+tb2 = osc_v2.table.numpy()
+tb1 = osc_v1.table.numpy()
+save("g3_lf_tables", Rd=Rd, v2_rows=v2[[0, 49, 99]], **v1_rows,
+     table_v2_rows=tb2[[0, 1, 49, 98, 99]], table_v1_rows=tb1[[0, 1, 49, 98, 99]],
+     table_v2_sha256=np.frombuffer(hashlib.sha256(tb2.tobytes()).digest(), dtype=np.uint8),
+     table_v2_colsum=tb2.astype(np.float64).sum(0), table_v1_colsum=tb1.astype(np.float64).sum(0),
+     table_v2_argmin=tb2.argmin(1), table_v1_argmin=tb1.argmin(1),
+     table_flow=osc_flow.table, table_none=osc_none.table, Rd_small=osc_flow.R_d_values)
+
+# ----------------------------------------------------------------------------- g4 upsample / mixed hop
+z = torch.from_numpy(rng.normal(0, 1, (2, 100)).astype(np.float32)).double()
+x10 = AT(z, hop_length=10)
+x1 = x10.reduce_hop_length()
+x2 = x10.reduce_hop_length(5)
+x3 = x1 + x2 * x10
+z3 = torch.from_numpy(rng.normal(0, 1, (2, 7, 3)).astype(np.float32)).double()
+a3 = AT(z3, hop_length=4).reduce_hop_length()
+ex = AT(torch.from_numpy(rng.normal(0, 1, (2, 40)).astype(np.float32)).double(), 1)
+g = AT(z3[..., 0], hop_length=4)
+save("g4_upsample", z=z, up10=x1.as_tensor(), up5=x2.as_tensor(), up5_hop=x2.hop_length, mixed=x3.as_tensor(),
+     z3=z3, up3=a3.as_tensor(), ex=ex.as_tensor(), ex_times_g=(ex * g).as_tensor())
+
+# ----------------------------------------------------------------------------- g5 wavetable generate
+ph = torch.from_numpy(rng.uniform(0, 1, (2, 333)).astype(np.float32)).double()
+tables = torch.from_numpy(rng.normal(0, 1, (2, 8, 64)).astype(np.float32)).double()
+out = rs.GlottalFlowTable.generate(AT(ph, 1), AT(tables, 48))
+tables_short = tables[:, :5]  # forces replicate-padding (synth.py:141-146)
+out_short = rs.GlottalFlowTable.generate(AT(ph, 1), AT(tables_short, 48))
+save("g5_generate", phase=ph, tables=tables, hop_t=48, out=out.as_tensor(), out_short=out_short.as_tensor())
+
+
+# ----------------------------------------------------------------------------- g6 oscillator forward
+def dyadic(shape, bits, lo, hi):
+    """values k * 2^-bits so that the reference's float32 cumsum (synth.py:250-251) is exact."""
+    k = rng.integers(int(lo * 2**bits), int(hi * 2**bits), shape)
+    return torch.from_numpy(k / 2.0**bits).float()  # the reference oscillator only runs in float32 (synth.py:251)
+
+
+d = {}
+for name, os_, eq in (("os1", 1, False), ("os1_eq", 1, True), ("os4_eq", 4, True)):
+    osc = rs.IndexedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                     align_peak=True, lf_v2=True, points=16, oversampling=os_, equal_energy=eq)
+    d[name + "_table"] = osc.table
+    # training style: phase hop 1, weight hop 16
+    phase = dyadic((2, 64), 10, 0.01, 0.12)
+    w = torch.from_numpy(rng.uniform(0, 1, (2, 5)).astype(np.float32))
+    w[0, 0] = 0.0
+    w[1, -1] = 1.0
+    Decimate.last_input = None
+    y = osc(AT(phase, 1), AT(w, 16))
+    d[name + "_phase"], d[name + "_w"] = phase, w
+    d[name + "_out"] = y.as_tensor()
+    if os_ > 1:
+        d[name + "_pre"] = Decimate.last_input
+    # test_rtf style: phase hop 8, weight hop 32, too few table frames -> replicate pad
+    phase2 = dyadic((2, 9), 10, 0.01, 0.12)
+    w2 = torch.from_numpy(rng.uniform(0, 1, (2, 3)).astype(np.float32))
+    Decimate.last_input = None
+    y2 = osc(AT(phase2, 8), AT(w2, 32))
+    d[name + "_phase2"], d[name + "_w2"] = phase2, w2
+    d[name + "_out2"] = y2.as_tensor()
+    if os_ > 1:
+        d[name + "_pre2"] = Decimate.last_input
+save("g6_oscillator", **d)
+
+# ----------------------------------------------------------------------------- g7 frame-wise (ff) forward
+B, F, hop, W, M = 2, 9, 8, 32, 4
+_, a = smooth_lpc(B, F, M)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+ex = torch.from_numpy(rng.normal(0, 1, (B, (F - 1) * hop + 5)).astype(np.float32)).double()
+d = dict(ex=ex, gain=gain, a=a, hop=hop, W=W)
+for centred in (True, False):
+    m = rf.LTVMinimumPhaseFilter(window="hanning", window_length=W, centred=centred, lpc_order=M)
+    m._kernel = m._kernel.double()
+    y = m(AT(ex, 1), AT(gain, hop), AT(a, hop))
+    d["y_centred" if centred else "y_uncentred"] = y.as_tensor()
+# W == 2*hop edge and a wider M
+m = rf.LTVMinimumPhaseFilter(window="hanning", window_length=16, centred=True, lpc_order=M)
+m._kernel = m._kernel.double()
+d["y_w16"] = m(AT(ex, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+# normaliser for the config shape (W=960, hop=240, F=200): OLA of ones, filters.py:171-177
+win = torch.hann_window(960).double()
+nfr = 200
+full = (nfr - 1) * 240 + 960
+norm = torch.zeros(full, dtype=torch.float64)
+for f in range(nfr):
+    norm[f * 240 : f * 240 + 960] += win
+norm = norm[480 : full - 480]
+mcfg = rf.LTVMinimumPhaseFilter(window="hanning", window_length=960, centred=True, lpc_order=2)
+mcfg._kernel = mcfg._kernel.double()
+ycfg = mcfg(AT(torch.ones(1, 48000, dtype=torch.float64), 1), AT(torch.ones(1, 200, dtype=torch.float64), 240),
+            AT(torch.zeros(1, 200, 2, dtype=torch.float64), 240)).as_tensor()
+d.update(norm_cfg_head=norm[:300], norm_cfg_tail=norm[-300:], norm_cfg_mid=norm[20000:20010], norm_cfg_len=norm.shape[0],
+         y_cfg_ones_len=ycfg.shape[1], y_cfg_ones_maxdev=(ycfg - 1).abs().max(), window_f32=torch.hann_window(W))
+save("g7_framewise", **d)
+
+# ----------------------------------------------------------------------------- g8 sample-wise (ss) forward
+B, F, hop, M = 2, 6, 8, 4
+_, a = smooth_lpc(B, F, M)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+ex = torch.from_numpy(rng.normal(0, 1, (B, 50)).astype(np.float32)).double()  # longer than (F-1)*hop+1 = 41
+ex_short = ex[:, :30]
+mss = rf.LTVMinimumPhaseFilterPrecise(lpc_order=M)
+y = mss(AT(ex, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+y_short = mss(AT(ex_short, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+d = dict(ex=ex, gain=gain, a=a, hop=hop, y=y, y_short=y_short)
+# mid-size, config order, used for fp32 kernels: B=3, F=12, hop=240, M=22
+B2, F2, hop2, M2 = 3, 12, 240, 22
+logits2, a2 = smooth_lpc(B2, F2, M2)
+gain2 = torch.exp(torch.from_numpy((-3 + np.cumsum(rng.normal(0, 0.05, (B2, F2)), 1)).astype(np.float32)).double())
+ex2 = torch.from_numpy(rng.normal(0, 1, (B2, (F2 - 1) * hop2 + 1)).astype(np.float32)).double()
+y2 = mss(AT(ex2, 1), AT(gain2, hop2), AT(a2, hop2)).as_tensor()
+d.update(logits2=logits2, a2=a2, gain2=gain2, ex2=ex2, hop2=hop2, y2=y2)
+# the ctrl transform of the module (filters.py:90-97): logits -> (gain, a)
+lg = torch.from_numpy(rng.normal(-3, 0.1, (B2, F2)).astype(np.float32)).double()
+(split, trsfm) = mss.ctrl(lambda s, t: (s, t))((), ())
+gg, aa = trsfm[0](AT(lg, hop2), AT(logits2, hop2))
+d.update(ctrl_log_gain=lg, ctrl_gain=gg.as_tensor(), ctrl_a=aa.as_tensor(), ctrl_split=np.array(split[0]))
+save("g8_samplewise", **d)
+
+# ----------------------------------------------------------------------------- g9 reverse (inverse filter)
+mff = rf.LTVMinimumPhaseFilter(window="hanning", window_length=32, lpc_order=4)
+B, F, hop, M = 2, 6, 8, 4
+_, a = smooth_lpc(B, F, M)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+ex = torch.from_numpy(rng.normal(0, 1, (B, 48)).astype(np.float32)).double()
+tgt = torch.from_numpy(rng.normal(0, 1, (B, 48)).astype(np.float32)).double()
+exg, e = mff.reverse(AT(ex, 1), AT(tgt, 1), AT(gain, hop), AT(a, hop))
+save("g9_reverse", ex=ex, target=tgt, gain=gain, a=a, hop=hop, ex_gain=exg.as_tensor(), e=e.as_tensor())
+
+# ----------------------------------------------------------------------------- g10 gradients of a-1
+B, F, hop, M = 2, 5, 8, 4
+_, a = smooth_lpc(B, F, M)
+a = a.detach().clone().requires_grad_(True)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double()).requires_grad_(True)
+ex = torch.from_numpy(rng.normal(0, 1, (B, 40)).astype(np.float32)).double().requires_grad_(True)
+y = mss(AT(ex, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+(y * gy).sum().backward()
+d = dict(ex=ex, gain=gain, a=a, hop=hop, y=y, gy=gy, g_ex=ex.grad, g_gain=gain.grad, g_a=a.grad)
+# config-order case: B=2, F=4, hop=24, M=22
+B, F, hop, M = 2, 4, 24, 22
+_, a = smooth_lpc(B, F, M)
+a = a.detach().clone().requires_grad_(True)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double()).requires_grad_(True)
+ex = torch.from_numpy(rng.normal(0, 1, (B, 80)).astype(np.float32)).double().requires_grad_(True)
+y = mss(AT(ex, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+(y * gy).sum().backward()
+d.update(ex22=ex, gain22=gain, a22=a, hop22=hop, y22=y, gy22=gy, g_ex22=ex.grad, g_gain22=gain.grad, g_a22=a.grad)
+save("g10_ss_grads", **d)
+
+
+# ----------------------------------------------------------------------------- g11 SourceFilterSynth composition
+class FixedNoise(rn.NoiseInterface):
+    def __init__(self, noise):
+        super().__init__(torch.distributions.Normal(0, 1))
+        self.noise = noise
+
+    def forward(self, ref, *args, **kwargs):
+        return AT(self.noise[:, : ref.shape[1]], 1)
+
+
+B, T, hop, M = 2, 129, 16, 6
+F = (T - 1) // hop + 1  # 9
+phase = dyadic((B, T), 10, 0.01, 0.08)
+w = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+noise = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32)).double()
+_, a = smooth_lpc(B, F, M)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+osc = rs.IndexedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                 align_peak=True, lf_v2=True, points=16, oversampling=1, equal_energy=True)
+dec = rsf.SourceFilterSynth(harm_oscillator=osc, noise_generator=FixedNoise(noise), noise_filter=rctrl.PassThrough(),
+                            end_filter=rf.LTVMinimumPhaseFilterPrecise(lpc_order=M), room_filter=None,
+                            subtract_harmonics=False)
+y = dec(phase=AT(phase, 1), harm_oscillator_params=(AT(w, 64),), noise_generator_params=(), noise_filter_params=(),
+        end_filter_params=(AT(gain, hop), AT(a, hop)))
+voicing = torch.from_numpy((rng.uniform(0, 1, (B, F)) > 0.4).astype(np.float64) * rng.uniform(0.5, 1, (B, F)))
+yv = dec(phase=AT(phase, 1), harm_oscillator_params=(AT(w, 64),), noise_generator_params=(), noise_filter_params=(),
+         end_filter_params=(AT(gain, hop), AT(a, hop)), voicing=AT(voicing, hop))
+save("g11_source_filter", phase=phase, w=w, w_hop=64, noise=noise, gain=gain, a=a, hop=hop, table=osc.table,
+     y=y.as_tensor(), voicing=voicing, y_voiced=yv.as_tensor())
+
+
+# ----------------------------------------------------------------------------- g12 control protocol
+def golf_decoder(end_filter):
+    return rsf.SourceFilterSynth(
+        harm_oscillator=rs.DownsampledIndexedGlottalFlowTable(
+            hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, table_type="derivative",
+            normalize_method="constant_power", align_peak=True, trainable=False, min_R_d=0.3, max_R_d=2.7,
+            lf_v2=True, points=64),
+        noise_generator=rn.StandardNormalNoise(),
+        noise_filter=rf.LTVZeroPhaseFIRFilter(window="hanning", n_mag=256),
+        end_filter=end_filter,
+        room_filter=rf.LTIAcousticFilter(length=128, conv_method="direct"),
+        subtract_harmonics=False)
+
+
+d = {}
+for name, ef in (("ss", rf.LTVMinimumPhaseFilterPrecise(lpc_order=22, lpc_parameterisation="rc2lpc")),
+                 ("ff", rf.LTVMinimumPhaseFilter(window="hanning", window_length=960, lpc_order=22,
+                                                 lpc_parameterisation="rc2lpc")),
+                 ("ss_coef", rf.LTVMinimumPhaseFilterPrecise(lpc_order=22, lpc_parameterisation="coef",
+                                                             max_abs_value=0.99))):
+    dec = golf_decoder(ef)
+    split_sizes, trsfms, keys = dec.split_sizes_and_trsfms
+    d[name + "_split_sizes"] = np.array([",".join(map(str, s)) for s in split_sizes])
+    d[name + "_keys"] = np.array(keys)
+    d[name + "_state_dict_keys"] = np.array(sorted(dec.state_dict().keys()))
+# downsampler ctrl (synth.py:297-340): h (B,200,64) hop 240 -> w (B,21) hop 2400
+dec = golf_decoder(rf.LTVMinimumPhaseFilterPrecise(lpc_order=22))
+osc = dec.harm_oscillator
+h = torch.from_numpy(rng.normal(0, 1, (2, 200, 64)).astype(np.float32))
+(wout,) = osc.ctrl(lambda s, t: (s, t))((), ())[1][0](AT(h, 240))
+sd = {k: v for k, v in osc.model.state_dict().items()}
+d.update(ds_h=h, ds_w=wout.as_tensor(), ds_w_hop=wout.hop_length,
+         **{"ds_model." + k: v for k, v in sd.items()})
+save("g12_ctrl_protocol", **d)
+print("done")
