@@ -1,0 +1,134 @@
+"""ctypes binding of libgolf_hip.so (include/golf_amd.h) — the ONLY compute backend.
+
+There is deliberately no CPU or pure-PyTorch fallback: if the HIP library is missing or the
+tensors are not on a ROCm device the ops raise.  (The CPU oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgolf_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip")
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/golf_amd.h exactly (checked by tests/test_abi.py)
+SIGNATURES = {
+    "golf_abi_version": (_int, []),
+    "golf_last_error": (ctypes.c_char_p, []),
+    "golf_target_arch": (ctypes.c_char_p, []),
+    "golf_ltv_allpole_workspace_bytes": (_sz, [_int] * 5),
+    "golf_ltv_allpole_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 5 + [_vp, _sz, _vp]),
+    "golf_ltv_allpole_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64,
+                                        _c_f32p, _c_f32p] + [_int] * 5 + [_vp, _sz, _vp]),
+    "golf_ltv_inverse_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _i64] + [_int] * 5 + [_vp]),
+    "golf_lti_frames_workspace_bytes": (_sz, [_int] * 6),
+    "golf_lti_frames_ola_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 7
+                                    + [_vp, _sz, _vp]),
+    "golf_glottal_osc_workspace_bytes": (_sz, [_int] * 7),
+    "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
+                                        _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),
+    "golf_glottal_osc_bwd_wsel_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p,
+                                             _int, _int, _int, _int, _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz,
+                                             _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into golf_amd/lib/libgolf_hip.so (hipcc cross-compiles
+    without a GPU).  Rebuilds only when a source/header is newer than the library."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "golf_amd.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-c", s,
+               "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
+    return LIB_PATH
+
+
+def load():
+    """dlopen the in-tree library and attach the prototypes.  Raises if it is not there."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"golf_amd: {LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback by design)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        ver = lib.golf_abi_version()
+        if ver != 1:
+            raise RuntimeError(f"golf_amd: ABI version {ver} != 1")
+        _lib = lib
+        return lib
+
+
+class GolfError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().golf_last_error().decode(errors="replace")
+        kind = "bad argument" if rc < 0 else "hipError"
+        raise GolfError(f"{what}: {kind} {rc}: {msg}")
+
+
+def require_device(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GolfError("golf_amd kernels need ROCm device tensors (got a %s tensor); there is no CPU path"
+                            % t.device.type)
+        if t.dtype != torch.float32:
+            raise GolfError(f"golf_amd kernels are fp32 (got {t.dtype})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

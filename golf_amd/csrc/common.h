@@ -1,0 +1,43 @@
+// Shared host-side helpers for libgolf_hip.so (gfx950 only; no other backend exists).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "golf_amd.h"
+
+namespace golf {
+
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Every launch goes through this: returns the hipError_t (>0) of a failed launch.
+#define GOLF_LAUNCH_CHECK()                                                              \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            snprintf(golf::err_buf(), 512, "%s:%d launch failed: %s", __FILE__, __LINE__, \
+                     hipGetErrorString(e__));                                            \
+            return (int)e__;                                                             \
+        }                                                                                \
+    } while (0)
+
+// ---- chunk plan shared by forward and backward of the sample-wise filter -------------------
+struct SsPlan {
+    int W;      // ring/unroll width: W >= M+1, hop % W == 0  (0 => generic fallback)
+    int NT;     // taps computed (>= M, zero padded)
+    int L;      // chunk length: L % W == 0 and (L % hop == 0 || hop % L == 0)
+    int NC;     // chunks per utterance = ceil(T/L)
+    int NP;     // chunks that own a transition matrix = NC-1
+    int seg;    // gradient segment length = min(L, hop)
+    int NSEG;   // ceil(T/seg)
+    // workspace offsets (bytes)
+    size_t off_phi, off_z, off_S, off_zadj, off_lam, off_pa, off_pg, total;
+};
+bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p);
+
+}  // namespace golf

@@ -1,0 +1,168 @@
+// Frame-wise LTI all-pole filter + windowed overlap-add for gfx950 — GOLF-ff end filter.
+//
+// Replaces LTVMinimumPhaseFilter.forward (reference models/filters.py:131-184): zero-pad, unfold to
+// (B*F, W) frames, torchaudio.functional.lfilter per frame (models/lpc.py:11-16), and the dense
+// diagonal conv_transpose1d that the reference uses for the windowed OLA (6.1 GMAC for 6.1 MMAC of
+// useful work at B=32) plus the ones-row normaliser.
+//
+// Here: F1  one lane per frame runs the Wl-step LTI recursion in a rotating register window
+//           (coefficients constant per frame => one FMA per tap), multiplies by the window and
+//           stores the windowed frame;  6400 lanes at B=32.
+//       F2  gathers the <= Wl/hop overlapping frames per output sample and divides by the
+//           window sum (computed on the fly from the same window values, like the reference's
+//           extra ones row).
+#include "common.h"
+
+namespace golf {
+
+template <int W, int NT>
+__global__ __launch_bounds__(64) void ff_frames_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                       const float* __restrict__ gain, const float* __restrict__ a,
+                                                       const float* __restrict__ window, float* __restrict__ wf,
+                                                       int Tx, int F, int M, int hop, int Wl, int nfr, int nq) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const int b = q / nfr, f = q - b * nfr;
+    const int pad = Wl / 2;
+    float a0[NT];
+    {
+        const float* pa = a + ((size_t)b * F + f) * M;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) a0[i] = i < M ? pa[i] : 0.f;
+    }
+    float h[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) h[k] = 0.f;
+    const float inv_hop = 1.0f / (float)hop;
+    const float* exb = ex + (size_t)b * ex_stride;
+    const float* gb = gain + (size_t)b * F;
+    float* out = wf + (size_t)q * Wl;
+    const int tstart = f * hop - pad;
+    const int nblk = (Wl + W - 1) / W;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int k0 = blk * W;
+        const int t0 = tstart + k0;
+        // gain line(s) for this block: at most one frame boundary inside (W <= hop)
+        const int tb = t0 > 0 ? t0 : 0;
+        int ft = tb / hop;
+        if (ft > F - 2) ft = F - 2;
+        const float gA = gb[ft];
+        const float gB = gb[ft + 1];
+        const float dA = (gB - gA) * inv_hop;
+        const float gC = ft + 2 < F ? gb[ft + 2] : gB;
+        const float dB = (gC - gB) * inv_hop;
+        const bool can_cross = ft < F - 2;
+        const int nbase = t0 - ft * hop;
+        float xin[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const int t = t0 + s;
+            xin[s] = (t >= 0 && t < Tx) ? exb[t] : 0.f;
+        }
+        float res[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const int n = nbase + s;
+            const float G = (can_cross && n >= hop) ? fmaf((float)(n - hop), dB, gB) : fmaf((float)n, dA, gA);
+            const float x = xin[s] * G;
+            float ra = 0.f, rb = 0.f;
+#pragma unroll
+            for (int i = NT - 1; i >= 1; --i) {
+                const int slot = (s - 1 - i + 2 * W) % W;
+                if (i & 1) ra = fmaf(a0[i], h[slot], ra);
+                else       rb = fmaf(a0[i], h[slot], rb);
+            }
+            const float y = fmaf(-a0[0], h[(s - 1 + W) % W], x - (ra + rb));
+            h[s] = y;
+            res[s] = y;
+        }
+#pragma unroll
+        for (int s = 0; s < W; ++s)
+            if (k0 + s < Wl) out[k0 + s] = res[s] * window[k0 + s];
+    }
+}
+
+__global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restrict__ window, float* __restrict__ y,
+                              int64_t y_stride, int B, int Ty, int hop, int Wl, int nfr) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * Ty) return;
+    const int b = (int)(idx / Ty), n = (int)(idx - (int64_t)b * Ty);
+    const int pad = Wl / 2;
+    const int m = n + pad;          // position in the padded signal
+    int fhi = m / hop;              // k = m - f*hop >= 0
+    if (fhi > nfr - 1) fhi = nfr - 1;
+    int flo = (m - Wl + hop) / hop; // smallest f with m - f*hop <= Wl-1  (ceil((m-Wl+1)/hop))
+    if (m - Wl + 1 <= 0) flo = 0;
+    float acc = 0.f, norm = 0.f;
+    for (int f = flo; f <= fhi; ++f) {
+        const int k = m - f * hop;
+        if (k < 0 || k >= Wl) continue;
+        acc += wf[((size_t)b * nfr + f) * Wl + k];
+        norm += window[k];
+    }
+    y[(size_t)b * y_stride + n] = acc / norm;
+}
+
+template <int W, int NT>
+static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, const float* a, const float* window,
+                     float* y, int64_t y_stride, int B, int Tx, int F, int M, int hop, int Wl, int Ty, int nfr,
+                     float* wf, hipStream_t st) {
+    const int nq = B * nfr;
+    hipLaunchKernelGGL((ff_frames_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex, ex_stride,
+                       gain, a, window, wf, Tx, F, M, hop, Wl, nfr, nq);
+    GOLF_LAUNCH_CHECK();
+    const int64_t n = (int64_t)B * Ty;
+    hipLaunchKernelGGL(ff_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)wf, window, y,
+                       y_stride, B, Ty, hop, Wl, nfr);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+static int ff_geometry(int Tx, int F, int hop, int Wl, int* nfr, int* Ty) {
+    const int pad = Wl / 2;
+    *nfr = (Tx + 2 * pad - Wl) / hop + 1;
+    *Ty = (*nfr - 1) * hop + Wl - 2 * pad;
+    return 0;
+}
+
+}  // namespace golf
+
+using namespace golf;
+
+extern "C" size_t golf_lti_frames_workspace_bytes(int B, int Tx, int F, int M, int hop, int W) {
+    if (B < 1 || Tx < 1 || F < 1 || hop < 1 || W < 1) return 0;
+    int nfr, Ty;
+    ff_geometry(Tx, F, hop, W, &nfr, &Ty);
+    if (nfr < 1) return 256;
+    return align_up(sizeof(float) * (size_t)B * nfr * W, 256);
+}
+
+extern "C" int golf_lti_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
+                                           const float* window, float* y, int64_t y_stride, int B, int Tx, int F,
+                                           int M, int hop, int W, int Ty, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 1 || Tx < 1 || F < 2 || M < 1 || hop < 1 || W < 1)
+        return fail(GOLF_EINVAL, "lti_frames: bad size (need F >= 2)");
+    if (!ex || !gain || !a || !window || !y) return fail(GOLF_EINVAL, "lti_frames: null pointer");
+    if (W < 2 * hop) return fail(GOLF_EINVAL, "lti_frames: window %d < 2*hop %d", W, 2 * hop);
+    if ((int64_t)Tx > (int64_t)(F - 1) * hop + 1) return fail(GOLF_EINVAL, "lti_frames: Tx exceeds (F-1)*hop+1");
+    int nfr, ty;
+    ff_geometry(Tx, F, hop, W, &nfr, &ty);
+    if (nfr < 1 || nfr > F) return fail(GOLF_EINVAL, "lti_frames: %d frames vs %d coefficient frames", nfr, F);
+    if (ty != Ty) return fail(GOLF_EINVAL, "lti_frames: Ty=%d, expected %d", Ty, ty);
+    if (ex_stride < Tx || y_stride < Ty) return fail(GOLF_EINVAL, "lti_frames: row stride too small");
+    const size_t need = align_up(sizeof(float) * (size_t)B * nfr * W, 256);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "lti_frames: workspace needs %zu bytes, 256-aligned (got %zu)", need, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* wf = (float*)ws;
+#define GOLF_FF_TRY(w, nt)                                                                                   \
+    if (M <= (nt) && (w) <= hop)                                                                             \
+        return launch_ff<w, nt>(ex, ex_stride, gain, a, window, y, y_stride, B, Tx, F, M, hop, W, Ty, nfr, wf, st);
+    GOLF_FF_TRY(8, 6)
+    GOLF_FF_TRY(16, 14)
+    GOLF_FF_TRY(24, 22)
+    GOLF_FF_TRY(32, 30)
+    GOLF_FF_TRY(40, 38)
+#undef GOLF_FF_TRY
+    return fail(GOLF_EUNSUPPORTED, "lti_frames: need M <= 38 and hop >= ring width (M=%d hop=%d)", M, hop);
+}

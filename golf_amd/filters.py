@@ -1,0 +1,129 @@
+"""Drop-in LPC synthesis filters (reference models/filters.py:52-195), MI355X-native.
+
+Same class names, constructor arguments, ``forward`` / ``reverse`` signatures and ``.ctrl`` protocol
+as the reference, so ``class_path: golf_amd.filters.LTVMinimumPhaseFilterPrecise`` replaces
+``models.filters.LTVMinimumPhaseFilterPrecise`` in a GOLF YAML config.  The filters own no parameters
+or persistent buffers (state_dict compatible with reference checkpoints).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from . import functional as GF
+from .audiotensor import AudioTensor
+from .ctrl import Controllable, wrap_ctrl_fn
+from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
+
+__all__ = ["FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
+           "convert2samplewise"]
+
+
+class FilterInterface(Controllable):
+    def forward(self, ex: Tensor, *args, **kwargs) -> Tensor:
+        raise NotImplementedError
+
+
+class LTVFilterInterface(FilterInterface):
+    def forward(self, ex: AudioTensor, *args, **kwargs) -> AudioTensor:
+        raise NotImplementedError
+
+    def reverse(self, ex: AudioTensor, *args, **kwargs) -> AudioTensor:
+        raise NotImplementedError
+
+
+def _check_filter_inputs(ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> int:
+    assert ex.ndim == 2, ex.shape
+    assert gain.ndim == 2, gain.shape
+    assert a.ndim == 3, a.shape
+    assert a.shape[1] == gain.shape[1], (a.shape, gain.shape)
+    assert ex.hop_length == 1, f"excitation must be at hop 1 (got {ex.hop_length})"
+    assert gain.hop_length == a.hop_length, (gain.hop_length, a.hop_length)
+    return int(gain.hop_length)
+
+
+class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
+    """GOLF-ss end filter: sample-wise time-varying all-pole filter with frame-rate controls
+    (reference models/filters.py:64-113).  ``forward`` runs golf_ltv_allpole_{fwd,bwd}_f32."""
+
+    def __init__(self, lpc_order: int = None, lpc_parameterisation: str = "rc2lpc", max_abs_value: float = 1.0):
+        super().__init__()
+        if lpc_parameterisation in ("coef", "conj", "real"):
+            to_biquads = get_logits2biquads(lpc_parameterisation, max_abs_value)
+
+            def logits2lpc(logits: Tensor) -> Tensor:
+                return biquads2lpc(to_biquads(logits.view(logits.shape[0], logits.shape[1], -1, 2)))
+
+            num_logits = lpc_order
+        elif lpc_parameterisation == "rc2lpc":
+            def logits2lpc(logits: Tensor) -> Tensor:
+                return rc2lpc(torch.tanh(logits) * max_abs_value)
+
+            num_logits = lpc_order
+        elif lpc_parameterisation == "lsp2lpc":
+            raise NotImplementedError("lsp2lpc needs diffsptk (not used by any shipped GOLF config)")
+        else:
+            raise ValueError(f"Unknown lpc_parameterisation: {lpc_parameterisation}")
+        self.logits2lpc = logits2lpc
+        if lpc_order is not None:
+            self.ctrl = wrap_ctrl_fn(
+                split_size=(1, num_logits),
+                trsfm_fn=lambda log_gain, lpc_logits: (
+                    torch.exp(log_gain),
+                    lpc_logits.new_tensor(logits2lpc(lpc_logits.as_tensor())),
+                ),
+            )
+
+    def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
+        hop = _check_filter_inputs(ex, gain, a)
+        y = GF.ltv_allpole_ss(ex.as_tensor(), gain.as_tensor(), a.as_tensor(), hop)
+        return AudioTensor(y)
+
+    def reverse(self, ex: AudioTensor, y: AudioTensor, gain: AudioTensor, a: AudioTensor
+                ) -> Tuple[AudioTensor, AudioTensor]:
+        """Inverse filtering of a target (reference models/filters.py:186-195): returns
+        (ex*gain, e) with e[t] = y[t] + sum_i up(a)[t,i] y[t-1-i]."""
+        hop = int(a.hop_length)
+        e = GF.ltv_inverse(y.as_tensor(), a.as_tensor(), hop)
+        return ex * gain, AudioTensor(e)
+
+
+class LTVMinimumPhaseFilter(LTVMinimumPhaseFilterPrecise):
+    """GOLF-ff end filter: per-frame LTI all-pole + windowed overlap-add
+    (reference models/filters.py:116-184).  Forward-only in this round."""
+
+    def __init__(self, window: str, window_length: int, centred: bool = True, **kwargs):
+        super().__init__(**kwargs)
+        # the reference keeps diag(window) as a non-persistent (W,1,W) conv kernel `_kernel`;
+        # only its diagonal is ever used, so that is all that is stored here (also non-persistent).
+        self.register_buffer("_window", get_window_fn(window)(window_length).float(), persistent=False)
+        self.centred = centred
+
+    def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
+        hop = _check_filter_inputs(ex, gain, a)
+        W = self._window.shape[0]
+        assert W >= hop * 2, f"{W} < {hop * 2}"
+        x = ex.as_tensor()
+        if not self.centred:
+            x = x[..., hop // 2:]
+        y = GF.lti_frames_ola(x, gain.as_tensor(), a.as_tensor(), self._window, hop)
+        if not self.centred:
+            y = torch.nn.functional.pad(y, (hop // 2, 0), "reflect")
+        return AudioTensor(y)
+
+
+def convert2samplewise(config: dict) -> dict:
+    """Rewrite a decoder config so frame-wise filters become their sample-wise counterparts
+    (reference models/filters.py:793-809; README.md:92-94)."""
+    for key, value in config.items():
+        if key == "class_path":
+            if ".LTVMinimumPhaseFilter" in value and not value.endswith("Precise"):
+                config["class_path"] = value.rsplit(".", 1)[0] + ".LTVMinimumPhaseFilterPrecise"
+                for k in ("window", "window_length", "centred"):
+                    config.get("init_args", {}).pop(k, None)
+                return config
+        elif isinstance(value, dict):
+            config[key] = convert2samplewise(value)
+    return config

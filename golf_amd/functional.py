@@ -1,0 +1,204 @@
+"""torch.autograd.Functions over the C ABI of libgolf_hip.so (include/golf_amd.h).
+
+Plain tensors in, plain tensors out; AudioTensor bookkeeping lives in the nn.Modules.
+Every function raises if the tensors are not fp32 ROCm-device tensors — no CPU path exists.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["ltv_allpole_ss", "ltv_inverse", "lti_frames_ola", "glottal_osc", "ss_output_length",
+           "ff_output_length", "osc_lengths"]
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """2-D tensor with unit inner stride (row stride may exceed the width)."""
+    assert t.ndim == 2
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def ss_output_length(Tx: int, F: int, hop: int) -> int:
+    return min(Tx, (F - 1) * hop + 1)
+
+
+# ------------------------------------------------------------------------------------------------
+class _LTVAllPoleSS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ex, gain, a, hop):
+        _lib.require_device(ex, gain, a)
+        lib = _lib.load()
+        ex = _rows(ex)
+        gain = gain.contiguous()
+        a = a.contiguous()
+        B, Tx = ex.shape
+        F, M = a.shape[1], a.shape[2]
+        assert gain.shape == (B, F) and a.shape[0] == B
+        T = ss_output_length(Tx, F, hop)
+        y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
+        ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
+        rc = lib.golf_ltv_allpole_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(), y.data_ptr(),
+                                          y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_ltv_allpole_fwd_f32")
+        ctx.hop = hop
+        ctx.save_for_backward(ex, gain, a, y, ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, gain, a, y, ws = ctx.saved_tensors
+        lib = _lib.load()
+        hop = ctx.hop
+        B, Tx = ex.shape
+        F, M = a.shape[1], a.shape[2]
+        T = y.shape[1]
+        gy = _rows(gy.float())
+        g_ex = torch.zeros_like(ex) if Tx > T else torch.empty_like(ex)
+        if g_ex.stride(1) != 1:
+            g_ex = torch.zeros(B, Tx, dtype=torch.float32, device=ex.device)
+        g_gain = torch.empty_like(gain)
+        g_a = torch.empty_like(a)
+        rc = lib.golf_ltv_allpole_bwd_f32(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), ex.data_ptr(),
+                                          ex.stride(0), gain.data_ptr(), a.data_ptr(), g_ex.data_ptr(),
+                                          g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
+                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_ltv_allpole_bwd_f32")
+        return g_ex, g_gain, g_a, None
+
+
+def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:
+    """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
+    Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward)."""
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop))
+
+
+def ltv_inverse(y: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:
+    """e[t] = y[t] + sum_i up(a)[t,i] y[t-1-i] (analysis filter; forward only)."""
+    _lib.require_device(y, a)
+    lib = _lib.load()
+    y = _rows(y)
+    a = a.contiguous()
+    B, Ty = y.shape
+    F, M = a.shape[1], a.shape[2]
+    T = ss_output_length(Ty, F, hop)
+    e = torch.empty(B, T, dtype=torch.float32, device=y.device)
+    rc = lib.golf_ltv_inverse_f32(y.data_ptr(), y.stride(0), a.data_ptr(), e.data_ptr(), e.stride(0), B, T, F, M, hop,
+                                  _lib.stream_ptr())
+    _lib.check(rc, "golf_ltv_inverse_f32")
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+def ff_output_length(Tx: int, F: int, hop: int, W: int):
+    """(Tx_used, nfr, Ty) of the frame-wise filter (reference models/filters.py:147-180)."""
+    Tx = min(Tx, (F - 1) * hop + 1)
+    pad = W // 2
+    nfr = (Tx + 2 * pad - W) // hop + 1
+    Ty = (nfr - 1) * hop + W - 2 * pad
+    return Tx, nfr, Ty
+
+
+class _LTIFramesOLA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ex, gain, a, window, hop):
+        _lib.require_device(ex, gain, a, window)
+        lib = _lib.load()
+        ex = _rows(ex)
+        gain = gain.contiguous()
+        a = a.contiguous()
+        window = window.contiguous()
+        B, Tx0 = ex.shape
+        F, M = a.shape[1], a.shape[2]
+        W = window.numel()
+        Tx, nfr, Ty = ff_output_length(Tx0, F, hop, W)
+        if nfr > F:
+            raise _lib.GolfError(f"frame-wise filter: {nfr} frames needed but only {F} coefficient frames")
+        y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
+        ws = _workspace(lib.golf_lti_frames_workspace_bytes(B, Tx, F, M, hop, W), ex.device)
+        rc = lib.golf_lti_frames_ola_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(),
+                                             window.data_ptr(), y.data_ptr(), y.stride(0), B, Tx, F, M, hop, W, Ty,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_lti_frames_ola_fwd_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        raise NotImplementedError("golf_amd: the frame-wise (GOLF-ff) filter is forward-only in this round; "
+                                  "train with LTVMinimumPhaseFilterPrecise (GOLF-ss)")
+
+
+def lti_frames_ola(ex, gain, a, window, hop: int) -> torch.Tensor:
+    return _LTIFramesOLA.apply(ex, gain, a, window, int(hop))
+
+
+# ------------------------------------------------------------------------------------------------
+def osc_lengths(Tp: int, phase_hop: int, os: int):
+    """(N oversampled length, Tout)."""
+    P = phase_hop * os
+    N = (Tp - 1) * P + 1 if P > 1 else Tp
+    Tout = (N - 1) // os + 1 if os > 1 else N
+    return N, Tout
+
+
+class _GlottalOsc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, phase, wsel, table, taps, phase_hop, w_hop, os, equal_energy, want_pre):
+        _lib.require_device(phase, wsel, table, taps)
+        if phase.requires_grad or table.requires_grad:
+            raise NotImplementedError("golf_amd: the glottal oscillator backward covers table_select_weight only "
+                                      "(phase / trainable tables are not differentiable in this round)")
+        lib = _lib.load()
+        phase = _rows(phase)
+        wsel = wsel.contiguous()
+        table = table.contiguous()
+        B, Tp = phase.shape
+        Fw = wsel.shape[1]
+        n_tab, L = table.shape
+        K = 0 if taps is None else taps.numel()
+        if os > 1:
+            assert taps is not None and K % 2 == 1, "decimation taps (odd length) required when oversampling > 1"
+            taps = taps.contiguous()
+        N, Tout = osc_lengths(Tp, phase_hop, os)
+        out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
+        pre = torch.empty(B, N, dtype=torch.float32, device=phase.device) if (want_pre and os > 1) else None
+        ws = _workspace(lib.golf_glottal_osc_workspace_bytes(B, Tp, phase_hop, Fw, w_hop, L, os), phase.device)
+        rc = lib.golf_glottal_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, wsel.data_ptr(), Fw, w_hop,
+                                          table.data_ptr(), n_tab, L, os, int(bool(equal_energy)), _lib.ptr(taps), K,
+                                          _lib.ptr(pre), out.data_ptr(), out.stride(0), B, Tout, ws.data_ptr(),
+                                          ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_glottal_osc_fwd_f32")
+        ctx.cfg = (phase_hop, w_hop, os, bool(equal_energy))
+        ctx.save_for_backward(phase, wsel, table, taps if taps is not None else phase.new_empty(0), ws)
+        ctx.mark_non_differentiable(*([pre] if pre is not None else []))
+        return (out, pre) if pre is not None else (out, None)
+
+    @staticmethod
+    def backward(ctx, g_out, _g_pre):
+        phase, wsel, table, taps, ws = ctx.saved_tensors
+        phase_hop, w_hop, os, eq = ctx.cfg
+        lib = _lib.load()
+        B, Tp = phase.shape
+        Fw = wsel.shape[1]
+        n_tab, L = table.shape
+        K = taps.numel()
+        g_out = _rows(g_out.float())
+        g_w = torch.empty_like(wsel)
+        rc = lib.golf_glottal_osc_bwd_wsel_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(), phase.stride(0), Tp,
+                                               phase_hop, wsel.data_ptr(), Fw, w_hop, table.data_ptr(), n_tab, L, os,
+                                               int(eq), _lib.ptr(taps) if K else 0, K, g_w.data_ptr(), B,
+                                               g_out.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_glottal_osc_bwd_wsel_f32")
+        return None, g_w, None, None, None, None, None, None, None
+
+
+def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampling: int = 1,
+                equal_energy: bool = False, return_pre: bool = False):
+    """Indexed glottal-flow wavetable oscillator (see include/golf_amd.h golf_glottal_osc_fwd_f32)."""
+    out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
+                                 bool(equal_energy), bool(return_pre))
+    return (out, pre) if return_pre else out

@@ -1,0 +1,148 @@
+"""Glottal-flow wavetable oscillators (reference models/synth.py:40-340), MI355X-native.
+
+``IndexedGlottalFlowTable`` / ``DownsampledIndexedGlottalFlowTable`` keep the reference's constructor
+arguments, buffers (``table``, ``R_d_values`` persistent; ``decimater.kernel`` non-persistent),
+``model.{1,3}`` parameter names and ``.ctrl`` transforms, so reference checkpoints load unchanged.
+``forward`` is one fused HIP path (golf_glottal_osc_fwd_f32): table blend, phase accumulation,
+bilinear lookup, equal-energy scaling and decimation.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import Tensor, nn
+
+from . import functional as GF
+from .audiotensor import AudioTensor
+from .ctrl import Controllable, wrap_ctrl_fn
+from .utils import get_transformed_lf, get_transformed_lf_v2
+
+__all__ = ["OscillatorInterface", "GlottalFlowTable", "IndexedGlottalFlowTable",
+           "DownsampledIndexedGlottalFlowTable", "Decimate", "get_downsampler"]
+
+
+class Decimate(nn.Module):
+    """Anti-aliased decimation filter holder — stand-in for ``kazane.Decimate(q)`` (third-party, absent,
+    taps unknown: decimation parity is unpinned).  Own design: Hann-windowed sinc,
+    K = 2*zeros*q+1 taps, cutoff rolloff/(2q), unity DC gain.  ``kernel`` has kazane's (1,1,K) shape so the
+    real taps can be copied in; the filtering itself is fused into the oscillator kernel."""
+
+    def __init__(self, q: int = 2, zeros: int = 16, rolloff: float = 0.945):
+        super().__init__()
+        self.q = q
+        n = torch.arange(-zeros * q, zeros * q + 1, dtype=torch.float64)
+        h = torch.sinc(n * rolloff / q) * (0.5 + 0.5 * torch.cos(math.pi * n / (zeros * q + 1)))
+        self.register_buffer("kernel", (h / h.sum()).float().view(1, 1, -1))
+
+    @property
+    def taps(self) -> Tensor:
+        return self.kernel.reshape(-1)
+
+
+class OscillatorInterface(Controllable):
+    """``check_ranges=True`` restores the reference's host-syncing input asserts
+    (models/synth.py:26-36: 2-D phase in [0, 0.5]); off by default to keep the stream asynchronous."""
+
+    def __init__(self, check_ranges: bool = False) -> None:
+        super().__init__()
+        self.check_ranges = check_ranges
+
+    def forward(self, phase: AudioTensor, *args, **kwargs) -> AudioTensor:
+        raise NotImplementedError
+
+
+class GlottalFlowTable(OscillatorInterface):
+    """(table_size, points) wavetable of LF glottal-flow (derivative) pulses over a log grid of R_d
+    (reference models/synth.py:58-120)."""
+
+    def __init__(self, table_size: int = 100, table_type: str = "derivative",
+                 normalize_method: str = "constant_power", align_peak: bool = True, trainable: bool = False,
+                 min_R_d: float = 0.3, max_R_d: float = 2.7, lf_v2: bool = False, check_ranges: bool = False,
+                 **kwargs):
+        super().__init__(check_ranges=check_ranges)
+        self.register_buffer("R_d_values",
+                             torch.exp(torch.linspace(math.log(min_R_d), math.log(max_R_d), table_size)))
+        if lf_v2:
+            table = get_transformed_lf_v2(self.R_d_values, **kwargs)
+        else:
+            table = torch.stack([get_transformed_lf(R_d=r, **kwargs) for r in self.R_d_values])
+        if table_type == "flow":
+            table = table.cumsum(dim=1)
+        elif table_type != "derivative":
+            raise ValueError(f"unknown table_type: {table_type}")
+        if align_peak:
+            peak = table.argmin(dim=1) if table_type == "derivative" else table.argmax(dim=1)
+            target = int(peak.max())
+            table = torch.stack([torch.roll(row, target - int(p)) for row, p in zip(table, peak)])
+        if normalize_method == "constant_power":
+            table = table / table.norm(dim=1, keepdim=True) * math.sqrt(table.shape[1])
+        elif normalize_method == "peak":
+            if table_type == "flow":
+                table = table / table.max(dim=1, keepdim=True).values
+        elif normalize_method is not None:
+            raise ValueError(f"unknown normalize_method: {normalize_method}")
+        if trainable:
+            self.register_parameter("table", nn.Parameter(table))
+        else:
+            self.register_buffer("table", table)
+
+
+class IndexedGlottalFlowTable(GlottalFlowTable):
+    def __init__(self, *args, oversampling: int = 1, equal_energy: bool = False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.ctrl = wrap_ctrl_fn(split_size=(1,), trsfm_fn=lambda x: (torch.sigmoid(x),))
+        self.equal_energy = equal_energy
+        self.oversampling = oversampling
+        if oversampling > 1:
+            self.decimater = Decimate(oversampling)
+            # non-persistent, like the reference's re-registration (models/synth.py:209-211)
+            kernel = self.decimater.kernel
+            del self.decimater._buffers["kernel"]
+            self.decimater.register_buffer("kernel", kernel, persistent=False)
+
+    def forward(self, phase: AudioTensor, table_select_weight: AudioTensor, phase_offset: AudioTensor = None,
+                return_pre: bool = False) -> AudioTensor:
+        assert phase.ndim == 2, phase.shape
+        assert table_select_weight.dim() == 2
+        if phase_offset is not None:
+            raise NotImplementedError("golf_amd: phase_offset is not supported by the fused oscillator")
+        if self.check_ranges:
+            assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
+            assert torch.all(table_select_weight >= 0) and torch.all(table_select_weight <= 1)
+        taps = self.decimater.taps if self.oversampling > 1 else None
+        res = GF.glottal_osc(phase.as_tensor(), table_select_weight.as_tensor(), self.table, taps,
+                             phase_hop=phase.hop_length, w_hop=table_select_weight.hop_length,
+                             oversampling=self.oversampling, equal_energy=self.equal_energy, return_pre=return_pre)
+        if return_pre:
+            return AudioTensor(res[0]), res[1]
+        return AudioTensor(res)
+
+
+def get_downsampler(hop_rate: int, in_channels: int, output_channels: int) -> nn.Sequential:
+    """AvgPool(hop_rate) -> 1x1 conv -> GLU -> 1x1 conv (reference models/synth.py:297-315);
+    indices 1 and 3 carry the parameters, matching checkpoint keys ``model.1.*`` / ``model.3.*``."""
+    return nn.Sequential(
+        nn.AvgPool1d(kernel_size=hop_rate, stride=hop_rate, padding=hop_rate // 2),
+        nn.Conv1d(in_channels, in_channels * 2, kernel_size=1),
+        nn.GLU(dim=1),
+        nn.Conv1d(in_channels, output_channels, kernel_size=1),
+    )
+
+
+class DownsampledIndexedGlottalFlowTable(IndexedGlottalFlowTable):
+    """Table selection weight predicted at hop_rate x the encoder hop from ``in_channels`` features."""
+
+    def __init__(self, hop_rate: int, in_channels: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.hop_rate = hop_rate
+        self.model = get_downsampler(hop_rate, in_channels, 1)
+        self.ctrl = wrap_ctrl_fn(
+            split_size=(in_channels,),
+            trsfm_fn=lambda h: (
+                AudioTensor(
+                    self.model(torch.transpose(h.as_tensor(), 1, 2)).squeeze(1).sigmoid(),
+                    hop_length=h.hop_length * self.hop_rate,
+                ),
+            ),
+        )

@@ -1,0 +1,42 @@
+"""Seeded synthetic GOLF decoder inputs — the reference ships no checkpoints
+(.MISSING_LARGE_BLOBS), so every benchmark/parity run uses these.  Generated on CPU with a fixed
+generator (seed 2434 = the reference's seed_everything, cfg/ae/vctk.yaml:2), then moved to the device.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .utils import rc2lpc
+
+SR = 24000
+
+
+def make_inputs(B: int = 32, T: int = 48000, hop: int = 240, M: int = 22, w_hop_rate: int = 10, seed: int = 2434,
+                device="cpu", dtype=torch.float32):
+    """phase (B,T) hop 1 · wsel (B,Fw) hop hop*w_hop_rate · noise (B,T) · gain (B,F) · a (B,F,M) · logits.
+
+    * f0: per-utterance base U(80,400) Hz x 3 % vibrato at 5.5 Hz  -> phase increment in [0.003, 0.02]
+    * table_select_weight: sigmoid of a random walk (sigma 0.3 / control frame)
+    * LPC logits: N(0,0.5^2) per utterance + random walk N(0,0.02^2) per frame -> tanh -> rc2lpc
+      (smooth on purpose: interpolating unrelated stable frames is unstable)
+    * log-gain: random walk around -3 (sigma 0.05)
+    """
+    g = torch.Generator().manual_seed(seed)
+    F = T // hop
+    t = torch.arange(T, dtype=torch.float64) / SR
+    f0 = torch.empty(B, 1, dtype=torch.float64).uniform_(80, 400, generator=g)
+    vib_phase = torch.empty(B, 1, dtype=torch.float64).uniform_(0, 2 * math.pi, generator=g)
+    phase = (f0 * (1 + 0.03 * torch.sin(2 * math.pi * 5.5 * t + vib_phase)) / SR).to(dtype)
+    w_hop = hop * w_hop_rate
+    Fw = T // w_hop + 1
+    wsel = torch.sigmoid(torch.cumsum(0.3 * torch.randn(B, Fw, generator=g), 1)).to(dtype)
+    logits = 0.5 * torch.randn(B, 1, M, generator=g) + torch.cumsum(0.02 * torch.randn(B, F, M, generator=g), 1)
+    a = rc2lpc(torch.tanh(logits.double())).to(dtype)
+    log_gain = -3 + torch.cumsum(0.05 * torch.randn(B, F, generator=g), 1)
+    gain = torch.exp(log_gain).to(dtype)
+    noise = torch.randn(B, T, generator=g).to(dtype)
+    out = dict(phase=phase, wsel=wsel, w_hop=w_hop, noise=noise, gain=gain, a=a, logits=logits.to(dtype),
+               log_gain=log_gain.to(dtype), hop=hop)
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in out.items()}

@@ -1,0 +1,171 @@
+"""Frame-rate DSP math of the GOLF decoder, in plain PyTorch (autograd for free).
+
+These run on (B, F, M)-sized control tensors (~140k elements at B=32) — not the hot loop — and mirror
+the semantics of reference models/utils.py (rc2lpc :581-593, get_logits2biquads :487-525,
+biquads2lpc/coeff_product :444-484, get_transformed_lf :308-360, get_transformed_lf_v2 :363-400,
+get_window_fn :414-430).  Written independently; parity is pinned by tests/golden (g1-g3).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable
+
+import torch
+from torch import Tensor
+
+__all__ = [
+    "rc2lpc", "get_logits2biquads", "biquads2lpc", "coeff_product", "get_window_fn",
+    "get_transformed_lf", "get_transformed_lf_v2", "linear_upsample", "TimeContext",
+]
+
+
+def rc2lpc(rc: Tensor) -> Tensor:
+    """Reflection coefficients (B,F,M) -> direct-form a_1..a_M via the Levinson step-up
+    A_n = [A_{n-1}, 0] + k_n * flip([A_{n-1}, 0])."""
+    assert rc.ndim == 3
+    order = rc.shape[-1]
+    if order == 1:
+        return rc
+    one = torch.ones_like(rc[..., :1])
+    zero = torch.zeros_like(rc[..., :1])
+    poly = torch.cat([one, rc[..., :1]], dim=-1)
+    for n in range(1, order):
+        ext = torch.cat([poly, zero], dim=-1)
+        poly = ext + rc[..., n:n + 1] * ext.flip(-1)
+    return poly[..., 1:]
+
+
+def get_logits2biquads(rep_type: str, max_abs_pole: float = 0.99) -> Callable[[Tensor], Tensor]:
+    """logits (...,2) -> second-order section [1, a1, a2] with poles inside |z| < max_abs_pole."""
+    if rep_type == "coef":
+        def f(logits: Tensor) -> Tensor:
+            assert logits.shape[-1] == 2
+            a1 = 2 * max_abs_pole * torch.tanh(logits[..., 0])
+            a1_abs = a1.abs()
+            a2 = 0.5 * ((2 - a1_abs) * torch.tanh(logits[..., 1]) * max_abs_pole + a1_abs)
+            return torch.stack([torch.ones_like(a1), a1, a2], dim=-1)
+    elif rep_type == "conj":
+        def f(logits: Tensor) -> Tensor:
+            assert logits.shape[-1] == 2
+            radius = torch.sigmoid(logits[..., 0]) * max_abs_pole
+            a1 = -2 * radius * torch.tanh(logits[..., 1])
+            return torch.stack([torch.ones_like(a1), a1, radius.square()], dim=-1)
+    elif rep_type == "real":
+        def f(logits: Tensor) -> Tensor:
+            assert logits.shape[-1] == 2
+            z = torch.tanh(logits) * max_abs_pole
+            a1 = -(z[..., 0] + z[..., 1])
+            return torch.stack([torch.ones_like(a1), a1, z[..., 0] * z[..., 1]], dim=-1)
+    else:
+        raise ValueError(f"Unknown rep_type: {rep_type}, expected coef, conj or real")
+    return f
+
+
+def coeff_product(polys: Tensor) -> Tensor:
+    """Product of K polynomials: polys (..., K, n) -> (..., K*(n-1)+1), lowest power first."""
+    out = polys[..., 0, :]
+    for k in range(1, polys.shape[-2]):
+        p = polys[..., k, :]
+        n_out = out.shape[-1] + p.shape[-1] - 1
+        acc = out.new_zeros(out.shape[:-1] + (n_out,))
+        for j in range(p.shape[-1]):
+            acc[..., j:j + out.shape[-1]] = acc[..., j:j + out.shape[-1]] + out * p[..., j:j + 1]
+        out = acc
+    return out
+
+
+def biquads2lpc(biquads: Tensor) -> Tensor:
+    """(..., K, 3) second-order sections -> direct-form a_1..a_2K (leading 1 dropped)."""
+    assert biquads.shape[-1] == 3
+    return coeff_product(biquads)[..., 1:]
+
+
+def get_window_fn(window: str = "hann"):
+    torch_windows = {"hanning": torch.hann_window, "hamming": torch.hamming_window,
+                     "blackman": torch.blackman_window, "bartlett": torch.bartlett_window}
+    if window in torch_windows:
+        return torch_windows[window]
+    from scipy.signal import get_window
+
+    get_window(window, 8)  # raise early on unknown names
+    return lambda n: torch.tensor(get_window(window, n))
+
+
+class TimeContext:
+    def __init__(self, hop_length: int):
+        self.hop_length = hop_length
+
+    def __call__(self, hop_length: int):
+        return TimeContext(hop_length * self.hop_length)
+
+
+def linear_upsample(ctx: TimeContext, x: Tensor) -> Tensor:
+    """Last-dim linear upsampling by ctx.hop_length, align_corners (length (n-1)*hop+1)."""
+    n = x.size(-1)
+    return torch.nn.functional.interpolate(
+        x.reshape(-1, 1, n), (n - 1) * ctx.hop_length + 1, mode="linear", align_corners=True
+    ).view(*x.shape[:-1], -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# LF glottal-flow derivative pulses
+# ---------------------------------------------------------------------------------------------
+def get_transformed_lf(R_d: float = 0.3, T_0: float = 5.0, n_iter_eps: int = 5, n_iter_a: int = 100,
+                       points: int = 1000) -> Tensor:
+    """One period of the transformed-LF derivative for shape parameter R_d (Newton solves for the
+    return-phase constant eps and the growth constant a); ``points`` samples of [0, T_0)."""
+    R_d = float(R_d)
+    R_ap = 0.048 * R_d - 0.01
+    R_kp = 0.118 * R_d + 0.224
+    R_gp = 0.25 * R_kp * (0.5 + 1.2 * R_kp) / (0.11 * R_d - R_ap * (0.5 + 1.2 * R_kp))
+    T_a = R_ap * T_0
+    T_p = 0.5 * T_0 / R_gp
+    T_e = T_p * (R_kp + 1)
+    T_b = T_0 - T_e
+    w_g = math.pi / T_p
+    E_e = 1.0
+    eps = 1.0
+    for _ in range(n_iter_eps):
+        val = eps * T_a + math.expm1(-eps * T_b)
+        slope = T_a - T_b * math.exp(-eps * T_b)
+        eps = abs(eps - val / slope)
+    a = 1.0
+    E_0 = 0.0
+    for _ in range(n_iter_a):
+        E_0 = -E_e * math.exp(-a * T_e) / math.sin(w_g * T_e)
+        area_open = (E_0 * math.exp(a * T_e) / math.sqrt(w_g ** 2 + a ** 2)
+                     * math.sin(w_g * T_e - math.atan(w_g / a)) + E_0 * w_g / (w_g ** 2 + a ** 2))
+        area_ret = -E_e / (eps ** 2 * T_a) * (1 - math.exp(-eps * T_b) * (1 + eps * T_b))
+        val = area_open + area_ret
+        slope = (1 - 2 * a * area_ret / E_e) * math.sin(w_g * T_e) - w_g * T_e * math.exp(-a * T_e)
+        a = a - val / slope
+    t = torch.linspace(0, T_0, points + 1)[:-1]
+    t_open = t[t < T_e]
+    t_ret = t[t >= T_e]
+    opening = E_0 * torch.exp(a * t_open) * torch.sin(w_g * t_open)
+    ret = -E_e / eps / T_a * (torch.exp(-eps * (t_ret - T_e)) - math.exp(-eps * T_b))
+    return torch.cat([opening, ret])
+
+
+def get_transformed_lf_v2(Rd: Tensor, points: int = 1024) -> Tensor:
+    """Closed-form LF derivative pulses for a vector of R_d values -> (len(Rd), points)."""
+    Rd = torch.as_tensor(Rd).view(-1, 1)
+    Ra = 0.048 * Rd - 0.01
+    Rk = 0.118 * Rd + 0.224
+    Rg = (Rk / 4) * (0.5 + 1.2 * Rk) / (0.11 * Rd - Ra * (0.5 + 1.2 * Rk))
+    Ta = Ra
+    Tp = 1 / (2 * Rg)
+    Te = Tp + Tp * Rk
+    eps = 1 / Ta
+    shift = torch.exp(-eps * (1 - Te))
+    delta = 1 - shift
+    tail = ((1 / eps) * (shift - 1) + (1 - Te) * shift) / delta
+    upper = (Te - Tp) / 2 - tail
+    w = torch.pi / Tp
+    s = torch.sin(w * Te)
+    alpha = torch.log(-torch.pi * s * upper / (Tp * 2)) / (Tp / 2 - Te)
+    E0 = -1 / (s * torch.exp(alpha * Te))
+    t = torch.linspace(0, 1, points + 1)[None, :-1]
+    opening = E0 * torch.exp(alpha * t) * torch.sin(w * t)
+    ret = (shift - torch.exp(-eps * (t - Te))) / delta
+    return torch.where(t < Te, opening, ret).squeeze()

@@ -1,0 +1,135 @@
+/*
+ * golf_amd.h — C ABI of libgolf_hip.so: the MI355X (gfx950) kernels behind GOLF's time-varying
+ * LPC synthesis filter and glottal-flow source path.
+ *
+ * The reference (iamycy/golf) has NO FFI boundary of its own: the arithmetic on this path lives in
+ * un-vendored Python/C++/numba packages that its nn.Modules call.  Each entry point below names the
+ * reference call site (file:line under /root/reference) whose computation it replaces; the Python
+ * binding a maintainer would add is golf_amd/_lib.py (ctypes) — see INTEGRATION.md.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers + sizes only; every pointer is a caller-owned DEVICE buffer (hipMalloc'd or a
+ *     torch tensor's data_ptr()), fp32 row-major contiguous unless a stride is given;
+ *   - the library never allocates or frees: scratch is passed in as (ws, ws_bytes), sized by the
+ *     matching *_workspace_bytes();  ws must be 256-byte aligned;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*), no internal sync,
+ *     no global mutable state => re-entrant from several host threads / streams;
+ *   - return 0 = ok; <0 = GOLF_E* bad-argument code (text via golf_last_error(), thread-local);
+ *     >0 = hipError_t from a launch.
+ */
+#ifndef GOLF_AMD_H
+#define GOLF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOLF_ABI_VERSION 1
+
+enum {
+    GOLF_OK = 0,
+    GOLF_EINVAL = -1,   /* bad size / null pointer                        */
+    GOLF_EWORKSPACE = -2, /* ws too small or misaligned                     */
+    GOLF_EUNSUPPORTED = -3 /* shape outside what the kernels cover (message) */
+};
+
+int golf_abi_version(void);
+const char* golf_last_error(void);
+/* "gfx950" — the only code object in the library. */
+const char* golf_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a-1 (+a-3 fused): sample-wise LTV all-pole filter — GOLF-ss end filter.
+ * Replaces LTVMinimumPhaseFilterPrecise.forward, models/filters.py:99-113:
+ *     ex*gain (AudioTensor broadcast -> linear upsampling, models/utils.py:538-544)
+ *     a.reduce_hop_length() -> (B,T,M) materialised coefficient tensor (never built here)
+ *     torchlpc.sample_wise_lpc(ex, a)  (models/filters.py:112)
+ *
+ *   y[b,t] = ex[b,t]*G[b,t] - sum_{i<M} A[b,t,i]*y[b,t-1-i],  y[<0] = 0,  t in [0,T)
+ *   G = up(gain), A = up(a): up(z)[t] = z[f]+(t-f*hop)*(z[f+1]-z[f])/hop, f = min(t/hop, F-2)
+ *
+ *   ex   (B, >=T) row stride ex_stride      gain (B,F)      a (B,F,M)
+ *   y    (B, T)   row stride y_stride       requires 1 <= T <= (F-1)*hop+1, 1 <= M <= 64
+ *   ws   scratch of golf_ltv_allpole_workspace_bytes(); it also carries the per-chunk transition
+ *        matrices the backward pass reuses — keep it alive (unmodified) until the backward ran.
+ * ------------------------------------------------------------------------------------------- */
+size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
+
+int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
+                             float* y, int64_t y_stride, int B, int T, int F, int M, int hop,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* Custom backward of the above (what torchlpc's autograd.Function + autograd through
+ * F.interpolate compute in the reference; closed form in SURVEY.md App. A-2):
+ *     g[t]      = gy[t] - sum_i A[t+1+i,i]*g[t+1+i]      (reverse-time recursion)
+ *     g_ex[t]   = g[t]*G[t]
+ *     g_gain[f] = up^T(g*ex)[f]         g_a[f,i] = up^T(-g[t]*y[t-1-i])[f,i]
+ *   gy,y (B,T) with strides; ws = the forward's workspace (same B,T,F,M,hop);
+ *   g_ex (B,T) stride g_ex_stride, g_gain (B,F), g_a (B,F,M) are fully overwritten. */
+int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
+                             const float* ex, int64_t ex_stride, const float* gain, const float* a,
+                             float* g_ex, int64_t g_ex_stride, float* g_gain, float* g_a,
+                             int B, int T, int F, int M, int hop,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* a-5: inverse (analysis) filter e[t] = y[t] + sum_i A[t,i]*y[t-1-i].
+ * Replaces LTVMinimumPhaseFilter.reverse -> fir_filt, models/filters.py:186-195, utils.py:433-441. */
+int golf_ltv_inverse_f32(const float* y, int64_t y_stride, const float* a, float* e, int64_t e_stride,
+                         int B, int T, int F, int M, int hop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a-4: frame-wise LTI all-pole + windowed overlap-add — GOLF-ff end filter.
+ * Replaces LTVMinimumPhaseFilter.forward, models/filters.py:131-184 (pad, unfold, lpc_synthesis ->
+ * torchaudio.functional.lfilter models/lpc.py:11-16, diagonal conv_transpose1d OLA, normalise).
+ *   x = ex*up(gain) (length Tx = min(T_ex, (F-1)*hop+1)), zero-padded by W/2 each side;
+ *   frame f = x_pad[f*hop .. f*hop+W), nfr = (Tx + 2*(W/2) - W)/hop + 1 <= F frames,
+ *   filt_f = LTI all-pole a[b,f,:] from zero state;
+ *   y[n] = sum_f window[k]*filt_f[k] / sum_f window[k],  n = f*hop - W/2 + k,  n in [0, Ty),
+ *   Ty = (nfr-1)*hop + W - 2*(W/2).
+ *   window (W) fp32; requires W >= 2*hop.  `centred==0` handling (drop hop/2, reflect pad) is done
+ *   by the host wrapper.  ws: golf_lti_frames_workspace_bytes(). */
+size_t golf_lti_frames_workspace_bytes(int B, int Tx, int F, int M, int hop, int W);
+
+int golf_lti_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
+                                const float* window, float* y, int64_t y_stride,
+                                int B, int Tx, int F, int M, int hop, int W, int Ty,
+                                void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a-8/a-9: indexed glottal-flow wavetable oscillator.
+ * Replaces IndexedGlottalFlowTable.forward, models/synth.py:213-263 (table blend, phase/oversampling,
+ * linear upsample, fp32 cumsum, %1, GlottalFlowTable.generate = F.grid_sample bilinear
+ * models/synth.py:124-177, * rsqrt(phase), kazane.Decimate(oversampling)).
+ *   phase (B,Tp) phase increment [cycles/sample] at hop phase_hop; wsel (B,Fw) in [0,1] at hop w_hop;
+ *   table (n_tab, L).  Oversampled length N = (Tp-1)*phase_hop*os + 1 (N = Tp if phase_hop*os==1).
+ *   pre (B,N) (optional, may be NULL) = the signal handed to the decimator;
+ *   out (B,Tout): os==1 -> out = pre (Tout = N); os>1 -> strided FIR with `taps` (K odd),
+ *   Tout = (N-1)/os + 1.
+ *   The running phase is accumulated in fp64 and wrapped (more accurate than the reference's fp32
+ *   cumsum; parity is against the float64 oracle). */
+size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fw, int w_hop, int L, int os);
+
+int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                             const float* wsel, int Fw, int w_hop,
+                             const float* table, int n_tab, int L,
+                             int os, int equal_energy, const float* taps, int K,
+                             float* pre, float* out, int64_t out_stride, int B, int Tout,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* Backward w.r.t. table_select_weight only (phase is data in GOLF training: train_with_true_f0,
+ * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = the forward's workspace. */
+int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_stride,
+                                  const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                                  const float* wsel, int Fw, int w_hop,
+                                  const float* table, int n_tab, int L,
+                                  int os, int equal_energy, const float* taps, int K,
+                                  float* g_wsel, int B, int Tout,
+                                  void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLF_AMD_H */

@@ -1,0 +1,194 @@
+"""GPU parity of the sample-wise LTV all-pole filter (golf_ltv_allpole_{fwd,bwd}_f32) against the
+float64 oracle and the golden vectors.  Bar: <= 1e-4 relative (max-norm and L2), fp32 kernels."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+
+
+def smooth_case(B, F, M, hop, Tx=None, seed=0, walk=0.02):
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(0, 0.5, (B, 1, M)) + np.cumsum(rng.normal(0, walk, (B, F, M)), 1)
+    a = O.rc2lpc(np.tanh(logits)).astype(np.float32)
+    gain = np.exp(-3 + np.cumsum(rng.normal(0, 0.05, (B, F)), 1)).astype(np.float32)
+    Tx = (F - 1) * hop + 1 if Tx is None else Tx
+    ex = rng.normal(0, 1, (B, Tx)).astype(np.float32)
+    return ex, gain, a
+
+
+def run_fwd(ex, gain, a, hop):
+    from golf_amd import functional as GF
+
+    y = GF.ltv_allpole_ss(dev(ex), dev(gain), dev(a), hop)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def check(y, ref, what, tol=TOL):
+    emax, el2 = rel_err(y, ref)
+    print(f"{what}: rel-max {emax:.3e} rel-l2 {el2:.3e}")
+    assert np.isfinite(y).all(), what
+    assert emax <= tol and el2 <= tol, (what, emax, el2)
+
+
+def test_golden_g8(golden):
+    g = golden("g8_samplewise")
+    y = run_fwd(g["ex"], g["gain"], g["a"], int(g["hop"]))
+    assert y.shape == g["y"].shape
+    check(y, g["y"], "g8 tiny (hop 8, M 4)")
+    check(run_fwd(g["ex"][:, :30], g["gain"], g["a"], int(g["hop"])), g["y_short"], "g8 short ex")
+    check(run_fwd(g["ex2"], g["gain2"], g["a2"], int(g["hop2"])), g["y2"], "g8 config order (hop 240, M 22)")
+
+
+@pytest.mark.parametrize("B,F,M,hop", [(1, 2, 22, 240), (4, 40, 22, 240), (3, 9, 4, 8), (2, 7, 6, 16),
+                                       (2, 30, 12, 24), (5, 50, 22, 120), (2, 12, 26, 240), (3, 6, 16, 480),
+                                       (2, 5, 30, 256)])
+def test_fwd_vs_oracle(B, F, M, hop):
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(B, F, M, hop, seed=B * 1000 + F)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    check(run_fwd(ex, gain, a, hop), ref, f"fwd B{B} F{F} M{M} hop{hop}")
+
+
+def test_fwd_ragged_lengths():
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(3, 10, 22, 240, Tx=2500, seed=5)  # longer than (F-1)*hop+1 = 2161
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, 240)
+    y = run_fwd(ex, gain, a, 240)
+    assert y.shape == (3, 2161)
+    check(y, ref, "ex longer than frames")
+    for Tx in (1, 23, 24, 25, 239, 240, 241, 1000):
+        ref = O.ltv_allpole_ss_forward(ex[:, :Tx], gain, a, 240)
+        y = run_fwd(ex[:, :Tx], gain, a, 240)
+        assert y.shape == (3, Tx)
+        check(y, ref, f"ex shorter Tx={Tx}")
+    # non-contiguous rows (row stride > width)
+    from golf_amd import functional as GF
+
+    big = dev(ex)
+    y = GF.ltv_allpole_ss(big[:, :2000], dev(gain), dev(a), 240).cpu().numpy()
+    check(y, O.ltv_allpole_ss_forward(ex[:, :2000], gain, a, 240), "strided ex view")
+
+
+def test_fwd_generic_fallback():
+    from oracle import golf_oracle as O
+
+    for (B, F, M, hop) in [(2, 30, 3, 10), (2, 200, 5, 1), (1, 1, 4, 7), (2, 9, 22, 20)]:
+        ex, gain, a = smooth_case(B, F, M, hop, seed=F)
+        ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+        check(run_fwd(ex, gain, a, hop), ref, f"generic B{B} F{F} M{M} hop{hop}")
+
+
+def test_fwd_impulse_constant_filter_matches_scipy():
+    """LTV path with constant coefficients == scipy.signal.lfilter (independent witness)."""
+    import scipy.signal
+
+    rng = np.random.default_rng(3)
+    from oracle import golf_oracle as O
+
+    a1 = O.rc2lpc(np.tanh(rng.normal(0, 0.5, (2, 1, 22))))
+    a = np.repeat(a1, 6, axis=1).astype(np.float32)
+    gain = np.ones((2, 6), np.float32)
+    ex = rng.normal(0, 1, (2, 1201)).astype(np.float32)
+    ref = np.stack([scipy.signal.lfilter([1.0], np.concatenate([[1.0], a[r, 0].astype(np.float64)]), ex[r].astype(np.float64))
+                    for r in range(2)])
+    check(run_fwd(ex, gain, a, 240), ref, "constant filter vs scipy")
+
+
+def run_bwd(ex, gain, a, gy, hop):
+    from golf_amd import functional as GF
+
+    ex_t, gain_t, a_t = dev(ex).requires_grad_(True), dev(gain).requires_grad_(True), dev(a).requires_grad_(True)
+    y = GF.ltv_allpole_ss(ex_t, gain_t, a_t, hop)
+    (y * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    return y.detach().cpu().numpy(), ex_t.grad.cpu().numpy(), gain_t.grad.cpu().numpy(), a_t.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("sfx", ["", "22"])
+def test_golden_g10_grads(golden, sfx):
+    g = golden("g10_ss_grads")
+    y, g_ex, g_gain, g_a = run_bwd(g["ex" + sfx], g["gain" + sfx], g["a" + sfx], g["gy" + sfx], int(g["hop" + sfx]))
+    check(y, g["y" + sfx], "g10 y")
+    check(g_ex, g["g_ex" + sfx], "g10 g_ex")
+    check(g_gain, g["g_gain" + sfx], "g10 g_gain")
+    check(g_a, g["g_a" + sfx], "g10 g_a")
+
+
+@pytest.mark.parametrize("B,F,M,hop,Tx", [(3, 12, 22, 240, None), (2, 9, 4, 8, None), (2, 30, 12, 24, None),
+                                          (3, 10, 22, 240, 2500), (2, 10, 22, 240, 1000), (2, 6, 16, 480, None),
+                                          (2, 20, 22, 120, None)])
+def test_bwd_vs_oracle(B, F, M, hop, Tx):
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=B * 100 + F)
+    T = min(ex.shape[1], (F - 1) * hop + 1)
+    gy = np.random.default_rng(1).normal(0, 1, (B, T)).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+    y, g_ex, g_gain, g_a = run_bwd(ex, gain, a, gy, hop)
+    check(y, O.ltv_allpole_ss_forward(ex, gain, a, hop), "y")
+    check(g_ex, r_ex, "g_ex")
+    check(g_gain, r_gain, "g_gain")
+    check(g_a, r_a, "g_a")
+
+
+def test_full_size_config(golden):
+    """BASELINE config: B=32, 2 s @ 24 kHz, F=200, hop 240, M=22 — forward and backward."""
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32)
+    ex = inp["noise"].numpy()
+    gain, a = inp["gain"].numpy(), inp["a"].numpy()
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, 240)
+    y = run_fwd(ex, gain, a, 240)
+    assert y.shape == (32, 47761)
+    check(y, ref, "full-size fwd")
+    # linearity (size-independent property): filter(2x + z) == 2 filter(x) + filter(z)
+    z = np.random.default_rng(9).normal(0, 1, ex.shape).astype(np.float32)
+    yz = run_fwd(z, gain, a, 240)
+    ymix = run_fwd(2 * ex + z, gain, a, 240)
+    check(ymix, 2 * y.astype(np.float64) + yz, "linearity")
+    # inverse filter round trip: analysis(synthesis(x)) == x*G
+    from golf_amd import functional as GF
+
+    e = GF.ltv_inverse(dev(y), dev(a), 240).cpu().numpy()
+    G = O.linear_upsample(gain, 240)[:, :47761]
+    check(e, ex[:, :47761] * G, "inverse(forward(x)) == x*gain", tol=2e-3)
+
+
+def test_full_size_backward():
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=4)
+    ex, gain, a = inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy()
+    gy = np.random.default_rng(1).normal(0, 1, (4, 47761)).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, 240)
+    y, g_ex, g_gain, g_a = run_bwd(ex, gain, a, gy, 240)
+    check(g_ex, r_ex, "full g_ex")
+    check(g_gain, r_gain, "full g_gain")
+    check(g_a, r_a, "full g_a")
+
+
+def test_errors_are_loud():
+    from golf_amd import functional as GF
+    from golf_amd._lib import GolfError
+
+    with pytest.raises(GolfError):
+        GF.ltv_allpole_ss(torch.zeros(2, 100), torch.ones(2, 3), torch.zeros(2, 3, 4), 50)  # CPU tensors
+    with pytest.raises(GolfError):
+        GF.ltv_allpole_ss(torch.zeros(2, 100).cuda(), torch.ones(2, 3).cuda(), torch.zeros(2, 3, 70).cuda(), 48)
