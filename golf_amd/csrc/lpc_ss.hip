@@ -68,10 +68,12 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
     p->NSEG = (int)ceil_div(T, p->seg);
     size_t o = 0;
     p->off_phi = o;  o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
+    p->off_phiT = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_z = o;    o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
     p->off_S = o;    o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
     p->off_zadj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
     p->off_lam = o;  o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
+    p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
     p->total = o;
@@ -79,20 +81,198 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// P1h: homogeneous trajectories in fp64 -> Phi[b][c][j][i] = d s_end[i] / d s_start[j]
-//   lane = flat chunk q = b*NP + c;  blockIdx.y = trajectory pair (j0, j0+1)
+// Tile I/O: a wave owns 64 consecutive chunks of one utterance.  For each W-step block the wave moves
+// a 64 x W tile between HBM and registers THROUGH LDS so that global accesses are coalesced
+// (element e = it*64 + lane  <->  row e/W (= chunk), col e%W) while each lane computes on its own row.
+// Row stride W+1 floats keeps both access patterns bank-conflict free.  Single-wave workgroups.
+// ------------------------------------------------------------------------------------------
+template <int W>
+struct Tile {
+    static constexpr int LD = W + 1;
+    static constexpr int SIZE = 64 * LD;
+
+    __device__ static __forceinline__ void rowcol(int it, int lq, int lr, int& row, int& col) {
+        const int q = (it * 64) / W, r = (it * 64) % W;  // constants after unrolling
+        col = r + lr;
+        row = q + lq;
+        if (col >= W) { col -= W; row += 1; }
+        if (col >= W) { col -= W; row += 1; }            // W < 64: lr + r < 2W, at most two wraps (W >= 8: lr<W)
+    }
+    // global -> registers, coalesced order; t = tbase + row*L + col must lie in [0,T) else 0
+    __device__ static __forceinline__ void fetch(float (&r)[W], const float* __restrict__ rowb, int tbase, int L,
+                                                 int T, int lq, int lr) {
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+            int row, col;
+            rowcol(it, lq, lr, row, col);
+            const int t = tbase + row * L + col;
+            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+            const float v = rowb[tc];
+            r[it] = (t >= 0 && t < T) ? v : 0.f;
+        }
+    }
+    __device__ static __forceinline__ void store(const float (&r)[W], float* __restrict__ rowb, int tbase, int L, int T,
+                                                 int lq, int lr) {
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+            int row, col;
+            rowcol(it, lq, lr, row, col);
+            const int t = tbase + row * L + col;
+            if (t >= 0 && t < T) rowb[t] = r[it];
+        }
+    }
+    __device__ static __forceinline__ void scatter(float* lds, const float (&r)[W], int lq, int lr) {
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+            int row, col;
+            rowcol(it, lq, lr, row, col);
+            lds[row * LD + col] = r[it];
+        }
+    }
+    __device__ static __forceinline__ void gather(float (&r)[W], const float* lds, int lq, int lr) {
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+            int row, col;
+            rowcol(it, lq, lr, row, col);
+            r[it] = lds[row * LD + col];
+        }
+    }
+    __device__ static __forceinline__ void rows_load(float (&x)[W], const float* lds, int lane) {
+#pragma unroll
+        for (int s = 0; s < W; ++s) x[s] = lds[lane * LD + s];
+    }
+    __device__ static __forceinline__ void rows_store(float* lds, const float (&x)[W], int lane) {
+#pragma unroll
+        for (int s = 0; s < W; ++s) lds[lane * LD + s] = x[s];
+    }
+};
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float f4get(const float4& v, int k) {
+    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward in-lane recursion over one chunk (fp32).  Wave = 64 consecutive chunks of utterance b.
+//   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
+//   MODE 1 (P3) : initial state S[(b*NCQ+c)*W + i], writes y[b][t]
+// ------------------------------------------------------------------------------------------
+template <int W, int NT, int MODE>
+__device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const float* __restrict__ ex,
+                                               int64_t ex_stride, const float* __restrict__ gain,
+                                               const float* __restrict__ a, const float* __restrict__ S,
+                                               float* __restrict__ out, int64_t y_stride, int T, int F, int M, int hop,
+                                               int L, int NCQ) {
+    using TL = Tile<W>;
+    float* xt = lds;
+    float* yt = lds + TL::SIZE;
+    const int lane = threadIdx.x;
+    const int lq = lane / W, lr = lane % W;
+    const int c0 = cg * 64;
+    const int c = c0 + lane;
+    const bool mine = c < NCQ;
+    const float* exb = ex + (size_t)b * ex_stride;
+    float* yb = MODE == 1 ? out + (size_t)b * y_stride : nullptr;
+    float h[W];
+    if (MODE == 1 && mine) {
+        const float* sp = S + ((size_t)b * NCQ + c) * W;
+#pragma unroll
+        for (int i = 0; i < W; ++i) h[W - 1 - i] = sp[i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) h[k] = 0.f;
+    }
+    float a0[NT], dd[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { a0[i] = 0.f; dd[i] = 0.f; }
+    float g0 = 0.f, dg = 0.f;
+    const float inv_hop = 1.0f / (float)hop;
+    int fcur = -1;
+    const int nblk = L / W;
+    float nx[W];
+    TL::fetch(nx, exb, c0 * L, L, T, lq, lr);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int tw = c0 * L + blk * W;  // block start of the wave's first chunk
+        if (tw >= T) break;               // wave-uniform: nothing left for any lane
+        TL::scatter(xt, nx, lq, lr);
+        __syncthreads();
+        float xin[W];
+        TL::rows_load(xin, xt, lane);
+        if (blk + 1 < nblk) TL::fetch(nx, exb, tw + W, L, T, lq, lr);  // prefetch next block
+        const int t0 = c * L + blk * W;
+        const bool act = mine && t0 < T;
+        if (act) {
+            int f = t0 / hop;
+            if (f > F - 2) f = F - 2;
+            if (f != fcur) {
+                fcur = f;
+                const float* pa0 = a + ((size_t)b * F + f) * M;
+                const float* pa1 = pa0 + M;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const float v0 = i < M ? pa0[i] : 0.f;
+                    const float v1 = i < M ? pa1[i] : 0.f;
+                    a0[i] = v0;
+                    dd[i] = (v1 - v0) * inv_hop;
+                }
+                g0 = gain[(size_t)b * F + f];
+                dg = (gain[(size_t)b * F + f + 1] - g0) * inv_hop;
+            }
+            const float n0 = (float)(t0 - f * hop);
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                const float n = n0 + (float)s;
+                const float x = xin[s] * fmaf(n, dg, g0);
+                float ra = 0.f, rb = 0.f;
+#pragma unroll
+                for (int i = NT - 1; i >= 1; --i) {
+                    const float cf = fmaf(n, dd[i], a0[i]);
+                    const int slot = (s - 1 - i + 2 * W) % W;
+                    if (i & 1) ra = fmaf(cf, h[slot], ra);
+                    else       rb = fmaf(cf, h[slot], rb);
+                }
+                const float cf0 = fmaf(n, dd[0], a0[0]);
+                h[s] = fmaf(-cf0, h[(s - 1 + W) % W], x - (ra + rb));
+            }
+        }
+        if (MODE == 1) {
+            TL::rows_store(yt, h, lane);
+            __syncthreads();
+            float o[W];
+            TL::gather(o, yt, lq, lr);
+            TL::store(o, yb, tw, L, T, lq, lr);
+        }
+        __syncthreads();
+    }
+    if (MODE == 0 && mine) {
+        float* zp = out + ((size_t)b * NCQ + c) * W;
+#pragma unroll
+        for (int i = 0; i < W; ++i) zp[i] = i < M ? h[W - 1 - i] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// P1h: homogeneous trajectories in fp64 -> transition matrix of chunk q = b*NP + c, stored twice:
+//   Phi [q][j][i] (row j contiguous: adjoint scan reads rows)   = d s_end[i] / d s_start[j]
+//   PhiT[q][i][j] (row i contiguous: forward scan reads rows)
+//   lane = flat chunk q;  `pair` selects trajectories (2*pair, 2*pair+1)
 // ------------------------------------------------------------------------------------------
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p1_hom_kernel(const float* __restrict__ a, float* __restrict__ Phi,
-                                                        int F, int M, int hop, int L, int NP, int nq) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void p1_hom_body(int qblk, int pair, const float* __restrict__ a, float* __restrict__ Phi,
+                                            float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
+    const int q = qblk * 64 + threadIdx.x;
     if (q >= nq) return;
-    const int j0 = 2 * blockIdx.y, j1 = j0 + 1;
+    const int j0 = 2 * pair, j1 = j0 + 1;
     float* out0 = Phi + ((size_t)q * NT + j0) * W;
     float* out1 = out0 + W;
-    if (j0 >= M) {  // padding rows: exact zeros
+    float* outT = PhiT + (size_t)q * NT * W + j0;
+    if (j0 >= M) {  // padding rows/columns: exact zeros
 #pragma unroll
         for (int i = 0; i < W; ++i) { out0[i] = 0.f; out1[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { outT[(size_t)i * W] = 0.f; outT[(size_t)i * W + 1] = 0.f; }
         return;
     }
     const int b = q / NP, c = q - b * NP;
@@ -143,159 +323,127 @@ __global__ __launch_bounds__(64) void lpc_p1_hom_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        out0[i] = i < M ? (float)h0[W - 1 - i] : 0.f;
-        out1[i] = (i < M && j1 < M) ? (float)h1[W - 1 - i] : 0.f;
+        const float v0 = i < M ? (float)h0[W - 1 - i] : 0.f;
+        const float v1 = (i < M && j1 < M) ? (float)h1[W - 1 - i] : 0.f;
+        out0[i] = v0;
+        out1[i] = v1;
+        if (i < NT) { outT[(size_t)i * W] = v0; outT[(size_t)i * W + 1] = v1; }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// P1z / P3: fp32 in-lane recursion over one chunk.  lane = flat chunk q = b*NCQ + c
-//   MODE 0 (P1z): zero initial state, store final state to zout[q][W]
-//   MODE 1 (P3) : initial state from S[q][W], store y[b][t]
-// ------------------------------------------------------------------------------------------
-template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_chunk_f32_kernel(const float* __restrict__ ex, int64_t ex_stride,
-                                                           const float* __restrict__ gain,
-                                                           const float* __restrict__ a,
-                                                           const float* __restrict__ S, float* __restrict__ out,
-                                                           int64_t y_stride, int T, int F, int M, int hop, int L,
-                                                           int NCQ, int nq) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nq) return;
-    const int b = q / NCQ, c = q - b * NCQ;
-    float h[W];
-    if (MODE == 1) {
-        const float* sp = S + (size_t)q * W;
-#pragma unroll
-        for (int i = 0; i < W; ++i) h[W - 1 - i] = sp[i];
-    } else {
-#pragma unroll
-        for (int k = 0; k < W; ++k) h[k] = 0.f;
-    }
-    float a0[NT], dd[NT];
-    float g0 = 0.f, dg = 0.f;
-    const float inv_hop = 1.0f / (float)hop;
-    const float* exb = ex + (size_t)b * ex_stride;
-    float* yb = MODE == 1 ? out + (size_t)b * y_stride : nullptr;
-    int fcur = -1;
-    const int nblk = L / W;
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int t0 = c * L + blk * W;
-        if (t0 >= T) break;
-        int f = t0 / hop;
-        if (f > F - 2) f = F - 2;
-        if (f != fcur) {
-            fcur = f;
-            const float* pa0 = a + ((size_t)b * F + f) * M;
-            const float* pa1 = pa0 + M;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const float v0 = i < M ? pa0[i] : 0.f;
-                const float v1 = i < M ? pa1[i] : 0.f;
-                a0[i] = v0;
-                dd[i] = (v1 - v0) * inv_hop;
-            }
-            g0 = gain[(size_t)b * F + f];
-            dg = (gain[(size_t)b * F + f + 1] - g0) * inv_hop;
-        }
-        const float n0 = (float)(t0 - f * hop);
-        float xin[W];
-#pragma unroll
-        for (int s = 0; s < W; ++s) xin[s] = (t0 + s < T) ? exb[t0 + s] : 0.f;
-#pragma unroll
-        for (int s = 0; s < W; ++s) {
-            const float n = n0 + (float)s;
-            const float x = xin[s] * fmaf(n, dg, g0);
-            float ra = 0.f, rb = 0.f;
-#pragma unroll
-            for (int i = NT - 1; i >= 1; --i) {
-                const float cf = fmaf(n, dd[i], a0[i]);
-                const int slot = (s - 1 - i + 2 * W) % W;
-                if (i & 1) ra = fmaf(cf, h[slot], ra);
-                else       rb = fmaf(cf, h[slot], rb);
-            }
-            const float cf0 = fmaf(n, dd[0], a0[0]);
-            const float base = x - (ra + rb);
-            const float y = fmaf(-cf0, h[(s - 1 + W) % W], base);
-            h[s] = y;
-        }
-        if (MODE == 1) {
-#pragma unroll
-            for (int s = 0; s < W; ++s)
-                if (t0 + s < T) yb[t0 + s] = h[s];
-        }
-    }
-    if (MODE == 0) {
-        float* zp = out + (size_t)q * W;
-#pragma unroll
-        for (int i = 0; i < W; ++i) zp[i] = i < M ? h[W - 1 - i] : 0.f;
-    }
+// Phase 1 kernels.  (Fusing both roles into one launch was tried: the fp32 role's 256 VGPRs halve the
+// occupancy of the fp64 role, which is the one that needs two waves per SIMD.)
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_p1z_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                     const float* __restrict__ gain, const float* __restrict__ a,
+                                                     float* __restrict__ z, int T, int F, int M, int hop, int L,
+                                                     int NP) {
+    __shared__ float lds[2 * Tile<W>::SIZE];
+    fwd_chunk_body<W, NT, 0>(lds, blockIdx.y, blockIdx.x, ex, ex_stride, gain, a, nullptr, z, 0, T, F, M, hop, L, NP);
+}
+
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
+                                                     float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
+                                                     int nq) {
+    const int idx = blockIdx.x;
+    const int pair = idx % (NT / 2), qblk = idx / (NT / 2);
+    p1_hom_body<W, NT>(qblk, pair, a, Phi, PhiT, F, M, hop, L, NP, nq);
+}
+
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_p3_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                    const float* __restrict__ gain, const float* __restrict__ a,
+                                                    const float* __restrict__ S, float* __restrict__ y,
+                                                    int64_t y_stride, int T, int F, int M, int hop, int L, int NC) {
+    __shared__ float lds[2 * Tile<W>::SIZE];
+    fwd_chunk_body<W, NT, 1>(lds, blockIdx.y, blockIdx.x, ex, ex_stride, gain, a, S, y, y_stride, T, F, M, hop, L, NC);
 }
 
 // ------------------------------------------------------------------------------------------
 // P2: chunk-boundary scan, one wave per utterance, lane i = state component.
-//   S[b][c][:] = state at the start of chunk c;  s_{c+1} = Phi_c s_c + z_c
+//   S[b][c][:] = state at the start of chunk c;  s_{c+1} = Phi_c s_c + z_c.
+//   The step is a 22x22 matvec with s broadcast by v_readlane; what bounds it is the latency of
+//   fetching Phi_c, so rows are read as float4 (7 loads per chunk: vmcnt only counts 63) and kept
+//   D chunks ahead in registers.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict__ Phi, const float* __restrict__ z,
+template <int W, int NT, int D>
+__global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict__ PhiT, const float* __restrict__ z,
                                                          float* __restrict__ S, int NC, int NP) {
     const int b = blockIdx.x;
     const int i = threadIdx.x;
-    const bool act = i < W;
+    const bool act = i < NT;
     const int ii = act ? i : 0;
-    const float* phib = Phi + (size_t)b * NP * NT * W;
-    const float* zb = z + (size_t)b * NP * W;
+    const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+    const size_t cstride4 = (size_t)NT * W / 4;
+    const float* zb = z + (size_t)b * NP * W + ii;
     float* Sb = S + (size_t)b * NC * W;
-    float s = 0.f;
-    float col[NT], zc = 0.f;
-    if (NP > 0) {
+    float4 buf[D][W / 4];
+    float zc[D];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) col[j] = phib[(size_t)j * W + ii];
-        zc = zb[ii];
-    }
-    for (int c = 0; c < NC; ++c) {
-        if (act) Sb[(size_t)c * W + i] = s;
-        if (c >= NP) break;
-        float ncol[NT], nz = 0.f;
-        const int cn = c + 1 < NP ? c + 1 : c;  // harmless re-load on the last step
+    for (int u = 0; u < D; ++u) {
+        if (u < NP) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) ncol[j] = phib[((size_t)cn * NT + j) * W + ii];
-        nz = zb[(size_t)cn * W + ii];
-        float acc0 = zc, acc1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; j += 2) {
-            acc0 = fmaf(col[j], lane_bcast(s, j), acc0);
-            acc1 = fmaf(col[j + 1], lane_bcast(s, j + 1), acc1);
+            for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)u * cstride4 + k];
+            zc[u] = zb[(size_t)u * W];
         }
-        s = acc0 + acc1;
+    }
+    float s = 0.f;
+    for (int c0 = 0; c0 < NC; c0 += D) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) col[j] = ncol[j];
-        zc = nz;
+        for (int u = 0; u < D; ++u) {
+            const int c = c0 + u;
+            if (c < NC) {
+                if (i < W) Sb[(size_t)c * W + i] = s;
+                if (c < NP) {
+                    float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float pj = f4get(buf[u][j / 4], j % 4);
+                        const float sj = lane_bcast(s, j);
+                        if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
+                        else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
+                        else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
+                        else acc3 = fmaf(pj, sj, acc3);
+                    }
+                    s = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+                    if (c + D < NP) {
+#pragma unroll
+                        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)(c + D) * cstride4 + k];
+                        zc[u] = zb[(size_t)(c + D) * W];
+                    }
+                }
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Backward.  Adjoint ring p[(k + r) % W] = lam_r[k], r = steps done in this block (W >= NT+1).
+//   MODE 0 (B1): lam_end = 0, lam at chunk start -> zadj[(b*NC+c)*W + k]
+//   MODE 1 (B3): lam_end from lamEnd, writes g[b][t] (the adjoint signal dL/dy_total)
 // ------------------------------------------------------------------------------------------
-// B1 (MODE 0): lam_end = 0, store lam at chunk start -> zadj[q][W]
-// B3 (MODE 1): lam_end from lamEnd[q][W]; writes g_ex and per-segment partial sums.
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(
-    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ y, int64_t y_stride,
-    const float* __restrict__ ex, int64_t ex_stride, const float* __restrict__ gain, const float* __restrict__ a,
-    const float* __restrict__ lamEnd, float* __restrict__ zadj, float* __restrict__ g_ex, int64_t g_ex_stride,
-    float* __restrict__ pa, float* __restrict__ pg, int T, int F, int M, int hop, int L, int NC, int seg, int NSEG,
-    int nq) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nq) return;
-    const int b = q / NC, c = q - b * NC;
+__global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restrict__ gy, int64_t gy_stride,
+                                                           const float* __restrict__ a,
+                                                           const float* __restrict__ lamEnd, float* __restrict__ out,
+                                                           int64_t g_stride, int T, int F, int M, int hop, int L,
+                                                           int NC) {
+    using TL = Tile<W>;
+    __shared__ float lds[2 * TL::SIZE];
+    float* xt = lds;
+    float* yt = lds + TL::SIZE;
+    const int b = blockIdx.y, cg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int lq = lane / W, lr = lane % W;
+    const int c0 = cg * 64;
+    const int c = c0 + lane;
+    const bool mine = c < NC;
+    const float* gyb = gy + (size_t)b * gy_stride;
+    float* gb = MODE == 1 ? out + (size_t)b * g_stride : nullptr;
     float p[W];
-    if (MODE == 1) {
-        const float* lp = lamEnd + (size_t)q * W;
+    if (MODE == 1 && mine) {
+        const float* lp = lamEnd + ((size_t)b * NC + c) * W;
 #pragma unroll
         for (int k = 0; k < W; ++k) p[k] = k < NT ? lp[k] : 0.f;
     } else {
@@ -303,129 +451,202 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(
         for (int k = 0; k < W; ++k) p[k] = 0.f;
     }
     float a0[NT], dd[NT];
-    float g0 = 0.f, dg = 0.f;
-    float V0[NT], V1[NT], U0 = 0.f, U1 = 0.f;
-    float ycur[W], yprev[W];
-    if (MODE == 1) {
 #pragma unroll
-        for (int k = 0; k < NT; ++k) { V0[k] = 0.f; V1[k] = 0.f; }
-    }
+    for (int i = 0; i < NT; ++i) { a0[i] = 0.f; dd[i] = 0.f; }
     const float inv_hop = 1.0f / (float)hop;
-    const float* gyb = gy + (size_t)b * gy_stride;
-    const float* yb = MODE == 1 ? y + (size_t)b * y_stride : nullptr;
-    const float* exb = MODE == 1 ? ex + (size_t)b * ex_stride : nullptr;
-    float* gxb = MODE == 1 ? g_ex + (size_t)b * g_ex_stride : nullptr;
     int fcur = -1;
     const int nblk = L / W;
-    bool have_prev = false;
-    for (int blk = nblk - 1; blk >= 0; --blk) {
+    // first block (descending) that the wave's first chunk still has samples in
+    int blk = nblk - 1;
+    while (blk > 0 && c0 * L + blk * W >= T) --blk;
+    float nx[W];
+    TL::fetch(nx, gyb, c0 * L + blk * W, L, T, lq, lr);
+    for (; blk >= 0; --blk) {
+        const int tw = c0 * L + blk * W;
+        TL::scatter(xt, nx, lq, lr);
+        __syncthreads();
+        float gin[W];
+        TL::rows_load(gin, xt, lane);
+        if (blk > 0) TL::fetch(nx, gyb, tw - W, L, T, lq, lr);
         const int t0 = c * L + blk * W;
-        if (t0 >= T) continue;  // lam is still identically zero there
-        int f = t0 / hop;
-        if (f > F - 2) f = F - 2;
-        if (f != fcur) {
-            fcur = f;
-            const float* pa0 = a + ((size_t)b * F + f) * M;
-            const float* pa1 = pa0 + M;
+        const bool act = mine && t0 < T;
+        float gout[W];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const float v0 = i < M ? pa0[i] : 0.f;
-                const float v1 = i < M ? pa1[i] : 0.f;
-                a0[i] = v0;
-                dd[i] = (v1 - v0) * inv_hop;
-            }
-            if (MODE == 1) {
-                g0 = gain[(size_t)b * F + f];
-                dg = (gain[(size_t)b * F + f + 1] - g0) * inv_hop;
-            }
-        }
-        const float n0 = (float)(t0 - f * hop);
-        float gin[W], xin[W];
+        for (int s = 0; s < W; ++s) gout[s] = 0.f;
+        if (act) {
+            int f = t0 / hop;
+            if (f > F - 2) f = F - 2;
+            if (f != fcur) {
+                fcur = f;
+                const float* pa0 = a + ((size_t)b * F + f) * M;
+                const float* pa1 = pa0 + M;
 #pragma unroll
-        for (int s = 0; s < W; ++s) gin[s] = (t0 + s < T) ? gyb[t0 + s] : 0.f;
-        if (MODE == 1) {
-#pragma unroll
-            for (int s = 0; s < W; ++s) xin[s] = (t0 + s < T) ? exb[t0 + s] : 0.f;
-            if (have_prev) {
-#pragma unroll
-                for (int s = 0; s < W; ++s) ycur[s] = yprev[s];
-            } else {
-#pragma unroll
-                for (int s = 0; s < W; ++s) ycur[s] = (t0 + s < T) ? yb[t0 + s] : 0.f;
-            }
-#pragma unroll
-            for (int s = 0; s < W; ++s) yprev[s] = (t0 - W + s >= 0) ? yb[t0 - W + s] : 0.f;
-            have_prev = true;
-        }
-#pragma unroll
-        for (int s = W - 1; s >= 0; --s) {
-            const int r = W - 1 - s;
-            const float n = n0 + (float)s;
-            const float g = gin[s] + p[r];
-            p[r] = 0.f;
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const float cf = fmaf(n, dd[k], a0[k]);
-                p[(k + r + 1) % W] = fmaf(-cf, g, p[(k + r + 1) % W]);
-            }
-            if (MODE == 1) {
-                const float gn = g * n;
-                const float G = fmaf(n, dg, g0);
-                if (t0 + s < T) gxb[t0 + s] = g * G;
-                U0 = fmaf(g, xin[s], U0);
-                U1 = fmaf(gn, xin[s], U1);
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    const int idx = s - 1 - k;
-                    const float yv = idx >= 0 ? ycur[idx >= 0 ? idx : 0] : yprev[idx >= 0 ? 0 : W + idx];
-                    V0[k] = fmaf(-g, yv, V0[k]);
-                    V1[k] = fmaf(-gn, yv, V1[k]);
+                for (int i = 0; i < NT; ++i) {
+                    const float v0 = i < M ? pa0[i] : 0.f;
+                    const float v1 = i < M ? pa1[i] : 0.f;
+                    a0[i] = v0;
+                    dd[i] = (v1 - v0) * inv_hop;
                 }
             }
-        }
-        if (MODE == 1 && (t0 % seg) == 0) {  // finished a gradient segment: flush
-            const int sg = t0 / seg;
-            float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
+            const float n0 = (float)(t0 - f * hop);
 #pragma unroll
-            for (int k = 0; k < NT; ++k) { pp[k] = V0[k]; pp[W + k] = V1[k]; V0[k] = 0.f; V1[k] = 0.f; }
-            pg[((size_t)b * NSEG + sg) * 2 + 0] = U0;
-            pg[((size_t)b * NSEG + sg) * 2 + 1] = U1;
-            U0 = 0.f;
-            U1 = 0.f;
+            for (int s = W - 1; s >= 0; --s) {
+                const int r = W - 1 - s;
+                const float n = n0 + (float)s;
+                const float g = gin[s] + p[r];
+                p[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const float cf = fmaf(n, dd[k], a0[k]);
+                    p[(k + r + 1) % W] = fmaf(-cf, g, p[(k + r + 1) % W]);
+                }
+                gout[s] = g;
+            }
         }
+        if (MODE == 1) {
+            TL::rows_store(yt, gout, lane);
+            __syncthreads();
+            float o[W];
+            TL::gather(o, yt, lq, lr);
+            TL::store(o, gb, tw, L, T, lq, lr);
+        }
+        __syncthreads();
     }
-    if (MODE == 0) {
-        float* zp = zadj + (size_t)q * W;
+    if (MODE == 0 && mine) {
+        float* zp = out + ((size_t)b * NC + c) * W;
 #pragma unroll
         for (int k = 0; k < W; ++k) zp[k] = k < NT ? p[k] : 0.f;
     }
 }
 
-// B2: lamEnd[b][c][:] = adjoint state at the END of chunk c; lam_start(c) = Phi_c^T lam_end(c) + zadj_c
-template <int W, int NT>
+// B2: lamEnd[b][c][:] = adjoint state at the END of chunk c; lam_start(c) = Phi_c^T lam_end(c) + zadj_c.
+//   lane j reads row j of Phi (float4 x W/4), D chunks ahead.
+template <int W, int NT, int D>
 __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restrict__ Phi, const float* __restrict__ zadj,
                                                           float* __restrict__ lamEnd, int NC, int NP) {
     const int b = blockIdx.x;
     const int j = threadIdx.x;
     const bool act = j < NT;
     const int jj = act ? j : 0;
-    const float* phib = Phi + (size_t)b * NP * NT * W;
-    float lam = 0.f;
-    for (int c = NC - 1; c >= 0; --c) {
-        if (j < W) lamEnd[((size_t)b * NC + c) * W + j] = act ? lam : 0.f;
-        float acc0 = zadj[((size_t)b * NC + c) * W + (j < W ? j : 0)], acc1 = 0.f;
-        if (c < NP) {
-            const float* row = phib + ((size_t)c * NT + jj) * W;
-            float r[NT];
+    const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + jj) * W);
+    const size_t cstride4 = (size_t)NT * W / 4;
+    const float* zb = zadj + (size_t)b * NC * W + jj;
+    float4 buf[D][W / 4];
+    float zc[D];
+    // chunk visited at local step u (descending): c = NC-1-u;  slot u holds chunk NC-1-u
 #pragma unroll
-            for (int i = 0; i < NT; ++i) r[i] = row[i];
+    for (int u = 0; u < D; ++u) {
+        const int c = NC - 1 - u;
+        if (c >= 0) {
+            zc[u] = zb[(size_t)c * W];
+            if (c < NP) {
 #pragma unroll
-            for (int i = 0; i < NT; i += 2) {
-                acc0 = fmaf(r[i], lane_bcast(lam, i), acc0);
-                acc1 = fmaf(r[i + 1], lane_bcast(lam, i + 1), acc1);
+                for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)c * cstride4 + k];
             }
         }
-        lam = act ? acc0 + acc1 : 0.f;
+    }
+    float lam = 0.f;
+    for (int u0 = 0; u0 < NC; u0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int c = NC - 1 - (u0 + u);
+            if (c >= 0) {
+                if (j < W) lamEnd[((size_t)b * NC + c) * W + j] = lam;
+                float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+                if (c < NP) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const float pj = f4get(buf[u][i / 4], i % 4);
+                        const float li = lane_bcast(lam, i);
+                        if ((i & 3) == 0) acc0 = fmaf(pj, li, acc0);
+                        else if ((i & 3) == 1) acc1 = fmaf(pj, li, acc1);
+                        else if ((i & 3) == 2) acc2 = fmaf(pj, li, acc2);
+                        else acc3 = fmaf(pj, li, acc3);
+                    }
+                }
+                lam = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+                const int cn = c - D;
+                if (cn >= 0) {
+                    zc[u] = zb[(size_t)cn * W];
+                    if (cn < NP) {
+#pragma unroll
+                        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// B3b: parallel part of the backward.  One workgroup per (gradient segment, utterance):
+//   g_ex[t] = g[t]*G[t];  per-segment hat-weighted correlations
+//   V0[k] = sum_t -g[t] y[t-1-k],  V1[k] = sum_t -n g[t] y[t-1-k]   (n = t - f*hop)
+//   U0    = sum_t  g[t] ex[t],     U1    = sum_t  n g[t] ex[t]
+// (the reference forms a (B,T,M) gradient tensor and back-propagates through F.interpolate).
+__global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restrict__ g, int64_t g_stride,
+                                                            const float* __restrict__ y, int64_t y_stride,
+                                                            const float* __restrict__ ex, int64_t ex_stride,
+                                                            const float* __restrict__ gain, float* __restrict__ g_ex,
+                                                            int64_t g_ex_stride, float* __restrict__ pa,
+                                                            float* __restrict__ pg, int T, int F, int NT, int W,
+                                                            int hop, int seg, int NSEG) {
+    __shared__ float gs[256], es[256], ys[256 + 64];
+    __shared__ float red[2][4][64];
+    const int sg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ts = sg * seg;
+    const int len = (ts + seg <= T ? seg : T - ts);  // >= 1
+    int f = ts / hop;
+    if (f > F - 2) f = F - 2;
+    const int nbase = ts - f * hop;
+    const float g0 = gain[(size_t)b * F + f];
+    const float dg = (gain[(size_t)b * F + f + 1] - g0) / (float)hop;
+    const float* gb = g + (size_t)b * g_stride;
+    const float* yb = y + (size_t)b * y_stride;
+    const float* eb = ex + (size_t)b * ex_stride;
+    if (tid < len) {
+        const float gv = gb[ts + tid];
+        gs[tid] = gv;
+        es[tid] = eb[ts + tid];
+        g_ex[(size_t)b * g_ex_stride + ts + tid] = gv * fmaf((float)(nbase + tid), dg, g0);
+    }
+    // ys[u] = y[ts - 64 + u], u in [0, len + 64)
+    for (int u = tid; u < len + 64; u += 256) {
+        const int t = ts - 64 + u;
+        ys[u] = (t >= 0 && t < T) ? yb[t] : 0.f;
+    }
+    __syncthreads();
+    const int k = tid & 63, part = tid >> 6;
+    float acc0 = 0.f, acc1 = 0.f;
+    const int per = (len + 3) / 4;
+    const int lo = part * per, hi = (lo + per < len ? lo + per : len);
+    if (k < NT) {
+        for (int t = lo; t < hi; ++t) {
+            const float gv = gs[t];
+            const float yv = ys[64 + t - 1 - k];
+            acc0 = fmaf(-gv, yv, acc0);
+            acc1 = fmaf(-gv * (float)(nbase + t), yv, acc1);
+        }
+    } else if (k == NT) {
+        for (int t = lo; t < hi; ++t) {
+            const float gv = gs[t] * es[t];
+            acc0 += gv;
+            acc1 = fmaf(gv, (float)(nbase + t), acc1);
+        }
+    }
+    red[0][part][k] = acc0;
+    red[1][part][k] = acc1;
+    __syncthreads();
+    if (part == 0 && k <= NT) {
+        const float v0 = (red[0][0][k] + red[0][1][k]) + (red[0][2][k] + red[0][3][k]);
+        const float v1 = (red[1][0][k] + red[1][1][k]) + (red[1][2][k] + red[1][3][k]);
+        if (k < NT) {
+            float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
+            pp[k] = v0;
+            pp[W + k] = v1;
+        } else {
+            pg[((size_t)b * NSEG + sg) * 2 + 0] = v0;
+            pg[((size_t)b * NSEG + sg) * 2 + 1] = v1;
+        }
     }
 }
 
@@ -523,22 +744,24 @@ template <int W, int NT>
 static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a, float* y,
                       int64_t y_stride, int B, int T, int F, int M, int hop, char* ws, hipStream_t st) {
     float* Phi = (float*)(ws + p.off_phi);
+    float* PhiT = (float*)(ws + p.off_phiT);
     float* z = (float*)(ws + p.off_z);
     float* S = (float*)(ws + p.off_S);
+    constexpr int D = 8;
     if (p.NP > 0) {
         const int nq = B * p.NP;
-        dim3 g1((unsigned)ceil_div(nq, 64), NT / 2);
-        hipLaunchKernelGGL((lpc_p1_hom_kernel<W, NT>), g1, dim3(64), 0, st, a, Phi, F, M, hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1z_kernel<W, NT>), dim3((unsigned)ceil_div(p.NP, 64), B), dim3(64), 0, st, ex,
+                           ex_stride, gain, a, z, T, F, M, hop, p.L, p.NP);
         GOLF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((lpc_chunk_f32_kernel<W, NT, 0>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * (NT / 2))), dim3(64), 0, st, a,
+                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
         GOLF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT>), dim3(B), dim3(64), 0, st, Phi, z, S, p.NC, p.NP);
+    hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
+                       S, p.NC, p.NP);
     GOLF_LAUNCH_CHECK();
-    const int nq3 = B * p.NC;
-    hipLaunchKernelGGL((lpc_chunk_f32_kernel<W, NT, 1>), dim3((unsigned)ceil_div(nq3, 64)), dim3(64), 0, st, ex,
-                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, nq3);
+    hipLaunchKernelGGL((lpc_p3_kernel<W, NT>), dim3((unsigned)ceil_div(p.NC, 64), B), dim3(64), 0, st, ex, ex_stride,
+                       gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -551,21 +774,22 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     const float* Phi = (const float*)(ws + p.off_phi);
     float* zadj = (float*)(ws + p.off_zadj);
     float* lam = (float*)(ws + p.off_lam);
+    float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
-    const int nq = B * p.NC;
-    const dim3 gq((unsigned)ceil_div(nq, 64));
-    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, (const float*)nullptr,
-                       (int64_t)0, (const float*)nullptr, (int64_t)0, gain, a, (const float*)nullptr, zadj,
-                       (float*)nullptr, (int64_t)0, (float*)nullptr, (float*)nullptr, T, F, M, hop, p.L, p.NC, p.seg,
-                       p.NSEG, nq);
+    constexpr int D = 8;
+    const dim3 gq((unsigned)ceil_div(p.NC, 64), B);
+    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
+                       zadj, (int64_t)0, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT>), dim3(B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
+    hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
                        p.NP);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, y, y_stride, ex,
-                       ex_stride, gain, a, (const float*)lam, (float*)nullptr, g_ex, g_ex_stride, pa, pg, T, F, M, hop,
-                       p.L, p.NC, p.seg, p.NSEG, nq);
+    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
+                       (int64_t)T, T, F, M, hop, p.L, p.NC);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3(p.NSEG, B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
+                       y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG);
     GOLF_LAUNCH_CHECK();
     const int n4 = B * F * (M + 1);
     hipLaunchKernelGGL(lpc_grad_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)pa,

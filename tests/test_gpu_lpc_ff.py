@@ -1,0 +1,70 @@
+"""GPU parity of the frame-wise LTI all-pole + OLA filter (golf_lti_frames_ola_fwd_f32, GOLF-ff)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+
+
+def check(y, ref, what, tol=TOL):
+    emax, el2 = rel_err(y, ref)
+    print(f"{what}: rel-max {emax:.3e} rel-l2 {el2:.3e}")
+    assert np.isfinite(y).all()
+    assert emax <= tol and el2 <= tol, (what, emax, el2)
+
+
+def run_module(ex, gain, a, hop, W, centred=True, M=None):
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTVMinimumPhaseFilter
+
+    m = LTVMinimumPhaseFilter(window="hanning", window_length=W, centred=centred, lpc_order=M or a.shape[-1]).cuda()
+    y = m(AudioTensor(dev(ex)), AudioTensor(dev(gain), hop), AudioTensor(dev(a), hop))
+    torch.cuda.synchronize()
+    assert y.hop_length == 1
+    return y.as_tensor().cpu().numpy()
+
+
+def test_golden_g7(golden):
+    g = golden("g7_framewise")
+    hop, W = int(g["hop"]), int(g["W"])
+    check(run_module(g["ex"], g["gain"], g["a"], hop, W, True), g["y_centred"], "g7 centred")
+    check(run_module(g["ex"], g["gain"], g["a"], hop, W, False), g["y_uncentred"], "g7 uncentred")
+    check(run_module(g["ex"], g["gain"], g["a"], hop, 16, True), g["y_w16"], "g7 W=2*hop")
+
+
+@pytest.mark.parametrize("B,F,M,hop,W,Tx", [(3, 12, 22, 240, 960, 2880), (2, 12, 22, 240, 960, 2500),
+                                            (2, 20, 12, 24, 96, 480), (2, 9, 6, 16, 50, 129), (1, 30, 26, 120, 480, 3600)])
+def test_ff_vs_oracle(B, F, M, hop, W, Tx):
+    from oracle import golf_oracle as O
+    from test_gpu_lpc_ss import smooth_case
+
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=F + M)
+    win = torch.hann_window(W).double().numpy()
+    ref, _ = O.lti_frames_ola_forward(ex, gain, a, hop, win, centred=True)
+    y = run_module(ex, gain, a, hop, W, True)
+    assert y.shape == ref.shape
+    check(y, ref, f"ff B{B} F{F} M{M} hop{hop} W{W}")
+
+
+def test_ff_full_size():
+    """BASELINE configs[1]: GOLF-ff, B=32, 2 s @ 24 kHz, W=960, hop 240, M=22, forward only."""
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32)
+    ex, gain, a = inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy()
+    y = run_module(ex, gain, a, 240, 960, True)
+    assert y.shape == (32, 47760)
+    ref, norm = O.lti_frames_ola_forward(ex[:4], gain[:4], a[:4], 240, torch.hann_window(960).double().numpy())
+    check(y[:4], ref, "ff full-size (first 4 utterances vs oracle)")
+    # size-independent property: zero coefficients => identity on x*gain (OLA of hann frames is a partition of unity)
+    y0 = run_module(ex, gain, 0 * a, 240, 960, True)
+    G = O.linear_upsample(gain, 240)[:, :47760]
+    check(y0, ex[:, :47760] * G, "ff with a=0 is x*gain")

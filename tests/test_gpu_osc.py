@@ -1,0 +1,126 @@
+"""GPU parity of the glottal wavetable oscillator (golf_glottal_osc_fwd_f32 / _bwd_wsel_f32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+
+
+def check(y, ref, what, tol=TOL):
+    emax, el2 = rel_err(y, ref)
+    print(f"{what}: rel-max {emax:.3e} rel-l2 {el2:.3e}")
+    assert np.isfinite(y).all()
+    assert emax <= tol and el2 <= tol, (what, emax, el2)
+
+
+def osc(phase, phase_hop, w, w_hop, table, os_, eq, taps=None, return_pre=False):
+    from golf_amd import functional as GF
+
+    t = None if taps is None else dev(taps)
+    res = GF.glottal_osc(dev(phase), dev(w), dev(table), t, phase_hop, w_hop, os_, eq, return_pre=return_pre)
+    torch.cuda.synchronize()
+    if return_pre:
+        return res[0].cpu().numpy(), (None if res[1] is None else res[1].cpu().numpy())
+    return res.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,os_,eq", [("os1", 1, False), ("os1_eq", 1, True), ("os4_eq", 4, True)])
+def test_golden_g6(golden, name, os_, eq):
+    from oracle import golf_oracle as O
+
+    g = golden("g6_oscillator")
+    tb = g[name + "_table"]
+    taps = O.default_decimation_taps(4) if os_ > 1 else None
+    for sfx, ph_hop, w_hop in (("", 1, 16), ("2", 8, 32)):
+        out, pre = osc(g[name + "_phase" + sfx], ph_hop, g[name + "_w" + sfx], w_hop, tb, os_, eq, taps, True)
+        if os_ == 1:
+            # golden produced by the reference in float32: tolerance covers ITS rounding
+            check(out, g[name + "_out" + sfx], f"g6 {name}{sfx} out", 5e-5)
+        else:
+            check(pre, g[name + "_pre" + sfx], f"g6 {name}{sfx} pre-decimation", 5e-5)
+            ref = O.decimate_fir(g[name + "_pre" + sfx], taps, os_)
+            assert out.shape == ref.shape
+            check(out, ref, f"g6 {name}{sfx} decimated", 5e-5)
+
+
+@pytest.mark.parametrize("B,Tp,ph_hop,w_hop,os_,eq", [(3, 2000, 1, 240, 4, True), (2, 1201, 1, 400, 1, False),
+                                                      (2, 41, 120, 2400, 4, True), (1, 500, 1, 100, 2, True),
+                                                      (2, 300, 1, 64, 1, True)])
+def test_osc_vs_oracle(B, Tp, ph_hop, w_hop, os_, eq):
+    from golf_amd.synth import IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(Tp)
+    f0 = rng.uniform(80, 400, (B, 1)) * (1 + 0.03 * np.sin(2 * np.pi * 5.5 * np.arange(Tp) * ph_hop / 24000))
+    phase = (f0 / 24000).astype(np.float32)
+    Fw = (Tp - 1) * ph_hop // w_hop + 2
+    w = rng.uniform(0, 1, (B, Fw)).astype(np.float32)
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=os_, equal_energy=eq)
+    table = m.table.numpy()
+    taps = m.decimater.taps.numpy() if os_ > 1 else None
+    ref = O.indexed_glottal_forward(phase, ph_hop, w, w_hop, table, os_, eq, decim_taps=taps)
+    out, pre = osc(phase, ph_hop, w, w_hop, table, os_, eq, taps, True)
+    if os_ > 1:
+        check(pre, ref["pre"], "pre")
+    assert out.shape == ref["out"].shape
+    check(out, ref["out"], f"osc B{B} Tp{Tp} hop{ph_hop} os{os_}")
+
+
+def test_osc_full_size_module():
+    """BASELINE shape: B=32, phase (32,48000) hop 1, weight (32,21) hop 2400, table 100x2048, 4x oversampling."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32)
+    m = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True,
+                                           lf_v2=True, points=2048).cuda()
+    y, pre = m(AudioTensor(inp["phase"].cuda()), AudioTensor(inp["wsel"].cuda(), inp["w_hop"]), return_pre=True)
+    torch.cuda.synchronize()
+    assert y.shape == (32, 48000) and pre.shape == (32, 191997) and y.hop_length == 1
+    ref = O.indexed_glottal_forward(inp["phase"].numpy()[:4], 1, inp["wsel"].numpy()[:4], inp["w_hop"],
+                                    m.table.cpu().numpy(), 4, True, decim_taps=m.decimater.taps.cpu().numpy())
+    check(pre.cpu().numpy()[:4], ref["pre"], "full-size pre (first 4)")
+    check(y.as_tensor().cpu().numpy()[:4], ref["out"], "full-size out (first 4)")
+
+
+@pytest.mark.parametrize("os_,eq", [(1, False), (4, True)])
+def test_osc_backward_wsel(os_, eq):
+    """d out / d table_select_weight against central differences of the float64 oracle
+    (out is piecewise linear in w, so the difference quotient is exact inside a table cell)."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(7)
+    B, Tp, w_hop = 2, 600, 128
+    phase = (rng.uniform(100, 300, (B, 1)) / 24000 * np.ones((1, Tp))).astype(np.float32)
+    Fw = 6
+    w = rng.uniform(0.05, 0.95, (B, Fw)).astype(np.float32)
+    m = IndexedGlottalFlowTable(table_size=20, lf_v2=True, points=256, oversampling=os_, equal_energy=eq)
+    table = m.table.numpy()
+    taps = m.decimater.taps.numpy() if os_ > 1 else None
+    wt = dev(w).requires_grad_(True)
+    out = GF.glottal_osc(dev(phase), wt, dev(table), None if taps is None else dev(taps), 1, w_hop, os_, eq)
+    gy = rng.normal(0, 1, tuple(out.shape)).astype(np.float32)
+    (out * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    got = wt.grad.cpu().numpy()
+    ref = np.zeros_like(w, dtype=np.float64)
+    eps = 1e-4
+    f = lambda ww: (O.indexed_glottal_forward(phase, 1, ww, w_hop, table, os_, eq, decim_taps=taps)["out"] * gy).sum()
+    for b in range(B):
+        for k in range(Fw):
+            wp, wm = w.astype(np.float64).copy(), w.astype(np.float64).copy()
+            wp[b, k] += eps
+            wm[b, k] -= eps
+            ref[b, k] = (f(wp) - f(wm)) / (2 * eps)
+    check(got, ref, f"g_wsel os{os_}", 2e-3)
