@@ -70,9 +70,9 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
     p->off_phi = o;  o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_phiT = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_z = o;    o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
-    p->off_S = o;    o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
+    p->off_S = o;    o = align_up(o + sizeof(float) * (size_t)B * p->NC * 64, 256);
     p->off_zadj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
-    p->off_lam = o;  o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
+    p->off_lam = o;  o = align_up(o + sizeof(float) * (size_t)B * p->NC * 64, 256);
     p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -86,6 +86,22 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
 // (element e = it*64 + lane  <->  row e/W (= chunk), col e%W) while each lane computes on its own row.
 // Row stride W+1 floats keeps both access patterns bank-conflict free.  Single-wave workgroups.
 // ------------------------------------------------------------------------------------------
+// Bounds-checked view of one utterance row of T floats (raw buffer descriptor, wave-uniform): loads outside
+// [0,T) return 0 and stores outside are dropped BY THE HARDWARE — masking without branches, which is what lets
+// hipcc keep the prefetch loads in flight (per-element `if (t<T)` made it wait for every load, 24 serial HBM
+// round trips per block).
+struct BufRow {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ BufRow(const float* p, int T)
+        : rs(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, T * 4, 0x00020000)) {}
+    __device__ __forceinline__ float ld(int t) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4, 0, 0));
+    }
+    __device__ __forceinline__ void st(int t, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, t * 4, 0, 0);
+    }
+};
+
 template <int W>
 struct Tile {
     static constexpr int LD = W + 1;
@@ -98,27 +114,22 @@ struct Tile {
         if (col >= W) { col -= W; row += 1; }
         if (col >= W) { col -= W; row += 1; }            // W < 64: lr + r < 2W, at most two wraps (W >= 8: lr<W)
     }
-    // global -> registers, coalesced order; t = tbase + row*L + col must lie in [0,T) else 0
-    __device__ static __forceinline__ void fetch(float (&r)[W], const float* __restrict__ rowb, int tbase, int L,
-                                                 int T, int lq, int lr) {
+    // global -> registers, coalesced order; element at t = tbase + row*L + col (0 outside [0,T))
+    __device__ static __forceinline__ void fetch(float (&r)[W], const BufRow& src, int tbase, int L, int lq, int lr) {
 #pragma unroll
         for (int it = 0; it < W; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
-            const int t = tbase + row * L + col;
-            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-            const float v = rowb[tc];
-            r[it] = (t >= 0 && t < T) ? v : 0.f;
+            r[it] = src.ld(tbase + row * L + col);
         }
     }
-    __device__ static __forceinline__ void store(const float (&r)[W], float* __restrict__ rowb, int tbase, int L, int T,
-                                                 int lq, int lr) {
+    __device__ static __forceinline__ void store(const float (&r)[W], const BufRow& dst, int tbase, int L, int lq,
+                                                 int lr) {
 #pragma unroll
         for (int it = 0; it < W; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
-            const int t = tbase + row * L + col;
-            if (t >= 0 && t < T) rowb[t] = r[it];
+            dst.st(tbase + row * L + col, r[it]);
         }
     }
     __device__ static __forceinline__ void scatter(float* lds, const float (&r)[W], int lq, int lr) {
@@ -173,11 +184,11 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
     const int c0 = cg * 64;
     const int c = c0 + lane;
     const bool mine = c < NCQ;
-    const float* exb = ex + (size_t)b * ex_stride;
-    float* yb = MODE == 1 ? out + (size_t)b * y_stride : nullptr;
+    const BufRow xrow(ex + (size_t)b * ex_stride, T);
+    const BufRow yrow(MODE == 1 ? out + (size_t)b * y_stride : nullptr, MODE == 1 ? T : 0);
     float h[W];
     if (MODE == 1 && mine) {
-        const float* sp = S + ((size_t)b * NCQ + c) * W;
+        const float* sp = S + ((size_t)b * NCQ + c) * 64;
 #pragma unroll
         for (int i = 0; i < W; ++i) h[W - 1 - i] = sp[i];
     } else {
@@ -192,7 +203,7 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
     int fcur = -1;
     const int nblk = L / W;
     float nx[W];
-    TL::fetch(nx, exb, c0 * L, L, T, lq, lr);
+    TL::fetch(nx, xrow, c0 * L, L, lq, lr);
     for (int blk = 0; blk < nblk; ++blk) {
         const int tw = c0 * L + blk * W;  // block start of the wave's first chunk
         if (tw >= T) break;               // wave-uniform: nothing left for any lane
@@ -200,7 +211,7 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
         __syncthreads();
         float xin[W];
         TL::rows_load(xin, xt, lane);
-        if (blk + 1 < nblk) TL::fetch(nx, exb, tw + W, L, T, lq, lr);  // prefetch next block
+        TL::fetch(nx, xrow, tw + W, L, lq, lr);  // prefetch next block (past the end: hardware returns 0)
         const int t0 = c * L + blk * W;
         const bool act = mine && t0 < T;
         if (act) {
@@ -242,7 +253,7 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
             __syncthreads();
             float o[W];
             TL::gather(o, yt, lq, lr);
-            TL::store(o, yb, tw, L, T, lq, lr);
+            TL::store(o, yrow, tw, L, lq, lr);
         }
         __syncthreads();
     }
@@ -374,48 +385,57 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
     const int i = threadIdx.x;
     const bool act = i < NT;
     const int ii = act ? i : 0;
+    float* Sb = S + (size_t)b * NC * 64 + i;  // rows padded to 64 floats: every lane stores, no predication
+    if (NP <= 0) { Sb[0] = 0.f; return; }
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* zb = z + (size_t)b * NP * W + ii;
-    float* Sb = S + (size_t)b * NC * W;
     float4 buf[D][W / 4];
     float zc[D];
 #pragma unroll
     for (int u = 0; u < D; ++u) {
-        if (u < NP) {
+        const int cl = u < NP ? u : NP - 1;
 #pragma unroll
-            for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)u * cstride4 + k];
-            zc[u] = zb[(size_t)u * W];
-        }
+        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
+        zc[u] = zb[(size_t)cl * W];
     }
     float s = 0.f;
-    for (int c0 = 0; c0 < NC; c0 += D) {
+#define GOLF_P2_STEP(u)                                                              \
+    {                                                                                \
+        float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;                      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                             \
+            const float pj = f4get(buf[u][j / 4], j % 4);                            \
+            const float sj = lane_bcast(s, j);                                       \
+            if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);                             \
+            else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);                        \
+            else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);                        \
+            else acc3 = fmaf(pj, sj, acc3);                                          \
+        }                                                                            \
+        s = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;                               \
+    }
+    int c0 = 0;
+    for (; c0 + D <= NP; c0 += D) {  // steady state: straight-line, loads stay D chunks ahead
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int c = c0 + u;
-            if (c < NC) {
-                if (i < W) Sb[(size_t)c * W + i] = s;
-                if (c < NP) {
-                    float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            Sb[(size_t)c * 64] = s;
+            GOLF_P2_STEP(u)
+            const int cn = c + D < NP ? c + D : NP - 1;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const float pj = f4get(buf[u][j / 4], j % 4);
-                        const float sj = lane_bcast(s, j);
-                        if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
-                        else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
-                        else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
-                        else acc3 = fmaf(pj, sj, acc3);
-                    }
-                    s = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-                    if (c + D < NP) {
-#pragma unroll
-                        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)(c + D) * cstride4 + k];
-                        zc[u] = zb[(size_t)(c + D) * W];
-                    }
-                }
-            }
+            for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
+            zc[u] = zb[(size_t)cn * W];
         }
     }
+#pragma unroll
+    for (int u = 0; u < D; ++u) {  // remainder (< D chunks), operands already in registers
+        const int c = c0 + u;
+        if (c < NP) {
+            Sb[(size_t)c * 64] = s;
+            GOLF_P2_STEP(u)
+        }
+    }
+#undef GOLF_P2_STEP
+    Sb[(size_t)NP * 64] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -439,11 +459,11 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restri
     const int c0 = cg * 64;
     const int c = c0 + lane;
     const bool mine = c < NC;
-    const float* gyb = gy + (size_t)b * gy_stride;
-    float* gb = MODE == 1 ? out + (size_t)b * g_stride : nullptr;
+    const BufRow gyrow(gy + (size_t)b * gy_stride, T);
+    const BufRow grow(MODE == 1 ? out + (size_t)b * g_stride : nullptr, MODE == 1 ? T : 0);
     float p[W];
     if (MODE == 1 && mine) {
-        const float* lp = lamEnd + ((size_t)b * NC + c) * W;
+        const float* lp = lamEnd + ((size_t)b * NC + c) * 64;
 #pragma unroll
         for (int k = 0; k < W; ++k) p[k] = k < NT ? lp[k] : 0.f;
     } else {
@@ -460,14 +480,14 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restri
     int blk = nblk - 1;
     while (blk > 0 && c0 * L + blk * W >= T) --blk;
     float nx[W];
-    TL::fetch(nx, gyb, c0 * L + blk * W, L, T, lq, lr);
+    TL::fetch(nx, gyrow, c0 * L + blk * W, L, lq, lr);
     for (; blk >= 0; --blk) {
         const int tw = c0 * L + blk * W;
         TL::scatter(xt, nx, lq, lr);
         __syncthreads();
         float gin[W];
         TL::rows_load(gin, xt, lane);
-        if (blk > 0) TL::fetch(nx, gyb, tw - W, L, T, lq, lr);
+        TL::fetch(nx, gyrow, tw - W, L, lq, lr);  // prefetch the earlier block (before 0: hardware returns 0)
         const int t0 = c * L + blk * W;
         const bool act = mine && t0 < T;
         float gout[W];
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restri
             __syncthreads();
             float o[W];
             TL::gather(o, yt, lq, lr);
-            TL::store(o, gb, tw, L, T, lq, lr);
+            TL::store(o, grow, tw, L, lq, lr);
         }
         __syncthreads();
     }
@@ -528,54 +548,59 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
     const int j = threadIdx.x;
     const bool act = j < NT;
     const int jj = act ? j : 0;
+    float* Lb = lamEnd + (size_t)b * NC * 64 + j;  // rows padded to 64 floats
+    const float* zb = zadj + (size_t)b * NC * W + jj;
+    // last chunk (c = NP) has no transition matrix and lam_end = 0
+    Lb[(size_t)NP * 64] = 0.f;
+    float lam = act ? zb[(size_t)NP * W] : 0.f;
+    if (NP <= 0) return;
     const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + jj) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
-    const float* zb = zadj + (size_t)b * NC * W + jj;
     float4 buf[D][W / 4];
     float zc[D];
-    // chunk visited at local step u (descending): c = NC-1-u;  slot u holds chunk NC-1-u
+    // slot u <-> chunk NP-1-(u0+u), descending
 #pragma unroll
     for (int u = 0; u < D; ++u) {
-        const int c = NC - 1 - u;
-        if (c >= 0) {
-            zc[u] = zb[(size_t)c * W];
-            if (c < NP) {
+        const int cl = NP - 1 - u > 0 ? NP - 1 - u : 0;
 #pragma unroll
-                for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)c * cstride4 + k];
-            }
-        }
+        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
+        zc[u] = zb[(size_t)cl * W];
     }
-    float lam = 0.f;
-    for (int u0 = 0; u0 < NC; u0 += D) {
+#define GOLF_B2_STEP(u)                                                              \
+    {                                                                                \
+        float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;                      \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                             \
+            const float pj = f4get(buf[u][i / 4], i % 4);                            \
+            const float li = lane_bcast(lam, i);                                     \
+            if ((i & 3) == 0) acc0 = fmaf(pj, li, acc0);                             \
+            else if ((i & 3) == 1) acc1 = fmaf(pj, li, acc1);                        \
+            else if ((i & 3) == 2) acc2 = fmaf(pj, li, acc2);                        \
+            else acc3 = fmaf(pj, li, acc3);                                          \
+        }                                                                            \
+        lam = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;                             \
+    }
+    int u0 = 0;
+    for (; u0 + D <= NP; u0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            const int c = NC - 1 - (u0 + u);
-            if (c >= 0) {
-                if (j < W) lamEnd[((size_t)b * NC + c) * W + j] = lam;
-                float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-                if (c < NP) {
+            const int c = NP - 1 - (u0 + u);
+            Lb[(size_t)c * 64] = lam;
+            GOLF_B2_STEP(u)
+            const int cn = c - D > 0 ? c - D : 0;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        const float pj = f4get(buf[u][i / 4], i % 4);
-                        const float li = lane_bcast(lam, i);
-                        if ((i & 3) == 0) acc0 = fmaf(pj, li, acc0);
-                        else if ((i & 3) == 1) acc1 = fmaf(pj, li, acc1);
-                        else if ((i & 3) == 2) acc2 = fmaf(pj, li, acc2);
-                        else acc3 = fmaf(pj, li, acc3);
-                    }
-                }
-                lam = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-                const int cn = c - D;
-                if (cn >= 0) {
-                    zc[u] = zb[(size_t)cn * W];
-                    if (cn < NP) {
-#pragma unroll
-                        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
-                    }
-                }
-            }
+            for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
+            zc[u] = zb[(size_t)cn * W];
         }
     }
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int c = NP - 1 - (u0 + u);
+        if (c >= 0) {
+            Lb[(size_t)c * 64] = lam;
+            GOLF_B2_STEP(u)
+        }
+    }
+#undef GOLF_B2_STEP
 }
 
 // B3b: parallel part of the backward.  One workgroup per (gradient segment, utterance):
