@@ -1,0 +1,274 @@
+#!/usr/bin/env python
+"""bench.py — GOLF-ss synthesis throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+  glottal wavetable oscillator (4x oversampled, equal energy, decimated) + injected N(0,1) noise
+  -> sample-wise LTV all-pole filter (GOLF-ss end filter), B=32 utterances x 2 s @ 24 kHz per GPU.
+For N>1 the batch is sharded 32/GPU (weak scaling, no data-path collective inside the path); the
+synthesised audio is all-gathered once per step over RCCL (BASELINE configs[3]).
+value = whole-job audio samples/s = N * B * T_out / max-over-ranks(step time).
+
+Extra objects on the JSON line (contract §4):
+  roofline      dominant kernel: algorithmic bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline  the C restatement of the reference algorithm (oracle/, "port") on the host cores,
+                bounded sample, rank 0 / N=1 only
+  stages_us     HIP-event time of each stage (informational)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+SR = 24000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--workload", default="golf-ss-synth",
+                    choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the audio (N>1)")
+    return ap.parse_args()
+
+
+def build_modules(device):
+    from golf_amd.filters import LTVMinimumPhaseFilter, LTVMinimumPhaseFilterPrecise
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+
+    osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True,
+                                             table_type="derivative", normalize_method="constant_power",
+                                             align_peak=True, trainable=False, min_R_d=0.3, max_R_d=2.7, lf_v2=True,
+                                             points=2048).to(device)
+    ss = LTVMinimumPhaseFilterPrecise(lpc_order=22, lpc_parameterisation="rc2lpc").to(device)
+    ff = LTVMinimumPhaseFilter(window="hanning", window_length=960, lpc_order=22,
+                               lpc_parameterisation="rc2lpc").to(device)
+    return osc, ss, ff
+
+
+def make_step(workload, inp, osc, ss, ff):
+    """Returns (step_fn, samples_per_step, stage_fns) working on plain tensors (module internals)."""
+    from golf_amd import functional as GF
+
+    phase, wsel, w_hop, noise, gain, a, hop = (inp[k] for k in ("phase", "wsel", "w_hop", "noise", "gain", "a", "hop"))
+    taps = osc.decimater.taps
+    table = osc.table
+    B = phase.shape[0]
+
+    def source():
+        o = GF.glottal_osc(phase, wsel, table, taps, 1, w_hop, 4, True)
+        return o + noise[:, : o.shape[1]]
+
+    if workload == "golf-ss-synth":
+        def step():
+            return GF.ltv_allpole_ss(source(), gain, a, hop)
+    elif workload == "lpc-ss-fwd":
+        def step():
+            return GF.ltv_allpole_ss(noise, gain, a, hop)
+    elif workload == "golf-ff-synth":
+        win = ff._window
+
+        def step():
+            return GF.lti_frames_ola(source(), gain, a, win, hop)
+    else:  # golf-ss-train: forward + custom backward w.r.t. gain, a, table_select_weight
+        gain_g = gain.clone().requires_grad_(True)
+        a_g = a.clone().requires_grad_(True)
+        w_g = wsel.clone().requires_grad_(True)
+        gy = torch.randn(B, 47761, device=phase.device)
+
+        def step():
+            o = GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True)
+            y = GF.ltv_allpole_ss(o + noise[:, : o.shape[1]], gain_g, a_g, hop)
+            gain_g.grad = a_g.grad = w_g.grad = None
+            y.backward(gy[:, : y.shape[1]])
+            return y
+
+    y = step()
+    return step, int(y.shape[0] * y.shape[1]), y.shape[1]
+
+
+def device_kernel_times(step, n=20):
+    """Per-kernel average duration measured live with the torch profiler (ROCm tracer = HIP activity records
+    on the stream the kernels ran on) — cross-checked by the rocprofv3 summary in profiles/."""
+    from torch.profiler import ProfilerActivity, profile
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+    out = {}
+    for ev in prof.key_averages():
+        dur = getattr(ev, "device_time_total", None)
+        if dur is None:
+            dur = getattr(ev, "cuda_time_total", 0.0)
+        if dur and ev.count:
+            out[ev.key] = dur / ev.count
+    return out
+
+
+def event_time_us(fn, n=50):
+    """HIP-event bracket on the current stream (the stream golf_amd launches on)."""
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        fn()
+    e0.record(s)
+    for _ in range(n):
+        fn()
+    e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / n
+
+
+def cpu_baseline(B, hop, M, budget_s=15.0):
+    """Time the reference algorithm's CPU structure (materialised sample-rate coefficients + fp32 sequential-tap
+    recursion, parallel over the batch only; oracle/golf_oracle.c) plus the oscillator restated with the
+    reference's PyTorch-CPU op sequence (oracle/cpu_baseline.py).  Same synthetic workload, bounded repetitions."""
+    from oracle.cpu_baseline import golf_ss_synth_cpu, num_threads
+    from golf_amd.synthetic import make_inputs
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+
+    inp = make_inputs(B=B, device="cpu")
+    osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, lf_v2=True,
+                                             points=2048)
+    run = lambda: golf_ss_synth_cpu(inp, osc.table, osc.decimater.kernel)
+    y = run()  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 12 and (time.time() - t_start < budget_s or len(times) < 3):
+        t0 = time.time()
+        run()
+        times.append(time.time() - t0)
+    ts = sorted(times)
+    core = ts[1:-1] if len(ts) > 4 else ts  # test_rtf.py:163-172: drop fastest and slowest, mean
+    mean = float(np.mean(core))
+    n = int(y.shape[0] * y.shape[1])
+    return {"value": n / mean, "unit": "audio samples/s", "cores": num_threads(), "kind": "port",
+            "rtf": mean / (B * 2.0), "ms_per_step": mean * 1e3,
+            "sample": f"{len(times)} repetitions of the full B={B} x 2 s step (osc via PyTorch-CPU ops as "
+                      f"models/synth.py:213-263 arranges them + C/OpenMP sample_wise_lpc port), drop min/max, mean"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from golf_amd.dist import shard_inputs, gather_audio
+    from golf_amd.synthetic import make_inputs
+
+    B = args.batch
+    inp_all = make_inputs(B=B * world, device="cpu")
+    inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
+           for k, v in shard_inputs(inp_all, rank, world).items()}
+    osc, ss, ff = build_modules(device)
+    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff)
+    do_gather = world > 1 and not args.no_gather
+    gather_buf = torch.empty(world * B, t_out, device=device) if do_gather else None
+
+    def full_step():
+        y = step()
+        if do_gather:
+            gather_audio(y.detach(), gather_buf)
+        return y
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        full_step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * samples / (elapsed / args.steps)
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, measured live
+        ktimes = device_kernel_times(step)
+        ours = {k: v for k, v in ktimes.items() if "golf::" in k}
+        dom, dom_us = max(ours.items(), key=lambda kv: kv[1]) if ours else ("n/a", float("nan"))
+        # algorithmic bytes of the stage the dominant kernel belongs to (SURVEY.md §8d / BASELINE.md §2)
+        bytes_per_sample = 8.0 if "osc" in dom else (8.38 if args.workload != "golf-ss-train" else 8.38)
+        alg_bytes = bytes_per_sample * samples
+        achieved = alg_bytes / (dom_us * 1e-6) / 1e9
+        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8}
+        step_us = event_time_us(step)
+        roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "path_frac": round(path_bytes[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "B=32 is bound by the serial T=47761 recursion (dependency/issue latency), not by HBM; "
+                            "see DESIGN.md §roofline"}
+        stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
+        result = {
+            "metric": "audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s",
+            "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "batch_per_gpu": B, "seconds": 2.0, "sample_rate": SR,
+                       "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
+                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + ("+allgather" if do_gather else "")},
+            "rtf": (elapsed / args.steps) / (B * 2.0),
+            "device_step_us": round(step_us, 2),
+            "roofline": roofline,
+            "stages_us": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(B, 240, 22)
+                result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
+            except Exception as e:  # the checker is optional for the measurement itself
+                result["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

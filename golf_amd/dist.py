@@ -1,0 +1,71 @@
+"""Multi-GPU: the hot path shards over utterances (every utterance is independent in every kernel —
+the recursion couples only along t), one process per GPU, no data-path collective.  The only exchange
+is the all-gather of the synthesised audio (north_star / BASELINE configs[3]): 6.1 MB per rank at
+B=32, one RCCL all_gather_into_tensor over xGMI.  Backend-agnostic so the same code runs under gloo
+(CPU, tests) and nccl (= RCCL on ROCm).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+__all__ = ["shard_bounds", "shard_inputs", "gather_audio", "synth_sharded"]
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """Contiguous equal shards of ceil(n/world) rows (the tail shard is padded by the caller).
+    Returns (start, stop, per_rank)."""
+    per = (n + world - 1) // world
+    start = min(rank * per, n)
+    return start, min(start + per, n), per
+
+
+def shard_inputs(inputs: Dict, rank: int, world: int) -> Dict:
+    """Slice every batch-major tensor of an input dict to this rank's utterances.  A ragged tail is padded
+    by repeating the last utterance so that all ranks run the same shapes (trimmed again by gather_audio)."""
+    tensors = [v for v in inputs.values() if isinstance(v, torch.Tensor)]
+    n = tensors[0].shape[0]
+    start, stop, per = shard_bounds(n, rank, world)
+    out = {}
+    for k, v in inputs.items():
+        if isinstance(v, torch.Tensor) and v.shape[0] == n:
+            s = v[start:stop]
+            if s.shape[0] < per:
+                filler = (s[-1:] if s.shape[0] else v[-1:]).expand(per - s.shape[0], *v.shape[1:])
+                s = torch.cat([s, filler], 0)
+            out[k] = s
+        else:
+            out[k] = v
+    return out
+
+
+def gather_audio(y: torch.Tensor, out: Optional[torch.Tensor] = None, total: Optional[int] = None) -> torch.Tensor:
+    """All-gather per-rank audio (B_local, T) into (world*B_local, T), trimmed to ``total`` rows."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return y if total is None else y[:total]
+    world = dist.get_world_size()
+    y = y.contiguous()
+    if out is None:
+        out = torch.empty((world * y.shape[0],) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+    try:
+        dist.all_gather_into_tensor(out, y)
+    except (RuntimeError, NotImplementedError):  # backends without the flat variant
+        dist.all_gather(list(out.chunk(world, 0)), y)
+    return out if total is None else out[:total]
+
+
+def synth_sharded(synth_fn, inputs: Dict, gather: bool = True) -> torch.Tensor:
+    """Run ``synth_fn(local_inputs) -> (B_local, T)`` on this rank's shard and (optionally) gather."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    tensors = [v for v in inputs.values() if isinstance(v, torch.Tensor)]
+    total = tensors[0].shape[0]
+    y = synth_fn(shard_inputs(inputs, rank, world))
+    return gather_audio(y, total=total) if gather else y
