@@ -268,7 +268,80 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
 // P1h: homogeneous trajectories in fp64 -> transition matrix of chunk q = b*NP + c, stored twice:
 //   Phi [q][j][i] (row j contiguous: adjoint scan reads rows)   = d s_end[i] / d s_start[j]
 //   PhiT[q][i][j] (row i contiguous: forward scan reads rows)
+//   lane = flat chunk q;  `pair` selects trajectories (2*pair, 2*pair+1)
 // ------------------------------------------------------------------------------------------
+template <int W, int NT>
+__device__ __forceinline__ void p1_hom_body(int qblk, int pair, const float* __restrict__ a, float* __restrict__ Phi,
+                                            float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
+    const int q = qblk * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const int j0 = 2 * pair, j1 = j0 + 1;
+    float* out0 = Phi + ((size_t)q * NT + j0) * W;
+    float* out1 = out0 + W;
+    float* outT = PhiT + (size_t)q * NT * W + j0;
+    if (j0 >= M) {  // padding rows/columns: exact zeros
+#pragma unroll
+        for (int i = 0; i < W; ++i) { out0[i] = 0.f; out1[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { outT[(size_t)i * W] = 0.f; outT[(size_t)i * W + 1] = 0.f; }
+        return;
+    }
+    const int b = q / NP, c = q - b * NP;
+    double h0[W], h1[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        h0[k] = (W - 1 - k == j0) ? 1.0 : 0.0;
+        h1[k] = (W - 1 - k == j1 && j1 < M) ? 1.0 : 0.0;
+    }
+    double a0[NT], dd[NT];
+    const double inv_hop = 1.0 / (double)hop;
+    int fcur = -1;
+    const int nblk = L / W;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int t0 = c * L + blk * W;
+        const int f = t0 / hop;  // <= F-2: chunks with a transition matrix end before (F-1)*hop
+        if (f != fcur) {
+            fcur = f;
+            const float* pa0 = a + ((size_t)b * F + f) * M;
+            const float* pa1 = pa0 + M;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const double v0 = i < M ? (double)pa0[i] : 0.0;
+                const double v1 = i < M ? (double)pa1[i] : 0.0;
+                a0[i] = v0;
+                dd[i] = (v1 - v0) * inv_hop;
+            }
+        }
+        const double n0 = (double)(t0 - f * hop);
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const double n = n0 + (double)s;
+            double r0a = 0.0, r0b = 0.0, r1a = 0.0, r1b = 0.0;
+#pragma unroll
+            for (int i = NT - 1; i >= 1; --i) {
+                const double cf = fma(n, dd[i], a0[i]);
+                const int slot = (s - 1 - i + 2 * W) % W;
+                if (i & 1) { r0a = fma(cf, h0[slot], r0a); r1a = fma(cf, h1[slot], r1a); }
+                else       { r0b = fma(cf, h0[slot], r0b); r1b = fma(cf, h1[slot], r1b); }
+            }
+            const double cf0 = fma(n, dd[0], a0[0]);
+            const int sp = (s - 1 + W) % W;
+            const double y0 = fma(-cf0, h0[sp], -(r0a + r0b));
+            const double y1 = fma(-cf0, h1[sp], -(r1a + r1b));
+            h0[s] = y0;
+            h1[s] = y1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const float v0 = i < M ? (float)h0[W - 1 - i] : 0.f;
+        const float v1 = (i < M && j1 < M) ? (float)h1[W - 1 - i] : 0.f;
+        out0[i] = v0;
+        out1[i] = v1;
+        if (i < NT) { outT[(size_t)i * W] = v0; outT[(size_t)i * W + 1] = v1; }
+    }
+}
+
 // Phase 1 kernels (separate launches: the fp32 zero-state role needs LDS tiles + ~250 VGPRs, the fp64 role 34 KB of
 // LDS coefficients — fusing them into one kernel only adds up their footprints).
 template <int W, int NT>
@@ -280,137 +353,17 @@ __global__ __launch_bounds__(64) void lpc_p1z_kernel(const float* __restrict__ e
     fwd_chunk_body<W, NT, 0>(lds, blockIdx.y, blockIdx.x, ex, ex_stride, gain, a, nullptr, z, 0, T, F, M, hop, L, NP);
 }
 
-// P1h v2.  fp64 FMA issue (16 lanes/clk) is what bounds this kernel, so the per-sample coefficient
-// interpolation — identical for all trajectories of a chunk — is computed ONCE per chunk into an LDS tile
-// and every lane runs KT=3 trajectories against it: 66 fp64 FMAs per lane-step for 3 trajectories instead
-// of 44 per trajectory.  Wave = CPW chunks x NGP trajectory groups; lane = cw*NGP + g.
-constexpr int p1h_kt(int W) { return W <= 24 ? 3 : 2; }  // trajectories per lane (register budget: KT*W doubles)
-constexpr int p1h_ngp(int W, int NT) {                   // lanes per chunk: next power of two >= ceil(NT/KT)
-    const int ng = (NT + p1h_kt(W) - 1) / p1h_kt(W);
-    return ng <= 8 ? 8 : (ng <= 16 ? 16 : 32);
-}
-constexpr int p1h_pad_words(int base) {  // chunk stride (32-bit words): stride % 64 must be an odd multiple of 4
-    int pad = 0;
-    while (((base + pad) % 64) % 8 != 4) pad += 4;
-    return pad;
-}
-
+// (A variant that interpolates the coefficients once per chunk into an LDS tile and runs 3 trajectories per lane
+// against it — 23 instead of 33 fp64 FMAs per trajectory-step — was measured SLOWER (84.7 vs 77.6 us): a lone wave
+// already sustains one fp64 FMA per ~5.2 cycles (tools/ubench/fma_issue.hip), and the LDS reads, waits and
+// producer bookkeeping cost more issue slots than the FMAs they saved.  See DESIGN.md.)
 template <int W, int NT>
 __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
                                                      int nq) {
-    constexpr int KT = p1h_kt(W);
-    constexpr int NGP = p1h_ngp(W, NT);
-    constexpr int CPW = 64 / NGP;
-    constexpr int CSTW = 2 * W * NT + p1h_pad_words(2 * W * NT);  // words per chunk tile
-    constexpr int CSTD = CSTW / 2;                                // doubles per chunk tile
-    constexpr int NPAIR = CPW * NT;
-    constexpr int PPL = (NPAIR + 63) / 64;                        // producer pairs per lane
-    __shared__ __attribute__((aligned(16))) double Ac[CPW * CSTD];
-    const int lane = threadIdx.x;
-    const int cw = lane / NGP, g = lane % NGP;
-    const int q = blockIdx.x * CPW + cw;
-    const bool qok = q < nq;
-    const int qq = qok ? q : nq - 1;
-    const int c = qq % NP;
-    // ---- consumer state: KT trajectories j = g*KT + r, unit initial states
-    double h[KT][W];
-#pragma unroll
-    for (int r = 0; r < KT; ++r) {
-        const int j = g * KT + r;
-#pragma unroll
-        for (int k = 0; k < W; ++k) h[r][k] = (W - 1 - k == j && j < M) ? 1.0 : 0.0;
-    }
-    // ---- producer state: PPL (chunk, tap) pairs per lane
-    int pcw[PPL], pi[PPL], pb_[PPL], pc_[PPL];
-    bool pok[PPL];
-    double pa0[PPL], pdd[PPL];
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-        const int pidx = lane + 64 * r;
-        pok[r] = pidx < NPAIR;
-        const int pp = pok[r] ? pidx : 0;
-        pcw[r] = pp / NT;
-        pi[r] = pp % NT;
-        int qp = blockIdx.x * CPW + pcw[r];
-        if (qp > nq - 1) qp = nq - 1;
-        pb_[r] = qp / NP;
-        pc_[r] = qp % NP;
-        pa0[r] = 0.0;
-        pdd[r] = 0.0;
-    }
-    const double inv_hop = 1.0 / (double)hop;
-    int fcur = -1;
-    const int nblk = L / W;
-    for (int blk = 0; blk < nblk; ++blk) {
-        // frame changes happen on the same block for every chunk (chunks are L-aligned, L | hop or hop | L)
-        const int t0 = c * L + blk * W;
-        const int f = t0 / hop;
-        if (f != fcur) {  // wave-uniform in effect; per-lane loads of the lane's producer pairs
-            fcur = f;
-#pragma unroll
-            for (int r = 0; r < PPL; ++r) {
-                const int fp = (pc_[r] * L + blk * W) / hop;
-                const float* pa = a + ((size_t)pb_[r] * F + fp) * M;
-                const double v0 = pi[r] < M ? (double)pa[pi[r]] : 0.0;
-                const double v1 = pi[r] < M ? (double)pa[M + pi[r]] : 0.0;
-                pa0[r] = v0;
-                pdd[r] = (v1 - v0) * inv_hop;
-            }
-        }
-        __syncthreads();  // previous block fully consumed
-#pragma unroll
-        for (int r = 0; r < PPL; ++r) {
-            if (pok[r]) {
-                const int tp = pc_[r] * L + blk * W;
-                const double n0 = (double)(tp - (tp / hop) * hop);
-                double* dst = Ac + pcw[r] * CSTD + pi[r];
-#pragma unroll
-                for (int s = 0; s < W; ++s) dst[s * NT] = fma(n0 + (double)s, pdd[r], pa0[r]);
-            }
-        }
-        __syncthreads();
-        const double* tile = Ac + cw * CSTD;
-#pragma unroll
-        for (int s = 0; s < W; ++s) {
-            double ra[KT], rb[KT];
-#pragma unroll
-            for (int r = 0; r < KT; ++r) { ra[r] = 0.0; rb[r] = 0.0; }
-            const double2* row = reinterpret_cast<const double2*>(tile + s * NT);
-#pragma unroll
-            for (int ip = NT / 2 - 1; ip >= 1; --ip) {  // taps 2ip, 2ip+1 (>= 2)
-                const double2 cf = row[ip];
-                const int s0 = (s - 1 - 2 * ip + 2 * W) % W, s1 = (s - 2 - 2 * ip + 2 * W) % W;
-#pragma unroll
-                for (int r = 0; r < KT; ++r) {
-                    ra[r] = fma(cf.y, h[r][s1], ra[r]);
-                    rb[r] = fma(cf.x, h[r][s0], rb[r]);
-                }
-            }
-            const double2 c01 = row[0];
-            const int sp = (s - 1 + W) % W, sp2 = (s - 2 + W) % W;
-#pragma unroll
-            for (int r = 0; r < KT; ++r) {
-                ra[r] = fma(c01.y, h[r][sp2], ra[r]);
-                h[r][s] = fma(-c01.x, h[r][sp], -(ra[r] + rb[r]));
-            }
-        }
-    }
-    if (!qok) return;
-#pragma unroll
-    for (int r = 0; r < KT; ++r) {
-        const int j = g * KT + r;
-        if (j < NT) {
-            float* out = Phi + ((size_t)q * NT + j) * W;
-            float* outT = PhiT + (size_t)q * NT * W + j;
-#pragma unroll
-            for (int i = 0; i < W; ++i) {
-                const float v = (i < M && j < M) ? (float)h[r][W - 1 - i] : 0.f;
-                out[i] = v;
-                if (i < NT) outT[(size_t)i * W] = v;
-            }
-        }
-    }
+    const int idx = blockIdx.x;
+    const int pair = idx % (NT / 2), qblk = idx / (NT / 2);
+    p1_hom_body<W, NT>(qblk, pair, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
 
 template <int W, int NT>
@@ -817,22 +770,52 @@ __global__ void lpc_inverse_kernel(const float* __restrict__ y, int64_t y_stride
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 template <int W, int NT>
-static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a, float* y,
-                      int64_t y_stride, int B, int T, int F, int M, int hop, char* ws, hipStream_t st) {
+static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int F, int M, int hop, char* ws,
+                              hipStream_t st) {
+    if (p.NP <= 0) return GOLF_OK;
     float* Phi = (float*)(ws + p.off_phi);
+    float* PhiT = (float*)(ws + p.off_phiT);
+    const int nq = B * p.NP;
+    hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * (NT / 2))), dim3(64), 0, st, a, Phi,
+                       PhiT, F, M, hop, p.L, p.NP, nq);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+// Fork/join helper: `side` runs P1h (needs only `a`) while `st` runs P1z (needs the excitation).
+struct ForkJoin {
+    hipEvent_t ev = nullptr;
+    int record_and_wait(hipStream_t from, hipStream_t to) {
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 1;
+        if (hipEventRecord(ev, from) != hipSuccess) return 1;
+        if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) return 1;
+        return 0;
+    }
+    ~ForkJoin() { if (ev) (void)hipEventDestroy(ev); }
+};
+
+template <int W, int NT>
+static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a, float* y,
+                      int64_t y_stride, int B, int T, int F, int M, int hop, char* ws, int flags, hipStream_t side,
+                      hipStream_t st) {
     float* PhiT = (float*)(ws + p.off_phiT);
     float* z = (float*)(ws + p.off_z);
     float* S = (float*)(ws + p.off_S);
     constexpr int D = 8;
+    ForkJoin fork, join;
     if (p.NP > 0) {
-        const int nq = B * p.NP;
+        if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
+            hipStream_t s1 = st;
+            if (side) {
+                if (fork.record_and_wait(st, side)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream fork failed");
+                s1 = side;
+            }
+            if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, s1)) return rc;
+        }
         hipLaunchKernelGGL((lpc_p1z_kernel<W, NT>), dim3((unsigned)ceil_div(p.NP, 64), B), dim3(64), 0, st, ex,
                            ex_stride, gain, a, z, T, F, M, hop, p.L, p.NP);
         GOLF_LAUNCH_CHECK();
-        constexpr int P1H_CPW = 64 / p1h_ngp(W, NT);  // chunks per wave, see lpc_p1h_kernel
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)ceil_div(nq, P1H_CPW)), dim3(64), 0, st, a, Phi,
-                           PhiT, F, M, hop, p.L, p.NP, nq);
-        GOLF_LAUNCH_CHECK();
+        if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
                        S, p.NC, p.NP);
@@ -924,9 +907,23 @@ extern "C" size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, i
     return p.total;
 }
 
+extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop, void* ws,
+                                                size_t ws_bytes, void* stream) {
+    if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
+    if (!a) return fail(GOLF_EINVAL, "ltv_allpole_transitions: null pointer");
+    SsPlan p;
+    if (!plan_fast(B, T, F, M, hop, &p)) return GOLF_OK;  // generic path has no transition matrices
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "ltv_allpole_transitions: workspace needs %zu bytes, 256-aligned (got %zu)",
+                    p.total, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    GOLF_SS_DISPATCH(launch_transitions, p, a, B, T, F, M, hop, (char*)ws, st)
+    return fail(GOLF_EUNSUPPORTED, "ltv_allpole_transitions: no kernel for W=%d NT=%d", p.W, p.NT);
+}
+
 extern "C" int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
                                         float* y, int64_t y_stride, int B, int T, int F, int M, int hop, void* ws,
-                                        size_t ws_bytes, void* stream) {
+                                        size_t ws_bytes, int flags, void* side_stream, void* stream) {
     if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
     if (!ex || !gain || !a || !y) return fail(GOLF_EINVAL, "ltv_allpole_fwd: null pointer");
     if (ex_stride < T || y_stride < T) return fail(GOLF_EINVAL, "ltv_allpole_fwd: row stride < T");
@@ -941,7 +938,9 @@ extern "C" int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, cons
     if (!ws || ws_bytes < p.total || ((uintptr_t)ws & 255))
         return fail(GOLF_EWORKSPACE, "ltv_allpole_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", p.total,
                     ws_bytes);
-    GOLF_SS_DISPATCH(launch_fwd, p, ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop, (char*)ws, st)
+    hipStream_t side = (hipStream_t)side_stream;
+    if (side == st) side = nullptr;
+    GOLF_SS_DISPATCH(launch_fwd, p, ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop, (char*)ws, flags, side, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_fwd: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

@@ -76,9 +76,20 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
                 ),
             )
 
+    def prefetch(self, gain: AudioTensor, a: AudioTensor, n_samples: int = None) -> None:
+        """Optional hook (not in the reference): start the excitation-independent phase of the filter — the
+        per-chunk transition matrices, the most expensive kernel — on a second HIP stream as soon as the
+        coefficients are known, so that it overlaps whatever produces the excitation (the oscillator).
+        ``SourceFilterSynth`` calls it when present; ``forward`` picks the result up if shapes match."""
+        hop = int(a.hop_length)
+        F = a.shape[1]
+        T = (F - 1) * hop + 1 if n_samples is None else min(int(n_samples), (F - 1) * hop + 1)
+        self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T)
+
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
         hop = _check_filter_inputs(ex, gain, a)
-        y = GF.ltv_allpole_ss(ex.as_tensor(), gain.as_tensor(), a.as_tensor(), hop)
+        prepared, self._prepared = getattr(self, "_prepared", None), None
+        y = GF.ltv_allpole_ss(ex.as_tensor(), gain.as_tensor(), a.as_tensor(), hop, prepared)
         return AudioTensor(y)
 
     def reverse(self, ex: AudioTensor, y: AudioTensor, gain: AudioTensor, a: AudioTensor
@@ -93,6 +104,9 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
 class LTVMinimumPhaseFilter(LTVMinimumPhaseFilterPrecise):
     """GOLF-ff end filter: per-frame LTI all-pole + windowed overlap-add
     (reference models/filters.py:116-184).  Forward-only in this round."""
+
+    def prefetch(self, *args, **kwargs) -> None:  # the frame-wise filter has no excitation-independent phase
+        return None
 
     def __init__(self, window: str, window_length: int, centred: bool = True, **kwargs):
         super().__init__(**kwargs)

@@ -9,8 +9,50 @@ import torch
 
 from . import _lib
 
-__all__ = ["ltv_allpole_ss", "ltv_inverse", "lti_frames_ola", "glottal_osc", "ss_output_length",
-           "ff_output_length", "osc_lengths"]
+__all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_ola", "glottal_osc",
+           "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions"]
+
+HAVE_TRANSITIONS = 1
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """One extra HIP stream per device for the excitation-independent phase (transition matrices)."""
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=key)
+    return s
+
+
+class PreparedTransitions:
+    """Handle returned by ltv_allpole_prepare: the workspace with the transition matrices in flight on the side
+    stream, plus the shape key they are valid for."""
+
+    def __init__(self, ws, key, stream, a):
+        self.ws, self.key, self.stream, self.a = ws, key, stream, a
+
+
+def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int) -> PreparedTransitions:
+    """Launch the transition-matrix kernel for coefficients ``a`` (B,F,M) and output length ``T`` on the side
+    stream; pass the handle to ltv_allpole_ss(..., prepared=handle).  Lets a decoder overlap the most expensive,
+    excitation-independent phase of the filter with the oscillator that produces the excitation."""
+    _lib.require_device(a)
+    lib = _lib.load()
+    a = a.detach().contiguous()
+    B, F, M = a.shape
+    ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), a.device)
+    cur = torch.cuda.current_stream(a.device)
+    side = _side_stream(a.device)
+    side.wait_stream(cur)  # `a` (and the fresh workspace) are ordered after the current stream's work
+    ws.record_stream(side)
+    a.record_stream(side)
+    rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
+                                              side.cuda_stream)
+    _lib.check(rc, "golf_ltv_allpole_transitions_f32")
+    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -30,7 +72,7 @@ def ss_output_length(Tx: int, F: int, hop: int) -> int:
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ex, gain, a, hop):
+    def forward(ctx, ex, gain, a, hop, prepared):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
         ex = _rows(ex)
@@ -41,9 +83,18 @@ class _LTVAllPoleSS(torch.autograd.Function):
         assert gain.shape == (B, F) and a.shape[0] == B
         T = ss_output_length(Tx, F, hop)
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
-        ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
+        side = _side_stream(ex.device)
+        flags = 0
+        if prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version):
+            ws, flags = prepared.ws, HAVE_TRANSITIONS
+            side = prepared.stream
+        else:
+            ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
+            ws.record_stream(side)
+            a.record_stream(side)
         rc = lib.golf_ltv_allpole_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(), y.data_ptr(),
-                                          y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                          y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
+                                          side.cuda_stream, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_fwd_f32")
         ctx.hop = hop
         ctx.save_for_backward(ex, gain, a, y, ws)
@@ -68,13 +119,15 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
-        return g_ex, g_gain, g_a, None
+        return g_ex, g_gain, g_a, None, None
 
 
-def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:
+def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
+                   prepared: "PreparedTransitions" = None) -> torch.Tensor:
     """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
-    Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward)."""
-    return _LTVAllPoleSS.apply(ex, gain, a, int(hop))
+    Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward).
+    ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match)."""
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared)
 
 
 def ltv_inverse(y: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:

@@ -32,6 +32,9 @@ class SourceFilterSynth(Synth):
                 noise_generator_params: Tuple[AudioTensor, ...], noise_filter_params: Tuple[AudioTensor, ...],
                 end_filter_params: Tuple[AudioTensor, ...], voicing: Optional[AudioTensor] = None,
                 target: Optional[AudioTensor] = None, **other_params) -> AudioTensor:
+        if target is None and hasattr(self.end_filter, "prefetch") and hasattr(self.harm_oscillator, "output_length"):
+            # overlap the filter's excitation-independent phase with the oscillator (second HIP stream)
+            self.end_filter.prefetch(*end_filter_params, n_samples=self.harm_oscillator.output_length(phase))
         harm_osc = self.harm_oscillator(phase, *harm_oscillator_params)
         if voicing is not None:
             if self.check_ranges:

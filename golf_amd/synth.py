@@ -101,6 +101,10 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
             del self.decimater._buffers["kernel"]
             self.decimater.register_buffer("kernel", kernel, persistent=False)
 
+    def output_length(self, phase: AudioTensor) -> int:
+        """Number of samples forward() will return for this phase input."""
+        return GF.osc_lengths(phase.shape[1], phase.hop_length, self.oversampling)[1]
+
     def forward(self, phase: AudioTensor, table_select_weight: AudioTensor, phase_offset: AudioTensor = None,
                 return_pre: bool = False) -> AudioTensor:
         assert phase.ndim == 2, phase.shape

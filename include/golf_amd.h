@@ -58,9 +58,22 @@ const char* golf_target_arch(void);
  * ------------------------------------------------------------------------------------------- */
 size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
 
+/* The per-chunk transition matrices depend only on the coefficients `a`, not on the excitation, and are the
+ * most expensive phase.  golf_ltv_allpole_transitions_f32 computes them into `ws` on its own — a caller that
+ * knows `a` before `ex` exists (the GOLF decoder: the encoder emits `a` while the oscillator still has to render
+ * the source) launches it on a second HIP stream and then passes GOLF_SS_HAVE_TRANSITIONS to the forward.
+ *   flags        GOLF_SS_HAVE_TRANSITIONS: `ws` already holds the transitions for (a,B,T,F,M,hop)
+ *   side_stream  optional second hipStream_t (may be NULL): without HAVE_TRANSITIONS the forward forks the
+ *                transition kernel onto it (event fork/join) so it overlaps the excitation-dependent phase;
+ *                with HAVE_TRANSITIONS the forward joins it (event wait) right before the boundary scan. */
+#define GOLF_SS_HAVE_TRANSITIONS 1
+
+int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
+                                     void* ws, size_t ws_bytes, void* stream);
+
 int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop,
-                             void* ws, size_t ws_bytes, void* stream);
+                             void* ws, size_t ws_bytes, int flags, void* side_stream, void* stream);
 
 /* Custom backward of the above (what torchlpc's autograd.Function + autograd through
  * F.interpolate compute in the reference; closed form in SURVEY.md App. A-2):

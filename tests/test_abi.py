@@ -41,11 +41,11 @@ def test_argument_checks_without_gpu():
     lib = _lib.load()
     assert lib.golf_ltv_allpole_workspace_bytes(32, 47761, 200, 22, 240) > 0
     assert lib.golf_ltv_allpole_workspace_bytes(0, 1, 1, 1, 1) == 0
-    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 100, 3, 4, 10, None, 0, None)
+    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 100, 3, 4, 10, None, 0, 0, None, None)
     assert rc == -1 and b"exceeds" in lib.golf_last_error()
-    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 10, 3, 4, 8, None, 0, None)
+    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 10, 3, 4, 8, None, 0, 0, None, None)
     assert rc == -1 and b"null" in lib.golf_last_error()
-    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 10, 3, 99, 8, None, 0, None)
+    rc = lib.golf_ltv_allpole_fwd_f32(None, 0, None, None, None, 0, 2, 10, 3, 99, 8, None, 0, 0, None, None)
     assert rc == -3
     rc = lib.golf_lti_frames_ola_fwd_f32(None, 0, None, None, None, None, 0, 1, 100, 5, 4, 8, 12, 0, None, 0, None)
     assert rc == -1
