@@ -79,10 +79,7 @@ def make_step(workload, inp, osc, ss, ff):
 
     if workload == "golf-ss-synth":
         def step():
-            # what SourceFilterSynth.forward does: transition matrices (need only `a`) on the side stream,
-            # overlapping the oscillator that renders the excitation
-            prep = GF.ltv_allpole_prepare(a, hop, t_ss)
-            return GF.ltv_allpole_ss(source(), gain, a, hop, prep)
+            return GF.ltv_allpole_ss(source(), gain, a, hop)
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)
@@ -98,9 +95,8 @@ def make_step(workload, inp, osc, ss, ff):
         gy = torch.randn(B, 47761, device=phase.device)
 
         def step():
-            prep = GF.ltv_allpole_prepare(a_g, hop, t_ss)
             o = GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True)
-            y = GF.ltv_allpole_ss(o + noise[:, : o.shape[1]], gain_g, a_g, hop, prep)
+            y = GF.ltv_allpole_ss(o + noise[:, : o.shape[1]], gain_g, a_g, hop)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y

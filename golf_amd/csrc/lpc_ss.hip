@@ -102,10 +102,11 @@ struct BufRow {
     }
 };
 
-template <int W>
+template <int W, int ROWS = 64>
 struct Tile {
     static constexpr int LD = W + 1;
-    static constexpr int SIZE = 64 * LD;
+    static constexpr int SIZE = ROWS * LD;
+    static constexpr int ITS = ROWS * W / 64;  // elements per lane
 
     __device__ static __forceinline__ void rowcol(int it, int lq, int lr, int& row, int& col) {
         const int q = (it * 64) / W, r = (it * 64) % W;  // constants after unrolling
@@ -115,46 +116,47 @@ struct Tile {
         if (col >= W) { col -= W; row += 1; }            // W < 64: lr + r < 2W, at most two wraps (W >= 8: lr<W)
     }
     // global -> registers, coalesced order; element at t = tbase + row*L + col (0 outside [0,T))
-    __device__ static __forceinline__ void fetch(float (&r)[W], const BufRow& src, int tbase, int L, int lq, int lr) {
+    __device__ static __forceinline__ void fetch(float (&r)[ITS], const BufRow& src, int tbase, int L, int lq,
+                                                 int lr) {
 #pragma unroll
-        for (int it = 0; it < W; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
             r[it] = src.ld(tbase + row * L + col);
         }
     }
-    __device__ static __forceinline__ void store(const float (&r)[W], const BufRow& dst, int tbase, int L, int lq,
+    __device__ static __forceinline__ void store(const float (&r)[ITS], const BufRow& dst, int tbase, int L, int lq,
                                                  int lr) {
 #pragma unroll
-        for (int it = 0; it < W; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
             dst.st(tbase + row * L + col, r[it]);
         }
     }
-    __device__ static __forceinline__ void scatter(float* lds, const float (&r)[W], int lq, int lr) {
+    __device__ static __forceinline__ void scatter(float* lds, const float (&r)[ITS], int lq, int lr) {
 #pragma unroll
-        for (int it = 0; it < W; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
             lds[row * LD + col] = r[it];
         }
     }
-    __device__ static __forceinline__ void gather(float (&r)[W], const float* lds, int lq, int lr) {
+    __device__ static __forceinline__ void gather(float (&r)[ITS], const float* lds, int lq, int lr) {
 #pragma unroll
-        for (int it = 0; it < W; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
             r[it] = lds[row * LD + col];
         }
     }
-    __device__ static __forceinline__ void rows_load(float (&x)[W], const float* lds, int lane) {
+    __device__ static __forceinline__ void rows_load(float (&x)[W], const float* lds, int row) {
 #pragma unroll
-        for (int s = 0; s < W; ++s) x[s] = lds[lane * LD + s];
+        for (int s = 0; s < W; ++s) x[s] = lds[row * LD + s];
     }
-    __device__ static __forceinline__ void rows_store(float* lds, const float (&x)[W], int lane) {
+    __device__ static __forceinline__ void rows_store(float* lds, const float (&x)[W], int row) {
 #pragma unroll
-        for (int s = 0; s < W; ++s) lds[lane * LD + s] = x[s];
+        for (int s = 0; s < W; ++s) lds[row * LD + s] = x[s];
     }
 };
 
@@ -166,43 +168,67 @@ __device__ __forceinline__ float f4get(const float4& v, int k) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward in-lane recursion over one chunk (fp32).  Wave = 64 consecutive chunks of utterance b.
-//   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
-//   MODE 1 (P3) : initial state S[(b*NCQ+c)*W + i], writes y[b][t]
+// Tap-parallel in-register recursion (fp32): a QUAD of 4 lanes runs one chunk, 16 chunks per wave.
+//   Lane r of the quad owns taps [r*TPL, (r+1)*TPL) and a TPL-deep rotating window holding the history delayed
+//   by r*TPL samples: w[k] ~ y[t-1-(r*TPL+k)].  Per sample: TPL coefficient FMAs + TPL dot FMAs, a 2-stage DPP
+//   butterfly (v_add_f32 with quad_perm operands) for the tap sum, and a 1-lane DPP shift that hands each lane the
+//   sample leaving its left neighbour's window (a 4-stage systolic delay line).  ~18 instructions per sample
+//   instead of ~62 for the one-lane-per-chunk version: a lone wave issues roughly one instruction per 4-5 cycles
+//   whatever it is, so instruction count IS the latency of these kernels.
 // ------------------------------------------------------------------------------------------
+constexpr int quad_tpl(int W, int NT) {
+    for (int d = 1; d <= W; ++d)
+        if (W % d == 0 && 4 * d >= NT) return d;
+    return W;
+}
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+#define DPP_XOR1 0xB1   /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E   /* quad_perm [2,3,0,1] */
+#define DPP_SHR1 0x90   /* quad_perm [0,0,1,2]: lane r reads lane r-1 */
+#define DPP_SHL1 0xF9   /* quad_perm [1,2,3,3]: lane r reads lane r+1 */
+#define DPP_BC0  0x00   /* quad_perm [0,0,0,0]: broadcast lane 0 of the quad */
+
+//   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
+//   MODE 1 (P3) : initial state S[(b*NCQ+c)*64 + i], writes y[b][t]
 template <int W, int NT, int MODE>
-__device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const float* __restrict__ ex,
-                                               int64_t ex_stride, const float* __restrict__ gain,
-                                               const float* __restrict__ a, const float* __restrict__ S,
-                                               float* __restrict__ out, int64_t y_stride, int T, int F, int M, int hop,
-                                               int L, int NCQ) {
-    using TL = Tile<W>;
-    float* xt = lds;
-    float* yt = lds + TL::SIZE;
+__global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                      const float* __restrict__ gain, const float* __restrict__ a,
+                                                      const float* __restrict__ S, float* __restrict__ out,
+                                                      int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ) {
+    constexpr int TPL = quad_tpl(W, NT);
+    constexpr int R = 16;
+    using TL = Tile<W, R>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
+    const int b = blockIdx.y, cg = blockIdx.x;
     const int lane = threadIdx.x;
     const int lq = lane / W, lr = lane % W;
-    const int c0 = cg * 64;
-    const int c = c0 + lane;
+    const int row = lane >> 2, r = lane & 3;
+    const int c0 = cg * R;
+    const int c = c0 + row;
     const bool mine = c < NCQ;
     const BufRow xrow(ex + (size_t)b * ex_stride, T);
     const BufRow yrow(MODE == 1 ? out + (size_t)b * y_stride : nullptr, MODE == 1 ? T : 0);
-    float h[W];
+    float w[TPL];
     if (MODE == 1 && mine) {
-        const float* sp = S + ((size_t)b * NCQ + c) * 64;
+        const float* sp = S + ((size_t)b * NCQ + c) * 64 + r * TPL;
 #pragma unroll
-        for (int i = 0; i < W; ++i) h[W - 1 - i] = sp[i];
+        for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
     } else {
 #pragma unroll
-        for (int k = 0; k < W; ++k) h[k] = 0.f;
+        for (int k = 0; k < TPL; ++k) w[k] = 0.f;
     }
-    float a0[NT], dd[NT];
+    float a0[TPL], dd[TPL];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { a0[i] = 0.f; dd[i] = 0.f; }
+    for (int k = 0; k < TPL; ++k) { a0[k] = 0.f; dd[k] = 0.f; }
     float g0 = 0.f, dg = 0.f;
     const float inv_hop = 1.0f / (float)hop;
     int fcur = -1;
     const int nblk = L / W;
-    float nx[W];
+    float nx[TL::ITS];
     TL::fetch(nx, xrow, c0 * L, L, lq, lr);
     for (int blk = 0; blk < nblk; ++blk) {
         const int tw = c0 * L + blk * W;  // block start of the wave's first chunk
@@ -210,10 +236,13 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
         TL::scatter(xt, nx, lq, lr);
         __syncthreads();
         float xin[W];
-        TL::rows_load(xin, xt, lane);
+        TL::rows_load(xin, xt, row);
         TL::fetch(nx, xrow, tw + W, L, lq, lr);  // prefetch next block (past the end: hardware returns 0)
         const int t0 = c * L + blk * W;
         const bool act = mine && t0 < T;
+        float keep[W / 4];
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
         if (act) {
             int f = t0 / hop;
             if (f > F - 2) f = F - 2;
@@ -222,11 +251,12 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
                 const float* pa0 = a + ((size_t)b * F + f) * M;
                 const float* pa1 = pa0 + M;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
+                for (int k = 0; k < TPL; ++k) {
+                    const int i = r * TPL + k;
                     const float v0 = i < M ? pa0[i] : 0.f;
                     const float v1 = i < M ? pa1[i] : 0.f;
-                    a0[i] = v0;
-                    dd[i] = (v1 - v0) * inv_hop;
+                    a0[k] = v0;
+                    dd[k] = (v1 - v0) * inv_hop;
                 }
                 g0 = gain[(size_t)b * F + f];
                 dg = (gain[(size_t)b * F + f + 1] - g0) * inv_hop;
@@ -236,22 +266,30 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
             for (int s = 0; s < W; ++s) {
                 const float n = n0 + (float)s;
                 const float x = xin[s] * fmaf(n, dg, g0);
-                float ra = 0.f, rb = 0.f;
+                float pa = 0.f, pb = 0.f;
 #pragma unroll
-                for (int i = NT - 1; i >= 1; --i) {
-                    const float cf = fmaf(n, dd[i], a0[i]);
-                    const int slot = (s - 1 - i + 2 * W) % W;
-                    if (i & 1) ra = fmaf(cf, h[slot], ra);
-                    else       rb = fmaf(cf, h[slot], rb);
+                for (int k = TPL - 1; k >= 1; --k) {
+                    const float cf = fmaf(n, dd[k], a0[k]);
+                    const int slot = (s - 1 - k + 4 * TPL) % TPL;
+                    if (k & 1) pa = fmaf(cf, w[slot], pa);
+                    else       pb = fmaf(cf, w[slot], pb);
                 }
                 const float cf0 = fmaf(n, dd[0], a0[0]);
-                h[s] = fmaf(-cf0, h[(s - 1 + W) % W], x - (ra + rb));
+                float part = fmaf(cf0, w[(s - 1 + TPL) % TPL], pa + pb);  // newest sample last: shortest chain
+                part += dppf<DPP_XOR1>(part);
+                part += dppf<DPP_XOR2>(part);
+                const float y = x - part;
+                const float oldest = w[s % TPL];
+                const float inc = dppf<DPP_SHR1>(oldest);
+                w[s % TPL] = r == 0 ? y : inc;
+                if (MODE == 1) keep[s >> 2] = ((s & 3) == r) ? y : keep[s >> 2];
             }
         }
         if (MODE == 1) {
-            TL::rows_store(yt, h, lane);
+#pragma unroll
+            for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
             __syncthreads();
-            float o[W];
+            float o[TL::ITS];
             TL::gather(o, yt, lq, lr);
             TL::store(o, yrow, tw, L, lq, lr);
         }
@@ -260,7 +298,10 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
     if (MODE == 0 && mine) {
         float* zp = out + ((size_t)b * NCQ + c) * W;
 #pragma unroll
-        for (int i = 0; i < W; ++i) zp[i] = i < M ? h[W - 1 - i] : 0.f;
+        for (int k = 0; k < TPL; ++k) {
+            const int i = r * TPL + k;
+            if (i < W) zp[i] = i < M ? w[TPL - 1 - k] : 0.f;
+        }
     }
 }
 
@@ -270,29 +311,36 @@ __device__ __forceinline__ void fwd_chunk_body(float* lds, int b, int cg, const 
 //   PhiT[q][i][j] (row i contiguous: forward scan reads rows)
 //   lane = flat chunk q;  `pair` selects trajectories (2*pair, 2*pair+1)
 // ------------------------------------------------------------------------------------------
+constexpr int p1h_kt(int W) { return W <= 24 ? 3 : 2; }  // trajectories per lane (register budget: KT*W doubles)
+
 template <int W, int NT>
-__device__ __forceinline__ void p1_hom_body(int qblk, int pair, const float* __restrict__ a, float* __restrict__ Phi,
+__device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __restrict__ a, float* __restrict__ Phi,
                                             float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
+    constexpr int KT = p1h_kt(W);
     const int q = qblk * 64 + threadIdx.x;
     if (q >= nq) return;
-    const int j0 = 2 * pair, j1 = j0 + 1;
-    float* out0 = Phi + ((size_t)q * NT + j0) * W;
-    float* out1 = out0 + W;
-    float* outT = PhiT + (size_t)q * NT * W + j0;
-    if (j0 >= M) {  // padding rows/columns: exact zeros
+    const int jb = KT * grp;  // trajectories jb .. jb+KT-1
+    if (jb >= M) {            // padding rows/columns: exact zeros
 #pragma unroll
-        for (int i = 0; i < W; ++i) { out0[i] = 0.f; out1[i] = 0.f; }
+        for (int r = 0; r < KT; ++r) {
+            const int j = jb + r;
+            if (j < NT) {
+                float* o = Phi + ((size_t)q * NT + j) * W;
+                float* oT = PhiT + (size_t)q * NT * W + j;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) { outT[(size_t)i * W] = 0.f; outT[(size_t)i * W + 1] = 0.f; }
+                for (int i = 0; i < W; ++i) o[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) oT[(size_t)i * W] = 0.f;
+            }
+        }
         return;
     }
     const int b = q / NP, c = q - b * NP;
-    double h0[W], h1[W];
+    double h[KT][W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
-        h0[k] = (W - 1 - k == j0) ? 1.0 : 0.0;
-        h1[k] = (W - 1 - k == j1 && j1 < M) ? 1.0 : 0.0;
-    }
+    for (int r = 0; r < KT; ++r)
+#pragma unroll
+        for (int k = 0; k < W; ++k) h[r][k] = (W - 1 - k == jb + r && jb + r < M) ? 1.0 : 0.0;
     double a0[NT], dd[NT];
     const double inv_hop = 1.0 / (double)hop;
     int fcur = -1;
@@ -316,41 +364,39 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int pair, const float* __r
 #pragma unroll
         for (int s = 0; s < W; ++s) {
             const double n = n0 + (double)s;
-            double r0a = 0.0, r0b = 0.0, r1a = 0.0, r1b = 0.0;
+            double ra[KT], rb[KT];
+#pragma unroll
+            for (int r = 0; r < KT; ++r) { ra[r] = 0.0; rb[r] = 0.0; }
 #pragma unroll
             for (int i = NT - 1; i >= 1; --i) {
                 const double cf = fma(n, dd[i], a0[i]);
                 const int slot = (s - 1 - i + 2 * W) % W;
-                if (i & 1) { r0a = fma(cf, h0[slot], r0a); r1a = fma(cf, h1[slot], r1a); }
-                else       { r0b = fma(cf, h0[slot], r0b); r1b = fma(cf, h1[slot], r1b); }
+#pragma unroll
+                for (int r = 0; r < KT; ++r) {
+                    if (i & 1) ra[r] = fma(cf, h[r][slot], ra[r]);
+                    else       rb[r] = fma(cf, h[r][slot], rb[r]);
+                }
             }
             const double cf0 = fma(n, dd[0], a0[0]);
             const int sp = (s - 1 + W) % W;
-            const double y0 = fma(-cf0, h0[sp], -(r0a + r0b));
-            const double y1 = fma(-cf0, h1[sp], -(r1a + r1b));
-            h0[s] = y0;
-            h1[s] = y1;
+#pragma unroll
+            for (int r = 0; r < KT; ++r) h[r][s] = fma(-cf0, h[r][sp], -(ra[r] + rb[r]));
         }
     }
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        const float v0 = i < M ? (float)h0[W - 1 - i] : 0.f;
-        const float v1 = (i < M && j1 < M) ? (float)h1[W - 1 - i] : 0.f;
-        out0[i] = v0;
-        out1[i] = v1;
-        if (i < NT) { outT[(size_t)i * W] = v0; outT[(size_t)i * W + 1] = v1; }
+    for (int r = 0; r < KT; ++r) {
+        const int j = jb + r;
+        if (j < NT) {
+            float* o = Phi + ((size_t)q * NT + j) * W;
+            float* oT = PhiT + (size_t)q * NT * W + j;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float v = (i < M && j < M) ? (float)h[r][W - 1 - i] : 0.f;
+                o[i] = v;
+                if (i < NT) oT[(size_t)i * W] = v;
+            }
+        }
     }
-}
-
-// Phase 1 kernels (separate launches: the fp32 zero-state role needs LDS tiles + ~250 VGPRs, the fp64 role 34 KB of
-// LDS coefficients — fusing them into one kernel only adds up their footprints).
-template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p1z_kernel(const float* __restrict__ ex, int64_t ex_stride,
-                                                     const float* __restrict__ gain, const float* __restrict__ a,
-                                                     float* __restrict__ z, int T, int F, int M, int hop, int L,
-                                                     int NP) {
-    __shared__ float lds[2 * Tile<W>::SIZE];
-    fwd_chunk_body<W, NT, 0>(lds, blockIdx.y, blockIdx.x, ex, ex_stride, gain, a, nullptr, z, 0, T, F, M, hop, L, NP);
 }
 
 // (A variant that interpolates the coefficients once per chunk into an LDS tile and runs 3 trajectories per lane
@@ -361,18 +407,10 @@ template <int W, int NT>
 __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
                                                      int nq) {
+    constexpr int NG = (NT + p1h_kt(W) - 1) / p1h_kt(W);  // trajectory groups per chunk
     const int idx = blockIdx.x;
-    const int pair = idx % (NT / 2), qblk = idx / (NT / 2);
-    p1_hom_body<W, NT>(qblk, pair, a, Phi, PhiT, F, M, hop, L, NP, nq);
-}
-
-template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p3_kernel(const float* __restrict__ ex, int64_t ex_stride,
-                                                    const float* __restrict__ gain, const float* __restrict__ a,
-                                                    const float* __restrict__ S, float* __restrict__ y,
-                                                    int64_t y_stride, int T, int F, int M, int hop, int L, int NC) {
-    __shared__ float lds[2 * Tile<W>::SIZE];
-    fwd_chunk_body<W, NT, 1>(lds, blockIdx.y, blockIdx.x, ex, ex_stride, gain, a, S, y, y_stride, T, F, M, hop, L, NC);
+    const int grp = idx % NG, qblk = idx / NG;
+    p1_hom_body<W, NT>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -443,60 +481,63 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward.  Adjoint ring p[(k + r) % W] = lam_r[k], r = steps done in this block (W >= NT+1).
+// Backward: transposed-form adjoint recursion, tap-parallel like the forward:
+//     g[t] = gy[t] + lam[0];   lam[k] <- lam[k+1] - A[t,k] g[t]
+//   lane r of a quad holds lam[r*TPL .. r*TPL+TPL-1] in a ring p[(k + step) % TPL]; per sample lane 0 forms g and
+//   broadcasts it (DPP), every lane pulls lam[(r+1)*TPL] from its right neighbour (DPP shift) and does TPL FMAs.
 //   MODE 0 (B1): lam_end = 0, lam at chunk start -> zadj[(b*NC+c)*W + k]
-//   MODE 1 (B3): lam_end from lamEnd, writes g[b][t] (the adjoint signal dL/dy_total)
+//   MODE 1 (B3): lam_end from lamEnd[(b*NC+c)*64 + k], writes g[b][t] (the adjoint signal dL/dy_total)
 // ------------------------------------------------------------------------------------------
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restrict__ gy, int64_t gy_stride,
-                                                           const float* __restrict__ a,
-                                                           const float* __restrict__ lamEnd, float* __restrict__ out,
-                                                           int64_t g_stride, int T, int F, int M, int hop, int L,
-                                                           int NC) {
-    using TL = Tile<W>;
-    __shared__ float lds[2 * TL::SIZE];
-    float* xt = lds;
-    float* yt = lds + TL::SIZE;
+__global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ gy, int64_t gy_stride,
+                                                      const float* __restrict__ a, const float* __restrict__ lamEnd,
+                                                      float* __restrict__ out, int64_t g_stride, int T, int F, int M,
+                                                      int hop, int L, int NC) {
+    constexpr int TPL = quad_tpl(W, NT);
+    constexpr int R = 16;
+    using TL = Tile<W, R>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
     const int b = blockIdx.y, cg = blockIdx.x;
     const int lane = threadIdx.x;
     const int lq = lane / W, lr = lane % W;
-    const int c0 = cg * 64;
-    const int c = c0 + lane;
+    const int row = lane >> 2, r = lane & 3;
+    const int c0 = cg * R;
+    const int c = c0 + row;
     const bool mine = c < NC;
     const BufRow gyrow(gy + (size_t)b * gy_stride, T);
     const BufRow grow(MODE == 1 ? out + (size_t)b * g_stride : nullptr, MODE == 1 ? T : 0);
-    float p[W];
+    float p[TPL];
     if (MODE == 1 && mine) {
-        const float* lp = lamEnd + ((size_t)b * NC + c) * 64;
+        const float* lp = lamEnd + ((size_t)b * NC + c) * 64 + r * TPL;
 #pragma unroll
-        for (int k = 0; k < W; ++k) p[k] = k < NT ? lp[k] : 0.f;
+        for (int k = 0; k < TPL; ++k) p[k] = lp[k];
     } else {
 #pragma unroll
-        for (int k = 0; k < W; ++k) p[k] = 0.f;
+        for (int k = 0; k < TPL; ++k) p[k] = 0.f;
     }
-    float a0[NT], dd[NT];
+    float a0[TPL], dd[TPL];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { a0[i] = 0.f; dd[i] = 0.f; }
+    for (int k = 0; k < TPL; ++k) { a0[k] = 0.f; dd[k] = 0.f; }
     const float inv_hop = 1.0f / (float)hop;
     int fcur = -1;
     const int nblk = L / W;
-    // first block (descending) that the wave's first chunk still has samples in
     int blk = nblk - 1;
-    while (blk > 0 && c0 * L + blk * W >= T) --blk;
-    float nx[W];
+    while (blk > 0 && c0 * L + blk * W >= T) --blk;  // wave-uniform: first block that still has samples
+    float nx[TL::ITS];
     TL::fetch(nx, gyrow, c0 * L + blk * W, L, lq, lr);
     for (; blk >= 0; --blk) {
         const int tw = c0 * L + blk * W;
         TL::scatter(xt, nx, lq, lr);
         __syncthreads();
         float gin[W];
-        TL::rows_load(gin, xt, lane);
+        TL::rows_load(gin, xt, row);
         TL::fetch(nx, gyrow, tw - W, L, lq, lr);  // prefetch the earlier block (before 0: hardware returns 0)
         const int t0 = c * L + blk * W;
         const bool act = mine && t0 < T;
-        float gout[W];
+        float keep[W / 4];
 #pragma unroll
-        for (int s = 0; s < W; ++s) gout[s] = 0.f;
+        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
         if (act) {
             int f = t0 / hop;
             if (f > F - 2) f = F - 2;
@@ -505,32 +546,38 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restri
                 const float* pa0 = a + ((size_t)b * F + f) * M;
                 const float* pa1 = pa0 + M;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
+                for (int k = 0; k < TPL; ++k) {
+                    const int i = r * TPL + k;
                     const float v0 = i < M ? pa0[i] : 0.f;
                     const float v1 = i < M ? pa1[i] : 0.f;
-                    a0[i] = v0;
-                    dd[i] = (v1 - v0) * inv_hop;
+                    a0[k] = v0;
+                    dd[k] = (v1 - v0) * inv_hop;
                 }
             }
             const float n0 = (float)(t0 - f * hop);
 #pragma unroll
             for (int s = W - 1; s >= 0; --s) {
-                const int r = W - 1 - s;
+                const int st = W - 1 - s;  // steps done in this block; ring index base (W % TPL == 0)
                 const float n = n0 + (float)s;
-                const float g = gin[s] + p[r];
-                p[r] = 0.f;
+                const float head = p[st % TPL];                 // this lane's lam[r*TPL]
+                const float g = dppf<DPP_BC0>(gin[s] + head);    // lane 0: gy + lam[0]
+                float inc = dppf<DPP_SHL1>(head);                // right neighbour's lam[(r+1)*TPL]
+                inc = r == 3 ? 0.f : inc;                        // lam[4*TPL] = 0
 #pragma unroll
-                for (int k = 0; k < NT; ++k) {
+                for (int k = 0; k < TPL - 1; ++k) {
                     const float cf = fmaf(n, dd[k], a0[k]);
-                    p[(k + r + 1) % W] = fmaf(-cf, g, p[(k + r + 1) % W]);
+                    p[(k + st + 1) % TPL] = fmaf(-cf, g, p[(k + st + 1) % TPL]);
                 }
-                gout[s] = g;
+                const float cfl = fmaf(n, dd[TPL - 1], a0[TPL - 1]);
+                p[st % TPL] = fmaf(-cfl, g, inc);
+                if (MODE == 1) keep[s >> 2] = ((s & 3) == r) ? g : keep[s >> 2];
             }
         }
         if (MODE == 1) {
-            TL::rows_store(yt, gout, lane);
+#pragma unroll
+            for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
             __syncthreads();
-            float o[W];
+            float o[TL::ITS];
             TL::gather(o, yt, lq, lr);
             TL::store(o, grow, tw, L, lq, lr);
         }
@@ -539,7 +586,10 @@ __global__ __launch_bounds__(64) void lpc_adj_chunk_kernel(const float* __restri
     if (MODE == 0 && mine) {
         float* zp = out + ((size_t)b * NC + c) * W;
 #pragma unroll
-        for (int k = 0; k < W; ++k) zp[k] = k < NT ? p[k] : 0.f;
+        for (int k = 0; k < TPL; ++k) {
+            const int i = r * TPL + k;
+            if (i < W) zp[i] = i < NT ? p[k] : 0.f;
+        }
     }
 }
 
@@ -776,22 +826,31 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * (NT / 2))), dim3(64), 0, st, a, Phi,
+    constexpr int NG = (NT + p1h_kt(W) - 1) / p1h_kt(W);
+    hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a, Phi,
                        PhiT, F, M, hop, p.L, p.NP, nq);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
 
 // Fork/join helper: `side` runs P1h (needs only `a`) while `st` runs P1z (needs the excitation).
+// Events come from a small per-thread ring that is never destroyed (destroying an event another stream still
+// waits on proved racy); an event is reused only 64 fork/joins later, long after its wait has been consumed.
 struct ForkJoin {
-    hipEvent_t ev = nullptr;
+    static hipEvent_t next_event() {
+        static thread_local hipEvent_t ring[64] = {};
+        static thread_local unsigned head = 0;
+        hipEvent_t& e = ring[head++ & 63];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        return e;
+    }
     int record_and_wait(hipStream_t from, hipStream_t to) {
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 1;
+        hipEvent_t ev = next_event();
+        if (!ev) return 1;
         if (hipEventRecord(ev, from) != hipSuccess) return 1;
         if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) return 1;
         return 0;
     }
-    ~ForkJoin() { if (ev) (void)hipEventDestroy(ev); }
 };
 
 template <int W, int NT>
@@ -812,16 +871,16 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             }
             if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, s1)) return rc;
         }
-        hipLaunchKernelGGL((lpc_p1z_kernel<W, NT>), dim3((unsigned)ceil_div(p.NP, 64), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, z, T, F, M, hop, p.L, p.NP);
+        hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
+                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP);
         GOLF_LAUNCH_CHECK();
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
                        S, p.NC, p.NP);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_p3_kernel<W, NT>), dim3((unsigned)ceil_div(p.NC, 64), B), dim3(64), 0, st, ex, ex_stride,
-                       gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC);
+    hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
+                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -838,14 +897,14 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
     constexpr int D = 8;
-    const dim3 gq((unsigned)ceil_div(p.NC, 64), B);
-    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
+    const dim3 gq((unsigned)ceil_div(p.NC, 16), B);
+    hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
                        zadj, (int64_t)0, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
                        p.NP);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adj_chunk_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
+    hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
                        (int64_t)T, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3(p.NSEG, B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,

@@ -76,15 +76,14 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
                 ),
             )
 
-    def prefetch(self, gain: AudioTensor, a: AudioTensor, n_samples: int = None) -> None:
+    def prefetch(self, gain: AudioTensor, a: AudioTensor, n_samples: int = None, overlap: bool = True) -> None:
         """Optional hook (not in the reference): start the excitation-independent phase of the filter — the
-        per-chunk transition matrices, the most expensive kernel — on a second HIP stream as soon as the
-        coefficients are known, so that it overlaps whatever produces the excitation (the oscillator).
-        ``SourceFilterSynth`` calls it when present; ``forward`` picks the result up if shapes match."""
+        per-chunk transition matrices — as soon as the coefficients are known, optionally on a second HIP stream.
+        ``SourceFilterSynth(overlap_prefetch=True)`` calls it; ``forward`` picks the result up if shapes match."""
         hop = int(a.hop_length)
         F = a.shape[1]
         T = (F - 1) * hop + 1 if n_samples is None else min(int(n_samples), (F - 1) * hop + 1)
-        self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T)
+        self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T, overlap=overlap)
 
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
         hop = _check_filter_inputs(ex, gain, a)

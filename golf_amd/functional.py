@@ -35,22 +35,27 @@ class PreparedTransitions:
         self.ws, self.key, self.stream, self.a = ws, key, stream, a
 
 
-def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int) -> PreparedTransitions:
-    """Launch the transition-matrix kernel for coefficients ``a`` (B,F,M) and output length ``T`` on the side
-    stream; pass the handle to ltv_allpole_ss(..., prepared=handle).  Lets a decoder overlap the most expensive,
-    excitation-independent phase of the filter with the oscillator that produces the excitation."""
+def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False) -> PreparedTransitions:
+    """Compute the transition matrices for coefficients ``a`` (B,F,M) and output length ``T`` ahead of the
+    excitation; pass the handle to ltv_allpole_ss(..., prepared=handle) (e.g. to filter several signals with the
+    same coefficients, or to start the most expensive, excitation-independent phase early).
+    ``overlap=True`` launches on a second HIP stream that the forward joins right before its boundary scan.
+    Measured on MI355X at B=32 this does NOT pay: the transition kernel already occupies every SIMD, so whatever
+    runs beside it slows down by as much as is saved — hence off by default."""
     _lib.require_device(a)
     lib = _lib.load()
     a = a.detach().contiguous()
     B, F, M = a.shape
     ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), a.device)
     cur = torch.cuda.current_stream(a.device)
-    side = _side_stream(a.device)
-    side.wait_stream(cur)  # `a` (and the fresh workspace) are ordered after the current stream's work
-    ws.record_stream(side)
-    a.record_stream(side)
+    side = None
+    if overlap:
+        side = _side_stream(a.device)
+        side.wait_stream(cur)  # `a` (and the fresh workspace) are ordered after the current stream's work
+        ws.record_stream(side)
+        a.record_stream(side)
     rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
-                                              side.cuda_stream)
+                                              (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
     return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a)
 
@@ -83,18 +88,14 @@ class _LTVAllPoleSS(torch.autograd.Function):
         assert gain.shape == (B, F) and a.shape[0] == B
         T = ss_output_length(Tx, F, hop)
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
-        side = _side_stream(ex.device)
-        flags = 0
+        side, flags = None, 0
         if prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version):
-            ws, flags = prepared.ws, HAVE_TRANSITIONS
-            side = prepared.stream
+            ws, flags, side = prepared.ws, HAVE_TRANSITIONS, prepared.stream
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
-            ws.record_stream(side)
-            a.record_stream(side)
         rc = lib.golf_ltv_allpole_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(), y.data_ptr(),
                                           y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
-                                          side.cuda_stream, _lib.stream_ptr())
+                                          side.cuda_stream if side is not None else 0, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_fwd_f32")
         ctx.hop = hop
         ctx.save_for_backward(ex, gain, a, y, ws)

@@ -17,8 +17,9 @@ class SourceFilterSynth(Synth):
     """GOLF-ss / GOLF-ff decoder: (oscillator + filtered noise) -> end filter -> room filter."""
 
     def __init__(self, harm_oscillator, noise_generator, noise_filter, end_filter, room_filter=None,
-                 subtract_harmonics: bool = True, check_ranges: bool = False):
+                 subtract_harmonics: bool = True, check_ranges: bool = False, overlap_prefetch: bool = False):
         super().__init__()
+        self.overlap_prefetch = overlap_prefetch  # see LTVMinimumPhaseFilterPrecise.prefetch (off: does not pay at B=32)
         self.subtract_harmonics = subtract_harmonics
         self.check_ranges = check_ranges  # the reference's host-syncing asserts, off by default
         # attribute order defines the encoder channel layout (models/ctrl.py:59-69)
@@ -32,7 +33,8 @@ class SourceFilterSynth(Synth):
                 noise_generator_params: Tuple[AudioTensor, ...], noise_filter_params: Tuple[AudioTensor, ...],
                 end_filter_params: Tuple[AudioTensor, ...], voicing: Optional[AudioTensor] = None,
                 target: Optional[AudioTensor] = None, **other_params) -> AudioTensor:
-        if target is None and hasattr(self.end_filter, "prefetch") and hasattr(self.harm_oscillator, "output_length"):
+        if (self.overlap_prefetch and target is None and hasattr(self.end_filter, "prefetch")
+                and hasattr(self.harm_oscillator, "output_length")):
             # overlap the filter's excitation-independent phase with the oscillator (second HIP stream)
             self.end_filter.prefetch(*end_filter_params, n_samples=self.harm_oscillator.output_length(phase))
         harm_osc = self.harm_oscillator(phase, *harm_oscillator_params)

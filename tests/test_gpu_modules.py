@@ -93,10 +93,12 @@ def test_prefetch_overlap_is_bit_identical():
     inp = make_inputs(B=4, T=9600, device="cuda")
     ex, gain, a = inp["noise"], inp["gain"], inp["a"]
     y0 = GF.ltv_allpole_ss(ex, gain, a, 240)
-    prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1])
-    y1 = GF.ltv_allpole_ss(ex, gain, a, 240, prep)
-    torch.cuda.synchronize()
-    assert torch.equal(y0, y1)
+    for overlap in (False, True):
+        prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1], overlap=overlap)
+        y1 = GF.ltv_allpole_ss(ex, gain, a, 240, prep)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1), overlap
+    prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1], overlap=True)
     a2 = a * 0.5
     y2 = GF.ltv_allpole_ss(ex, gain, a2, 240, prep)  # handle is for `a`: must be ignored
     y2_ref = GF.ltv_allpole_ss(ex, gain, a2, 240)
@@ -104,7 +106,7 @@ def test_prefetch_overlap_is_bit_identical():
     assert torch.equal(y2, y2_ref) and not torch.equal(y2, y0)
     # backward through a prepared forward
     ag = a.clone().requires_grad_(True)
-    prep = GF.ltv_allpole_prepare(ag, 240, y0.shape[1])
+    prep = GF.ltv_allpole_prepare(ag, 240, y0.shape[1], overlap=True)
     GF.ltv_allpole_ss(ex, gain, ag, 240, prep).square().sum().backward()
     ag2 = a.clone().requires_grad_(True)
     GF.ltv_allpole_ss(ex, gain, ag2, 240).square().sum().backward()
