@@ -99,7 +99,7 @@ def test_prefetch_overlap_is_bit_identical():
         torch.cuda.synchronize()
         assert torch.equal(y0, y1), overlap
     prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1], overlap=True)
-    a2 = a * 0.5
+    a2 = make_inputs(B=4, T=9600, device="cuda", seed=7)["a"]  # another STABLE coefficient set
     y2 = GF.ltv_allpole_ss(ex, gain, a2, 240, prep)  # handle is for `a`: must be ignored
     y2_ref = GF.ltv_allpole_ss(ex, gain, a2, 240)
     torch.cuda.synchronize()
