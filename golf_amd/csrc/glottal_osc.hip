@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void osc_phase_tile_kernel(const float* __rest
 // ---- O2 ---------------------------------------------------------------------------------------
 // MODE 0: forward render (writes fine samples);  MODE 1: backward w.r.t. table_select_weight
 // (reduces g_pre * d(pre)/d(p_row) over the interval into part[b][interval][2]).
-#define OSC_RENDER_THREADS 1024
+#define OSC_RENDER_THREADS 512  // 4 blocks/CU: the 640 blocks of the B=32 config run in one round
 template <int MODE>
 __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const double* __restrict__ Cloc,

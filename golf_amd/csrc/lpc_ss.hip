@@ -28,6 +28,7 @@
 //   reverse recursion that also accumulates d/d gain and d/d a at frame rate (hat weights),
 //   B4 tiny segment->frame reduction.  No (B,T,M) gradient tensor either.
 #include "common.h"
+#include <cstdlib>
 
 namespace golf {
 
@@ -312,12 +313,12 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
 //   PhiT[q][i][j] (row i contiguous: forward scan reads rows)
 //   lane = flat chunk q;  `pair` selects trajectories (2*pair, 2*pair+1)
 // ------------------------------------------------------------------------------------------
-constexpr int p1h_kt(int W) { return W <= 24 ? 3 : 2; }  // trajectories per lane (register budget: KT*W doubles)
+// trajectories per lane.  Measured on MI355X, B=32 (GOLF_P1H_KT=1/2/3): 93.6 / 76.8 / 85.4 us -> 2.
+constexpr int p1h_kt(int W) { return 2; }
 
-template <int W, int NT>
+template <int W, int NT, int KT>
 __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __restrict__ a, float* __restrict__ Phi,
                                             float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
-    constexpr int KT = p1h_kt(W);
     const int q = qblk * 64 + threadIdx.x;
     if (q >= nq) return;
     const int jb = KT * grp;  // trajectories jb .. jb+KT-1
@@ -414,14 +415,14 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 // against it — 23 instead of 33 fp64 FMAs per trajectory-step — was measured SLOWER (84.7 vs 77.6 us): a lone wave
 // already sustains one fp64 FMA per ~5.2 cycles (tools/ubench/fma_issue.hip), and the LDS reads, waits and
 // producer bookkeeping cost more issue slots than the FMAs they saved.  See DESIGN.md.)
-template <int W, int NT>
+template <int W, int NT, int KT>
 __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
                                                      int nq) {
-    constexpr int NG = (NT + p1h_kt(W) - 1) / p1h_kt(W);  // trajectory groups per chunk
+    constexpr int NG = (NT + KT - 1) / KT;  // trajectory groups per chunk
     const int idx = blockIdx.x;
     const int grp = idx % NG, qblk = idx / NG;
-    p1_hom_body<W, NT>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
+    p1_hom_body<W, NT, KT>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -837,9 +838,19 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    constexpr int NG = (NT + p1h_kt(W) - 1) / p1h_kt(W);
-    hipLaunchKernelGGL((lpc_p1h_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a, Phi,
-                       PhiT, F, M, hop, p.L, p.NP, nq);
+    static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
+    if (kt_env == 1) {
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 1>), dim3((unsigned)(ceil_div(nq, 64) * NT)), dim3(64), 0, st, a,
+                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+    } else if (p1h_kt(W) == 3 && kt_env != 2) {
+        constexpr int NG = (NT + 2) / 3;
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
+                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+    } else {
+        constexpr int NG = (NT + 1) / 2;
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
+                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+    }
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
