@@ -57,7 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into golf_amd/lib/libgolf_hip.so (hipcc cross-compiles
     without a GPU).  Rebuilds only when a source/header is newer than the library."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "golf_amd.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_common.h"),
+                   os.path.join(INCLUDE, "golf_amd.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH

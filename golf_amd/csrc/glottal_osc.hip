@@ -292,6 +292,78 @@ __global__ void osc_decimate_T_kernel(const float* __restrict__ g_out, int64_t g
     g_pre[idx] = acc;
 }
 
+// Register-blocked transposed decimator for os == 4 (the GOLF configs): for every output phase p,
+//   g_pre[j*4 + p] = sum_d h_p[d] g_out[j - d]  — a plain 33-tap FIR over g_out with reversed taps, evaluated with the
+//   same 4-outputs-per-thread sliding window as the forward decimator; the 16 results of a thread are the 16
+//   consecutive fine samples (4j..4j+15), staged through LDS for a coalesced store.
+__global__ __launch_bounds__(256) void osc_decimate_T4_kernel(const float* __restrict__ g_out, int64_t g_out_stride,
+                                                              int Tout, const float* __restrict__ taps, int K,
+                                                              float* __restrict__ g_pre, int N, int RS4, int dmax,
+                                                              int ngrp) {
+    constexpr int OS = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: G = smem[0 .. 4*RS4), H (16-aligned) [OS][ngrp*4+8], O = output tile [OSC_TILE*OS]
+    float* G = smem;
+    const int hoff = (4 * RS4 + 3) & ~3;
+    float* H = smem + hoff;
+    const int HS = ngrp * 4 + 8;
+    float* O = H + OS * HS;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int j0 = blockIdx.x * OSC_TILE;
+    const float* gb = g_out + (size_t)b * g_out_stride;
+    const int half = (K - 1) / 2;
+    const int span = OSC_TILE + ngrp * 4 + 4;
+    for (int i = tid; i < span; i += 256) {  // Gt[i] = g_out[j0 - dmax + i]
+        const int j = j0 - dmax + i;
+        G[(i & 3) * RS4 + (i >> 2)] = (j >= 0 && j < Tout) ? gb[j] : 0.f;
+    }
+    for (int e = tid; e < OS * HS; e += 256) {  // H[p][3 + q'] = h_p[dmax - q'] = taps[half + 4*(dmax-q') + p]
+        const int p = e / HS, q = e - p * HS - 3;
+        const int k = half + OS * (dmax - q) + p;
+        H[e] = (q >= 0 && k >= 0 && k < K) ? taps[k] : 0.f;
+    }
+    __syncthreads();
+    const int u = tid;
+    float acc[4][OS];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int p = 0; p < OS; ++p) acc[r][p] = 0.f;
+    const float* Gp = G + u;
+    float4 hprev[OS];
+#pragma unroll
+    for (int p = 0; p < OS; ++p) hprev[p] = reinterpret_cast<const float4*>(H + p * HS)[0];
+    for (int g = 0; g <= ngrp; ++g) {
+        const float x0 = Gp[0 * RS4 + g], x1 = Gp[1 * RS4 + g], x2 = Gp[2 * RS4 + g], x3 = Gp[3 * RS4 + g];
+#pragma unroll
+        for (int p = 0; p < OS; ++p) {
+            const float4 hc = reinterpret_cast<const float4*>(H + p * HS)[g + 1];
+            const float4 hp = hprev[p];
+            acc[0][p] = fmaf(hp.w, x0, acc[0][p]); acc[1][p] = fmaf(hp.z, x0, acc[1][p]);
+            acc[2][p] = fmaf(hp.y, x0, acc[2][p]); acc[3][p] = fmaf(hp.x, x0, acc[3][p]);
+            acc[0][p] = fmaf(hc.x, x1, acc[0][p]); acc[1][p] = fmaf(hp.w, x1, acc[1][p]);
+            acc[2][p] = fmaf(hp.z, x1, acc[2][p]); acc[3][p] = fmaf(hp.y, x1, acc[3][p]);
+            acc[0][p] = fmaf(hc.y, x2, acc[0][p]); acc[1][p] = fmaf(hc.x, x2, acc[1][p]);
+            acc[2][p] = fmaf(hp.w, x2, acc[2][p]); acc[3][p] = fmaf(hp.z, x2, acc[3][p]);
+            acc[0][p] = fmaf(hc.z, x3, acc[0][p]); acc[1][p] = fmaf(hc.y, x3, acc[1][p]);
+            acc[2][p] = fmaf(hc.x, x3, acc[2][p]); acc[3][p] = fmaf(hp.w, x3, acc[3][p]);
+            hprev[p] = hc;
+        }
+    }
+    // fine index within the tile: (4u + r)*4 + p ; transposed so that the copy-out is conflict-light and coalesced
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int p = 0; p < OS; ++p) O[(4 * u + r) * OS + p] = acc[r][p];
+    __syncthreads();
+    float* ob = g_pre + (size_t)b * N;
+    const int64_t m0 = (int64_t)j0 * OS;
+    for (int e = tid; e < OSC_TILE * OS; e += 256) {
+        const int64_t m = m0 + e;
+        if (m < N) ob[m] = O[e];
+    }
+}
+
 // partials -> g_wsel:  row k receives interval k (as row0) and interval k-1 (as row1); rows beyond
 // Fw-1 were clamped onto Fw-1.  d pre / d wsel = (n_tab-1) * d pre / d p.
 __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_wsel, int B, int Fw,
@@ -395,7 +467,21 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
     const double* Cw = (const double*)((char*)ws + g.off_cw);  // still valid from the forward
     float* g_pre = (float*)((char*)ws + g.off_pre);
     float* part = (float*)((char*)ws + g.off_part);
-    if (os > 1) {
+    if (os == 4) {
+        const int half = (K - 1) / 2;
+        const int dmin = -((half + os - 1) / os);
+        const int dmax = half / os;
+        const int nq = dmax - dmin + 1;
+        const int ngrp = (nq + 2) / 4;
+        int RS4 = OSC_TILE / 4 + ngrp + 2;
+        while (RS4 % 32 != 8) ++RS4;
+        const int hoff = (4 * RS4 + 3) & ~3;
+        const size_t ldsT = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) + (size_t)OSC_TILE * os);
+        if (ldsT > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_bwd: %d taps exceed LDS", K);
+        hipLaunchKernelGGL(osc_decimate_T4_kernel, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), ldsT, st,
+                           g_out, g_out_stride, Tout, taps, K, g_pre, g.N, RS4, dmax, ngrp);
+        GOLF_LAUNCH_CHECK();
+    } else if (os > 1) {
         const int64_t n = (int64_t)B * g.N;
         hipLaunchKernelGGL(osc_decimate_T_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, g_out,
                            g_out_stride, Tout, taps, K, os, g_pre, g.N, B);

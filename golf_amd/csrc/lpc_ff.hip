@@ -12,6 +12,7 @@
 //           window sum (computed on the fly from the same window values, like the reference's
 //           extra ones row).
 #include "common.h"
+#include "device_common.h"
 
 namespace golf {
 
@@ -82,6 +83,98 @@ __global__ __launch_bounds__(64) void ff_frames_kernel(const float* __restrict__
     }
 }
 
+// Quad version (fast path, Wl % W == 0): 4 lanes per frame, each owning TPL taps and a TPL-deep systolic window
+// (see lpc_ss.hip / device_common.h), 16 frames per wave, coalesced bounds-checked tile I/O.  The frame's
+// zero padding is what the buffer descriptor returns outside [0,Tx).
+template <int W, int NT>
+__global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                        const float* __restrict__ gain, const float* __restrict__ a,
+                                                        const float* __restrict__ window, float* __restrict__ wf,
+                                                        int Tx, int F, int M, int hop, int Wl, int nfr) {
+    constexpr int TPL = quad_tpl(W, NT);
+    constexpr int R = 16;
+    using TL = Tile<W, R>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
+    const int b = blockIdx.y, fg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int lq = lane / W, lr = lane % W;
+    const int row = lane >> 2, r = lane & 3;
+    const int f0 = fg * R;
+    const int f = f0 + row;
+    const bool mine = f < nfr;
+    const int pad = Wl / 2;
+    const BufRow xrow(ex + (size_t)b * ex_stride, Tx);
+    const BufRow orow(wf + (size_t)b * nfr * Wl, nfr * Wl);
+    float cf[TPL];
+    {
+        const float* pa = a + ((size_t)b * F + (mine ? f : 0)) * M;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            const int i = r * TPL + k;
+            cf[k] = (mine && i < M) ? pa[i] : 0.f;
+        }
+    }
+    float w[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) w[k] = 0.f;
+    const float inv_hop = 1.0f / (float)hop;
+    const float* gb = gain + (size_t)b * F;
+    const int nblk = Wl / W;
+    float nx[TL::ITS];
+    TL::fetch(nx, xrow, f0 * hop - pad, hop, lq, lr);
+    for (int blk = 0; blk < nblk; ++blk) {
+        TL::scatter(xt, nx, lq, lr);
+        __syncthreads();
+        float xin[W];
+        TL::rows_load(xin, xt, row);
+        TL::fetch(nx, xrow, f0 * hop - pad + (blk + 1) * W, hop, lq, lr);
+        const int k0 = blk * W;
+        const int t0 = f * hop - pad + k0;
+        // gain line(s) for this block: at most one frame boundary inside (W <= hop)
+        const int tb = t0 > 0 ? t0 : 0;
+        int ft = tb / hop;
+        if (ft > F - 2) ft = F - 2;
+        const float gA = gb[ft];
+        const float gB = gb[ft + 1];
+        const float dA = (gB - gA) * inv_hop;
+        const float gC = ft + 2 < F ? gb[ft + 2] : gB;
+        const float dB = (gC - gB) * inv_hop;
+        const bool can_cross = ft < F - 2;
+        const int nbase = t0 - ft * hop;
+        float keep[W / 4];
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const int n = nbase + s;
+            const float G = (can_cross && n >= hop) ? fmaf((float)(n - hop), dB, gB) : fmaf((float)n, dA, gA);
+            const float x = xin[s] * G;
+            float pa_ = 0.f, pb_ = 0.f;
+#pragma unroll
+            for (int k = TPL - 1; k >= 1; --k) {
+                const int slot = (s - 1 - k + 4 * TPL) % TPL;
+                if (k & 1) pa_ = fmaf(cf[k], w[slot], pa_);
+                else       pb_ = fmaf(cf[k], w[slot], pb_);
+            }
+            float part = fmaf(cf[0], w[(s - 1 + TPL) % TPL], pa_ + pb_);
+            part += dppf<DPP_XOR1>(part);
+            part += dppf<DPP_XOR2>(part);
+            const float y = x - part;
+            const float inc = dppf<DPP_SHR1>(w[s % TPL]);
+            w[s % TPL] = r == 0 ? y : inc;
+            keep[s >> 2] = ((s & 3) == r) ? y * window[k0 + s] : keep[s >> 2];
+        }
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
+        __syncthreads();
+        float o[TL::ITS];
+        TL::gather(o, yt, lq, lr);
+        TL::store(o, orow, f0 * Wl + k0, Wl, lq, lr);
+        __syncthreads();
+    }
+}
+
 __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restrict__ window, float* __restrict__ y,
                               int64_t y_stride, int B, int Ty, int hop, int Wl, int nfr) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,8 +201,13 @@ static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, cons
                      float* y, int64_t y_stride, int B, int Tx, int F, int M, int hop, int Wl, int Ty, int nfr,
                      float* wf, hipStream_t st) {
     const int nq = B * nfr;
-    hipLaunchKernelGGL((ff_frames_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex, ex_stride,
-                       gain, a, window, wf, Tx, F, M, hop, Wl, nfr, nq);
+    if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29)) {
+        hipLaunchKernelGGL((ff_framesq_kernel<W, NT>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64), 0, st, ex,
+                           ex_stride, gain, a, window, wf, Tx, F, M, hop, Wl, nfr);
+    } else {
+        hipLaunchKernelGGL((ff_frames_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex, ex_stride,
+                           gain, a, window, wf, Tx, F, M, hop, Wl, nfr, nq);
+    }
     GOLF_LAUNCH_CHECK();
     const int64_t n = (int64_t)B * Ty;
     hipLaunchKernelGGL(ff_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)wf, window, y,

@@ -28,6 +28,7 @@
 //   reverse recursion that also accumulates d/d gain and d/d a at frame rate (hat weights),
 //   B4 tiny segment->frame reduction.  No (B,T,M) gradient tensor either.
 #include "common.h"
+#include "device_common.h"
 #include <cstdlib>
 
 namespace golf {
@@ -82,93 +83,6 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Tile I/O: a wave owns 64 consecutive chunks of one utterance.  For each W-step block the wave moves
-// a 64 x W tile between HBM and registers THROUGH LDS so that global accesses are coalesced
-// (element e = it*64 + lane  <->  row e/W (= chunk), col e%W) while each lane computes on its own row.
-// Row stride W+1 floats keeps both access patterns bank-conflict free.  Single-wave workgroups.
-// ------------------------------------------------------------------------------------------
-// Bounds-checked view of one utterance row of T floats (raw buffer descriptor, wave-uniform): loads outside
-// [0,T) return 0 and stores outside are dropped BY THE HARDWARE — masking without branches, which is what lets
-// hipcc keep the prefetch loads in flight (per-element `if (t<T)` made it wait for every load, 24 serial HBM
-// round trips per block).
-struct BufRow {
-    __amdgpu_buffer_rsrc_t rs;
-    __device__ __forceinline__ BufRow(const float* p, int T)
-        : rs(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, T * 4, 0x00020000)) {}
-    __device__ __forceinline__ float ld(int t) const {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4, 0, 0));
-    }
-    __device__ __forceinline__ void st(int t, float v) const {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, t * 4, 0, 0);
-    }
-};
-
-template <int W, int ROWS = 64>
-struct Tile {
-    static constexpr int LD = W + 1;
-    static constexpr int SIZE = ROWS * LD;
-    static constexpr int ITS = ROWS * W / 64;  // elements per lane
-
-    __device__ static __forceinline__ void rowcol(int it, int lq, int lr, int& row, int& col) {
-        const int q = (it * 64) / W, r = (it * 64) % W;  // constants after unrolling
-        col = r + lr;
-        row = q + lq;
-        if (col >= W) { col -= W; row += 1; }
-        if (col >= W) { col -= W; row += 1; }            // W < 64: lr + r < 2W, at most two wraps (W >= 8: lr<W)
-    }
-    // global -> registers, coalesced order; element at t = tbase + row*L + col (0 outside [0,T))
-    __device__ static __forceinline__ void fetch(float (&r)[ITS], const BufRow& src, int tbase, int L, int lq,
-                                                 int lr) {
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            int row, col;
-            rowcol(it, lq, lr, row, col);
-            r[it] = src.ld(tbase + row * L + col);
-        }
-    }
-    __device__ static __forceinline__ void store(const float (&r)[ITS], const BufRow& dst, int tbase, int L, int lq,
-                                                 int lr) {
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            int row, col;
-            rowcol(it, lq, lr, row, col);
-            dst.st(tbase + row * L + col, r[it]);
-        }
-    }
-    __device__ static __forceinline__ void scatter(float* lds, const float (&r)[ITS], int lq, int lr) {
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            int row, col;
-            rowcol(it, lq, lr, row, col);
-            lds[row * LD + col] = r[it];
-        }
-    }
-    __device__ static __forceinline__ void gather(float (&r)[ITS], const float* lds, int lq, int lr) {
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            int row, col;
-            rowcol(it, lq, lr, row, col);
-            r[it] = lds[row * LD + col];
-        }
-    }
-    __device__ static __forceinline__ void rows_load(float (&x)[W], const float* lds, int row) {
-#pragma unroll
-        for (int s = 0; s < W; ++s) x[s] = lds[row * LD + s];
-    }
-    __device__ static __forceinline__ void rows_store(float* lds, const float (&x)[W], int row) {
-#pragma unroll
-        for (int s = 0; s < W; ++s) lds[row * LD + s] = x[s];
-    }
-};
-
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float f4get(const float4& v, int k) {
-    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
-}
-
-// ------------------------------------------------------------------------------------------
 // Tap-parallel in-register recursion (fp32): a QUAD of 4 lanes runs one chunk, 16 chunks per wave.
 //   Lane r of the quad owns taps [r*TPL, (r+1)*TPL) and a TPL-deep rotating window holding the history delayed
 //   by r*TPL samples: w[k] ~ y[t-1-(r*TPL+k)].  Per sample: TPL coefficient FMAs + TPL dot FMAs, a 2-stage DPP
@@ -177,21 +91,6 @@ __device__ __forceinline__ float f4get(const float4& v, int k) {
 //   instead of ~62 for the one-lane-per-chunk version: a lone wave issues roughly one instruction per 4-5 cycles
 //   whatever it is, so instruction count IS the latency of these kernels.
 // ------------------------------------------------------------------------------------------
-constexpr int quad_tpl(int W, int NT) {
-    for (int d = 1; d <= W; ++d)
-        if (W % d == 0 && 4 * d >= NT) return d;
-    return W;
-}
-template <int CTRL>
-__device__ __forceinline__ float dppf(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-#define DPP_XOR1 0xB1   /* quad_perm [1,0,3,2] */
-#define DPP_XOR2 0x4E   /* quad_perm [2,3,0,1] */
-#define DPP_SHR1 0x90   /* quad_perm [0,0,1,2]: lane r reads lane r-1 */
-#define DPP_SHL1 0xF9   /* quad_perm [1,2,3,3]: lane r reads lane r+1 */
-#define DPP_BC0  0x00   /* quad_perm [0,0,0,0]: broadcast lane 0 of the quad */
-
 //   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
 //   MODE 1 (P3) : initial state S[(b*NCQ+c)*64 + i], writes y[b][t]
 template <int W, int NT, int MODE>
@@ -669,7 +568,8 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
 #undef GOLF_B2_STEP
 }
 
-// B3b: parallel part of the backward.  One workgroup per (gradient segment, utterance):
+// B3b: parallel part of the backward.  One WAVE per gradient segment (4 segments per workgroup), lane k = tap
+//   (lane NT = the gain term):
 //   g_ex[t] = g[t]*G[t];  per-segment hat-weighted correlations
 //   V0[k] = sum_t -g[t] y[t-1-k],  V1[k] = sum_t -n g[t] y[t-1-k]   (n = t - f*hop)
 //   U0    = sum_t  g[t] ex[t],     U1    = sum_t  n g[t] ex[t]
@@ -681,11 +581,15 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
                                                             int64_t g_ex_stride, float* __restrict__ pa,
                                                             float* __restrict__ pg, int T, int F, int NT, int W,
                                                             int hop, int seg, int NSEG) {
-    __shared__ float gs[256], es[256], ys[256 + 64];
-    __shared__ float red[2][4][64];
-    const int sg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float gs_[4][256 + 4], ge_[4][256 + 4], ys_[4][256 + 64 + 4];
+    const int wv = threadIdx.x >> 6, k = threadIdx.x & 63;
+    const int sg = blockIdx.x * 4 + wv, b = blockIdx.y;
+    if (sg >= NSEG) return;  // whole wave
+    float* gs = gs_[wv];
+    float* ge = ge_[wv];  // g*ex
+    float* ys = ys_[wv];
     const int ts = sg * seg;
-    const int len = (ts + seg <= T ? seg : T - ts);  // >= 1
+    const int len = (ts + seg <= T ? seg : T - ts);  // 1..256
     int f = ts / hop;
     if (f > F - 2) f = F - 2;
     const int nbase = ts - f * hop;
@@ -694,50 +598,49 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     const float* gb = g + (size_t)b * g_stride;
     const float* yb = y + (size_t)b * y_stride;
     const float* eb = ex + (size_t)b * ex_stride;
-    if (tid < len) {
-        const float gv = gb[ts + tid];
-        gs[tid] = gv;
-        es[tid] = eb[ts + tid];
-        g_ex[(size_t)b * g_ex_stride + ts + tid] = gv * fmaf((float)(nbase + tid), dg, g0);
+    for (int u = k; u < 256; u += 64) {
+        float gv = 0.f, ev = 0.f;
+        if (u < len) {
+            gv = gb[ts + u];
+            ev = eb[ts + u];
+            g_ex[(size_t)b * g_ex_stride + ts + u] = gv * fmaf((float)(nbase + u), dg, g0);
+        }
+        gs[u] = gv;      // zero padded to a multiple of 4 and beyond
+        ge[u] = gv * ev;
     }
-    // ys[u] = y[ts - 64 + u], u in [0, len + 64)
-    for (int u = tid; u < len + 64; u += 256) {
+    for (int u = k; u < 256 + 64; u += 64) {  // ys[u] = y[ts - 64 + u]
         const int t = ts - 64 + u;
         ys[u] = (t >= 0 && t < T) ? yb[t] : 0.f;
     }
-    __syncthreads();
-    const int k = tid & 63, part = tid >> 6;
-    float acc0 = 0.f, acc1 = 0.f;
-    const int per = (len + 3) / 4;
-    const int lo = part * per, hi = (lo + per < len ? lo + per : len);
+    __builtin_amdgcn_s_waitcnt(0);  // single wave owns its LDS rows
+    __builtin_amdgcn_wave_barrier();
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    const int len4 = (len + 3) & ~3;
     if (k < NT) {
-        for (int t = lo; t < hi; ++t) {
-            const float gv = gs[t];
-            const float yv = ys[64 + t - 1 - k];
-            acc0 = fmaf(-gv, yv, acc0);
-            acc1 = fmaf(-gv * (float)(nbase + t), yv, acc1);
+        const float* yk = ys + 63 - k;  // yk[t] = y[ts + t - 1 - k]
+        for (int t = 0; t < len4; t += 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(gs + t);
+            const float n = (float)(nbase + t);
+            const float y0 = yk[t], y1 = yk[t + 1], y2 = yk[t + 2], y3 = yk[t + 3];
+            a0 = fmaf(gv.x, y0, a0);              b0 = fmaf(gv.y, y1, b0);
+            a0 = fmaf(gv.z, y2, a0);              b0 = fmaf(gv.w, y3, b0);
+            a1 = fmaf(gv.x * n, y0, a1);          b1 = fmaf(gv.y * (n + 1.f), y1, b1);
+            a1 = fmaf(gv.z * (n + 2.f), y2, a1);  b1 = fmaf(gv.w * (n + 3.f), y3, b1);
         }
+        float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
+        pp[k] = -(a0 + b0);
+        pp[W + k] = -(a1 + b1);
     } else if (k == NT) {
-        for (int t = lo; t < hi; ++t) {
-            const float gv = gs[t] * es[t];
-            acc0 += gv;
-            acc1 = fmaf(gv, (float)(nbase + t), acc1);
+        for (int t = 0; t < len4; t += 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(ge + t);
+            const float n = (float)(nbase + t);
+            a0 += gv.x + gv.z;
+            b0 += gv.y + gv.w;
+            a1 = fmaf(gv.x, n, a1);          b1 = fmaf(gv.y, n + 1.f, b1);
+            a1 = fmaf(gv.z, n + 2.f, a1);    b1 = fmaf(gv.w, n + 3.f, b1);
         }
-    }
-    red[0][part][k] = acc0;
-    red[1][part][k] = acc1;
-    __syncthreads();
-    if (part == 0 && k <= NT) {
-        const float v0 = (red[0][0][k] + red[0][1][k]) + (red[0][2][k] + red[0][3][k]);
-        const float v1 = (red[1][0][k] + red[1][1][k]) + (red[1][2][k] + red[1][3][k]);
-        if (k < NT) {
-            float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
-            pp[k] = v0;
-            pp[W + k] = v1;
-        } else {
-            pg[((size_t)b * NSEG + sg) * 2 + 0] = v0;
-            pg[((size_t)b * NSEG + sg) * 2 + 1] = v1;
-        }
+        pg[((size_t)b * NSEG + sg) * 2 + 0] = a0 + b0;
+        pg[((size_t)b * NSEG + sg) * 2 + 1] = a1 + b1;
     }
 }
 
@@ -929,7 +832,7 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
                        (int64_t)T, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3(p.NSEG, B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
+    hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
                        y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG);
     GOLF_LAUNCH_CHECK();
     const int n4 = B * F * (M + 1);
