@@ -87,6 +87,14 @@ struct Tile {
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// acc += s * v with the broadcast value taken straight from an SGPR (v_readlane result): one instruction.
+// (Left to itself hipcc SLP-packs pairs of these into v_pk_fma_f32 and spends a v_mov per operand to build the
+// register pairs — ~17 extra instructions per scan step.)
+__device__ __forceinline__ float fmac_sgpr(float acc, float v, float lane_src, int lane) {
+    const int sj = __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_src), lane);
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(sj), "v"(v));
+    return acc;
+}
 __device__ __forceinline__ float f4get(const float4& v, int k) {
     return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }

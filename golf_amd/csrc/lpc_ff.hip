@@ -121,6 +121,12 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
     const float inv_hop = 1.0f / (float)hop;
     const float* gb = gain + (size_t)b * F;
     const int nblk = Wl / W;
+    // window tile in LDS (applied per element in the coalesced store phase, not per recursion step)
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    for (int k = lane; k < Wl; k += 64) wl[k] = window[k];
+    float gA = 0.f, dA = 0.f, gB = 0.f, dB = 0.f;
+    bool can_cross = false;
+    int ftcur = -1;
     float nx[TL::ITS];
     TL::fetch(nx, xrow, f0 * hop - pad, hop, lq, lr);
     for (int blk = 0; blk < nblk; ++blk) {
@@ -131,16 +137,19 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
         TL::fetch(nx, xrow, f0 * hop - pad + (blk + 1) * W, hop, lq, lr);
         const int k0 = blk * W;
         const int t0 = f * hop - pad + k0;
-        // gain line(s) for this block: at most one frame boundary inside (W <= hop)
+        // gain line(s) for this block: at most one frame boundary inside (W <= hop); reload only on change
         const int tb = t0 > 0 ? t0 : 0;
         int ft = tb / hop;
         if (ft > F - 2) ft = F - 2;
-        const float gA = gb[ft];
-        const float gB = gb[ft + 1];
-        const float dA = (gB - gA) * inv_hop;
-        const float gC = ft + 2 < F ? gb[ft + 2] : gB;
-        const float dB = (gC - gB) * inv_hop;
-        const bool can_cross = ft < F - 2;
+        if (ft != ftcur) {
+            ftcur = ft;
+            gA = gb[ft];
+            gB = gb[ft + 1];
+            dA = (gB - gA) * inv_hop;
+            const float gC = ft + 2 < F ? gb[ft + 2] : gB;
+            dB = (gC - gB) * inv_hop;
+            can_cross = ft < F - 2;
+        }
         const int nbase = t0 - ft * hop;
         float keep[W / 4];
 #pragma unroll
@@ -163,13 +172,19 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
             const float y = x - part;
             const float inc = dppf<DPP_SHR1>(w[s % TPL]);
             w[s % TPL] = r == 0 ? y : inc;
-            keep[s >> 2] = ((s & 3) == r) ? y * window[k0 + s] : keep[s >> 2];
+            keep[s >> 2] = ((s & 3) == r) ? y : keep[s >> 2];
         }
 #pragma unroll
         for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
         __syncthreads();
         float o[TL::ITS];
         TL::gather(o, yt, lq, lr);
+#pragma unroll
+        for (int it = 0; it < TL::ITS; ++it) {
+            int trow, tcol;
+            TL::rowcol(it, lq, lr, trow, tcol);
+            o[it] *= wl[k0 + tcol];
+        }
         TL::store(o, orow, f0 * Wl + k0, Wl, lq, lr);
         __syncthreads();
     }
@@ -201,8 +216,9 @@ static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, cons
                      float* y, int64_t y_stride, int B, int Tx, int F, int M, int hop, int Wl, int Ty, int nfr,
                      float* wf, hipStream_t st) {
     const int nq = B * nfr;
-    if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29)) {
-        hipLaunchKernelGGL((ff_framesq_kernel<W, NT>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64), 0, st, ex,
+    if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29) && Wl <= 32768) {
+        hipLaunchKernelGGL((ff_framesq_kernel<W, NT>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64),
+                           sizeof(float) * (size_t)Wl, st, ex,
                            ex_stride, gain, a, window, wf, Tx, F, M, hop, Wl, nfr);
     } else {
         hipLaunchKernelGGL((ff_frames_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex, ex_stride,
