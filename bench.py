@@ -45,6 +45,8 @@ def parse():
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the audio (N>1)")
+    ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
+                    help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
     return ap.parse_args()
 
 
@@ -183,7 +185,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from golf_amd.dist import shard_inputs, gather_audio
+    from golf_amd.dist import shard_inputs, gather_audio, gather_audio_async
     from golf_amd.synthetic import make_inputs
 
     B = args.batch
@@ -193,12 +195,29 @@ def main():
     osc, ss, ff = build_modules(device)
     step, samples, t_out = make_step(args.workload, inp, osc, ss, ff)
     do_gather = world > 1 and not args.no_gather
-    gather_buf = torch.empty(world * B, t_out, device=device) if do_gather else None
+    pipelined = args.gather_mode == "pipelined"
+    gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(2)] if do_gather else None
+    pending = []  # (work handle, source tensor kept alive)
+
+    def drain(keep=0):
+        while len(pending) > keep:
+            work, _src = pending.pop(0)
+            if work is not None:
+                work.wait()
+
+    step_no = [0]
 
     def full_step():
         y = step()
         if do_gather:
-            gather_audio(y.detach(), gather_buf)
+            buf = gather_bufs[step_no[0] & 1]
+            step_no[0] += 1
+            if pipelined:
+                drain(keep=1)  # the buffer about to be reused was gathered two steps ago
+                yd = y.detach()
+                pending.append((gather_audio_async(yd, buf), yd))
+            else:
+                gather_audio(y.detach(), buf)
         return y
 
     def barrier():
@@ -209,11 +228,13 @@ def main():
 
     for _ in range(args.warmup):
         full_step()
+    drain()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
+    drain()  # every gather issued inside the timed region completes inside it
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -253,7 +274,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": B, "seconds": 2.0, "sample_rate": SR,
                        "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
-                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + ("+allgather" if do_gather else "")},
+                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode})" if do_gather else "")},
             "rtf": (elapsed / args.steps) / (B * 2.0),
             "device_step_us": round(step_us, 2),
             "roofline": roofline,
@@ -265,10 +286,11 @@ def main():
                 result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
             except Exception as e:  # the checker is optional for the measurement itself
                 result["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
 
+        dist.barrier()  # ranks > 0 wait for rank 0's profiling pass before tearing the communicator down
         dist.destroy_process_group()
 
 

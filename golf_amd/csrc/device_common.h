@@ -88,8 +88,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 // acc += s * v with the broadcast value taken straight from an SGPR (v_readlane result): one instruction.
-// (Left to itself hipcc SLP-packs pairs of these into v_pk_fma_f32 and spends a v_mov per operand to build the
-// register pairs — ~17 extra instructions per scan step.)
+// NOT used by the scans: measured SLOWER than what hipcc emits on its own (it SLP-packs pairs into v_pk_fma_f32 at
+// the cost of ~17 v_mov per step): P2 31.2 -> 36.6 us.  Kept for the record.
 __device__ __forceinline__ float fmac_sgpr(float acc, float v, float lane_src, int lane) {
     const int sj = __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_src), lane);
     asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(sj), "v"(v));

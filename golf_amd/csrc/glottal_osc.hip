@@ -150,14 +150,22 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
     const float inv_P = 1.0f / (float)P;
     const float inv_osf = 1.0f / (float)os;
     const double inv_os = 1.0 / (double)os;
+    const int dj = NTH / P, dk = NTH % P;  // advance of (j,k) per NTH fine samples
+    int m = m_lo + tid;
+    int j = m / P;
+    int k = m - j * P;
     float acc0 = 0.f, acc1 = 0.f;
-    // Two samples per thread per iteration (m and m+NTH): all global loads of both are issued before either is
-    // consumed, which is what hides the L2 latency of this otherwise dependent load->LDS->store chain.
-    auto sample = [&](int m, float p0, float p1, double cjv, int jc) {
-        const float d = (p1 - p0) * inv_P;
+    for (; m < m_hi; m += NTH) {
+        // coarse sample j (clamped for the final point: k == 0 there, and d == 0 because j+1 clamps to j)
+        const int jc = j < Tp - 1 ? j : Tp - 1;
+        const int jn = jc + 1 < Tp ? jc + 1 : Tp - 1;
+        const float p0 = pb[jc];
+        const float d = (pb[jn] - p0) * inv_P;
+        const double cj = cb[jc] + toff[jc / OSC_SCAN_TILE];
         const int kk_i = m - jc * P;
         const double kk = (double)kk_i;
-        double ph = cjv + ((kk + 1.0) * (double)p0 + (double)d * (kk * (kk + 1.0) * 0.5)) * inv_os;
+        // inclusive cumulative phase: C_j + ((k+1) p0 + d k(k+1)/2)/os, in fp64, wrapped
+        double ph = cj + ((kk + 1.0) * (double)p0 + (double)d * (kk * (kk + 1.0) * 0.5)) * inv_os;
         ph -= floor(ph);
         const float c = (float)ph * (float)L;
         int c0 = (int)c;
@@ -176,22 +184,9 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
             acc0 = fmaf(g * (1.0f - rf), top, acc0);
             acc1 = fmaf(g * rf, bot, acc1);
         }
-    };
-    for (int m = m_lo + tid; m < m_hi; m += 2 * NTH) {
-        const int mb = m + NTH;
-        const bool hasb = mb < m_hi;
-        // coarse sample index, clamped for the final point (k == 0 there, and d == 0 because j+1 clamps to j)
-        int ja = m / P;
-        ja = ja < Tp - 1 ? ja : Tp - 1;
-        int jb = (hasb ? mb : m) / P;
-        jb = jb < Tp - 1 ? jb : Tp - 1;
-        const int jan = ja + 1 < Tp ? ja + 1 : Tp - 1;
-        const int jbn = jb + 1 < Tp ? jb + 1 : Tp - 1;
-        const float pa0 = pb[ja], pa1 = pb[jan], pb0 = pb[jb], pb1 = pb[jbn];
-        const double ca = cb[ja] + toff[ja / OSC_SCAN_TILE];
-        const double cbv = cb[jb] + toff[jb / OSC_SCAN_TILE];
-        sample(m, pa0, pa1, ca, ja);
-        if (hasb) sample(mb, pb0, pb1, cbv, jb);
+        j += dj;
+        k += dk;
+        if (k >= P) { k -= P; j += 1; }
     }
     if (MODE == 1) {
         __syncthreads();

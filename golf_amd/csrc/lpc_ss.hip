@@ -358,10 +358,11 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
         float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;                      \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                             \
             const float pj = f4get(buf[u][j / 4], j % 4);                            \
-            if ((j & 3) == 0) acc0 = fmac_sgpr(acc0, pj, s, j);                      \
-            else if ((j & 3) == 1) acc1 = fmac_sgpr(acc1, pj, s, j);                 \
-            else if ((j & 3) == 2) acc2 = fmac_sgpr(acc2, pj, s, j);                 \
-            else acc3 = fmac_sgpr(acc3, pj, s, j);                                   \
+            const float sj = lane_bcast(s, j);                                       \
+            if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);                             \
+            else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);                        \
+            else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);                        \
+            else acc3 = fmaf(pj, sj, acc3);                                          \
         }                                                                            \
         s = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;                               \
     }
@@ -535,10 +536,11 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
         float acc0 = zc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;                      \
         _Pragma("unroll") for (int i = 0; i < NT; ++i) {                             \
             const float pj = f4get(buf[u][i / 4], i % 4);                            \
-            if ((i & 3) == 0) acc0 = fmac_sgpr(acc0, pj, lam, i);                    \
-            else if ((i & 3) == 1) acc1 = fmac_sgpr(acc1, pj, lam, i);               \
-            else if ((i & 3) == 2) acc2 = fmac_sgpr(acc2, pj, lam, i);               \
-            else acc3 = fmac_sgpr(acc3, pj, lam, i);                                 \
+            const float li = lane_bcast(lam, i);                                     \
+            if ((i & 3) == 0) acc0 = fmaf(pj, li, acc0);                             \
+            else if ((i & 3) == 1) acc1 = fmaf(pj, li, acc1);                        \
+            else if ((i & 3) == 2) acc2 = fmaf(pj, li, acc2);                        \
+            else acc3 = fmaf(pj, li, acc3);                                          \
         }                                                                            \
         lam = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;                             \
     }

@@ -10,7 +10,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-__all__ = ["shard_bounds", "shard_inputs", "gather_audio", "synth_sharded"]
+__all__ = ["shard_bounds", "shard_inputs", "gather_audio", "gather_audio_async", "synth_sharded"]
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int, int]:
@@ -55,6 +55,22 @@ def gather_audio(y: torch.Tensor, out: Optional[torch.Tensor] = None, total: Opt
     except (RuntimeError, NotImplementedError):  # backends without the flat variant
         dist.all_gather(list(out.chunk(world, 0)), y)
     return out if total is None else out[:total]
+
+
+def gather_audio_async(y: torch.Tensor, out: torch.Tensor):
+    """Start the all-gather of ``y`` into ``out`` without blocking the compute stream and return a handle with
+    ``.wait()`` (None when there is nothing to do).  A serving loop issues it after step k and waits before reusing
+    ``out`` (double buffering), so the 6 MB/rank exchange over xGMI hides behind step k+1's kernels — these are
+    latency-bound and leave most CUs idle for RCCL's channels."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    y = y.contiguous()
+    try:
+        return dist.all_gather_into_tensor(out, y, async_op=True)
+    except (RuntimeError, NotImplementedError):
+        return dist.all_gather(list(out.chunk(dist.get_world_size(), 0)), y, async_op=True)
 
 
 def synth_sharded(synth_fn, inputs: Dict, gather: bool = True) -> torch.Tensor:

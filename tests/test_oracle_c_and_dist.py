@@ -84,6 +84,20 @@ def _worker(rank, world, port, total, q):
     # the CPU oracle stands in for the HIP kernels here: what is under test is sharding + gather
     fn = lambda loc: CB.ltv_ss_c(loc["noise"], loc["gain"], loc["a"], 240)
     y = synth_sharded(fn, inp)
+    # pipelined (double-buffered) gather, as bench.py / a serving loop uses it
+    from golf_amd.dist import gather_audio_async, shard_inputs
+
+    loc = fn(shard_inputs(inp, rank, world))
+    bufs = [torch.empty(world * loc.shape[0], loc.shape[1]) for _ in range(2)]
+    pending = []
+    for k in range(3):
+        while len(pending) > 1:
+            pending.pop(0)[0].wait()
+        src = loc + k
+        pending.append((gather_audio_async(src, bufs[k & 1]), src))
+    while pending:
+        pending.pop(0)[0].wait()
+    assert torch.equal(bufs[0][:total], y + 2) and torch.equal(bufs[1][:total], y + 1)
     if rank == 0:
         q.put(y.numpy())
     dist.barrier()
