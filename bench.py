@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the K steps are issued on round-robin (independent batches in flight)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (dry runs)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dev: map every rank to cuda:0 (control-flow dry run of the N>1 path on a 1-GPU box)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the audio (N>1)")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
                     help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
@@ -181,7 +186,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        dist.init_process_group(backend=args.dist_backend)  # "nccl" is RCCL on ROCm
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -206,8 +213,18 @@ def main():
                 work.wait()
 
     step_no = [0]
+    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
+    issued = [0]
 
     def full_step():
+        if streams is not None:
+            st = streams[issued[0] % len(streams)]
+            issued[0] += 1
+            with torch.cuda.stream(st):
+                return _full_step()
+        return _full_step()
+
+    def _full_step():
         y = step()
         if do_gather:
             buf = gather_bufs[step_no[0] & 1]
@@ -259,9 +276,17 @@ def main():
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
         path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8}
         step_us = event_time_us(step)
+        traffic = None
+        try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            for kname, v in tr.get("kernels", {}).items():
+                if kname in dom and tr.get("batch") == B:
+                    traffic = v["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "path_frac": round(path_bytes[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "note": "B=32 is bound by the serial T=47761 recursion (dependency/issue latency), not by HBM; "

@@ -319,8 +319,24 @@ __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a
                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
                                                      int nq) {
     constexpr int NG = (NT + KT - 1) / KT;  // trajectory groups per chunk
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  All NG trajectory
+    // groups of one block of 64 chunks are placed on the SAME XCD so that (i) their 8-byte pieces of the transposed
+    // matrix PhiT merge into full lines in that XCD's L2 before write-back (measured: 80 MB -> see DESIGN.md of HBM
+    // writes for 27 MB of matrices otherwise), (ii) they share the coefficient rows of `a` in L2.
+    const int nqb = (nq + 63) / 64;
     const int idx = blockIdx.x;
-    const int grp = idx % NG, qblk = idx / NG;
+    const int xcd = idx & 7, slot = idx >> 3;       // slot-th workgroup of this XCD
+    const int nfull = nqb & ~7;                      // chunk blocks that map 1:1 onto the 8 XCDs
+    int grp, qblk;
+    if (slot < (nfull >> 3) * NG) {
+        grp = slot % NG;
+        qblk = (slot / NG) * 8 + xcd;
+    } else {                                          // tail (< 8 chunk blocks): plain order
+        const int rem = idx - nfull * NG;
+        grp = rem % NG;
+        qblk = nfull + rem / NG;
+    }
+    if (qblk >= nqb) return;
     p1_hom_body<W, NT, KT>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
 
