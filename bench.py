@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the K steps are issued on round-robin (independent batches in flight)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent batches in flight: the K steps are issued round-robin on this many HIP streams")
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="issue every step eagerly instead of replaying one captured hipGraph per stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (dry runs)")
     ap.add_argument("--single-device", action="store_true",
                     help="dev: map every rank to cuda:0 (control-flow dry run of the N>1 path on a 1-GPU box)")
@@ -202,40 +204,67 @@ def main():
     osc, ss, ff = build_modules(device)
     step, samples, t_out = make_step(args.workload, inp, osc, ss, ff)
     do_gather = world > 1 and not args.no_gather
+    gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(max(1, args.streams))] if do_gather else None
     pipelined = args.gather_mode == "pipelined"
-    gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(2)] if do_gather else None
-    pending = []  # (work handle, source tensor kept alive)
-
-    def drain(keep=0):
-        while len(pending) > keep:
-            work, _src = pending.pop(0)
-            if work is not None:
-                work.wait()
+    pending = []  # keeps gather sources alive
+    # ---- execution mode: S independent batches in flight.  The serial phases of the filter occupy a few dozen
+    # waves for tens of microseconds (the boundary scan: B waves), so one batch leaves most of the chip idle;
+    # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
+    # (9 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
+    S = max(1, args.streams)
+    use_graphs = (not args.no_graphs) and args.workload != "golf-ss-train"  # autograd is issued eagerly
+    streams = [torch.cuda.Stream(device=device) for _ in range(S)]
+    graphs, outs = [], []
+    if use_graphs:
+        for i in range(S):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(streams[i])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg = step()
+            graphs.append(g)
+            outs.append(yg)
+        torch.cuda.synchronize()
+        ref = step()
+        graphs[0].replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref), "hipGraph replay differs from eager execution"
 
     step_no = [0]
-    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
-    issued = [0]
+    slot_pending = [None] * S  # gather still reading slot i's output
 
     def full_step():
-        if streams is not None:
-            st = streams[issued[0] % len(streams)]
-            issued[0] += 1
-            with torch.cuda.stream(st):
-                return _full_step()
-        return _full_step()
-
-    def _full_step():
-        y = step()
-        if do_gather:
-            buf = gather_bufs[step_no[0] & 1]
-            step_no[0] += 1
-            if pipelined:
-                drain(keep=1)  # the buffer about to be reused was gathered two steps ago
-                yd = y.detach()
-                pending.append((gather_audio_async(yd, buf), yd))
+        i = step_no[0] % S
+        step_no[0] += 1
+        with torch.cuda.stream(streams[i]):
+            if do_gather and slot_pending[i] is not None:  # output buffer of this slot is about to be overwritten
+                slot_pending[i].wait()
+                slot_pending[i] = None
+            if use_graphs:
+                graphs[i].replay()
+                y = outs[i]
             else:
-                gather_audio(y.detach(), buf)
+                y = step()
+            if do_gather:
+                buf = gather_bufs[i]
+                if pipelined:
+                    yd = y.detach()
+                    slot_pending[i] = gather_audio_async(yd, buf)
+                    pending.append((None, yd))
+                    del pending[:-2 * S]
+                else:
+                    gather_audio(y.detach(), buf)
         return y
+
+    def drain(keep=0):
+        for i in range(S):
+            if slot_pending[i] is not None:
+                with torch.cuda.stream(streams[i]):
+                    slot_pending[i].wait()
+                slot_pending[i] = None
 
     def barrier():
         if world > 1:
@@ -299,9 +328,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": B, "seconds": 2.0, "sample_rate": SR,
                        "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
-                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode})" if do_gather else "")},
+                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode})" if do_gather else ""),
+                       "batches_in_flight": S, "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),
-            "device_step_us": round(step_us, 2),
+            "single_batch_latency_us": round(step_us, 2),  # one batch alone, eager, HIP events on the launch stream
             "roofline": roofline,
             "stages_us": stages,
         }
