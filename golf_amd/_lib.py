@@ -32,7 +32,7 @@ SIGNATURES = {
     "golf_last_error": (ctypes.c_char_p, []),
     "golf_target_arch": (ctypes.c_char_p, []),
     "golf_ltv_allpole_workspace_bytes": (_sz, [_int] * 5),
-    "golf_ltv_allpole_transitions_f32": (_int, [_c_f32p] + [_int] * 5 + [_vp, _sz, _vp]),
+    "golf_ltv_allpole_transitions_f32": (_int, [_c_f32p] + [_int] * 5 + [_vp, _sz, _int, _vp]),
     "golf_ltv_allpole_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 5
                                  + [_vp, _sz, _int, _vp, _vp]),
     "golf_ltv_allpole_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64,

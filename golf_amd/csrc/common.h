@@ -36,7 +36,7 @@ struct SsPlan {
     int seg;    // gradient segment length = min(L, hop)
     int NSEG;   // ceil(T/seg)
     // workspace offsets (bytes)
-    size_t off_phi, off_phiT, off_z, off_S, off_zadj, off_lam, off_g, off_pa, off_pg, total;
+    size_t off_phi, off_phiT, off_z, off_E, off_z2, off_S, off_zadj, off_lam, off_g, off_pa, off_pg, total;
 };
 bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p);
 

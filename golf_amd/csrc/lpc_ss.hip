@@ -72,6 +72,8 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
     p->off_phi = o;  o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_phiT = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_z = o;    o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
+    p->off_E = o;    o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
+    p->off_z2 = o;   o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
     p->off_S = o;    o = align_up(o + sizeof(float) * (size_t)B * p->NC * 64, 256);
     p->off_zadj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
     p->off_lam = o;  o = align_up(o + sizeof(float) * (size_t)B * p->NC * 64, 256);
@@ -92,12 +94,14 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
 //   whatever it is, so instruction count IS the latency of these kernels.
 // ------------------------------------------------------------------------------------------
 //   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
-//   MODE 1 (P3) : initial state S[(b*NCQ+c)*64 + i], writes y[b][t]
+//   MODE 1 (P3) : initial state S[(b*NCS+c)*64 + i], writes y[b][t]
+//   MODE 2      : initial state S[(b*NCS+c)*64 + i], chunks c < NCQ=NP, final state -> out (refinement sweep)
 template <int W, int NT, int MODE>
 __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                       const float* __restrict__ gain, const float* __restrict__ a,
                                                       const float* __restrict__ S, float* __restrict__ out,
-                                                      int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ) {
+                                                      int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ,
+                                                      int NCS) {
     constexpr int TPL = quad_tpl(W, NT);
     constexpr int R = 16;
     using TL = Tile<W, R>;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
     const BufRow xrow(ex + (size_t)b * ex_stride, T);
     const BufRow yrow(MODE == 1 ? out + (size_t)b * y_stride : nullptr, MODE == 1 ? T : 0);
     float w[TPL];
-    if (MODE == 1 && mine) {
-        const float* sp = S + ((size_t)b * NCQ + c) * 64 + r * TPL;
+    if (MODE >= 1 && mine) {
+        const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
     } else {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    if (MODE == 0 && mine) {
+    if (MODE != 1 && mine) {
         float* zp = out + ((size_t)b * NCQ + c) * W;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
@@ -204,6 +208,21 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
             if (i < W) zp[i] = i < M ? w[TPL - 1 - k] : 0.f;
         }
     }
+}
+
+// Refinement sweep glue: z2[b][c][i] = z[b][c][i] + E[b][c][i] - S[b][c+1][i]   (c < NP)
+// With transitions Phi~ of limited (fp32) accuracy the scanned boundary states S0 are ~1e-4 off.  Re-running every
+// chunk from S0 (exactly, in-lane) gives its true end state E_c; feeding the scan z + (E_c - S0_{c+1}) makes it
+// return S1 with S1_{c+1} = Phi~_c (S1_c - S0_c) + E_c: the error is now second order in the Phi~ error
+// (one Parareal iteration; measured 1.8e-4 -> 2.3e-5 = the accuracy of a sequential fp32 recursion).
+__global__ void lpc_zfix_kernel(const float* __restrict__ z, const float* __restrict__ E, const float* __restrict__ S,
+                                float* __restrict__ z2, int B, int NP, int NC, int W) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * NP * W) return;
+    const int i = idx % W;
+    const int c = (idx / W) % NP;
+    const int b = idx / (W * NP);
+    z2[idx] = z[idx] + E[idx] - S[((size_t)b * NC + c + 1) * 64 + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
 // trajectories per lane.  Measured on MI355X, B=32 (GOLF_P1H_KT=1/2/3): 93.6 / 76.8 / 85.4 us -> 2.
 constexpr int p1h_kt(int W) { return 2; }
 
-template <int W, int NT, int KT>
+template <int W, int NT, int KT, typename R>
 __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __restrict__ a, float* __restrict__ Phi,
                                             float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
     const int q = qblk * 64 + threadIdx.x;
@@ -237,13 +256,13 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
         return;
     }
     const int b = q / NP, c = q - b * NP;
-    double h[KT][W];
+    R h[KT][W];
 #pragma unroll
     for (int r = 0; r < KT; ++r)
 #pragma unroll
-        for (int k = 0; k < W; ++k) h[r][k] = (W - 1 - k == jb + r && jb + r < M) ? 1.0 : 0.0;
-    double a0[NT], dd[NT];
-    const double inv_hop = 1.0 / (double)hop;
+        for (int k = 0; k < W; ++k) h[r][k] = (W - 1 - k == jb + r && jb + r < M) ? (R)1 : (R)0;
+    R a0[NT], dd[NT];
+    const R inv_hop = (R)1 / (R)hop;
     int fcur = -1;
     const int nblk = L / W;
     for (int blk = 0; blk < nblk; ++blk) {
@@ -255,42 +274,42 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
             const float* pa1 = pa0 + M;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const double v0 = i < M ? (double)pa0[i] : 0.0;
-                const double v1 = i < M ? (double)pa1[i] : 0.0;
+                const R v0 = i < M ? (R)pa0[i] : (R)0;
+                const R v1 = i < M ? (R)pa1[i] : (R)0;
                 a0[i] = v0;
                 dd[i] = (v1 - v0) * inv_hop;
             }
         }
-        const double n0 = (double)(t0 - f * hop);
+        const R n0 = (R)(t0 - f * hop);
 #pragma unroll
         for (int s = 0; s < W; ++s) {
-            const double n = n0 + (double)s;
-            double ra[KT], rb[KT];
+            const R n = n0 + (R)s;
+            R ra[KT], rb[KT];
 #pragma unroll
-            for (int r = 0; r < KT; ++r) { ra[r] = 0.0; rb[r] = 0.0; }
+            for (int r = 0; r < KT; ++r) { ra[r] = (R)0; rb[r] = (R)0; }
             // The interpolated coefficient is produced PD taps before it is consumed: hipcc otherwise places each
-            // `cf = fma(n,dd,a0)` right in front of its uses and every tap eats the fp64 FMA latency (measured:
+            // `cf = __builtin_elementwise_fma(n,dd,a0)` right in front of its uses and every tap eats the fp64 FMA latency (measured:
             // 11.6 cycles per FMA instead of 4.8).  sched_barrier pins the order written here.
             constexpr int PD = 2;
-            double cfq[PD];
+            R cfq[PD];
 #pragma unroll
-            for (int j = 0; j < PD; ++j) cfq[j] = fma(n, dd[NT - 1 - j], a0[NT - 1 - j]);
+            for (int j = 0; j < PD; ++j) cfq[j] = __builtin_elementwise_fma(n, dd[NT - 1 - j], a0[NT - 1 - j]);
 #pragma unroll
             for (int i = NT - 1; i >= 1; --i) {
-                const double cf = cfq[(NT - 1 - i) % PD];
-                if (i - PD >= 0) cfq[(NT - 1 - i) % PD] = fma(n, dd[i - PD], a0[i - PD]);
+                const R cf = cfq[(NT - 1 - i) % PD];
+                if (i - PD >= 0) cfq[(NT - 1 - i) % PD] = __builtin_elementwise_fma(n, dd[i - PD], a0[i - PD]);
                 const int slot = (s - 1 - i + 2 * W) % W;
 #pragma unroll
                 for (int r = 0; r < KT; ++r) {
-                    if (i & 1) ra[r] = fma(cf, h[r][slot], ra[r]);
-                    else       rb[r] = fma(cf, h[r][slot], rb[r]);
+                    if (i & 1) ra[r] = __builtin_elementwise_fma(cf, h[r][slot], ra[r]);
+                    else       rb[r] = __builtin_elementwise_fma(cf, h[r][slot], rb[r]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double cf0 = cfq[(NT - 1) % PD];
+            const R cf0 = cfq[(NT - 1) % PD];
             const int sp = (s - 1 + W) % W;
 #pragma unroll
-            for (int r = 0; r < KT; ++r) h[r][s] = fma(-cf0, h[r][sp], -(ra[r] + rb[r]));
+            for (int r = 0; r < KT; ++r) h[r][s] = __builtin_elementwise_fma(-cf0, h[r][sp], -(ra[r] + rb[r]));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -314,7 +333,7 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 // against it — 23 instead of 33 fp64 FMAs per trajectory-step — was measured SLOWER (84.7 vs 77.6 us): a lone wave
 // already sustains one fp64 FMA per ~5.2 cycles (tools/ubench/fma_issue.hip), and the LDS reads, waits and
 // producer bookkeeping cost more issue slots than the FMAs they saved.  See DESIGN.md.)
-template <int W, int NT, int KT>
+template <int W, int NT, int KT, typename R>
 __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
                                                      int nq) {
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a
         qblk = nfull + rem / NG;
     }
     if (qblk >= nqb) return;
-    p1_hom_body<W, NT, KT>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
+    p1_hom_body<W, NT, KT, R>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -752,22 +771,29 @@ __global__ void lpc_inverse_kernel(const float* __restrict__ y, int64_t y_stride
 // ------------------------------------------------------------------------------------------
 template <int W, int NT>
 static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int F, int M, int hop, char* ws,
-                              hipStream_t st) {
+                              int fast, hipStream_t st) {
     if (p.NP <= 0) return GOLF_OK;
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
+    if (fast) {  // fp32 trajectories, 3 per lane (the forward then runs one refinement sweep)
+        constexpr int NG = (NT + 2) / 3;
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3, float>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st,
+                           a, Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+        GOLF_LAUNCH_CHECK();
+        return GOLF_OK;
+    }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
     if (kt_env == 1) {
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 1>), dim3((unsigned)(ceil_div(nq, 64) * NT)), dim3(64), 0, st, a,
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 1, double>), dim3((unsigned)(ceil_div(nq, 64) * NT)), dim3(64), 0, st, a,
                            Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     } else if (p1h_kt(W) == 3 && kt_env != 2) {
         constexpr int NG = (NT + 2) / 3;
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3, double>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
                            Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     } else {
         constexpr int NG = (NT + 1) / 2;
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2, double>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
                            Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     }
     GOLF_LAUNCH_CHECK();
@@ -802,6 +828,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     float* z = (float*)(ws + p.off_z);
     float* S = (float*)(ws + p.off_S);
     constexpr int D = 8;
+    const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
     ForkJoin fork, join;
     if (p.NP > 0) {
         if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
@@ -810,18 +837,32 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                 if (fork.record_and_wait(st, side)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream fork failed");
                 s1 = side;
             }
-            if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, s1)) return rc;
+            if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, s1)) return rc;
         }
         hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP);
+                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP);
         GOLF_LAUNCH_CHECK();
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
                        S, p.NC, p.NP);
     GOLF_LAUNCH_CHECK();
+    if (fast && p.NP > 0) {  // one refinement sweep (see lpc_zfix_kernel)
+        float* E = (float*)(ws + p.off_E);
+        float* z2 = (float*)(ws + p.off_z2);
+        hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 2>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
+                           ex_stride, gain, a, (const float*)S, E, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC);
+        GOLF_LAUNCH_CHECK();
+        const int nz = B * p.NP * W;
+        hipLaunchKernelGGL(lpc_zfix_kernel, dim3((unsigned)ceil_div(nz, 256)), dim3(256), 0, st, (const float*)z,
+                           (const float*)E, (const float*)S, z2, B, p.NP, p.NC, W);
+        GOLF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT,
+                           (const float*)z2, S, p.NC, p.NP);
+        GOLF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
-                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC);
+                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -908,7 +949,7 @@ extern "C" size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, i
 }
 
 extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop, void* ws,
-                                                size_t ws_bytes, void* stream) {
+                                                size_t ws_bytes, int flags, void* stream) {
     if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
     if (!a) return fail(GOLF_EINVAL, "ltv_allpole_transitions: null pointer");
     SsPlan p;
@@ -917,7 +958,8 @@ extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, in
         return fail(GOLF_EWORKSPACE, "ltv_allpole_transitions: workspace needs %zu bytes, 256-aligned (got %zu)",
                     p.total, ws_bytes);
     hipStream_t st = (hipStream_t)stream;
-    GOLF_SS_DISPATCH(launch_transitions, p, a, B, T, F, M, hop, (char*)ws, st)
+    const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
+    GOLF_SS_DISPATCH(launch_transitions, p, a, B, T, F, M, hop, (char*)ws, fast, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_transitions: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

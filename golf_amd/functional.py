@@ -13,6 +13,7 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
            "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions"]
 
 HAVE_TRANSITIONS = 1
+FAST_TRANSITIONS = 2
 _side_streams = {}
 
 
@@ -54,7 +55,7 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
         side.wait_stream(cur)  # `a` (and the fresh workspace) are ordered after the current stream's work
         ws.record_stream(side)
         a.record_stream(side)
-    rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
+    rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(), 0,
                                               (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
     return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a)
@@ -77,7 +78,7 @@ def ss_output_length(Tx: int, F: int, hop: int) -> int:
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ex, gain, a, hop, prepared):
+    def forward(ctx, ex, gain, a, hop, prepared, fast_inference):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
         ex = _rows(ex)
@@ -89,10 +90,13 @@ class _LTVAllPoleSS(torch.autograd.Function):
         T = ss_output_length(Tx, F, hop)
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
         side, flags = None, 0
+        needs_grad = any(ctx.needs_input_grad[:3])
         if prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version):
             ws, flags, side = prepared.ws, HAVE_TRANSITIONS, prepared.stream
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
+            if not needs_grad and fast_inference:
+                flags = FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
         rc = lib.golf_ltv_allpole_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(), y.data_ptr(),
                                           y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
                                           side.cuda_stream if side is not None else 0, _lib.stream_ptr())
@@ -120,15 +124,17 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
-        return g_ex, g_gain, g_a, None, None
+        return g_ex, g_gain, g_a, None, None, None
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
-                   prepared: "PreparedTransitions" = None) -> torch.Tensor:
+                   prepared: "PreparedTransitions" = None, fast_inference: bool = True) -> torch.Tensor:
     """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
     Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward).
-    ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match)."""
-    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared)
+    ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match).
+    ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
+    fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel)."""
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference))
 
 
 def ltv_inverse(y: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:

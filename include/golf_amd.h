@@ -59,17 +59,24 @@ const char* golf_target_arch(void);
 size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
 
 /* The per-chunk transition matrices depend only on the coefficients `a`, not on the excitation, and are the
- * most expensive phase.  golf_ltv_allpole_transitions_f32 computes them into `ws` on its own — a caller that
- * knows `a` before `ex` exists (the GOLF decoder: the encoder emits `a` while the oscillator still has to render
- * the source) launches it on a second HIP stream and then passes GOLF_SS_HAVE_TRANSITIONS to the forward.
- *   flags        GOLF_SS_HAVE_TRANSITIONS: `ws` already holds the transitions for (a,B,T,F,M,hop)
+ * most expensive phase.  golf_ltv_allpole_transitions_f32 computes them into `ws` on its own, so a caller that
+ * knows `a` before `ex` exists can start it early (optionally on a second HIP stream) or reuse it for several
+ * excitations, and then pass GOLF_SS_HAVE_TRANSITIONS to the forward.
+ *   flags  GOLF_SS_HAVE_TRANSITIONS  `ws` already holds the transitions for (a,B,T,F,M,hop)
+ *          GOLF_SS_FAST_TRANSITIONS  inference mode: transition matrices from fp32 instead of fp64 trajectories
+ *                (about 4x cheaper) and the forward runs one refinement sweep over the chunk boundary states
+ *                (re-run the chunks from the scanned states, rescan with the observed end-state defects), which
+ *                makes the result second order in the matrix error: same accuracy as a sequential fp32 recursion.
+ *                The matrices left in `ws` are then only fp32-accurate: the host binding never sets FAST when a
+ *                gradient is required (golf_ltv_allpole_bwd_f32 expects the fp64-derived matrices).
  *   side_stream  optional second hipStream_t (may be NULL): without HAVE_TRANSITIONS the forward forks the
  *                transition kernel onto it (event fork/join) so it overlaps the excitation-dependent phase;
  *                with HAVE_TRANSITIONS the forward joins it (event wait) right before the boundary scan. */
 #define GOLF_SS_HAVE_TRANSITIONS 1
+#define GOLF_SS_FAST_TRANSITIONS 2
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
-                                     void* ws, size_t ws_bytes, void* stream);
+                                     void* ws, size_t ws_bytes, int flags, void* stream);
 
 int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop,

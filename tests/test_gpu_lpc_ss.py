@@ -27,10 +27,11 @@ def smooth_case(B, F, M, hop, Tx=None, seed=0, walk=0.02):
     return ex, gain, a
 
 
-def run_fwd(ex, gain, a, hop):
+def run_fwd(ex, gain, a, hop, fast=True):
+    """fast=True: inference path (fp32 transitions + refinement sweep); False: fp64 transitions (training path)."""
     from golf_amd import functional as GF
 
-    y = GF.ltv_allpole_ss(dev(ex), dev(gain), dev(a), hop)
+    y = GF.ltv_allpole_ss(dev(ex), dev(gain), dev(a), hop, fast_inference=fast)
     torch.cuda.synchronize()
     return y.cpu().numpy()
 
@@ -59,7 +60,8 @@ def test_fwd_vs_oracle(B, F, M, hop):
 
     ex, gain, a = smooth_case(B, F, M, hop, seed=B * 1000 + F)
     ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
-    check(run_fwd(ex, gain, a, hop), ref, f"fwd B{B} F{F} M{M} hop{hop}")
+    check(run_fwd(ex, gain, a, hop, fast=True), ref, f"fwd(fast) B{B} F{F} M{M} hop{hop}")
+    check(run_fwd(ex, gain, a, hop, fast=False), ref, f"fwd(fp64 Phi) B{B} F{F} M{M} hop{hop}")
 
 
 def test_fwd_ragged_lengths():
@@ -154,9 +156,10 @@ def test_full_size_config(golden):
     ex = inp["noise"].numpy()
     gain, a = inp["gain"].numpy(), inp["a"].numpy()
     ref = O.ltv_allpole_ss_forward(ex, gain, a, 240)
-    y = run_fwd(ex, gain, a, 240)
+    y = run_fwd(ex, gain, a, 240, fast=True)
     assert y.shape == (32, 47761)
-    check(y, ref, "full-size fwd")
+    check(y, ref, "full-size fwd (inference path: fp32 transitions + refinement sweep)")
+    check(run_fwd(ex, gain, a, 240, fast=False), ref, "full-size fwd (fp64 transitions)")
     # linearity (size-independent property): filter(2x + z) == 2 filter(x) + filter(z)
     z = np.random.default_rng(9).normal(0, 1, ex.shape).astype(np.float32)
     yz = run_fwd(z, gain, a, 240)
