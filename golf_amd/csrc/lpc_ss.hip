@@ -329,6 +329,108 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
     }
 }
 
+// fp32 homogeneous trajectories for the inference path (GOLF_SS_FAST_TRANSITIONS): 4 trajectories per lane held as
+// two float2 rings, so that every dot-product step is a v_pk_fma_f32 with the coefficient broadcast to both halves
+// and the coefficient interpolation is packed over tap pairs.  (The scalar fp32 instantiation of p1_hom_body is
+// unusable: hipcc's SLP vectoriser re-packs the unrolled body into 256 VGPR + 256 AGPR + 1 KB of scratch, 425 us.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ Phi,
+                                                     float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
+                                                     int nq) {
+    constexpr int KT = 4;
+    constexpr int NG = (NT + KT - 1) / KT;
+    constexpr int NP2 = NT / 2;  // tap pairs (NT is even)
+    const int idx = blockIdx.x;
+    const int grp = idx % NG, qblk = idx / NG;
+    const int q = qblk * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const int jb = KT * grp;
+    if (jb >= M) {
+#pragma unroll
+        for (int r = 0; r < KT; ++r) {
+            const int j = jb + r;
+            if (j < NT) {
+                float* o = Phi + ((size_t)q * NT + j) * W;
+                float* oT = PhiT + (size_t)q * NT * W + j;
+#pragma unroll
+                for (int i = 0; i < W; ++i) o[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) oT[(size_t)i * W] = 0.f;
+            }
+        }
+        return;
+    }
+    const int b = q / NP, c = q - b * NP;
+    f32x2 hA[W], hB[W];  // hA = trajectories (jb, jb+1), hB = (jb+2, jb+3)
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int j = W - 1 - k;
+        hA[k] = f32x2{(j == jb && jb < M) ? 1.f : 0.f, (j == jb + 1 && jb + 1 < M) ? 1.f : 0.f};
+        hB[k] = f32x2{(j == jb + 2 && jb + 2 < M) ? 1.f : 0.f, (j == jb + 3 && jb + 3 < M) ? 1.f : 0.f};
+    }
+    f32x2 a0p[NP2], ddp[NP2];
+    const float inv_hop = 1.0f / (float)hop;
+    int fcur = -1;
+    const int nblk = L / W;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int t0 = c * L + blk * W;
+        const int f = t0 / hop;
+        if (f != fcur) {
+            fcur = f;
+            const float* pa0 = a + ((size_t)b * F + f) * M;
+            const float* pa1 = pa0 + M;
+#pragma unroll
+            for (int pp = 0; pp < NP2; ++pp) {
+                const int i0 = 2 * pp, i1 = 2 * pp + 1;
+                const float u0 = i0 < M ? pa0[i0] : 0.f, u1 = i1 < M ? pa0[i1] : 0.f;
+                const float v0 = i0 < M ? pa1[i0] : 0.f, v1 = i1 < M ? pa1[i1] : 0.f;
+                a0p[pp] = f32x2{u0, u1};
+                ddp[pp] = f32x2{(v0 - u0) * inv_hop, (v1 - u1) * inv_hop};
+            }
+        }
+        const float n0 = (float)(t0 - f * hop);
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const float n = n0 + (float)s;
+            const f32x2 n2 = f32x2{n, n};
+            f32x2 cfp[NP2];
+#pragma unroll
+            for (int pp = 0; pp < NP2; ++pp) cfp[pp] = __builtin_elementwise_fma(n2, ddp[pp], a0p[pp]);
+            f32x2 raA = f32x2{0.f, 0.f}, rbA = raA, raB = raA, rbB = raA;
+#pragma unroll
+            for (int i = NT - 1; i >= 1; --i) {
+                const float cf = (i & 1) ? cfp[i / 2].y : cfp[i / 2].x;
+                const f32x2 c2 = f32x2{cf, cf};
+                const int slot = (s - 1 - i + 2 * W) % W;
+                if (i & 1) { raA = __builtin_elementwise_fma(c2, hA[slot], raA); raB = __builtin_elementwise_fma(c2, hB[slot], raB); }
+                else       { rbA = __builtin_elementwise_fma(c2, hA[slot], rbA); rbB = __builtin_elementwise_fma(c2, hB[slot], rbB); }
+            }
+            const float cf0 = cfp[0].x;
+            const f32x2 c0 = f32x2{-cf0, -cf0};
+            const int sp = (s - 1 + W) % W;
+            hA[s] = __builtin_elementwise_fma(c0, hA[sp], -(raA + rbA));
+            hB[s] = __builtin_elementwise_fma(c0, hB[sp], -(raB + rbB));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KT; ++r) {
+        const int j = jb + r;
+        if (j < NT) {
+            float* o = Phi + ((size_t)q * NT + j) * W;
+            float* oT = PhiT + (size_t)q * NT * W + j;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const f32x2 hv = (r < 2) ? hA[W - 1 - i] : hB[W - 1 - i];
+                const float v = (i < M && j < M) ? ((r & 1) ? hv.y : hv.x) : 0.f;
+                o[i] = v;
+                if (i < NT) oT[(size_t)i * W] = v;
+            }
+        }
+    }
+}
+
 // (A variant that interpolates the coefficients once per chunk into an LDS tile and runs 3 trajectories per lane
 // against it — 23 instead of 33 fp64 FMAs per trajectory-step — was measured SLOWER (84.7 vs 77.6 us): a lone wave
 // already sustains one fp64 FMA per ~5.2 cycles (tools/ubench/fma_issue.hip), and the LDS reads, waits and
@@ -776,10 +878,10 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    if (fast) {  // fp32 trajectories, 3 per lane (the forward then runs one refinement sweep)
-        constexpr int NG = (NT + 2) / 3;
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3, float>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st,
-                           a, Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+    if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
+        constexpr int NG = (NT + 3) / 4;
+        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a, Phi,
+                           PhiT, F, M, hop, p.L, p.NP, nq);
         GOLF_LAUNCH_CHECK();
         return GOLF_OK;
     }
