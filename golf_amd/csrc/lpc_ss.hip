@@ -246,11 +246,8 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
             const int j = jb + r;
             if (j < NT) {
                 float* o = Phi + ((size_t)q * NT + j) * W;
-                float* oT = PhiT + (size_t)q * NT * W + j;
 #pragma unroll
                 for (int i = 0; i < W; ++i) o[i] = 0.f;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) oT[(size_t)i * W] = 0.f;
             }
         }
         return;
@@ -318,13 +315,8 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
         const int j = jb + r;
         if (j < NT) {
             float* o = Phi + ((size_t)q * NT + j) * W;
-            float* oT = PhiT + (size_t)q * NT * W + j;
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                const float v = (i < M && j < M) ? (float)h[r][W - 1 - i] : 0.f;
-                o[i] = v;
-                if (i < NT) oT[(size_t)i * W] = v;
-            }
+            for (int i = 0; i < W; ++i) o[i] = (i < M && j < M) ? (float)h[r][W - 1 - i] : 0.f;
         }
     }
 }
@@ -336,33 +328,22 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ Phi,
-                                                     float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
-                                                     int nq) {
+__global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT, int F,
+                                                     int M, int hop, int L, int NP, int nq) {
     constexpr int KT = 4;
-    constexpr int NG = (NT + KT - 1) / KT;
-    constexpr int NP2 = NT / 2;  // tap pairs (NT is even)
-    const int idx = blockIdx.x;
-    const int grp = idx % NG, qblk = idx / NG;
-    const int q = qblk * 64 + threadIdx.x;
-    if (q >= nq) return;
+    constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
+    constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
+    constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
+    constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float tile[CPW * NT * LDT];
+    const int lane = threadIdx.x;
+    const int cl = lane / NG, grp = lane - cl * NG;
+    const int q0 = blockIdx.x * CPW;
+    const int q = q0 + cl;
+    const bool live = cl < CPW && q < nq;
     const int jb = KT * grp;
-    if (jb >= M) {
-#pragma unroll
-        for (int r = 0; r < KT; ++r) {
-            const int j = jb + r;
-            if (j < NT) {
-                float* o = Phi + ((size_t)q * NT + j) * W;
-                float* oT = PhiT + (size_t)q * NT * W + j;
-#pragma unroll
-                for (int i = 0; i < W; ++i) o[i] = 0.f;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) oT[(size_t)i * W] = 0.f;
-            }
-        }
-        return;
-    }
-    const int b = q / NP, c = q - b * NP;
+    const int qq = live ? q : (nq - 1);
+    const int b = qq / NP, c = qq - b * NP;
     f32x2 hA[W], hB[W];  // hA = trajectories (jb, jb+1), hB = (jb+2, jb+3)
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -414,20 +395,53 @@ __global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a
             hB[s] = __builtin_elementwise_fma(c0, hB[sp], -(raB + rbB));
         }
     }
+    // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
+    if (cl < CPW) {
+        float* trow = tile + (size_t)cl * NT * LDT + jb;
 #pragma unroll
-    for (int r = 0; r < KT; ++r) {
-        const int j = jb + r;
-        if (j < NT) {
-            float* o = Phi + ((size_t)q * NT + j) * W;
-            float* oT = PhiT + (size_t)q * NT * W + j;
-#pragma unroll
-            for (int i = 0; i < W; ++i) {
-                const f32x2 hv = (r < 2) ? hA[W - 1 - i] : hB[W - 1 - i];
-                const float v = (i < M && j < M) ? ((r & 1) ? hv.y : hv.x) : 0.f;
-                o[i] = v;
-                if (i < NT) oT[(size_t)i * W] = v;
-            }
+        for (int i = 0; i < NT; ++i) {
+            const bool ok = i < M;
+            const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
+            float4 v;
+            v.x = (ok && jb < M) ? va.x : 0.f;
+            v.y = (ok && jb + 1 < M) ? va.y : 0.f;
+            v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
+            v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
+            if (jb + 3 < W) *reinterpret_cast<float4*>(trow + (size_t)i * LDT) = v;
         }
+    }
+    __syncthreads();
+    // coalesced copy-out: CPW chunks x NT rows x W floats are contiguous in PhiT
+    const int nch = nq - q0 < CPW ? nq - q0 : CPW;
+    float4* dst = reinterpret_cast<float4*>(PhiT + (size_t)q0 * NT * W);
+    constexpr int RW4 = W / 4;
+    for (int e = lane; e < nch * NT * RW4; e += 64) {
+        const int rowi = e / RW4, c4 = e - rowi * RW4;
+        dst[e] = *reinterpret_cast<const float4*>(tile + (size_t)rowi * LDT + c4 * 4);
+    }
+}
+
+// Phi[q][j][i] -> PhiT[q][i][j] (training path: the fp64 kernel writes Phi with float4 stores; transposing here costs
+// 27 MB of coalesced traffic instead of ~3 M scattered 4-byte stores inside the trajectory kernel: -28 us there).
+template <int W, int NT>
+__global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restrict__ Phi, float* __restrict__ PhiT,
+                                                            int nq) {
+    __shared__ float t[4][NT * (W + 1)];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq) return;
+    const float* src = Phi + (size_t)q * NT * W;
+    float* dst = PhiT + (size_t)q * NT * W;
+    float* tt = t[wv];
+    for (int e = lane; e < NT * W; e += 64) {  // e = j*W + i
+        const int j = e / W, i = e - j * W;
+        tt[j * (W + 1) + i] = src[e];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NT * W; e += 64) {  // e = i*W + j
+        const int i = e / W, j = e - i * W;
+        dst[e] = (j < NT) ? tt[j * (W + 1) + i] : 0.f;
     }
 }
 
@@ -879,9 +893,9 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
     if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
-        constexpr int NG = (NT + 3) / 4;
-        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a, Phi,
-                           PhiT, F, M, hop, p.L, p.NP, nq);
+        constexpr int CPW = 64 / ((NT + 3) / 4);
+        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW)), dim3(64), 0, st, a, PhiT, F, M,
+                           hop, p.L, p.NP, nq);
         GOLF_LAUNCH_CHECK();
         return GOLF_OK;
     }
@@ -898,6 +912,9 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
         hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2, double>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
                            Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     }
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
+                       (const float*)Phi, PhiT, nq);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
