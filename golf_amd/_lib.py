@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgolf_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip")
+SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip")
 
 _c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -47,6 +47,15 @@ SIGNATURES = {
     "golf_glottal_osc_bwd_wsel_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p,
                                              _int, _int, _int, _int, _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz,
                                              _vp]),
+    "golf_zero_phase_fir_row_stride": (_int, [_int]),
+    "golf_zero_phase_fir_basis_bytes": (_sz, [_int]),
+    "golf_zero_phase_fir_basis_f32": (_int, [_int, _vp, _sz, _vp]),
+    "golf_zero_phase_fir_kernels_f32": (_int, [_c_f32p, _c_f32p, _vp, _c_f32p, _int, _int, _vp]),
+    "golf_zero_phase_fir_kernels_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _vp, _c_f32p, _int, _int, _vp]),
+    "golf_ltv_fir_frames_length": (_int, [_int] * 4),
+    "golf_ltv_fir_frames_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64] + [_int] * 5 + [_vp]),
+    "golf_ltv_fir_frames_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64, _c_f32p]
+                                    + [_int] * 5 + [_vp]),
 }
 
 _lock = threading.Lock()

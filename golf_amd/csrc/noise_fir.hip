@@ -1,0 +1,473 @@
+// Zero-phase FIR noise filter of the GOLF decoders for gfx950.
+//
+// Reference: LTVZeroPhaseFIRFilter, models/filters.py:286-384
+//   kernel[b,f,:] = fftshift(irfft(exp(log_mag[b,f,:]))) * window                (filters.py:294-306)
+//   y[b, f*hop+n] = sum_k pad(ex)[b, f*hop+n+k] * kernel[b,f,k]                  (filters.py:355-383: unfold +
+//                                                                                  grouped F.conv1d, one group per frame)
+// Two different shapes of work, two different engines:
+//   * the inverse real FFT of a zero-phase spectrum is a cosine transform, i.e. a dense contraction
+//       u[g,d] = sum_k exp(log_mag[g,k]) * basis[k,d],   basis[k,d] = c_k cos(2 pi k d / N) / N,
+//     (G = B*F = 6400 rows, K = D = n_mag = 256): that one goes to the matrix cores with the exact-fp32
+//     v_mfma_f32_16x16x4_f32 (bf16 would cost 1e-3 of accuracy; the parity bar is 1e-4).  exp() is fused into the
+//     A-operand staging, the window / fftshift / mirror (the kernel is symmetric about tap N/2) into the epilogue.
+//   * the per-frame FIR has a different kernel in every group and no reuse across groups: matrix-vector work,
+//     done on the VALU.  A wave owns one frame; the frame's taps are wave-uniform, so they arrive as SGPRs
+//     (s_load_dwordx16) and every multiply-add is a v_pk_fma_f32 with a scalar operand; the signal window slides
+//     through registers fed by one ds_read_b128 per 4 taps.  Packed math needs 8-byte aligned register pairs, which
+//     a sliding window only offers for every other tap; the odd taps therefore accumulate into a second family of
+//     accumulators that belongs to the outputs shifted by one sample ("E/O split"), so that they see the same aligned
+//     pairs, and the two families are merged once at the end with a single cross-lane shift.
+//   The same routine serves the backward pass: with the roles swapped (taps = the incoming gradient of the frame,
+//   signal = the padded excitation, resp. the reversed kernel row) it yields g_kernel and g_ex.
+#include "common.h"
+#include "device_common.h"
+
+namespace golf {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// Packed FIR core: out[o] = sum_{n < ntaps} coef[n] * sig[o + n],  o = 4*lane + j, j = 0..3   (ntaps % 4 == 0)
+// sig: 16-byte aligned LDS region of >= 256 + ntaps + 4 floats owned by this wave; coef: wave-uniform global pointer.
+// Lane 63 only contributes its shifted accumulator: a pass yields FIR_TILE = 252 valid outputs.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FIR_TILE = 252;
+constexpr int FIR_WAVES = 4;
+
+struct FirAcc {
+    f32x2 e01, e23;  // even taps -> outputs 4l .. 4l+3
+    f32x2 o01, o23;  // odd taps  -> outputs 4l-1 .. 4l+2
+};
+
+__device__ __forceinline__ void fir_zero(FirAcc& A) {
+    A.e01 = A.e23 = A.o01 = A.o23 = (f32x2){0.f, 0.f};
+}
+
+__device__ __forceinline__ void fir_accum(FirAcc& A, const float* sig, const float* __restrict__ coef, int ntaps,
+                                          int lane) {
+    const f32x4* sig4 = reinterpret_cast<const f32x4*>(sig);
+    f32x4 cur = sig4[lane];
+    const int nq = ntaps >> 2;
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 nxt = sig4[lane + q + 1];
+        const float c0 = coef[4 * q], c1 = coef[4 * q + 1], c2 = coef[4 * q + 2], c3 = coef[4 * q + 3];
+        const f32x2 x01 = {cur.x, cur.y}, x23 = {cur.z, cur.w}, x45 = {nxt.x, nxt.y};
+        A.e01 = __builtin_elementwise_fma((f32x2){c0, c0}, x01, A.e01);
+        A.e23 = __builtin_elementwise_fma((f32x2){c0, c0}, x23, A.e23);
+        A.o01 = __builtin_elementwise_fma((f32x2){c1, c1}, x01, A.o01);
+        A.o23 = __builtin_elementwise_fma((f32x2){c1, c1}, x23, A.o23);
+        A.e01 = __builtin_elementwise_fma((f32x2){c2, c2}, x23, A.e01);
+        A.e23 = __builtin_elementwise_fma((f32x2){c2, c2}, x45, A.e23);
+        A.o01 = __builtin_elementwise_fma((f32x2){c3, c3}, x23, A.o01);
+        A.o23 = __builtin_elementwise_fma((f32x2){c3, c3}, x45, A.o23);
+        cur = nxt;
+    }
+}
+
+// merge the families: out[4l+j] = E_j + O_{j+1}; the last one needs O_0 of the next lane
+__device__ __forceinline__ f32x4 fir_finish(const FirAcc& A) {
+    const float onext = __shfl_down(A.o01.x, 1);
+    return (f32x4){A.e01.x + A.o01.y, A.e01.y + A.o23.x, A.e23.x + A.o23.y, A.e23.y + onext};
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward: unit = (utterance b, frame f, pass c over the frame's hop outputs)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_fwd_kernel(
+    const float* __restrict__ ex, int64_t ex_stride, const float* __restrict__ kern, int KS, float* __restrict__ y,
+    int64_t y_stride, int B, int T, int nfr, int F, int N, int hop, int npass, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * FIR_WAVES + wv;
+    if (unit >= B * nfr * npass) return;
+    const int c = unit % npass, f = (unit / npass) % nfr, b = unit / (npass * nfr);
+    float* sig = fir_lds + wv * RS;
+    const int P = (N - 1) >> 1;
+    const int ntaps = (N + 3) & ~3;  // kernel rows are zero padded to KS >= ntaps
+    const int span = 256 + ntaps + 4;
+    const int t0 = f * hop + c * FIR_TILE;  // first output of this pass
+    const BufRow xr(ex + b * ex_stride, T);
+    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 + i - P);
+    wave_lds_fence();
+    FirAcc A;
+    fir_zero(A);
+    fir_accum(A, sig, kern + (size_t)(b * F + f) * KS, ntaps, lane);
+    const f32x4 r = fir_finish(A);
+    const BufRow yr(y + b * y_stride, nfr * hop);
+    const int o = 4 * lane;
+    const int lim = min(FIR_TILE, hop - c * FIR_TILE);
+    yr.st(o + 0 < lim ? t0 + o + 0 : -1, r.x);
+    yr.st(o + 1 < lim ? t0 + o + 1 : -1, r.y);
+    yr.st(o + 2 < lim ? t0 + o + 2 : -1, r.z);
+    yr.st(o + 3 < lim ? t0 + o + 3 : -1, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward w.r.t. the kernels: g_kern[b,f,k] = sum_{n<hop} gy[b,f*hop+n] * pad(ex)[b, f*hop+n+k]
+// unit = (b, f, pass c over the N taps); taps of the core = the frame's hop gradient samples
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ ex, int64_t ex_stride,
+    float* __restrict__ g_kern, int KS, int B, int T, int nfr, int F, int N, int hop, int npass, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * FIR_WAVES + wv;
+    if (unit >= B * F * npass) return;
+    const int c = unit % npass, f = (unit / npass) % F, b = unit / (npass * F);
+    const BufRow gr(g_kern + (size_t)(b * F + f) * KS, N);
+    const int k0 = c * FIR_TILE, o = 4 * lane;
+    const int lim = min(FIR_TILE, N - k0);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (f < nfr) {  // wave-uniform
+        float* sig = fir_lds + wv * RS;
+        const int P = (N - 1) >> 1;
+        const int span = 256 + hop + 4;
+        const BufRow xr(ex + b * ex_stride, T);
+        for (int i = lane; i < span; i += 64) sig[i] = xr.ld(f * hop + k0 + i - P);
+        wave_lds_fence();
+        FirAcc A;
+        fir_zero(A);
+        fir_accum(A, sig, gy + b * gy_stride + (size_t)f * hop, hop, lane);
+        r = fir_finish(A);
+    }
+    gr.st(o + 0 < lim ? k0 + o + 0 : -1, r.x);
+    gr.st(o + 1 < lim ? k0 + o + 1 : -1, r.y);
+    gr.st(o + 2 < lim ? k0 + o + 2 : -1, r.z);
+    gr.st(o + 3 < lim ? k0 + o + 3 : -1, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward w.r.t. the excitation, in padded coordinates m = t + P:
+//   g_xp[m] = sum_f sum_{n<hop} gy[f*hop+n] * kernel[f][m - f*hop - n]
+// unit = (b, tile of TILE consecutive m); outputs are taken in DEscending m so that the signal index ascends with
+// the tap index: sig_f[i] = kernel[f][m_hi - f*hop - i] (0 outside the kernel), taps = gy of frame f; the frames
+// whose support reaches the tile are accumulated one after the other.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ kern, int KS,
+    float* __restrict__ g_ex, int64_t g_ex_stride, int B, int T, int nfr, int F, int N, int hop, int TILE,
+    int tile_lo, int ntile, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * FIR_WAVES + wv;
+    if (unit >= B * ntile) return;
+    const int tile = tile_lo + unit % ntile, b = unit / ntile;
+    float* sig = fir_lds + wv * RS;
+    const int P = (N - 1) >> 1;
+    const int m_lo = tile * TILE, m_hi = m_lo + TILE - 1;
+    int f_lo = m_lo - (N - 1) - (hop - 1);  // f*hop >= this
+    f_lo = f_lo <= 0 ? 0 : (f_lo + hop - 1) / hop;
+    const int f_hi = min(nfr - 1, m_hi / hop);
+    const int span = 256 + hop + 4;
+    FirAcc A;
+    fir_zero(A);
+    for (int f = f_lo; f <= f_hi; ++f) {
+        const BufRow kr(kern + (size_t)(b * F + f) * KS, N);
+        wave_lds_fence();
+        for (int i = lane; i < span; i += 64) sig[i] = kr.ld(m_hi - f * hop - i);
+        wave_lds_fence();
+        fir_accum(A, sig, gy + b * gy_stride + (size_t)f * hop, hop, lane);
+    }
+    const f32x4 r = fir_finish(A);
+    const BufRow gr(g_ex + b * g_ex_stride, T);
+    const int o = 4 * lane;
+    const int t_hi = m_hi - P;  // output o <-> t = t_hi - o; hardware drops t outside [0,T)
+    gr.st(o + 0 < TILE ? t_hi - o - 0 : -1, r.x);
+    gr.st(o + 1 < TILE ? t_hi - o - 1 : -1, r.y);
+    gr.st(o + 2 < TILE ? t_hi - o - 2 : -1, r.z);
+    gr.st(o + 3 < TILE ? t_hi - o - 3 : -1, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cosine basis (both orientations), fp64 evaluation with exact integer argument reduction, rounded once to fp32
+//   bas [k*Pd + d] = c_k cos(2 pi k d / N) / N   (k, d < n_mag; 0 in the padding),  basT[d*Pd + k] = same
+// ------------------------------------------------------------------------------------------------------------
+__global__ void zp_basis_kernel(float* __restrict__ bas, float* __restrict__ basT, int n_mag, int Pd) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (d >= Pd) return;
+    const int N = 2 * (n_mag - 1);
+    float v = 0.f;
+    if (k < n_mag && d < n_mag) {
+        const long long r = ((long long)k * d) % N;
+        const double ck = (k == 0 || k == n_mag - 1) ? 1.0 : 2.0;
+        v = (float)(ck * cospi(2.0 * (double)r / (double)N) / (double)N);
+    }
+    bas[(size_t)k * Pd + d] = v;
+    basT[(size_t)d * Pd + k] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// exact-fp32 MFMA contraction  C[g, c] = sum_k A[g, k] * Bm[k, c]   (Bm: Pd x Pd, zero padded)
+//   MODE 0 (forward):  A = exp(log_mag), Bm = bas;  epilogue: kernel row g gets u*window at taps N/2 +- c
+//   MODE 1 (backward): A[g, d] = window-folded g_kernel, Bm = basT; epilogue: g_log_mag = C * exp(log_mag)
+// block = 4 waves, 64 rows x 128 columns; wave w owns all 64 rows x 32 columns = 4 x 2 tiles of 16x16.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ZG_ROWS = 64, ZG_COLS = 128, ZG_KC = 256;
+constexpr int ZG_LDA = ZG_KC + 2;  // row stride = 2 mod 32: the (row, k) pattern of the A operand hits 32 distinct banks
+constexpr int ZG_LDC = ZG_COLS + 1;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ src, int src_stride,
+                                                      const float* __restrict__ log_mag,
+                                                      const float* __restrict__ window,
+                                                      const float* __restrict__ Bm, float* __restrict__ out,
+                                                      int out_stride, int G, int n_mag, int Pd) {
+    __shared__ float As[ZG_ROWS * ZG_LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g0 = blockIdx.x * ZG_ROWS, c0 = blockIdx.y * ZG_COLS;
+    const int N = 2 * (n_mag - 1), H = N >> 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < Pd; kc0 += ZG_KC) {
+        __syncthreads();
+        // stage the A chunk (64 rows x 256 k) with the transform fused.  All loads go to clamped (always valid)
+        // addresses and the mask is applied to the value: no branches, so the loads of an unrolled batch overlap.
+        {
+            const int k = tid, kk = kc0 + k;  // one column per thread, 64 rows
+            const bool kin = kk < n_mag;
+            float wa = 0.f, wb = 0.f;
+            int ia = -1, ib = -1;  // element offsets inside a row; -1 (out of range for the descriptor) reads 0
+            if (MODE == 0) {
+                ia = kin ? kk : -1;
+            } else {  // adjoint of (mirror + window): taps H+d (d < H) and H-d (d >= 1) both came from u[d]
+                const BufRow wr(window, N);
+                if (kin && kk < H) ia = H + kk;
+                if (kin && kk >= 1) ib = H - kk;
+                wa = wr.ld(ia);
+                wb = wr.ld(ib);
+            }
+            const int nrow = min(ZG_ROWS, G - g0);
+#pragma unroll 16
+            for (int r = 0; r < ZG_ROWS; ++r) {
+                // one descriptor per row (wave-uniform): rows past G are empty descriptors
+                const BufRow row(src + (size_t)min(g0 + r, G - 1) * src_stride, r < nrow ? src_stride : 0);
+                float v;
+                if (MODE == 0) {
+                    v = __expf(row.ld(ia));
+                    v = kin ? v : 0.f;
+                } else {
+                    v = row.ld(ia) * wa + row.ld(ib) * wb;
+                }
+                As[r * ZG_LDA + k] = v;
+            }
+        }
+        __syncthreads();
+        const int ksteps = min(ZG_KC, Pd - kc0) >> 2;  // multiple of 32 (Pd is a multiple of 128)
+        const float* bp = Bm + (size_t)(kc0 + lk) * Pd + c0 + w * 32 + li;
+        const float* ap = As + li * ZG_LDA + lk;
+        float bq[2][8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bq[0][i][0] = bp[(size_t)(4 * i) * Pd];
+            bq[0][i][1] = bp[(size_t)(4 * i) * Pd + 16];
+        }
+        for (int s0 = 0; s0 < ksteps; s0 += 16) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                // prefetch the B fragments of the next 8 k-steps (clamped at the end of the chunk: a redundant reload)
+                const int sn = min(s0 + 8 * ph + 8, ksteps - 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    bq[ph ^ 1][i][0] = bp[(size_t)(4 * (sn + i)) * Pd];
+                    bq[ph ^ 1][i][1] = bp[(size_t)(4 * (sn + i)) * Pd + 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the 16 prefetch loads ahead of this phase's MFMAs
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s = s0 + 8 * ph + i;
+                    float a[4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) a[rt] = ap[rt * 16 * ZG_LDA + 4 * s];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][0], acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][1], acc[rt][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue through LDS so that global stores run along rows
+    __syncthreads();
+    float* Cs = As;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(rt * 16 + lk * 4 + r) * ZG_LDC + w * 32 + ct * 16 + li] = acc[rt][ct][r];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cc = lane + 64 * h, c = c0 + cc;
+        if (MODE == 0) {
+            const bool up = c < H, dn = c >= 1 && c <= H;
+            const float wu = window[H + min(c, H - 1)], wd = window[H - min(c, H)];
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = w * 16 + rr, g = g0 + row;
+                const float u = Cs[row * ZG_LDC + cc];
+                float* orow = out + (size_t)g * out_stride;
+                if (g < G && up) orow[H + c] = u * wu;
+                if (g < G && dn) orow[H - c] = u * wd;
+            }
+        } else {
+            const int ccl = min(c, n_mag - 1);
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = w * 16 + rr, g = g0 + row;
+                const float u = Cs[row * ZG_LDC + cc];
+                const float e = __expf(log_mag[(size_t)min(g, G - 1) * n_mag + ccl]);
+                if (g < G && c < n_mag) out[(size_t)g * out_stride + c] = u * e;
+            }
+        }
+    }
+    if (MODE == 0 && blockIdx.y == 0) {  // zero the row padding [N, out_stride)
+        for (int rr = 0; rr < 16; ++rr) {
+            const int g = g0 + w * 16 + rr;
+            if (g >= G) break;
+            for (int j = N + lane; j < out_stride; j += 64) out[(size_t)g * out_stride + j] = 0.f;
+        }
+    }
+}
+
+static inline int zp_pad(int n_mag) { return (int)align_up((size_t)n_mag, ZG_COLS); }
+
+}  // namespace golf
+
+using namespace golf;
+
+extern "C" {
+
+int golf_zero_phase_fir_row_stride(int n_mag) {
+    if (n_mag < 2) return 0;
+    return (int)align_up((size_t)(2 * (n_mag - 1)), 16);
+}
+
+size_t golf_zero_phase_fir_basis_bytes(int n_mag) {
+    if (n_mag < 2) return 0;
+    const size_t Pd = zp_pad(n_mag);
+    return 2 * Pd * Pd * sizeof(float);
+}
+
+int golf_zero_phase_fir_basis_f32(int n_mag, void* basis, size_t basis_bytes, void* stream) {
+    if (n_mag < 2 || !basis) return fail(GOLF_EINVAL, "zero_phase_fir_basis: n_mag=%d basis=%p", n_mag, basis);
+    if (basis_bytes < golf_zero_phase_fir_basis_bytes(n_mag))
+        return fail(GOLF_EWORKSPACE, "zero_phase_fir_basis: need %zu bytes, got %zu",
+                    golf_zero_phase_fir_basis_bytes(n_mag), basis_bytes);
+    const int Pd = zp_pad(n_mag);
+    float* bas = (float*)basis;
+    hipLaunchKernelGGL(zp_basis_kernel, dim3((Pd + 255) / 256, Pd), dim3(256), 0, (hipStream_t)stream, bas,
+                       bas + (size_t)Pd * Pd, n_mag, Pd);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+int golf_zero_phase_fir_kernels_f32(const float* log_mag, const float* window, const void* basis, float* kern,
+                                    int G, int n_mag, void* stream) {
+    if (!log_mag || !window || !basis || !kern || G < 1 || n_mag < 2)
+        return fail(GOLF_EINVAL, "zero_phase_fir_kernels: bad argument (G=%d n_mag=%d)", G, n_mag);
+    const int Pd = zp_pad(n_mag), KS = golf_zero_phase_fir_row_stride(n_mag);
+    hipLaunchKernelGGL(zp_gemm_kernel<0>, dim3((G + ZG_ROWS - 1) / ZG_ROWS, Pd / ZG_COLS), dim3(256), 0,
+                       (hipStream_t)stream, log_mag, n_mag, (const float*)nullptr, window, (const float*)basis, kern,
+                       KS, G, n_mag, Pd);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+int golf_zero_phase_fir_kernels_bwd_f32(const float* g_kern, const float* log_mag, const float* window,
+                                        const void* basis, float* g_log_mag, int G, int n_mag, void* stream) {
+    if (!g_kern || !log_mag || !window || !basis || !g_log_mag || G < 1 || n_mag < 2)
+        return fail(GOLF_EINVAL, "zero_phase_fir_kernels_bwd: bad argument (G=%d n_mag=%d)", G, n_mag);
+    const int Pd = zp_pad(n_mag), KS = golf_zero_phase_fir_row_stride(n_mag);
+    const float* basT = (const float*)basis + (size_t)Pd * Pd;
+    hipLaunchKernelGGL(zp_gemm_kernel<1>, dim3((G + ZG_ROWS - 1) / ZG_ROWS, Pd / ZG_COLS), dim3(256), 0,
+                       (hipStream_t)stream, g_kern, KS, log_mag, window, basT, g_log_mag, n_mag, G, n_mag, Pd);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+static int fir_geometry(const char* who, int B, int T, int F, int N, int hop, int KS, int* nfr_out) {
+    if (B < 1 || T < 1 || F < 1 || N < 2 || hop < 1 || KS < ((N + 3) & ~3))
+        return fail(GOLF_EINVAL, "%s: bad sizes B=%d T=%d F=%d N=%d hop=%d row_stride=%d", who, B, T, F, N, hop, KS);
+    const int P = (N - 1) / 2, span = N + hop - 1;
+    if (T + 2 * P < span)
+        return fail(GOLF_EINVAL, "%s: excitation (T=%d) shorter than one frame span (%d)", who, T, span - 2 * P);
+    int nfr = (T + 2 * P - span) / hop + 1;
+    if (nfr > F) nfr = F;
+    *nfr_out = nfr;
+    return GOLF_OK;
+}
+
+int golf_ltv_fir_frames_length(int T, int F, int N, int hop) {
+    int nfr = 0;
+    if (fir_geometry("ltv_fir_frames_length", 1, T, F, N, hop, (N + 3) & ~3, &nfr)) return -1;
+    return nfr * hop;
+}
+
+int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float* kern, int kern_row_stride, float* y,
+                                int64_t y_stride, int B, int T, int F, int N, int hop, void* stream) {
+    if (!ex || !kern || !y) return fail(GOLF_EINVAL, "ltv_fir_frames_fwd: null pointer");
+    int nfr = 0;
+    if (int rc = fir_geometry("ltv_fir_frames_fwd", B, T, F, N, hop, kern_row_stride, &nfr)) return rc;
+    const int npass = (hop + FIR_TILE - 1) / FIR_TILE;
+    const int RS = 256 + ((N + 3) & ~3) + 8;
+    const long long units = (long long)B * nfr * npass;
+    hipLaunchKernelGGL(fir_frames_fwd_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
+                       dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, kern,
+                       kern_row_stride, y, y_stride, B, T, nfr, F, N, hop, npass, RS);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
+                                const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,
+                                float* g_kern, int B, int T, int F, int N, int hop, void* stream) {
+    if (!gy || !ex || !kern) return fail(GOLF_EINVAL, "ltv_fir_frames_bwd: null pointer");
+    int nfr = 0;
+    if (int rc = fir_geometry("ltv_fir_frames_bwd", B, T, F, N, hop, kern_row_stride, &nfr)) return rc;
+    if (hop % 4 != 0)
+        return fail(GOLF_EUNSUPPORTED, "ltv_fir_frames_bwd: hop=%d must be a multiple of 4 (the frame's gradient "
+                    "samples are the packed taps of the backward kernels)", hop);
+    const int RS = 256 + hop + 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_kern) {
+        const int npass = (N + FIR_TILE - 1) / FIR_TILE;
+        const long long units = (long long)B * F * npass;
+        hipLaunchKernelGGL(fir_frames_bwd_kern_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
+                           dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, ex, ex_stride,
+                           g_kern, kern_row_stride, B, T, nfr, F, N, hop, npass, RS);
+        GOLF_LAUNCH_CHECK();
+    }
+    if (g_ex) {
+        const int P = (N - 1) / 2;
+        const int TILE = hop <= FIR_TILE ? hop : FIR_TILE;
+        const int tile_lo = P / TILE, tile_hi = (P + T - 1) / TILE;
+        const int ntile = tile_hi - tile_lo + 1;
+        const long long units = (long long)B * ntile;
+        hipLaunchKernelGGL(fir_frames_bwd_ex_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
+                           dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, kern,
+                           kern_row_stride, g_ex, g_ex_stride, B, T, nfr, F, N, hop, TILE, tile_lo, ntile, RS);
+        GOLF_LAUNCH_CHECK();
+    }
+    return GOLF_OK;
+}
+
+}  // extern "C"

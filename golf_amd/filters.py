@@ -18,7 +18,7 @@ from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
 
 __all__ = ["FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
-           "convert2samplewise"]
+           "LTVZeroPhaseFIRFilter", "LTVAPZeroPhaseFIRFilter", "convert2samplewise"]
 
 
 class FilterInterface(Controllable):
@@ -125,6 +125,61 @@ class LTVMinimumPhaseFilter(LTVMinimumPhaseFilterPrecise):
         if not self.centred:
             y = torch.nn.functional.pad(y, (hop // 2, 0), "reflect")
         return AudioTensor(y)
+
+
+class LTVZeroPhaseFIRFilter(LTVFilterInterface):
+    """Noise filter of every GOLF decoder: per-frame zero-phase FIR designed from log magnitudes
+    (reference models/filters.py:286-306,340-384).  ``forward`` runs golf_zero_phase_fir_kernels_f32 (cosine
+    transform on the matrix cores) + golf_ltv_fir_frames_{fwd,bwd}_f32; differentiable w.r.t. ``ex`` and ``log_mag``.
+
+    ``conv_method`` ("direct" | "fft") only selected between two numerically equivalent convolution routines in the
+    reference; it is accepted and validated for config compatibility, there is one kernel here."""
+
+    def __init__(self, window: str, conv_method: str = "direct", n_mag: int = None):
+        super().__init__()
+        if conv_method not in ("direct", "fft"):
+            raise ValueError(f"Unknown conv_method: {conv_method}")
+        self.window_fn = get_window_fn(window)
+        self._windows = {}
+        if n_mag is not None:
+            self.ctrl = wrap_ctrl_fn(split_size=(n_mag,), trsfm_fn=lambda x: (x,))
+
+    def _window(self, n: int, device) -> Tensor:
+        key = (n, str(device))
+        w = self._windows.get(key)
+        if w is None:
+            w = self._windows[key] = self.window_fn(n).to(device=device, dtype=torch.float32).contiguous()
+        return w
+
+    def get_zero_phase_fir(self, log_mag: Tensor) -> Tensor:
+        """(…,F,n_mag) -> (…,F,N) zero-phase impulse responses, *not* windowed (filters.py:294-300)."""
+        lm = log_mag.reshape(-1, log_mag.shape[-2], log_mag.shape[-1]) if log_mag.dim() != 3 else log_mag
+        n = 2 * (lm.shape[-1] - 1)
+        k = GF.zero_phase_fir_kernels(lm, torch.ones(n, device=lm.device))
+        return k.reshape(*log_mag.shape[:-1], n)
+
+    def windowing(self, kernel: Tensor) -> Tensor:
+        return kernel * self._window(kernel.shape[-1], kernel.device)
+
+    def forward(self, ex: AudioTensor, log_mag: AudioTensor) -> AudioTensor:
+        assert ex.ndim == 2, ex.shape
+        assert log_mag.ndim == 3, log_mag.shape
+        assert ex.hop_length == 1, f"excitation must be at hop 1 (got {ex.hop_length})"
+        n = 2 * (log_mag.shape[-1] - 1)
+        y = GF.zero_phase_fir_filter(ex.as_tensor(), log_mag.as_tensor(), self._window(n, ex.as_tensor().device),
+                                     int(log_mag.hop_length))
+        return AudioTensor(y)
+
+
+class LTVAPZeroPhaseFIRFilter(LTVZeroPhaseFIRFilter):
+    """Reference models/filters.py:387-397: same filter, sigmoid-bounded magnitudes."""
+
+    def __init__(self, window: str, conv_method: str = "direct", n_mag: int = None):
+        super().__init__(window, conv_method, n_mag)
+        n_fft = 2 * (n_mag - 1)
+        if n_mag is not None:
+            self.ctrl = wrap_ctrl_fn(split_size=(n_mag,),
+                                     trsfm_fn=lambda x: (torch.log(torch.sigmoid(x) * n_fft ** 0.5),))
 
 
 def convert2samplewise(config: dict) -> dict:

@@ -10,7 +10,9 @@ import torch
 from . import _lib
 
 __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_ola", "glottal_osc",
-           "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions"]
+           "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
+           "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
+           "fir_frames_length"]
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
@@ -262,3 +264,131 @@ def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampli
     out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
                                  bool(equal_energy), bool(return_pre))
     return (out, pre) if return_pre else out
+
+
+# ------------------------------------------------------------------------------------------------
+# zero-phase FIR noise filter (reference models/filters.py:286-384)
+# ------------------------------------------------------------------------------------------------
+_basis_cache = {}
+
+
+def zero_phase_fir_basis(n_mag: int, device) -> torch.Tensor:
+    """The constant cosine-transform matrix for ``n_mag`` bins (both orientations), built once per device."""
+    dev = torch.device(device)
+    key = (n_mag, dev.index if dev.index is not None else torch.cuda.current_device())
+    b = _basis_cache.get(key)
+    if b is None:
+        lib = _lib.load()
+        nbytes = lib.golf_zero_phase_fir_basis_bytes(n_mag)
+        b = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.golf_zero_phase_fir_basis_f32(n_mag, b.data_ptr(), nbytes, _lib.stream_ptr()),
+                   "golf_zero_phase_fir_basis_f32")
+        _basis_cache[key] = b
+    return b
+
+
+def fir_frames_length(T: int, F: int, N: int, hop: int) -> int:
+    lib = _lib.load()
+    n = lib.golf_ltv_fir_frames_length(T, F, N, hop)
+    if n < 0:
+        raise _lib.GolfError(lib.golf_last_error().decode(errors="replace"))
+    return n
+
+
+def _zp_kernels_raw(lib, log_mag, window, basis):
+    B, F, n_mag = log_mag.shape
+    KS = lib.golf_zero_phase_fir_row_stride(n_mag)
+    kern = torch.empty(B * F, KS, dtype=torch.float32, device=log_mag.device)
+    _lib.check(lib.golf_zero_phase_fir_kernels_f32(log_mag.data_ptr(), window.data_ptr(), basis.data_ptr(),
+                                                   kern.data_ptr(), B * F, n_mag, _lib.stream_ptr()),
+               "golf_zero_phase_fir_kernels_f32")
+    return kern
+
+
+def zero_phase_fir_kernels(log_mag: torch.Tensor, window: torch.Tensor) -> torch.Tensor:
+    """(B,F,n_mag) log magnitudes -> (B,F,N) windowed zero-phase FIR kernels, N = 2*(n_mag-1) (no autograd)."""
+    _lib.require_device(log_mag, window)
+    lib = _lib.load()
+    log_mag = log_mag.detach().contiguous()
+    B, F, n_mag = log_mag.shape
+    N = 2 * (n_mag - 1)
+    kern = _zp_kernels_raw(lib, log_mag, window.contiguous(), zero_phase_fir_basis(n_mag, log_mag.device))
+    return kern.view(B, F, -1)[..., :N]
+
+
+class _ZeroPhaseFIR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ex, log_mag, window, hop):
+        _lib.require_device(ex, log_mag, window)
+        lib = _lib.load()
+        ex = _rows(ex)
+        log_mag = log_mag.contiguous()
+        window = window.contiguous()
+        B, T = ex.shape
+        if log_mag.dim() != 3 or log_mag.shape[0] != B:
+            raise _lib.GolfError(f"zero_phase_fir_filter: ex {tuple(ex.shape)} vs log_mag {tuple(log_mag.shape)}")
+        F, n_mag = log_mag.shape[1], log_mag.shape[2]
+        N = 2 * (n_mag - 1)
+        if window.numel() != N:
+            raise _lib.GolfError(f"zero_phase_fir_filter: window has {window.numel()} taps, expected {N}")
+        Ty = fir_frames_length(T, F, N, hop)
+        basis = zero_phase_fir_basis(n_mag, ex.device)
+        kern = _zp_kernels_raw(lib, log_mag, window, basis)
+        y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
+        _lib.check(lib.golf_ltv_fir_frames_fwd_f32(ex.data_ptr(), ex.stride(0), kern.data_ptr(), kern.shape[1],
+                                                   y.data_ptr(), y.stride(0), B, T, F, N, hop, _lib.stream_ptr()),
+                   "golf_ltv_fir_frames_fwd_f32")
+        ctx.save_for_backward(ex, log_mag, window, kern, basis)
+        ctx.hop = hop
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, log_mag, window, kern, basis = ctx.saved_tensors
+        lib = _lib.load()
+        gy = _rows(gy)
+        B, T = ex.shape
+        F, n_mag = log_mag.shape[1], log_mag.shape[2]
+        N = 2 * (n_mag - 1)
+        need_ex, need_lm = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_ex = torch.empty_like(ex) if need_ex else None
+        g_kern = torch.empty_like(kern) if need_lm else None
+        _lib.check(lib.golf_ltv_fir_frames_bwd_f32(gy.data_ptr(), gy.stride(0), ex.data_ptr(), ex.stride(0),
+                                                   kern.data_ptr(), kern.shape[1],
+                                                   g_ex.data_ptr() if need_ex else None,
+                                                   g_ex.stride(0) if need_ex else 0,
+                                                   g_kern.data_ptr() if need_lm else None,
+                                                   B, T, F, N, ctx.hop, _lib.stream_ptr()),
+                   "golf_ltv_fir_frames_bwd_f32")
+        g_lm = None
+        if need_lm:
+            g_lm = torch.empty_like(log_mag)
+            _lib.check(lib.golf_zero_phase_fir_kernels_bwd_f32(g_kern.data_ptr(), log_mag.data_ptr(),
+                                                               window.data_ptr(), basis.data_ptr(), g_lm.data_ptr(),
+                                                               B * F, n_mag, _lib.stream_ptr()),
+                       "golf_zero_phase_fir_kernels_bwd_f32")
+        return g_ex, g_lm, None, None
+
+
+def zero_phase_fir_filter(ex: torch.Tensor, log_mag: torch.Tensor, window: torch.Tensor, hop: int) -> torch.Tensor:
+    """LTVZeroPhaseFIRFilter.forward on plain tensors: ex (B,T), log_mag (B,F,n_mag) at ``hop`` -> (B, nfr*hop);
+    differentiable w.r.t. ex and log_mag."""
+    return _ZeroPhaseFIR.apply(ex, log_mag, window, hop)
+
+
+def ltv_fir_frames(ex: torch.Tensor, kernels: torch.Tensor, hop: int) -> torch.Tensor:
+    """Frame-wise FIR with arbitrary per-frame kernels (B,F,N): y[b,f*hop+n] = sum_k pad(ex)[b,f*hop+n+k] *
+    kernels[b,f,k] (forward only)."""
+    _lib.require_device(ex, kernels)
+    lib = _lib.load()
+    ex = _rows(ex)
+    B, T = ex.shape
+    _, F, N = kernels.shape
+    KS = (N + 15) // 16 * 16
+    kern = torch.zeros(B * F, KS, dtype=torch.float32, device=ex.device)
+    kern[:, :N] = kernels.reshape(B * F, N)
+    y = torch.empty(B, fir_frames_length(T, F, N, hop), dtype=torch.float32, device=ex.device)
+    _lib.check(lib.golf_ltv_fir_frames_fwd_f32(ex.data_ptr(), ex.stride(0), kern.data_ptr(), KS, y.data_ptr(),
+                                               y.stride(0), B, T, F, N, hop, _lib.stream_ptr()),
+               "golf_ltv_fir_frames_fwd_f32")
+    return y

@@ -149,6 +149,44 @@ int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_stride,
                                   float* g_wsel, int B, int Tout,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f-1: zero-phase FIR noise filter of every GOLF decoder.
+ * Replaces LTVZeroPhaseFIRFilter.forward, models/filters.py:340-384:
+ *     kernel = fftshift(irfft(exp(log_mag))) * window                    (filters.py:294-306)
+ *     frames of N+hop-1 samples of the zero-padded excitation every hop  (filters.py:357-364)
+ *     one cross-correlation per frame with that frame's kernel (grouped F.conv1d, filters.py:371-383)
+ *
+ *   N = 2*(n_mag-1) taps, P = (N-1)/2,  nfr = min((T + 2P - (N+hop-1))/hop + 1, F) frames,
+ *   y[b, f*hop+n] = sum_{k<N} xp[b, f*hop+n+k] * kernel[b,f,k],  xp = ex zero-padded by P both sides,
+ *   output length nfr*hop (golf_ltv_fir_frames_length; -1 if T is shorter than one frame span).
+ *
+ * The inverse real FFT of a zero-phase spectrum is a cosine transform: a dense (B*F, n_mag) x (n_mag, n_mag)
+ * contraction, run on the matrix cores in exact fp32.  Its constant matrix (`basis`, both orientations) is built
+ * once per n_mag by golf_zero_phase_fir_basis_f32 into a caller-owned buffer of golf_zero_phase_fir_basis_bytes().
+ * Kernel rows live in a (B*F, row_stride) buffer, row_stride = golf_zero_phase_fir_row_stride(n_mag) >= N floats
+ * (taps [N, row_stride) are written as zeros); golf_ltv_fir_frames_* accept any per-frame kernels in that layout.
+ * ------------------------------------------------------------------------------------------- */
+int golf_zero_phase_fir_row_stride(int n_mag);
+size_t golf_zero_phase_fir_basis_bytes(int n_mag);
+int golf_zero_phase_fir_basis_f32(int n_mag, void* basis, size_t basis_bytes, void* stream);
+
+/* log_mag (G, n_mag), window (N) -> kern (G, row_stride);  G = B*F */
+int golf_zero_phase_fir_kernels_f32(const float* log_mag, const float* window, const void* basis, float* kern,
+                                    int G, int n_mag, void* stream);
+/* g_kern (G, row_stride) -> g_log_mag (G, n_mag): the adjoint of window * fftshift * irfft, times exp(log_mag) */
+int golf_zero_phase_fir_kernels_bwd_f32(const float* g_kern, const float* log_mag, const float* window,
+                                        const void* basis, float* g_log_mag, int G, int n_mag, void* stream);
+
+int golf_ltv_fir_frames_length(int T, int F, int N, int hop);
+/* ex (B, >=T) stride ex_stride; kern (B*F, kern_row_stride), zero in [N, ceil4(N)); y (B, nfr*hop) stride y_stride */
+int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float* kern, int kern_row_stride, float* y,
+                                int64_t y_stride, int B, int T, int F, int N, int hop, void* stream);
+/* gy (B, nfr*hop).  g_ex (B,T) and g_kern (B*F, kern_row_stride; rows of unused frames zeroed) are fully
+ * overwritten; either may be NULL to skip it.  Requires hop % 4 == 0. */
+int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
+                                const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,
+                                float* g_kern, int B, int T, int F, int N, int hop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

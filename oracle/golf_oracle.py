@@ -47,6 +47,12 @@ __all__ = [
     "decimate_fir",
     "default_decimation_taps",
     "source_filter_ss",
+    "zero_phase_fir_kernels",
+    "ltv_fir_frames_forward",
+    "ltv_fir_frames_backward",
+    "lti_acoustic_filter_forward",
+    "lti_acoustic_filter_backward",
+    "golf_ss_decoder",
 ]
 
 
@@ -515,3 +521,124 @@ def source_filter_ss(phase, phase_hop, weight, weight_hop, table, noise, gain, a
     T = min(osc.shape[1], np.asarray(noise).shape[1])
     src = osc[:, :T] + np.asarray(noise, dtype=np.float64)[:, :T]
     return src, ltv_allpole_ss_forward(src, gain, a, hop)
+
+
+# --------------------------------------------------------------------------------------
+# f-1  zero-phase FIR noise filter
+# --------------------------------------------------------------------------------------
+def zero_phase_fir_kernels(log_mag: np.ndarray, window: np.ndarray) -> np.ndarray:
+    """models/filters.py:294-306 (get_zero_phase_fir + windowing):
+    kernel = fftshift(irfft(exp(log_mag))) * window, n_fft = 2*(n_mag-1) taps."""
+    mag = np.exp(np.asarray(log_mag, dtype=np.float64))
+    fir = np.fft.fftshift(np.fft.irfft(mag, axis=-1), axes=-1)
+    return fir * np.asarray(window, dtype=np.float64)
+
+
+def _fir_frames_geometry(T: int, F: int, N: int, hop: int):
+    pad = (N - 1) // 2                       # filters.py:357
+    span = N + hop - 1                       # unfold size, filters.py:362
+    if T + 2 * pad < span:
+        raise ValueError("excitation shorter than one frame span")
+    nfr = min((T + 2 * pad - span) // hop + 1, F)   # filters.py:368-369 mutual truncation
+    return pad, span, nfr
+
+
+def ltv_fir_frames_forward(ex, kernel, hop: int) -> np.ndarray:
+    """models/filters.py:340-384 LTVZeroPhaseFIRFilter.forward after the kernel is built: zero-pad by
+    (N-1)//2 both sides, frames of N+hop-1 samples every hop, one cross-correlation (F.conv1d, groups =
+    B*nfr) per frame with that frame's kernel -> hop outputs per frame, concatenated: (B, nfr*hop)."""
+    ex = np.asarray(ex, dtype=np.float64)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    B, T = ex.shape
+    _, F, N = kernel.shape
+    pad, span, nfr = _fir_frames_geometry(T, F, N, hop)
+    xp = np.pad(ex, ((0, 0), (pad, pad)))
+    y = np.zeros((B, nfr * hop))
+    for f in range(nfr):
+        seg = xp[:, f * hop : f * hop + span]
+        win = np.lib.stride_tricks.sliding_window_view(seg, N, axis=1)       # (B, hop, N)
+        y[:, f * hop : (f + 1) * hop] = np.einsum("bnk,bk->bn", win, kernel[:, f])
+    return y
+
+
+def ltv_fir_frames_backward(gy, ex, log_mag, window, hop: int):
+    """Closed-form gradients of zero_phase_fir_kernels + ltv_fir_frames_forward (what autograd computes in
+    the reference through conv1d, the window product, fftshift, irfft and exp; pinned by tests/golden/g13)."""
+    gy = np.asarray(gy, dtype=np.float64)
+    ex = np.asarray(ex, dtype=np.float64)
+    log_mag = np.asarray(log_mag, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    B, T = ex.shape
+    _, F, n_mag = log_mag.shape
+    N = 2 * (n_mag - 1)
+    kernel = zero_phase_fir_kernels(log_mag, window)
+    pad, span, nfr = _fir_frames_geometry(T, F, N, hop)
+    xp = np.pad(ex, ((0, 0), (pad, pad)))
+    g_xp = np.zeros_like(xp)
+    g_kernel = np.zeros_like(kernel)
+    for f in range(nfr):
+        g = gy[:, f * hop : (f + 1) * hop]                                    # (B, hop)
+        seg = xp[:, f * hop : f * hop + span]
+        win = np.lib.stride_tricks.sliding_window_view(seg, N, axis=1)       # (B, hop, N)
+        g_kernel[:, f] = np.einsum("bn,bnk->bk", g, win)
+        for n in range(hop):
+            g_xp[:, f * hop + n : f * hop + n + N] += g[:, n : n + 1] * kernel[:, f]
+    g_ex = g_xp[:, pad : pad + T]
+    g_fir = np.fft.ifftshift(g_kernel * window, axes=-1)                      # adjoint of fftshift (N even: same roll)
+    # irfft: fir[n] = (1/N) * sum_k c_k mag[k] cos(2 pi k n / N), c_0 = c_{N/2} = 1, else 2
+    n = np.arange(N)
+    k = np.arange(n_mag)
+    c = np.full(n_mag, 2.0)
+    c[0] = c[-1] = 1.0
+    basis = c[:, None] * np.cos(2 * np.pi * k[:, None] * n[None, :] / N) / N  # (n_mag, N)
+    g_mag = g_fir @ basis.T
+    return g_ex, g_mag * np.exp(log_mag)
+
+
+# --------------------------------------------------------------------------------------
+# f-2  room filter
+# --------------------------------------------------------------------------------------
+def lti_acoustic_filter_forward(ex, kernel) -> np.ndarray:
+    """models/filters.py:426-449 LTIAcousticFilter.forward: y = ex + conv1d(pad(ex[:, :-1], (K, 0)), kernel),
+    K = len(kernel) = length-1, i.e. y[t] = ex[t] + sum_k kernel[k]*ex[t-(K-k)]  (strictly causal tail)."""
+    ex = np.asarray(ex, dtype=np.float64)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    K = kernel.shape[0]
+    T = ex.shape[1]
+    zp = np.pad(ex[:, :-1], ((0, 0), (K, 0)))
+    y = ex.copy()
+    for k in range(K):
+        y += kernel[k] * zp[:, k : k + T]
+    return y
+
+
+def lti_acoustic_filter_backward(gy, ex, kernel):
+    gy = np.asarray(gy, dtype=np.float64)
+    ex = np.asarray(ex, dtype=np.float64)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    K = kernel.shape[0]
+    T = ex.shape[1]
+    zp = np.pad(ex[:, :-1], ((0, 0), (K, 0)))
+    g_kernel = np.array([(gy * zp[:, k : k + T]).sum() for k in range(K)])
+    g_zp = np.zeros_like(zp)
+    for k in range(K):
+        g_zp[:, k : k + T] += kernel[k] * gy
+    g_ex = gy.copy()
+    g_ex[:, :-1] += g_zp[:, K:]
+    return g_ex, g_kernel
+
+
+def golf_ss_decoder(phase, phase_hop, weight, weight_hop, table, noise, log_mag, fir_window, gain, a, hop,
+                    room_kernel=None, oversampling=1, equal_energy=False, decim_taps=None):
+    """models/sf.py:35-64 as configured by cfg/ae/decoder/golf-precise.yaml: src = osc + noise_filter(noise);
+    y = room_filter(end_filter(src)); binary ops truncate to the shorter operand (utils.py:230-232)."""
+    osc = indexed_glottal_forward(phase, phase_hop, weight, weight_hop, table, oversampling,
+                                  equal_energy, None, decim_taps)["out"]
+    nz = np.asarray(noise, dtype=np.float64)[:, : osc.shape[1]]
+    fn = ltv_fir_frames_forward(nz, zero_phase_fir_kernels(log_mag, fir_window), hop)
+    T = min(osc.shape[1], fn.shape[1])
+    src = osc[:, :T] + fn[:, :T]
+    y = ltv_allpole_ss_forward(src, gain, a, hop)
+    if room_kernel is not None:
+        y = lti_acoustic_filter_forward(y, room_kernel)
+    return src, y

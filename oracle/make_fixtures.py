@@ -376,4 +376,60 @@ sd = {k: v for k, v in osc.model.state_dict().items()}
 d.update(ds_h=h, ds_w=wout.as_tensor(), ds_w_hop=wout.hop_length,
          **{"ds_model." + k: v for k, v in sd.items()})
 save("g12_ctrl_protocol", **d)
+# ----------------------------------------------------------------------------- g13 zero-phase FIR noise filter
+# LTVZeroPhaseFIRFilter.forward (filters.py:340-384) in float64, with autograd gradients.
+def run_zp(B, T, F, hop, n_mag, window="hanning"):
+    flt = rf.LTVZeroPhaseFIRFilter(window=window, conv_method="direct", n_mag=n_mag)
+    ex = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32)).double().requires_grad_(True)
+    lm = torch.from_numpy(rng.normal(-1, 0.7, (B, F, n_mag)).astype(np.float32)).double().requires_grad_(True)
+    y = flt(AT(ex, 1), AT(lm, hop)).as_tensor()
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+    (y * gy).sum().backward()
+    kern = flt.windowing(flt.get_zero_phase_fir(lm.detach()))
+    return dict(ex=ex, log_mag=lm, hop=hop, y=y, gy=gy, g_ex=ex.grad, g_log_mag=lm.grad, kernel=kern)
+
+
+d = {}
+# even n_fft (N = 16), more frames than the unfold yields, and fewer (kernel[:, :nfr] / unfolded[:, :F] truncation)
+for tag, (B, T, F, hop, n_mag) in (("a", (2, 61, 9, 8, 9)), ("b", (2, 100, 5, 8, 9)), ("c", (1, 200, 6, 24, 33))):
+    for k, v in run_zp(B, T, F, hop, n_mag).items():
+        d[f"{tag}_{k}"] = v
+for k, v in run_zp(2, 75, 8, 8, 9, window="hamming").items():
+    d[f"h_{k}"] = v
+save("g13_zero_phase_fir", **d)
+
+# ----------------------------------------------------------------------------- g14 room filter + full GOLF-ss decoder
+# LTIAcousticFilter.forward (filters.py:426-449) and the complete SourceFilterSynth of golf-precise.yaml at toy size
+room = rf.LTIAcousticFilter(length=16, conv_method="direct").double()
+with torch.no_grad():
+    room.kernel.copy_(torch.from_numpy(rng.normal(0, 0.2, (15,))).double())
+ex = torch.from_numpy(rng.normal(0, 1, (2, 50)).astype(np.float32)).double().requires_grad_(True)
+y = room(AT(ex, 1)).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+(y * gy).sum().backward()
+d = dict(room_ex=ex, room_kernel=room.kernel.detach(), room_y=y, room_gy=gy, room_g_ex=ex.grad,
+         room_g_kernel=room.kernel.grad)
+
+B, T, hop, M, n_mag = 2, 161, 16, 6, 9
+F = (T - 1) // hop + 1  # 11
+phase = dyadic((B, T), 10, 0.01, 0.08)
+w = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+noise = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32)).double()
+_, a = smooth_lpc(B, F, M)
+gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+lm = torch.from_numpy(rng.normal(-1, 0.7, (B, F, n_mag)).astype(np.float32)).double()
+osc = rs.IndexedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                 align_peak=True, lf_v2=True, points=16, oversampling=1, equal_energy=True)
+room2 = rf.LTIAcousticFilter(length=8, conv_method="direct").double()
+with torch.no_grad():
+    room2.kernel.copy_(torch.from_numpy(rng.normal(0, 0.2, (7,))).double())
+dec = rsf.SourceFilterSynth(harm_oscillator=osc, noise_generator=FixedNoise(noise),
+                            noise_filter=rf.LTVZeroPhaseFIRFilter(window="hanning", n_mag=n_mag),
+                            end_filter=rf.LTVMinimumPhaseFilterPrecise(lpc_order=M), room_filter=room2,
+                            subtract_harmonics=False)
+y = dec(phase=AT(phase, 1), harm_oscillator_params=(AT(w, 64),), noise_generator_params=(),
+        noise_filter_params=(AT(lm, hop),), end_filter_params=(AT(gain, hop), AT(a, hop)))
+d.update(phase=phase, w=w, w_hop=64, noise=noise, gain=gain, a=a, log_mag=lm, hop=hop, table=osc.table,
+         room2_kernel=room2.kernel.detach(), y=y.as_tensor())
+save("g14_room_and_full_decoder", **d)
 print("done")
