@@ -42,7 +42,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
-                    choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd"])
+                    choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd", "golf-ss-decoder",
+                             "golf-ss-decoder-train"],
+                    help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
+                         "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
+                         "and the room filter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight: the K steps are issued round-robin on this many HIP streams")
@@ -92,6 +96,31 @@ def make_step(workload, inp, osc, ss, ff):
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)
+    elif workload in ("golf-ss-decoder", "golf-ss-decoder-train"):
+        lm, rk = inp["log_mag"], inp["room_kernel"]
+        fir_win = torch.hann_window(2 * (lm.shape[-1] - 1), device=phase.device)
+        K = rk.numel()
+        train = workload.endswith("train")
+        if train:
+            gain, a, wsel_g, lm = (t.clone().requires_grad_(True) for t in (gain, a, wsel, lm))
+            rk = rk.clone().requires_grad_(True)
+            gy = torch.randn(B, 47760, device=phase.device)
+        else:
+            wsel_g = wsel
+            room_taps = torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)])
+
+        def step():
+            o = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True)
+            nz = GF.zero_phase_fir_filter(noise[:, : o.shape[1]], lm, fir_win, hop)
+            src = o[:, : nz.shape[1]] + nz
+            y = GF.ltv_allpole_ss(src, gain, a, hop)
+            if not train:
+                return GF.lti_fir(y, room_taps, K)
+            y = GF.lti_fir(y, torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)]), K)
+            for t in (gain, a, wsel_g, lm, rk):
+                t.grad = None
+            y.backward(gy)
+            return y
     elif workload == "golf-ff-synth":
         win = ff._window
 
@@ -198,7 +227,7 @@ def main():
     from golf_amd.synthetic import make_inputs
 
     B = args.batch
-    inp_all = make_inputs(B=B * world, device="cpu")
+    inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
     inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
            for k, v in shard_inputs(inp_all, rank, world).items()}
     osc, ss, ff = build_modules(device)
@@ -212,7 +241,7 @@ def main():
     # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
     # (9 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
     S = max(1, args.streams)
-    use_graphs = (not args.no_graphs) and args.workload != "golf-ss-train"  # autograd is issued eagerly
+    use_graphs = (not args.no_graphs) and not args.workload.endswith("train")  # autograd is issued eagerly
     graphs, outs = [], []
     if use_graphs:
         for i in range(S):
@@ -303,10 +332,12 @@ def main():
         ours = {k: v for k, v in ktimes.items() if "golf::" in k}
         dom, dom_us = max(ours.items(), key=lambda kv: kv[1]) if ours else ("n/a", float("nan"))
         # algorithmic bytes of the stage the dominant kernel belongs to (SURVEY.md §8d / BASELINE.md §2)
-        bytes_per_sample = 8.0 if "osc" in dom else (8.38 if args.workload != "golf-ss-train" else 8.38)
+        bytes_per_sample = 8.0 if "osc" in dom else (12.27 if ("fir_frames" in dom or "zp_gemm" in dom) else 8.38)
         alg_bytes = bytes_per_sample * samples
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
-        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8}
+        # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
+        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8,
+                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0)}
         step_us = event_time_us(step)
         traffic = None
         try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed
@@ -325,7 +356,8 @@ def main():
                             "see DESIGN.md §roofline"}
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
         result = {
-            "metric": "audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s",
+            "metric": "audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s" if args.workload == "golf-ss-synth"
+                      else f"audio samples/sec (24 kHz) {args.workload}, batch={B}x2 s",
             "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -56,6 +56,10 @@ SIGNATURES = {
     "golf_ltv_fir_frames_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64] + [_int] * 5 + [_vp]),
     "golf_ltv_fir_frames_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64, _c_f32p]
                                     + [_int] * 5 + [_vp]),
+    "golf_lti_fir_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
+    "golf_lti_fir_taps_grad_workspace_bytes": (_sz, [_int] * 3),
+    "golf_lti_fir_taps_grad_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _int, _vp, _sz,
+                                          _vp]),
 }
 
 _lock = threading.Lock()

@@ -327,18 +327,28 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 // unusable: hipcc's SLP vectoriser re-packs the unrolled body into 256 VGPR + 256 AGPR + 1 KB of scratch, 425 us.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT, int F,
-                                                     int M, int hop, int L, int NP, int nq) {
+__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
+                                                               int F, int M, int hop, int L, int NP, int nq) {
+    // Workgroups of P1F_WPB = 4 independent waves: there are fewer waves than SIMDs (637 for B=32) and every wave is
+    // FMA-issue bound, so two waves sharing a SIMD double the kernel.  With single-wave workgroups the dispatcher's
+    // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
+    // puts one wave on each SIMD of its CU.
     constexpr int KT = 4;
     constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
     constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
     constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
     constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
-    __shared__ __attribute__((aligned(16))) float tile[CPW * NT * LDT];
-    const int lane = threadIdx.x;
+    constexpr int CPP0 = (16384 / 4) / (NT * LDT);          // chunks staged per copy-out pass: <= 16 KB per wave
+    constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
+    __shared__ __attribute__((aligned(16))) float tile_all[P1F_WPB * CPP * NT * LDT];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = tile_all + wv * (CPP * NT * LDT);
     const int cl = lane / NG, grp = lane - cl * NG;
-    const int q0 = blockIdx.x * CPW;
+    const int q0 = (blockIdx.x * P1F_WPB + wv) * CPW;
+    if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
     const int jb = KT * grp;
@@ -396,28 +406,33 @@ __global__ __launch_bounds__(64) void lpc_p1f_kernel(const float* __restrict__ a
         }
     }
     // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
-    if (cl < CPW) {
-        float* trow = tile + (size_t)cl * NT * LDT + jb;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const bool ok = i < M;
-            const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
-            float4 v;
-            v.x = (ok && jb < M) ? va.x : 0.f;
-            v.y = (ok && jb + 1 < M) ? va.y : 0.f;
-            v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
-            v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
-            if (jb + 3 < W) *reinterpret_cast<float4*>(trow + (size_t)i * LDT) = v;
-        }
-    }
-    __syncthreads();
-    // coalesced copy-out: CPW chunks x NT rows x W floats are contiguous in PhiT
-    const int nch = nq - q0 < CPW ? nq - q0 : CPW;
-    float4* dst = reinterpret_cast<float4*>(PhiT + (size_t)q0 * NT * W);
+    // Copy-out through the wave's LDS tile, CPP chunks per pass: CPP chunks x NT rows x W floats are contiguous in PhiT.
     constexpr int RW4 = W / 4;
-    for (int e = lane; e < nch * NT * RW4; e += 64) {
-        const int rowi = e / RW4, c4 = e - rowi * RW4;
-        dst[e] = *reinterpret_cast<const float4*>(tile + (size_t)rowi * LDT + c4 * 4);
+    for (int c0 = 0; c0 < CPW; c0 += CPP) {
+        wave_lds_fence();
+        if (cl >= c0 && cl < c0 + CPP && cl < CPW) {
+            float* trow = tile + (size_t)(cl - c0) * NT * LDT + jb;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const bool ok = i < M;
+                const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
+                float4 v;
+                v.x = (ok && jb < M) ? va.x : 0.f;
+                v.y = (ok && jb + 1 < M) ? va.y : 0.f;
+                v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
+                v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
+                if (jb + 3 < W) *reinterpret_cast<float4*>(trow + (size_t)i * LDT) = v;
+            }
+        }
+        wave_lds_fence();
+        int nch = nq - (q0 + c0);
+        nch = nch < 0 ? 0 : (nch > CPP ? CPP : nch);
+        nch = nch > CPW - c0 ? CPW - c0 : nch;
+        float4* dst = reinterpret_cast<float4*>(PhiT + (size_t)(q0 + c0) * NT * W);
+        for (int e = lane; e < nch * NT * RW4; e += 64) {
+            const int rowi = e / RW4, c4 = e - rowi * RW4;
+            dst[e] = *reinterpret_cast<const float4*>(tile + (size_t)rowi * LDT + c4 * 4);
+        }
     }
 }
 
@@ -894,8 +909,8 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     const int nq = B * p.NP;
     if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
         constexpr int CPW = 64 / ((NT + 3) / 4);
-        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW)), dim3(64), 0, st, a, PhiT, F, M,
-                           hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
+                           st, a, PhiT, F, M, hop, p.L, p.NP, nq);
         GOLF_LAUNCH_CHECK();
         return GOLF_OK;
     }

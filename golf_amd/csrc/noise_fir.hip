@@ -71,12 +71,6 @@ __device__ __forceinline__ f32x4 fir_finish(const FirAcc& A) {
     return (f32x4){A.e01.x + A.o01.y, A.e01.y + A.o23.x, A.e23.x + A.o23.y, A.e23.y + onext};
 }
 
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // forward: unit = (utterance b, frame f, pass c over the frame's hop outputs)
 // ------------------------------------------------------------------------------------------------------------
@@ -186,6 +180,96 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
     gr.st(o + 1 < TILE ? t_hi - o - 1 : -1, r.y);
     gr.st(o + 2 < TILE ? t_hi - o - 2 : -1, r.z);
     gr.st(o + 3 < TILE ? t_hi - o - 3 : -1, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LTI FIR shared by the whole batch (room filter; reference LTIAcousticFilter,
+// models/filters.py:426-449):  y[b,t] = sum_{n<ntaps} taps[n] * ex[b, t - lead + n],  zero outside [0,T).
+// unit = (b, tile of FIR_TILE outputs).  The same kernel with flipped taps and lead' = ntaps-1-lead is its adjoint.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                                 const float* __restrict__ taps, int ntaps, int lead,
+                                                                 float* __restrict__ y, int64_t y_stride, int B, int T,
+                                                                 int ntile, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * FIR_WAVES + wv;
+    if (unit >= B * ntile) return;
+    const int tile = unit % ntile, b = unit / ntile;
+    float* sig = fir_lds + wv * RS;
+    const int t0 = tile * FIR_TILE;
+    const int span = 256 + ntaps + 4;
+    const BufRow xr(ex + b * ex_stride, T);
+    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 - lead + i);
+    wave_lds_fence();
+    FirAcc A;
+    fir_zero(A);
+    fir_accum(A, sig, taps, ntaps, lane);
+    const f32x4 r = fir_finish(A);
+    const BufRow yr(y + b * y_stride, T);
+    const int o = 4 * lane;
+    yr.st(o + 0 < FIR_TILE ? t0 + o + 0 : -1, r.x);
+    yr.st(o + 1 < FIR_TILE ? t0 + o + 1 : -1, r.y);
+    yr.st(o + 2 < FIR_TILE ? t0 + o + 2 : -1, r.z);
+    yr.st(o + 3 < FIR_TILE ? t0 + o + 3 : -1, r.w);
+}
+
+// gradient w.r.t. the shared taps: g_taps[n] = sum_{b,t} gy[b,t] * ex[b, t - lead + n].
+// unit = (b, stretch of LT samples, pass over the taps): the stretch's gradient samples are the packed taps of the
+// core, the outputs are the filter taps; per-unit partial sums, then a deterministic reduction.
+constexpr int LTI_GRAD_LT = 960;
+
+__global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_taps_grad_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ ex, int64_t ex_stride,
+    float* __restrict__ part, int ntaps, int lead, int B, int T, int nstretch, int npass, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * FIR_WAVES + wv;
+    if (unit >= B * nstretch * npass) return;
+    const int c = unit % npass, st = (unit / npass) % nstretch, b = unit / (npass * nstretch);
+    float* sig = fir_lds + wv * RS;
+    const int t0 = st * LTI_GRAD_LT, n0 = c * FIR_TILE;
+    const int len = min(LTI_GRAD_LT, T - t0), len4 = len & ~3;
+    const int span = 256 + LTI_GRAD_LT + 4;
+    const BufRow xr(ex + b * ex_stride, T);
+    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 - lead + n0 + i);
+    wave_lds_fence();
+    FirAcc A;
+    fir_zero(A);
+    const float* g = gy + b * gy_stride + t0;
+    fir_accum(A, sig, g, len4, lane);
+    f32x4 r = fir_finish(A);
+    const int o = 4 * lane;
+    for (int n = len4; n < len; ++n) {  // ragged tail of the last stretch (< 4 samples)
+        const float gv = g[n];
+        r.x += gv * sig[o + n];
+        r.y += gv * sig[o + 1 + n];
+        r.z += gv * sig[o + 2 + n];
+        r.w += gv * sig[o + 3 + n];
+    }
+    const BufRow pr(part + (size_t)(b * nstretch + st) * ntaps, ntaps);
+    const int lim = min(FIR_TILE, ntaps - n0);
+    pr.st(o + 0 < lim ? n0 + o + 0 : -1, r.x);
+    pr.st(o + 1 < lim ? n0 + o + 1 : -1, r.y);
+    pr.st(o + 2 < lim ? n0 + o + 2 : -1, r.z);
+    pr.st(o + 3 < lim ? n0 + o + 3 : -1, r.w);
+}
+
+__global__ __launch_bounds__(256) void lti_fir_taps_reduce_kernel(const float* __restrict__ part,
+                                                                  float* __restrict__ g_taps, int ntaps, int nrows) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < nrows; r += 256) s += part[(size_t)r * ntaps + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g_taps[n] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -467,6 +551,55 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
                            kern_row_stride, g_ex, g_ex_stride, B, T, nfr, F, N, hop, TILE, tile_lo, ntile, RS);
         GOLF_LAUNCH_CHECK();
     }
+    return GOLF_OK;
+}
+
+static int lti_check(const char* who, int B, int T, int ntaps, int lead) {
+    if (B < 1 || T < 1 || ntaps < 4 || (ntaps & 3) || lead < 0 || lead >= ntaps)
+        return fail(GOLF_EINVAL, "%s: bad sizes B=%d T=%d ntaps=%d (multiple of 4) lead=%d (in [0,ntaps))", who, B, T,
+                    ntaps, lead);
+    return GOLF_OK;
+}
+
+int golf_lti_fir_f32(const float* ex, int64_t ex_stride, const float* taps, int ntaps, int lead, float* y,
+                     int64_t y_stride, int B, int T, void* stream) {
+    if (!ex || !taps || !y) return fail(GOLF_EINVAL, "lti_fir: null pointer");
+    if (int rc = lti_check("lti_fir", B, T, ntaps, lead)) return rc;
+    const int ntile = (T + FIR_TILE - 1) / FIR_TILE;
+    const int RS = 256 + ntaps + 8;
+    const long long units = (long long)B * ntile;
+    hipLaunchKernelGGL(lti_fir_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)), dim3(64 * FIR_WAVES),
+                       FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, taps, ntaps, lead, y,
+                       y_stride, B, T, ntile, RS);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+size_t golf_lti_fir_taps_grad_workspace_bytes(int B, int T, int ntaps) {
+    if (B < 1 || T < 1 || ntaps < 1) return 0;
+    const size_t nstretch = (T + LTI_GRAD_LT - 1) / LTI_GRAD_LT;
+    return align_up((size_t)B * nstretch * ntaps * sizeof(float), 256);
+}
+
+int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, float* g_taps,
+                               int ntaps, int lead, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!gy || !ex || !g_taps || !ws) return fail(GOLF_EINVAL, "lti_fir_taps_grad: null pointer");
+    if (int rc = lti_check("lti_fir_taps_grad", B, T, ntaps, lead)) return rc;
+    if (ws_bytes < golf_lti_fir_taps_grad_workspace_bytes(B, T, ntaps) || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "lti_fir_taps_grad: workspace too small or misaligned (%zu < %zu)", ws_bytes,
+                    golf_lti_fir_taps_grad_workspace_bytes(B, T, ntaps));
+    const int nstretch = (T + LTI_GRAD_LT - 1) / LTI_GRAD_LT;
+    const int npass = (ntaps + FIR_TILE - 1) / FIR_TILE;
+    const int RS = 256 + LTI_GRAD_LT + 8;
+    const long long units = (long long)B * nstretch * npass;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lti_fir_taps_grad_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
+                       dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, ex, ex_stride,
+                       (float*)ws, ntaps, lead, B, T, nstretch, npass, RS);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lti_fir_taps_reduce_kernel, dim3(ntaps), dim3(256), 0, st, (const float*)ws, g_taps, ntaps,
+                       B * nstretch);
+    GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
 

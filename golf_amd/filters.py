@@ -18,7 +18,7 @@ from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
 
 __all__ = ["FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
-           "LTVZeroPhaseFIRFilter", "LTVAPZeroPhaseFIRFilter", "convert2samplewise"]
+           "LTVZeroPhaseFIRFilter", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter", "convert2samplewise"]
 
 
 class FilterInterface(Controllable):
@@ -180,6 +180,29 @@ class LTVAPZeroPhaseFIRFilter(LTVZeroPhaseFIRFilter):
         if n_mag is not None:
             self.ctrl = wrap_ctrl_fn(split_size=(n_mag,),
                                      trsfm_fn=lambda x: (torch.log(torch.sigmoid(x) * n_fft ** 0.5),))
+
+
+class LTIAcousticFilter(FilterInterface):
+    """Room filter of the GOLF decoders (reference models/filters.py:426-456): y = ex + causal FIR tail with a
+    learnable ``kernel`` of ``length - 1`` taps (zeros at init => identity); same parameter name/shape as the
+    reference so checkpoints load.  Runs golf_lti_fir_f32 (+ its adjoint / taps gradient)."""
+
+    def __init__(self, length: int, conv_method: str = "direct"):
+        super().__init__()
+        if conv_method not in ("direct", "fft"):
+            raise ValueError(f"Unknown conv_method: {conv_method}")
+        self.kernel = torch.nn.Parameter(torch.zeros(length - 1))
+        self._padding = length - 1
+
+    def forward(self, ex: AudioTensor) -> AudioTensor:
+        K = self._padding
+        pad = (-(K + 1)) % 4
+        taps = torch.cat([self.kernel, self.kernel.new_ones(1), self.kernel.new_zeros(pad)])
+        return AudioTensor(GF.lti_fir(ex.as_tensor(), taps, K), hop_length=ex.hop_length)
+
+    @property
+    def impulse_response(self) -> Tensor:
+        return torch.cat([self.kernel, torch.ones(1, device=self.kernel.device)]).flip(0)
 
 
 def convert2samplewise(config: dict) -> dict:

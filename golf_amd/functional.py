@@ -12,7 +12,7 @@ from . import _lib
 __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_ola", "glottal_osc",
            "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
            "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
-           "fir_frames_length"]
+           "fir_frames_length", "lti_fir"]
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
@@ -392,3 +392,51 @@ def ltv_fir_frames(ex: torch.Tensor, kernels: torch.Tensor, hop: int) -> torch.T
                                                y.stride(0), B, T, F, N, hop, _lib.stream_ptr()),
                "golf_ltv_fir_frames_fwd_f32")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# LTI FIR shared by the batch (room filter, reference models/filters.py:426-449)
+# ------------------------------------------------------------------------------------------------
+class _LTIFIR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ex, taps, lead):
+        _lib.require_device(ex, taps)
+        lib = _lib.load()
+        ex = _rows(ex)
+        taps = taps.contiguous()
+        B, T = ex.shape
+        y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
+        _lib.check(lib.golf_lti_fir_f32(ex.data_ptr(), ex.stride(0), taps.data_ptr(), taps.numel(), lead,
+                                        y.data_ptr(), y.stride(0), B, T, _lib.stream_ptr()), "golf_lti_fir_f32")
+        ctx.save_for_backward(ex, taps)
+        ctx.lead = lead
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, taps = ctx.saved_tensors
+        lib = _lib.load()
+        gy = _rows(gy)
+        B, T = ex.shape
+        n = taps.numel()
+        g_ex = g_taps = None
+        if ctx.needs_input_grad[0]:
+            g_ex = torch.empty_like(ex)
+            rev = taps.flip(0).contiguous()
+            _lib.check(lib.golf_lti_fir_f32(gy.data_ptr(), gy.stride(0), rev.data_ptr(), n, n - 1 - ctx.lead,
+                                            g_ex.data_ptr(), g_ex.stride(0), B, T, _lib.stream_ptr()),
+                       "golf_lti_fir_f32 (adjoint)")
+        if ctx.needs_input_grad[1]:
+            g_taps = torch.empty_like(taps)
+            ws = _workspace(lib.golf_lti_fir_taps_grad_workspace_bytes(B, T, n), ex.device)
+            _lib.check(lib.golf_lti_fir_taps_grad_f32(gy.data_ptr(), gy.stride(0), ex.data_ptr(), ex.stride(0),
+                                                      g_taps.data_ptr(), n, ctx.lead, B, T, ws.data_ptr(),
+                                                      ws.numel(), _lib.stream_ptr()),
+                       "golf_lti_fir_taps_grad_f32")
+        return g_ex, g_taps, None
+
+
+def lti_fir(ex: torch.Tensor, taps: torch.Tensor, lead: int) -> torch.Tensor:
+    """y[b,t] = sum_n taps[n] * ex[b, t-lead+n] (zero outside the signal); taps.numel() % 4 == 0; differentiable
+    w.r.t. both arguments."""
+    return _LTIFIR.apply(ex, taps, lead)

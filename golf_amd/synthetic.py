@@ -14,7 +14,8 @@ SR = 24000
 
 
 def make_inputs(B: int = 32, T: int = 48000, hop: int = 240, M: int = 22, w_hop_rate: int = 10, seed: int = 2434,
-                device="cpu", dtype=torch.float32):
+                device="cpu", dtype=torch.float32, with_noise_filter: bool = False, n_mag: int = 256,
+                room_length: int = 128):
     """phase (B,T) hop 1 · wsel (B,Fw) hop hop*w_hop_rate · noise (B,T) · gain (B,F) · a (B,F,M) · logits.
 
     * f0: per-utterance base U(80,400) Hz x 3 % vibrato at 5.5 Hz  -> phase increment in [0.003, 0.02]
@@ -22,6 +23,9 @@ def make_inputs(B: int = 32, T: int = 48000, hop: int = 240, M: int = 22, w_hop_
     * LPC logits: N(0,0.5^2) per utterance + random walk N(0,0.02^2) per frame -> tanh -> rc2lpc
       (smooth on purpose: interpolating unrelated stable frames is unstable)
     * log-gain: random walk around -3 (sigma 0.05)
+    * with_noise_filter: also log_mag (B,F,n_mag) for the zero-phase FIR noise filter (smooth spectral envelope
+      around -3 with a per-frame random walk) and room_kernel (room_length-1), an exponentially decaying tail.
+      Drawn after everything else, so the other tensors do not depend on the flag.
     """
     g = torch.Generator().manual_seed(seed)
     F = T // hop
@@ -39,4 +43,45 @@ def make_inputs(B: int = 32, T: int = 48000, hop: int = 240, M: int = 22, w_hop_
     noise = torch.randn(B, T, generator=g).to(dtype)
     out = dict(phase=phase, wsel=wsel, w_hop=w_hop, noise=noise, gain=gain, a=a, logits=logits.to(dtype),
                log_gain=log_gain.to(dtype), hop=hop)
+    if with_noise_filter:
+        env = torch.cumsum(0.15 * torch.randn(B, 1, n_mag, generator=g), 2)
+        walk = torch.cumsum(0.03 * torch.randn(B, F, n_mag, generator=g), 1)
+        out["log_mag"] = (-3.0 + env + walk).clamp(-8, 1).to(dtype)
+        K = room_length - 1
+        decay = torch.exp(-torch.arange(K, 0, -1, dtype=torch.float64) / 20.0)  # kernel[k] acts at delay K-k
+        out["room_kernel"] = (0.3 * torch.randn(K, generator=g).double() * decay).to(dtype)
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+
+
+def make_decoder(noise_filter: bool = True, room_filter: bool = True, injected_noise: torch.Tensor = None,
+                 in_channels: int = 64, framewise: bool = False):
+    """The GOLF decoder as cfg/ae/decoder/golf-precise.yaml (or golf.yaml with ``framewise``) instantiates it,
+    from this package's drop-in classes.  ``injected_noise`` replaces the RNG by a fixed tensor (parity runs)."""
+    from .audiotensor import AudioTensor
+    from .ctrl import PassThrough
+    from .filters import (LTIAcousticFilter, LTVMinimumPhaseFilter, LTVMinimumPhaseFilterPrecise,
+                          LTVZeroPhaseFIRFilter)
+    from .noise import NoiseInterface, StandardNormalNoise
+    from .sf import SourceFilterSynth
+    from .synth import DownsampledIndexedGlottalFlowTable
+
+    if injected_noise is not None:
+        class _Fixed(NoiseInterface):
+            def forward(self, ref, *args, **kwargs):
+                return AudioTensor(injected_noise[:, : ref.shape[1]])
+
+        gen = _Fixed()
+    else:
+        gen = StandardNormalNoise()
+    end = (LTVMinimumPhaseFilter(window="hanning", window_length=960, lpc_order=22, lpc_parameterisation="rc2lpc")
+           if framewise else LTVMinimumPhaseFilterPrecise(lpc_order=22, lpc_parameterisation="rc2lpc"))
+    return SourceFilterSynth(
+        harm_oscillator=DownsampledIndexedGlottalFlowTable(
+            hop_rate=10, in_channels=in_channels, oversampling=4, equal_energy=True, table_type="derivative",
+            normalize_method="constant_power", align_peak=True, trainable=False, min_R_d=0.3, max_R_d=2.7,
+            lf_v2=True, points=2048),
+        noise_generator=gen,
+        noise_filter=LTVZeroPhaseFIRFilter(window="hanning", n_mag=256) if noise_filter else PassThrough(),
+        end_filter=end,
+        room_filter=LTIAcousticFilter(length=128, conv_method="direct") if room_filter else None,
+        subtract_harmonics=False)

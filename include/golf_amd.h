@@ -187,6 +187,21 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
                                 const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,
                                 float* g_kern, int B, int T, int F, int N, int hop, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f-2: LTI FIR shared by the whole batch — the room filter after the end filter.
+ * Replaces LTIAcousticFilter.forward, models/filters.py:426-449 (pad + F.conv1d with one learnable kernel):
+ *     y[b,t] = sum_{n<ntaps} taps[n] * ex[b, t - lead + n],   ex = 0 outside [0,T)
+ *   (the reference's y = ex + conv(pad(ex[:, :-1], (K,0)), kernel) is taps = [kernel, 1], lead = K).
+ *   ntaps must be a multiple of 4 (pad with zero taps), 0 <= lead < ntaps.
+ *   The adjoint w.r.t. ex is the same call with the taps reversed and lead' = ntaps-1-lead.
+ * golf_lti_fir_taps_grad_f32: g_taps[n] = sum_{b,t} gy[b,t] * ex[b, t - lead + n]  (deterministic two-stage sum).
+ * ------------------------------------------------------------------------------------------- */
+int golf_lti_fir_f32(const float* ex, int64_t ex_stride, const float* taps, int ntaps, int lead, float* y,
+                     int64_t y_stride, int B, int T, void* stream);
+size_t golf_lti_fir_taps_grad_workspace_bytes(int B, int T, int ntaps);
+int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, float* g_taps,
+                               int ntaps, int lead, int B, int T, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,112 @@ def test_prefetch_overlap_is_bit_identical():
     GF.ltv_allpole_ss(ex, gain, ag2, 240).square().sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(ag.grad, ag2.grad)
+
+
+def test_room_filter_g14(golden):
+    """LTIAcousticFilter (golf_lti_fir_f32 + adjoint + taps gradient) against the reference's own run."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTIAcousticFilter
+
+    g = golden("g14_room_and_full_decoder")
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    room = LTIAcousticFilter(length=16).cuda()
+    assert list(room.state_dict().keys()) == ["kernel"] and room.kernel.shape == (15,)
+    ex = dev(g["room_ex"]).requires_grad_(True)
+    np.testing.assert_array_equal(room(AudioTensor(ex)).as_tensor().detach().cpu().numpy(),
+                                  ex.detach().cpu().numpy())  # zero-initialised kernel = identity
+    with torch.no_grad():
+        room.kernel.copy_(dev(g["room_kernel"]))
+    y = room(AudioTensor(ex)).as_tensor()
+    (y * dev(g["room_gy"])).sum().backward()
+    for got, ref, what in ((y, "room_y", "y"), (ex.grad, "room_g_ex", "g_ex"), (room.kernel.grad, "room_g_kernel", "g_kernel")):
+        emax, el2 = rel_err(got.detach().cpu().numpy(), g[ref])
+        print("g14 room", what, emax, el2)
+        assert emax < 1e-5 and el2 < 1e-5
+    np.testing.assert_allclose(room.impulse_response.detach().cpu().numpy()[0], 1.0)
+
+
+@pytest.mark.parametrize("B,T,K", [(3, 5000, 127), (2, 253, 5), (1, 960 * 3 + 2, 130), (2, 100, 300)])
+def test_room_filter_vs_oracle(B, T, K):
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTIAcousticFilter
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(K)
+    ex, kern, gy = rng.normal(0, 1, (B, T)), rng.normal(0, 0.1, K), rng.normal(0, 1, (B, T))
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    room = LTIAcousticFilter(length=K + 1).cuda()
+    with torch.no_grad():
+        room.kernel.copy_(dev(kern))
+    x = dev(ex).requires_grad_(True)
+    y = room(AudioTensor(x)).as_tensor()
+    (y * dev(gy)).sum().backward()
+    ref = O.lti_acoustic_filter_forward(ex, kern)
+    rgx, rgk = O.lti_acoustic_filter_backward(gy, ex, kern)
+    for got, r, what in ((y, ref, "y"), (x.grad, rgx, "g_ex"), (room.kernel.grad, rgk, "g_kernel")):
+        emax, el2 = rel_err(got.detach().cpu().numpy(), r)
+        print(f"room B{B} T{T} K{K}", what, emax, el2)
+        assert emax < 2e-5 and el2 < 2e-5
+
+
+def test_full_golf_ss_decoder_g14(golden):
+    """The complete decoder of cfg/ae/decoder/golf-precise.yaml (oscillator + noise -> zero-phase FIR noise filter,
+    LPC end filter, room filter) against the reference's own run at toy size."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTIAcousticFilter, LTVMinimumPhaseFilterPrecise, LTVZeroPhaseFIRFilter
+    from golf_amd.noise import NoiseInterface
+    from golf_amd.sf import SourceFilterSynth
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    g = golden("g14_room_and_full_decoder")
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    noise = dev(g["noise"])
+
+    class FixedNoise(NoiseInterface):
+        def forward(self, ref, *args, **kwargs):
+            return AudioTensor(noise[:, : ref.shape[1]])
+
+    osc = IndexedGlottalFlowTable(table_size=7, lf_v2=True, points=16, oversampling=1, equal_energy=True)
+    room = LTIAcousticFilter(length=8)
+    with torch.no_grad():
+        room.kernel.copy_(torch.as_tensor(g["room2_kernel"], dtype=torch.float32))
+    dec = SourceFilterSynth(harm_oscillator=osc, noise_generator=FixedNoise(),
+                            noise_filter=LTVZeroPhaseFIRFilter(window="hanning", n_mag=9),
+                            end_filter=LTVMinimumPhaseFilterPrecise(lpc_order=6), room_filter=room,
+                            subtract_harmonics=False).cuda()
+    hop, w_hop = int(g["hop"]), int(g["w_hop"])
+    y = dec(phase=AudioTensor(dev(g["phase"])), harm_oscillator_params=(AudioTensor(dev(g["w"]), w_hop),),
+            noise_generator_params=(), noise_filter_params=(AudioTensor(dev(g["log_mag"]), hop),),
+            end_filter_params=(AudioTensor(dev(g["gain"]), hop), AudioTensor(dev(g["a"]), hop)))
+    y = y.as_tensor().detach().cpu().numpy()
+    emax, el2 = rel_err(y, g["y"])
+    print("g14 full decoder", emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4
+
+
+def test_full_size_decoder_vs_oracle():
+    """golf-precise.yaml decoder at the BASELINE shape (B=32, 2 s) with injected noise vs the float64 oracle on a
+    slice of the batch."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synthetic import make_decoder, make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32, device="cuda", with_noise_filter=True)
+    dec = make_decoder(noise_filter=True, room_filter=True, injected_noise=inp["noise"]).cuda()
+    with torch.no_grad():
+        dec.room_filter.kernel.copy_(inp["room_kernel"])
+    y = dec(phase=AudioTensor(inp["phase"]), harm_oscillator_params=(AudioTensor(inp["wsel"], inp["w_hop"]),),
+            noise_generator_params=(), noise_filter_params=(AudioTensor(inp["log_mag"], 240),),
+            end_filter_params=(AudioTensor(inp["gain"], 240), AudioTensor(inp["a"], 240))).as_tensor()
+    assert y.shape == (32, 47760)
+    nb = 2
+    c = lambda k: inp[k][:nb].double().cpu().numpy()
+    osc = dec.harm_oscillator
+    win = torch.hann_window(510, dtype=torch.float64).numpy()
+    _, ref = O.golf_ss_decoder(c("phase"), 1, c("wsel"), inp["w_hop"], osc.table.double().cpu().numpy(), c("noise"),
+                               c("log_mag"), win, c("gain"), c("a"), 240,
+                               room_kernel=inp["room_kernel"].double().cpu().numpy(), oversampling=4,
+                               equal_energy=True, decim_taps=osc.decimater.kernel.double().cpu().numpy().ravel())
+    emax, el2 = rel_err(y[:nb].detach().cpu().numpy(), ref)
+    print("full-size decoder", emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4
