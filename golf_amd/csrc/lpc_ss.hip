@@ -231,13 +231,14 @@ __global__ void lpc_zfix_kernel(const float* __restrict__ z, const float* __rest
 //   PhiT[q][i][j] (row i contiguous: forward scan reads rows)
 //   lane = flat chunk q;  `pair` selects trajectories (2*pair, 2*pair+1)
 // ------------------------------------------------------------------------------------------
-// trajectories per lane.  Measured on MI355X, B=32 (GOLF_P1H_KT=1/2/3): 93.6 / 76.8 / 85.4 us -> 2.
-constexpr int p1h_kt(int W) { return 2; }
+// trajectories per lane (GOLF_P1H_KT=1/2/3 overrides).  B=32: 22 trajectories / KT groups x 100 chunk blocks =
+// 2200 / 1100 / 800 waves of relative length 0.67 / 1 / 1.33 on 1024 SIMDs: only KT=3 fits one wave per SIMD.
+constexpr int p1h_kt(int W) { return 3; }
 
 template <int W, int NT, int KT, typename R>
 __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __restrict__ a, float* __restrict__ Phi,
                                             float* __restrict__ PhiT, int F, int M, int hop, int L, int NP, int nq) {
-    const int q = qblk * 64 + threadIdx.x;
+    const int q = qblk * 64 + (threadIdx.x & 63);
     if (q >= nq) return;
     const int jb = KT * grp;  // trajectories jb .. jb+KT-1
     if (jb >= M) {            // padding rows/columns: exact zeros
@@ -465,27 +466,18 @@ __global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restr
 // already sustains one fp64 FMA per ~5.2 cycles (tools/ubench/fma_issue.hip), and the LDS reads, waits and
 // producer bookkeeping cost more issue slots than the FMAs they saved.  See DESIGN.md.)
 template <int W, int NT, int KT, typename R>
-__global__ __launch_bounds__(64) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
-                                                     float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
-                                                     int nq) {
+__global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ a, float* __restrict__ Phi,
+                                                      float* __restrict__ PhiT, int F, int M, int hop, int L, int NP,
+                                                      int nq) {
     constexpr int NG = (NT + KT - 1) / KT;  // trajectory groups per chunk
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  All NG trajectory
-    // groups of one block of 64 chunks are placed on the SAME XCD so that (i) their 8-byte pieces of the transposed
-    // matrix PhiT merge into full lines in that XCD's L2 before write-back (measured: 80 MB -> see DESIGN.md of HBM
-    // writes for 27 MB of matrices otherwise), (ii) they share the coefficient rows of `a` in L2.
+    // Workgroups of 4 independent waves, unit = (block of 64 chunks, trajectory group).  Every wave is FMA-issue
+    // bound, so two waves on one SIMD take twice as long: what matters is that the number of waves stays below the
+    // 1024 SIMDs AND that they are spread one per SIMD, which a 4-wave workgroup per CU guarantees and single-wave
+    // workgroups did not (see lpc_p1f_kernel).  The groups of one chunk block sit in the same / neighbouring
+    // workgroups and share the coefficient rows of `a` in cache.
     const int nqb = (nq + 63) / 64;
-    const int idx = blockIdx.x;
-    const int xcd = idx & 7, slot = idx >> 3;       // slot-th workgroup of this XCD
-    const int nfull = nqb & ~7;                      // chunk blocks that map 1:1 onto the 8 XCDs
-    int grp, qblk;
-    if (slot < (nfull >> 3) * NG) {
-        grp = slot % NG;
-        qblk = (slot / NG) * 8 + xcd;
-    } else {                                          // tail (< 8 chunk blocks): plain order
-        const int rem = idx - nfull * NG;
-        grp = rem % NG;
-        qblk = nfull + rem / NG;
-    }
+    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qblk = unit / NG, grp = unit - qblk * NG;
     if (qblk >= nqb) return;
     p1_hom_body<W, NT, KT, R>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
 }
@@ -916,16 +908,16 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
     if (kt_env == 1) {
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 1, double>), dim3((unsigned)(ceil_div(nq, 64) * NT)), dim3(64), 0, st, a,
-                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 1, double>), dim3((unsigned)ceil_div(ceil_div(nq, 64) * NT, 4)),
+                           dim3(256), 0, st, a, Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     } else if (p1h_kt(W) == 3 && kt_env != 2) {
         constexpr int NG = (NT + 2) / 3;
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3, double>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
-                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 3, double>), dim3((unsigned)ceil_div(ceil_div(nq, 64) * NG, 4)),
+                           dim3(256), 0, st, a, Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     } else {
         constexpr int NG = (NT + 1) / 2;
-        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2, double>), dim3((unsigned)(ceil_div(nq, 64) * NG)), dim3(64), 0, st, a,
-                           Phi, PhiT, F, M, hop, p.L, p.NP, nq);
+        hipLaunchKernelGGL((lpc_p1h_kernel<W, NT, 2, double>), dim3((unsigned)ceil_div(ceil_div(nq, 64) * NG, 4)),
+                           dim3(256), 0, st, a, Phi, PhiT, F, M, hop, p.L, p.NP, nq);
     }
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
