@@ -44,6 +44,25 @@ __device__ __forceinline__ void fir_zero(FirAcc& A) {
     A.e01 = A.e23 = A.o01 = A.o23 = (f32x2){0.f, 0.f};
 }
 
+// one group of 4 taps on the aligned window x0..x5 (x = sig[4(l+q) ...])
+__device__ __forceinline__ void fir_group(FirAcc& A, const f32x4 cur, const f32x2 x45, float c0, float c1, float c2,
+                                          float c3) {
+    const f32x2 x01 = {cur.x, cur.y}, x23 = {cur.z, cur.w};
+    A.e01 = __builtin_elementwise_fma((f32x2){c0, c0}, x01, A.e01);
+    A.e23 = __builtin_elementwise_fma((f32x2){c0, c0}, x23, A.e23);
+    A.o01 = __builtin_elementwise_fma((f32x2){c1, c1}, x01, A.o01);
+    A.o23 = __builtin_elementwise_fma((f32x2){c1, c1}, x23, A.o23);
+    A.e01 = __builtin_elementwise_fma((f32x2){c2, c2}, x23, A.e01);
+    A.e23 = __builtin_elementwise_fma((f32x2){c2, c2}, x45, A.e23);
+    A.o01 = __builtin_elementwise_fma((f32x2){c3, c3}, x23, A.o01);
+    A.o23 = __builtin_elementwise_fma((f32x2){c3, c3}, x45, A.o23);
+}
+
+// The tap loop is left to the compiler (it unrolls 8 groups: one s_load_dwordx16 x2 + 8 ds_read_b128 per 64 packed
+// FMAs, then waits for all of them).  That wait is exposed in one wave, and is hidden by the other waves of the SIMD:
+// the loop needs 44 VGPRs, so all ~6 waves per SIMD of the B=32 problem are resident at once.  A hand-pipelined
+// version (taps and window of the next 32 taps prefetched during the FMAs of the current ones; 152 VGPRs, 3 waves per
+// SIMD) measured no faster (22.2 vs 22.4 us): what cost the time was the staging loop below, not this one.
 __device__ __forceinline__ void fir_accum(FirAcc& A, const float* sig, const float* __restrict__ coef, int ntaps,
                                           int lane) {
     const f32x4* sig4 = reinterpret_cast<const f32x4*>(sig);
@@ -51,17 +70,36 @@ __device__ __forceinline__ void fir_accum(FirAcc& A, const float* sig, const flo
     const int nq = ntaps >> 2;
     for (int q = 0; q < nq; ++q) {
         const f32x4 nxt = sig4[lane + q + 1];
-        const float c0 = coef[4 * q], c1 = coef[4 * q + 1], c2 = coef[4 * q + 2], c3 = coef[4 * q + 3];
-        const f32x2 x01 = {cur.x, cur.y}, x23 = {cur.z, cur.w}, x45 = {nxt.x, nxt.y};
-        A.e01 = __builtin_elementwise_fma((f32x2){c0, c0}, x01, A.e01);
-        A.e23 = __builtin_elementwise_fma((f32x2){c0, c0}, x23, A.e23);
-        A.o01 = __builtin_elementwise_fma((f32x2){c1, c1}, x01, A.o01);
-        A.o23 = __builtin_elementwise_fma((f32x2){c1, c1}, x23, A.o23);
-        A.e01 = __builtin_elementwise_fma((f32x2){c2, c2}, x23, A.e01);
-        A.e23 = __builtin_elementwise_fma((f32x2){c2, c2}, x45, A.e23);
-        A.o01 = __builtin_elementwise_fma((f32x2){c3, c3}, x23, A.o01);
-        A.o23 = __builtin_elementwise_fma((f32x2){c3, c3}, x45, A.o23);
+        fir_group(A, cur, (f32x2){nxt.x, nxt.y}, coef[4 * q], coef[4 * q + 1], coef[4 * q + 2], coef[4 * q + 3]);
         cur = nxt;
+    }
+}
+
+// Stage `span` floats src[base + i] into the wave's LDS region, FIR_STAGE_U loads per lane in flight at a time.
+// The region must hold fir_region(span) floats: loads past `span` are harmless (the descriptor bounds them) and are
+// stored too, so that the loop has no branch — a per-element guard made hipcc wait for every single load (13 serial
+// HBM round trips per wave: 26 us for a kernel whose FMAs need 13).
+constexpr int FIR_STAGE_U = 8;
+__host__ __device__ constexpr int fir_region(int span) {
+    return (span + 64 * FIR_STAGE_U - 1) / (64 * FIR_STAGE_U) * (64 * FIR_STAGE_U);
+}
+template <bool REVERSE>
+__device__ __forceinline__ void fir_stage(float* sig, const BufRow& src, int base, int span, int lane) {
+    for (int i0 = 0; i0 < span; i0 += 64 * FIR_STAGE_U) {
+        float v[FIR_STAGE_U];
+#pragma unroll
+        for (int u = 0; u < FIR_STAGE_U; ++u) {
+            const int i = i0 + u * 64 + lane;
+            const int idx = REVERSE ? base - i : base + i;
+            // negative indices are masked here, not by the descriptor: hipcc folds the unrolled `u * 64` into the
+            // instruction's immediate offset, and (negative voffset) + (positive immediate) is range-checked WITHOUT
+            // wrapping, so elements that are in range only after the addition came back as 0.  max() keeps voffset
+            // non-negative (and un-foldable); indices past the end are still dropped by the hardware.
+            const float x = src.ld(max(idx, 0));
+            v[u] = idx >= 0 ? x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FIR_STAGE_U; ++u) sig[i0 + u * 64 + lane] = v[u];
     }
 }
 
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_fwd_kernel(
     const int span = 256 + ntaps + 4;
     const int t0 = f * hop + c * FIR_TILE;  // first output of this pass
     const BufRow xr(ex + b * ex_stride, T);
-    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 + i - P);
+    fir_stage<false>(sig, xr, t0 - P, span, lane);
     wave_lds_fence();
     FirAcc A;
     fir_zero(A);
@@ -126,7 +164,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
         const int P = (N - 1) >> 1;
         const int span = 256 + hop + 4;
         const BufRow xr(ex + b * ex_stride, T);
-        for (int i = lane; i < span; i += 64) sig[i] = xr.ld(f * hop + k0 + i - P);
+        fir_stage<false>(sig, xr, f * hop + k0 - P, span, lane);
         wave_lds_fence();
         FirAcc A;
         fir_zero(A);
@@ -168,7 +206,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
     for (int f = f_lo; f <= f_hi; ++f) {
         const BufRow kr(kern + (size_t)(b * F + f) * KS, N);
         wave_lds_fence();
-        for (int i = lane; i < span; i += 64) sig[i] = kr.ld(m_hi - f * hop - i);
+        fir_stage<true>(sig, kr, m_hi - f * hop, span, lane);
         wave_lds_fence();
         fir_accum(A, sig, gy + b * gy_stride + (size_t)f * hop, hop, lane);
     }
@@ -201,7 +239,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_kernel(const float* __
     const int t0 = tile * FIR_TILE;
     const int span = 256 + ntaps + 4;
     const BufRow xr(ex + b * ex_stride, T);
-    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 - lead + i);
+    fir_stage<false>(sig, xr, t0 - lead, span, lane);
     wave_lds_fence();
     FirAcc A;
     fir_zero(A);
@@ -234,7 +272,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_taps_grad_kernel(
     const int len = min(LTI_GRAD_LT, T - t0), len4 = len & ~3;
     const int span = 256 + LTI_GRAD_LT + 4;
     const BufRow xr(ex + b * ex_stride, T);
-    for (int i = lane; i < span; i += 64) sig[i] = xr.ld(t0 - lead + n0 + i);
+    fir_stage<false>(sig, xr, t0 - lead + n0, span, lane);
     wave_lds_fence();
     FirAcc A;
     fir_zero(A);
@@ -512,7 +550,7 @@ int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float*
     int nfr = 0;
     if (int rc = fir_geometry("ltv_fir_frames_fwd", B, T, F, N, hop, kern_row_stride, &nfr)) return rc;
     const int npass = (hop + FIR_TILE - 1) / FIR_TILE;
-    const int RS = 256 + ((N + 3) & ~3) + 8;
+    const int RS = fir_region(256 + ((N + 3) & ~3) + 4);
     const long long units = (long long)B * nfr * npass;
     hipLaunchKernelGGL(fir_frames_fwd_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
                        dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, kern,
@@ -530,7 +568,7 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
     if (hop % 4 != 0)
         return fail(GOLF_EUNSUPPORTED, "ltv_fir_frames_bwd: hop=%d must be a multiple of 4 (the frame's gradient "
                     "samples are the packed taps of the backward kernels)", hop);
-    const int RS = 256 + hop + 8;
+    const int RS = fir_region(256 + hop + 4);
     hipStream_t st = (hipStream_t)stream;
     if (g_kern) {
         const int npass = (N + FIR_TILE - 1) / FIR_TILE;
@@ -566,7 +604,7 @@ int golf_lti_fir_f32(const float* ex, int64_t ex_stride, const float* taps, int 
     if (!ex || !taps || !y) return fail(GOLF_EINVAL, "lti_fir: null pointer");
     if (int rc = lti_check("lti_fir", B, T, ntaps, lead)) return rc;
     const int ntile = (T + FIR_TILE - 1) / FIR_TILE;
-    const int RS = 256 + ntaps + 8;
+    const int RS = fir_region(256 + ntaps + 4);
     const long long units = (long long)B * ntile;
     hipLaunchKernelGGL(lti_fir_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)), dim3(64 * FIR_WAVES),
                        FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, taps, ntaps, lead, y,
@@ -590,7 +628,7 @@ int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* 
                     golf_lti_fir_taps_grad_workspace_bytes(B, T, ntaps));
     const int nstretch = (T + LTI_GRAD_LT - 1) / LTI_GRAD_LT;
     const int npass = (ntaps + FIR_TILE - 1) / FIR_TILE;
-    const int RS = 256 + LTI_GRAD_LT + 8;
+    const int RS = fir_region(256 + LTI_GRAD_LT + 4);
     const long long units = (long long)B * nstretch * npass;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(lti_fir_taps_grad_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
