@@ -332,11 +332,71 @@ __global__ void zp_basis_kernel(float* __restrict__ bas, float* __restrict__ bas
 // exact-fp32 MFMA contraction  C[g, c] = sum_k A[g, k] * Bm[k, c]   (Bm: Pd x Pd, zero padded)
 //   MODE 0 (forward):  A = exp(log_mag), Bm = bas;  epilogue: kernel row g gets u*window at taps N/2 +- c
 //   MODE 1 (backward): A[g, d] = window-folded g_kernel, Bm = basT; epilogue: g_log_mag = C * exp(log_mag)
-// block = 4 waves, 64 rows x 128 columns; wave w owns all 64 rows x 32 columns = 4 x 2 tiles of 16x16.
+// block = 4 waves, 32 rows x 128 columns; wave w owns all 32 rows x 32 columns = 2 x 2 tiles of 16x16.  (With 64-row
+// blocks the 200 workgroups ran one wave per SIMD and staging, MFMAs and epilogue simply added up: 5.8 + 7.4 + 2.7 +
+// 1.7 + 2.2 us measured piecewise, tools/ubench/gemm_parts.hip; 400 smaller workgroups let two of them share a CU.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int ZG_ROWS = 64, ZG_COLS = 128, ZG_KC = 256;
+constexpr int ZG_ROWS = 32, ZG_COLS = 128, ZG_KC = 64;
+constexpr int ZG_RT = ZG_ROWS / 16;  // 16-row MFMA tiles per wave
+constexpr int ZG_RPW = ZG_ROWS / 4;  // epilogue rows per wave
 constexpr int ZG_LDA = ZG_KC + 2;  // row stride = 2 mod 32: the (row, k) pattern of the A operand hits 32 distinct banks
 constexpr int ZG_LDC = ZG_COLS + 1;
+constexpr int ZG_EPT = ZG_ROWS * ZG_KC / 256;  // A elements staged per thread per chunk
+
+// A-chunk staging, split in two so that the loads of chunk c+1 fly during the MFMAs of chunk c:
+// zg_fetch issues the (bounds-checked, branch-free) loads, zg_commit applies the fused transform and writes LDS.
+template <int MODE>
+struct ZgStage {
+    float x[ZG_EPT], x2[ZG_EPT];
+    float wa, wb;
+    bool kin;
+};
+template <int MODE>
+__device__ __forceinline__ void zg_fetch(ZgStage<MODE>& st, const float* __restrict__ src, int src_stride,
+                                         const float* __restrict__ window, int g0, int G, int n_mag, int kc0, int tid) {
+    const int N = 2 * (n_mag - 1), H = N >> 1;
+    // one column per thread, rows r0, r0+4, ...; r0 = wave index: provably uniform, so the row descriptors below
+    // stay in SGPRs without a waterfall loop
+    const int k = tid & (ZG_KC - 1), r0 = __builtin_amdgcn_readfirstlane(tid / ZG_KC);
+    const int kk = kc0 + k;
+    st.kin = kk < n_mag;
+    int ia = -1, ib = -1;  // element offsets inside a row; -1 (out of range for the descriptor) reads 0
+    st.wa = st.wb = 0.f;
+    if (MODE == 0) {
+        ia = st.kin ? kk : -1;
+    } else {  // adjoint of (mirror + window): taps H+d (d < H) and H-d (d >= 1) both came from u[d]
+        const BufRow wr(window, N);
+        if (st.kin && kk < H) ia = H + kk;
+        if (st.kin && kk >= 1) ib = H - kk;
+        st.wa = wr.ld(ia);
+        st.wb = wr.ld(ib);
+    }
+    const int nrow = min(ZG_ROWS, G - g0);
+#pragma unroll
+    for (int j = 0; j < ZG_EPT; ++j) {
+        const int r = r0 + j * (256 / ZG_KC);
+        // one descriptor per row (wave-uniform): rows past G are empty descriptors
+        const BufRow row(src + (size_t)min(g0 + r, G - 1) * src_stride, r < nrow ? src_stride : 0);
+        st.x[j] = row.ld(ia);
+        if (MODE == 1) st.x2[j] = row.ld(ib);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void zg_commit(const ZgStage<MODE>& st, float* As, int tid) {
+    const int k = tid & (ZG_KC - 1), r0 = __builtin_amdgcn_readfirstlane(tid / ZG_KC);
+#pragma unroll
+    for (int j = 0; j < ZG_EPT; ++j) {
+        const int r = r0 + j * (256 / ZG_KC);
+        float v;
+        if (MODE == 0) {
+            v = __expf(st.x[j]);
+            v = st.kin ? v : 0.f;
+        } else {
+            v = st.x[j] * st.wa + st.x2[j] * st.wb;
+        }
+        As[r * ZG_LDA + k] = v;
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ src, int src_stride,
@@ -344,92 +404,69 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ window,
                                                       const float* __restrict__ Bm, float* __restrict__ out,
                                                       int out_stride, int G, int n_mag, int Pd) {
-    __shared__ float As[ZG_ROWS * ZG_LDA];
+    __shared__ float Asm[2 * ZG_ROWS * ZG_LDA > ZG_ROWS * ZG_LDC ? 2 * ZG_ROWS * ZG_LDA : ZG_ROWS * ZG_LDC];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g0 = blockIdx.x * ZG_ROWS, c0 = blockIdx.y * ZG_COLS;
     const int N = 2 * (n_mag - 1), H = N >> 1;
     const int li = lane & 15, lk = lane >> 4;
 
-    f32x4 acc[4][2];
+    f32x4 acc[ZG_RT][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < ZG_RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kc0 = 0; kc0 < Pd; kc0 += ZG_KC) {
-        __syncthreads();
-        // stage the A chunk (64 rows x 256 k) with the transform fused.  All loads go to clamped (always valid)
-        // addresses and the mask is applied to the value: no branches, so the loads of an unrolled batch overlap.
-        {
-            const int k = tid, kk = kc0 + k;  // one column per thread, 64 rows
-            const bool kin = kk < n_mag;
-            float wa = 0.f, wb = 0.f;
-            int ia = -1, ib = -1;  // element offsets inside a row; -1 (out of range for the descriptor) reads 0
-            if (MODE == 0) {
-                ia = kin ? kk : -1;
-            } else {  // adjoint of (mirror + window): taps H+d (d < H) and H-d (d >= 1) both came from u[d]
-                const BufRow wr(window, N);
-                if (kin && kk < H) ia = H + kk;
-                if (kin && kk >= 1) ib = H - kk;
-                wa = wr.ld(ia);
-                wb = wr.ld(ib);
-            }
-            const int nrow = min(ZG_ROWS, G - g0);
-#pragma unroll 16
-            for (int r = 0; r < ZG_ROWS; ++r) {
-                // one descriptor per row (wave-uniform): rows past G are empty descriptors
-                const BufRow row(src + (size_t)min(g0 + r, G - 1) * src_stride, r < nrow ? src_stride : 0);
-                float v;
-                if (MODE == 0) {
-                    v = __expf(row.ld(ia));
-                    v = kin ? v : 0.f;
-                } else {
-                    v = row.ld(ia) * wa + row.ld(ib) * wb;
-                }
-                As[r * ZG_LDA + k] = v;
-            }
-        }
-        __syncthreads();
-        const int ksteps = min(ZG_KC, Pd - kc0) >> 2;  // multiple of 32 (Pd is a multiple of 128)
-        const float* bp = Bm + (size_t)(kc0 + lk) * Pd + c0 + w * 32 + li;
-        const float* ap = As + li * ZG_LDA + lk;
-        float bq[2][8][2];
+    // B fragments run 8 k-steps ahead across the whole K range (Bm rows are contiguous in k)
+    const int ksteps_all = Pd >> 2;  // multiple of 32 (Pd is a multiple of 128)
+    const float* bp = Bm + (size_t)lk * Pd + c0 + w * 32 + li;
+    float bq[2][8][2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            bq[0][i][0] = bp[(size_t)(4 * i) * Pd];
-            bq[0][i][1] = bp[(size_t)(4 * i) * Pd + 16];
-        }
-        for (int s0 = 0; s0 < ksteps; s0 += 16) {
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                // prefetch the B fragments of the next 8 k-steps (clamped at the end of the chunk: a redundant reload)
-                const int sn = min(s0 + 8 * ph + 8, ksteps - 8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    bq[ph ^ 1][i][0] = bp[(size_t)(4 * (sn + i)) * Pd];
-                    bq[ph ^ 1][i][1] = bp[(size_t)(4 * (sn + i)) * Pd + 16];
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the 16 prefetch loads ahead of this phase's MFMAs
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int s = s0 + 8 * ph + i;
-                    float a[4];
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) a[rt] = ap[rt * 16 * ZG_LDA + 4 * s];
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
-                        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][0], acc[rt][0], 0, 0, 0);
-                        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][1], acc[rt][1], 0, 0, 0);
-                    }
-                }
-            }
-        }
+    for (int i = 0; i < 8; ++i) {
+        bq[0][i][0] = bp[(size_t)(4 * i) * Pd];
+        bq[0][i][1] = bp[(size_t)(4 * i) * Pd + 16];
     }
-    // epilogue through LDS so that global stores run along rows
+    ZgStage<MODE> st;
+    zg_fetch<MODE>(st, src, src_stride, window, g0, G, n_mag, 0, tid);
+    zg_commit<MODE>(st, Asm, tid);
     __syncthreads();
+    const int nchunk = Pd / ZG_KC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        float* Acur = Asm + (ch & 1) * (ZG_ROWS * ZG_LDA);
+        float* Anxt = Asm + ((ch + 1) & 1) * (ZG_ROWS * ZG_LDA);
+        const bool more = ch + 1 < nchunk;
+        if (more) zg_fetch<MODE>(st, src, src_stride, window, g0, G, n_mag, (ch + 1) * ZG_KC, tid);
+        const float* ap = Acur + li * ZG_LDA + lk;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {  // ZG_KC / 4 = 16 k-steps per chunk = 2 phases of 8
+            const int sg = ch * (ZG_KC / 4) + 8 * ph;  // global k-step of this phase
+            const int sn = min(sg + 8, ksteps_all - 8);  // clamped at the very end: a redundant reload
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bq[ph ^ 1][i][0] = bp[(size_t)(4 * (sn + i)) * Pd];
+                bq[ph ^ 1][i][1] = bp[(size_t)(4 * (sn + i)) * Pd + 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the 16 prefetch loads ahead of this phase's MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = 8 * ph + i;
+                float a[ZG_RT];
+#pragma unroll
+                for (int rt = 0; rt < ZG_RT; ++rt) a[rt] = ap[rt * 16 * ZG_LDA + 4 * s];
+#pragma unroll
+                for (int rt = 0; rt < ZG_RT; ++rt) {
+                    acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][0], acc[rt][0], 0, 0, 0);
+                    acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ph][i][1], acc[rt][1], 0, 0, 0);
+                }
+            }
+        }
+        if (more) zg_commit<MODE>(st, Anxt, tid);
+        __syncthreads();
+    }
+    float* As = Asm;
+    // epilogue through LDS so that global stores run along rows (the last loop iteration ended with a barrier)
     float* Cs = As;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < ZG_RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -443,8 +480,8 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
             const bool up = c < H, dn = c >= 1 && c <= H;
             const float wu = window[H + min(c, H - 1)], wd = window[H - min(c, H)];
 #pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = w * 16 + rr, g = g0 + row;
+            for (int rr = 0; rr < ZG_RPW; ++rr) {
+                const int row = w * ZG_RPW + rr, g = g0 + row;
                 const float u = Cs[row * ZG_LDC + cc];
                 float* orow = out + (size_t)g * out_stride;
                 if (g < G && up) orow[H + c] = u * wu;
@@ -453,8 +490,8 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
         } else {
             const int ccl = min(c, n_mag - 1);
 #pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = w * 16 + rr, g = g0 + row;
+            for (int rr = 0; rr < ZG_RPW; ++rr) {
+                const int row = w * ZG_RPW + rr, g = g0 + row;
                 const float u = Cs[row * ZG_LDC + cc];
                 const float e = __expf(log_mag[(size_t)min(g, G - 1) * n_mag + ccl]);
                 if (g < G && c < n_mag) out[(size_t)g * out_stride + c] = u * e;
@@ -462,8 +499,8 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
         }
     }
     if (MODE == 0 && blockIdx.y == 0) {  // zero the row padding [N, out_stride)
-        for (int rr = 0; rr < 16; ++rr) {
-            const int g = g0 + w * 16 + rr;
+        for (int rr = 0; rr < ZG_RPW; ++rr) {
+            const int g = g0 + w * ZG_RPW + rr;
             if (g >= G) break;
             for (int j = N + lane; j < out_stride; j += 64) out[(size_t)g * out_stride + j] = 0.f;
         }
