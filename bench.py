@@ -42,8 +42,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
-                    choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "lpc-ss-fwd", "golf-ss-decoder",
-                             "golf-ss-decoder-train"],
+                    choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
+                             "golf-ss-decoder", "golf-ss-decoder-train"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
                          "and the room filter)")
@@ -126,6 +126,17 @@ def make_step(workload, inp, osc, ss, ff):
 
         def step():
             return GF.lti_frames_ola(source(), gain, a, win, hop)
+    elif workload == "golf-ff-train":
+        win = ff._window
+        gain_g, a_g, w_g = (t.clone().requires_grad_(True) for t in (gain, a, wsel))
+        gy = torch.randn(B, 47760, device=phase.device)
+
+        def step():
+            o = GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True)
+            y = GF.lti_frames_ola(o + noise[:, : o.shape[1]], gain_g, a_g, win, hop)
+            gain_g.grad = a_g.grad = w_g.grad = None
+            y.backward(gy[:, : y.shape[1]])
+            return y
     else:  # golf-ss-train: forward + custom backward w.r.t. gain, a, table_select_weight
         gain_g = gain.clone().requires_grad_(True)
         a_g = a.clone().requires_grad_(True)
@@ -337,7 +348,8 @@ def main():
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
         # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
         path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8,
-                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0)}
+                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
+                      "golf-ff-train": 16.4 + 16.8}
         step_us = event_time_us(step)
         traffic = None
         try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed

@@ -40,22 +40,25 @@ struct Tile {
         if (col >= W) { col -= W; row += 1; }            // W < 64: lr + r < 2W, at most two wraps (W >= 8: lr<W)
     }
     // global -> registers, coalesced order; element at t = tbase + row*L + col (0 outside [0,T))
+    // DIR = -1 walks each row backwards in memory (time-reversed recursions): element (row, col) at tbase + row*L - col
+    template <int DIR = 1>
     __device__ static __forceinline__ void fetch(float (&r)[ITS], const BufRow& src, int tbase, int L, int lq,
                                                  int lr) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
-            r[it] = src.ld(tbase + row * L + col);
+            r[it] = src.ld(tbase + row * L + DIR * col);
         }
     }
+    template <int DIR = 1>
     __device__ static __forceinline__ void store(const float (&r)[ITS], const BufRow& dst, int tbase, int L, int lq,
                                                  int lr) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             int row, col;
             rowcol(it, lq, lr, row, col);
-            dst.st(tbase + row * L + col, r[it]);
+            dst.st(tbase + row * L + DIR * col, r[it]);
         }
     }
     __device__ static __forceinline__ void scatter(float* lds, const float (&r)[ITS], int lq, int lr) {

@@ -5,12 +5,16 @@
 // diagonal conv_transpose1d that the reference uses for the windowed OLA (6.1 GMAC for 6.1 MMAC of
 // useful work at B=32) plus the ones-row normaliser.
 //
-// Here: F1  one lane per frame runs the Wl-step LTI recursion in a rotating register window
-//           (coefficients constant per frame => one FMA per tap), multiplies by the window and
-//           stores the windowed frame;  6400 lanes at B=32.
-//       F2  gathers the <= Wl/hop overlapping frames per output sample and divides by the
-//           window sum (computed on the fly from the same window values, like the reference's
-//           extra ones row).
+// Here: F1  a quad of lanes per frame runs the Wl-step LTI recursion (coefficients constant per frame) and
+//           stores the filtered frame y_f (kept for the backward pass);  6400 frames at B=32.
+//       F2  gathers the <= Wl/hop overlapping frames per output sample, applies the window and divides by the
+//           window sum (computed on the fly from the same window values, like the reference's extra ones row).
+// Backward (what autograd does in the reference through conv_transpose1d, lfilter, unfold and the gain product):
+//       B0  g_q = gy / norm
+//       B1  the SAME recursion kernel run backwards in time on window * g_q frames -> u_f (the adjoint of an
+//           LTI all-pole filter is the filter itself applied to the time-reversed signal)
+//       B2  g_a[f,i] = -sum_k u_f[k] * y_f[k-1-i]   (one wave per frame)
+//       B3  g_x = overlap-add of the u_f; g_ex = g_x * G; hat-weighted partial sums of g_x * ex -> g_gain
 #include "common.h"
 #include "device_common.h"
 
@@ -79,20 +83,24 @@ __global__ __launch_bounds__(64) void ff_frames_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int s = 0; s < W; ++s)
-            if (k0 + s < Wl) out[k0 + s] = res[s] * window[k0 + s];
+            if (k0 + s < Wl) out[k0 + s] = res[s];  // unwindowed: the window is applied by the overlap-add
     }
 }
 
 // Quad version (fast path, Wl % W == 0): 4 lanes per frame, each owning TPL taps and a TPL-deep systolic window
 // (see lpc_ss.hip / device_common.h), 16 frames per wave, coalesced bounds-checked tile I/O.  The frame's
 // zero padding is what the buffer descriptor returns outside [0,Tx).
-template <int W, int NT>
+//   REV = false  forward:  input ex * up(gain), frame position k ascending, output y_f[k] (unwindowed)
+//   REV = true   adjoint:  input window[k] * g_q[f*hop + k - pad], k DEscending, no gain, output u_f[k]
+//                (`ex` = g_q with Tx = Ty; the recursion is the same one, run on the time-reversed frame)
+template <int W, int NT, bool REV>
 __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                         const float* __restrict__ gain, const float* __restrict__ a,
                                                         const float* __restrict__ window, float* __restrict__ wf,
                                                         int Tx, int F, int M, int hop, int Wl, int nfr) {
     constexpr int TPL = quad_tpl(W, NT);
     constexpr int R = 16;
+    constexpr int DIR = REV ? -1 : 1;
     using TL = Tile<W, R>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[TL::SIZE];
@@ -121,44 +129,56 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
     const float inv_hop = 1.0f / (float)hop;
     const float* gb = gain + (size_t)b * F;
     const int nblk = Wl / W;
-    // window tile in LDS (applied per element in the coalesced store phase, not per recursion step)
+    // window in LDS (REV only: applied to the incoming gradient frame)
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    for (int k = lane; k < Wl; k += 64) wl[k] = window[k];
+    if (REV) {
+        for (int k = lane; k < Wl; k += 64) wl[k] = window[k];
+    }
     float gA = 0.f, dA = 0.f, gB = 0.f, dB = 0.f;
     bool can_cross = false;
     int ftcur = -1;
     float nx[TL::ITS];
-    TL::fetch(nx, xrow, f0 * hop - pad, hop, lq, lr);
+    // block blk covers frame positions k0 .. k0+W-1 (forward) resp. Wl-1-k0 .. Wl-W-k0 (adjoint, descending)
+    const int in0 = REV ? f0 * hop - pad + Wl - 1 : f0 * hop - pad;
+    TL::template fetch<DIR>(nx, xrow, in0, hop, lq, lr);
     for (int blk = 0; blk < nblk; ++blk) {
         TL::scatter(xt, nx, lq, lr);
         __syncthreads();
         float xin[W];
         TL::rows_load(xin, xt, row);
-        TL::fetch(nx, xrow, f0 * hop - pad + (blk + 1) * W, hop, lq, lr);
+        TL::template fetch<DIR>(nx, xrow, in0 + DIR * (blk + 1) * W, hop, lq, lr);
         const int k0 = blk * W;
-        const int t0 = f * hop - pad + k0;
-        // gain line(s) for this block: at most one frame boundary inside (W <= hop); reload only on change
-        const int tb = t0 > 0 ? t0 : 0;
-        int ft = tb / hop;
-        if (ft > F - 2) ft = F - 2;
-        if (ft != ftcur) {
-            ftcur = ft;
-            gA = gb[ft];
-            gB = gb[ft + 1];
-            dA = (gB - gA) * inv_hop;
-            const float gC = ft + 2 < F ? gb[ft + 2] : gB;
-            dB = (gC - gB) * inv_hop;
-            can_cross = ft < F - 2;
+        int nbase = 0;
+        if (!REV) {
+            const int t0 = f * hop - pad + k0;
+            // gain line(s) for this block: at most one frame boundary inside (W <= hop); reload only on change
+            const int tb = t0 > 0 ? t0 : 0;
+            int ft = tb / hop;
+            if (ft > F - 2) ft = F - 2;
+            if (ft != ftcur) {
+                ftcur = ft;
+                gA = gb[ft];
+                gB = gb[ft + 1];
+                dA = (gB - gA) * inv_hop;
+                const float gC = ft + 2 < F ? gb[ft + 2] : gB;
+                dB = (gC - gB) * inv_hop;
+                can_cross = ft < F - 2;
+            }
+            nbase = t0 - ft * hop;
         }
-        const int nbase = t0 - ft * hop;
         float keep[W / 4];
 #pragma unroll
         for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
 #pragma unroll
         for (int s = 0; s < W; ++s) {
-            const int n = nbase + s;
-            const float G = (can_cross && n >= hop) ? fmaf((float)(n - hop), dB, gB) : fmaf((float)n, dA, gA);
-            const float x = xin[s] * G;
+            float x;
+            if (REV) {
+                x = xin[s] * wl[Wl - 1 - k0 - s];
+            } else {
+                const int n = nbase + s;
+                const float G = (can_cross && n >= hop) ? fmaf((float)(n - hop), dB, gB) : fmaf((float)n, dA, gA);
+                x = xin[s] * G;
+            }
             float pa_ = 0.f, pb_ = 0.f;
 #pragma unroll
             for (int k = TPL - 1; k >= 1; --k) {
@@ -179,13 +199,7 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
         __syncthreads();
         float o[TL::ITS];
         TL::gather(o, yt, lq, lr);
-#pragma unroll
-        for (int it = 0; it < TL::ITS; ++it) {
-            int trow, tcol;
-            TL::rowcol(it, lq, lr, trow, tcol);
-            o[it] *= wl[k0 + tcol];
-        }
-        TL::store(o, orow, f0 * Wl + k0, Wl, lq, lr);
+        TL::template store<DIR>(o, orow, REV ? f0 * Wl + Wl - 1 - k0 : f0 * Wl + k0, Wl, lq, lr);
         __syncthreads();
     }
 }
@@ -205,10 +219,182 @@ __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restr
     for (int f = flo; f <= fhi; ++f) {
         const int k = m - f * hop;
         if (k < 0 || k >= Wl) continue;
-        acc += wf[((size_t)b * nfr + f) * Wl + k];
-        norm += window[k];
+        const float wk = window[k];
+        acc = fmaf(wk, wf[((size_t)b * nfr + f) * Wl + k], acc);
+        norm += wk;
     }
     y[(size_t)b * y_stride + n] = acc / norm;
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------
+// B0: g_q[b,n] = gy[b,n] / norm[n]
+__global__ void ff_gq_kernel(const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ window,
+                             float* __restrict__ gq, int B, int Ty, int hop, int Wl, int nfr) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * Ty) return;
+    const int b = (int)(idx / Ty), n = (int)(idx - (int64_t)b * Ty);
+    const int m = n + Wl / 2;
+    int fhi = m / hop;
+    if (fhi > nfr - 1) fhi = nfr - 1;
+    int flo = (m - Wl + hop) / hop;
+    if (m - Wl + 1 <= 0) flo = 0;
+    float norm = 0.f;
+    for (int f = flo; f <= fhi; ++f) {
+        const int k = m - f * hop;
+        if (k >= 0 && k < Wl) norm += window[k];
+    }
+    gq[idx] = gy[(size_t)b * gy_stride + n] / norm;
+}
+
+// B2: g_a[b,f,i] = -sum_k u_f[k] * y_f[k-1-i].  One wave per frame; both rows staged in LDS (y_f behind NT zeros).
+template <int NT>
+__global__ __launch_bounds__(256) void ff_grad_a_kernel(const float* __restrict__ uf, const float* __restrict__ yf,
+                                                        float* __restrict__ g_a, int F, int M, int Wl, int nfr,
+                                                        int nq, int RS) {
+    extern __shared__ __attribute__((aligned(16))) float ga_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + wv;   // (b, f) over ALL F coefficient frames: unused frames get zeros
+    if (q >= nq) return;
+    const int b = q / F, f = q - b * F;
+    float acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = 0.f;
+    if (f < nfr) {
+        float* us = ga_lds + wv * RS;          // Wl floats
+        float* ys = us + Wl;                   // NT zeros, then Wl floats
+        const size_t base = ((size_t)b * nfr + f) * Wl;
+        for (int k = lane; k < Wl; k += 64) {
+            us[k] = uf[base + k];
+            ys[NT + k] = yf[base + k];
+        }
+        if (lane < NT) ys[lane] = 0.f;
+        wave_lds_fence();
+        for (int k = lane; k < Wl; k += 64) {
+            const float u = us[k];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = fmaf(u, ys[NT + k - 1 - i], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        acc[i] = v;
+    }
+    if (lane == 0) {
+        float* o = g_a + (size_t)q * M;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (i < M) o[i] = -acc[i];
+    }
+}
+
+// B3: g_x[t] = sum_f u_f[t + pad - f*hop]; g_ex = g_x * G(t); per gain segment s (t in [s*hop, (s+1)*hop), the last
+// one also takes t = (F-1)*hop) the hat-weighted sums P0 = sum (1-w) g_x ex, P1 = sum w g_x ex.
+__global__ __launch_bounds__(256) void ff_bwd_ola_kernel(const float* __restrict__ uf, const float* __restrict__ ex,
+                                                         int64_t ex_stride, const float* __restrict__ gain,
+                                                         float* __restrict__ g_ex, int64_t g_ex_stride,
+                                                         float* __restrict__ part, int Tx, int Tfull, int F, int hop,
+                                                         int Wl, int nfr) {
+    __shared__ float red0[256], red1[256];
+    const int sgm = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int pad = Wl / 2;
+    const float g0 = gain[(size_t)b * F + sgm], g1 = gain[(size_t)b * F + sgm + 1];
+    const float inv_hop = 1.0f / (float)hop;
+    const int t_lo = sgm * hop;
+    const int t_hi = (sgm == F - 2) ? t_lo + hop + 1 : t_lo + hop;  // exclusive
+    float p0 = 0.f, p1 = 0.f;
+    for (int t = t_lo + tid; t < t_hi && t < Tfull; t += 256) {
+        float gx = 0.f;
+        if (t < Tx) {
+            const int m = t + pad;
+            int fhi = m / hop;
+            if (fhi > nfr - 1) fhi = nfr - 1;
+            int flo = (m - Wl + hop) / hop;
+            if (m - Wl + 1 <= 0) flo = 0;
+            for (int f = flo; f <= fhi; ++f) {
+                const int k = m - f * hop;
+                if (k >= 0 && k < Wl) gx += uf[((size_t)b * nfr + f) * Wl + k];
+            }
+            const float w = (float)(t - t_lo) * inv_hop;
+            const float e = ex[(size_t)b * ex_stride + t];
+            g_ex[(size_t)b * g_ex_stride + t] = gx * fmaf(w, g1 - g0, g0);
+            p0 = fmaf((1.0f - w) * gx, e, p0);
+            p1 = fmaf(w * gx, e, p1);
+        } else {
+            g_ex[(size_t)b * g_ex_stride + t] = 0.f;
+        }
+    }
+    red0[tid] = p0;
+    red1[tid] = p1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { red0[tid] += red0[tid + off]; red1[tid] += red1[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[((size_t)b * (F - 1) + sgm) * 2 + 0] = red0[0];
+        part[((size_t)b * (F - 1) + sgm) * 2 + 1] = red1[0];
+    }
+}
+
+__global__ void ff_gain_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_gain, int B, int F) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * F) return;
+    const int b = idx / F, f = idx - b * F;
+    float v = 0.f;
+    if (f < F - 1) v += part[((size_t)b * (F - 1) + f) * 2 + 0];
+    if (f >= 1) v += part[((size_t)b * (F - 1) + f - 1) * 2 + 1];
+    g_gain[idx] = v;
+}
+
+struct FfBwdPlan {
+    size_t off_gq, off_uf, off_part, total;
+};
+static FfBwdPlan ff_bwd_plan(int B, int F, int Wl, int nfr, int Ty) {
+    FfBwdPlan p;
+    size_t o = 0;
+    p.off_gq = o;   o += align_up(sizeof(float) * (size_t)B * Ty, 256);
+    p.off_uf = o;   o += align_up(sizeof(float) * (size_t)B * nfr * Wl, 256);
+    p.off_part = o; o += align_up(sizeof(float) * (size_t)B * (F - 1) * 2, 256);
+    p.total = o;
+    return p;
+}
+
+template <int W, int NT>
+static int launch_ff_bwd(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, const float* gain,
+                         const float* a, const float* window, float* g_ex, int64_t g_ex_stride, float* g_gain,
+                         float* g_a, int B, int Tx, int Tfull, int F, int M, int hop, int Wl, int Ty, int nfr,
+                         const float* yf, char* ws, hipStream_t st) {
+    if (Wl % W != 0 || (int64_t)nfr * Wl >= (1ll << 29) || Wl > 16384)
+        return fail(GOLF_EUNSUPPORTED, "lti_frames_bwd: window length %d must be a multiple of the ring width %d "
+                    "(and <= 16384)", Wl, W);
+    const FfBwdPlan p = ff_bwd_plan(B, F, Wl, nfr, Ty);
+    float* gq = (float*)(ws + p.off_gq);
+    float* uf = (float*)(ws + p.off_uf);
+    float* part = (float*)(ws + p.off_part);
+    const int64_t n = (int64_t)B * Ty;
+    hipLaunchKernelGGL(ff_gq_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, gy, gy_stride, window, gq, B,
+                       Ty, hop, Wl, nfr);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((ff_framesq_kernel<W, NT, true>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64),
+                       sizeof(float) * (size_t)Wl, st, (const float*)gq, (int64_t)Ty, gain, a, window, uf, Ty, F, M,
+                       hop, Wl, nfr);
+    GOLF_LAUNCH_CHECK();
+    const int nq = B * F;
+    const int RS = 2 * Wl + NT + 8;
+    hipLaunchKernelGGL((ff_grad_a_kernel<NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 4 * RS * sizeof(float), st,
+                       (const float*)uf, yf, g_a, F, M, Wl, nfr, nq, RS);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ff_bwd_ola_kernel, dim3((unsigned)(F - 1), B), dim3(256), 0, st, (const float*)uf, ex,
+                       ex_stride, gain, g_ex, g_ex_stride, part, Tx, Tfull, F, hop, Wl, nfr);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ff_gain_reduce_kernel, dim3((unsigned)ceil_div(B * F, 256)), dim3(256), 0, st,
+                       (const float*)part, g_gain, B, F);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
 }
 
 template <int W, int NT>
@@ -217,8 +403,7 @@ static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, cons
                      float* wf, hipStream_t st) {
     const int nq = B * nfr;
     if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29) && Wl <= 32768) {
-        hipLaunchKernelGGL((ff_framesq_kernel<W, NT>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64),
-                           sizeof(float) * (size_t)Wl, st, ex,
+        hipLaunchKernelGGL((ff_framesq_kernel<W, NT, false>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64), 0, st, ex,
                            ex_stride, gain, a, window, wf, Tx, F, M, hop, Wl, nfr);
     } else {
         hipLaunchKernelGGL((ff_frames_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, st, ex, ex_stride,
@@ -279,4 +464,49 @@ extern "C" int golf_lti_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, c
     GOLF_FF_TRY(40, 38)
 #undef GOLF_FF_TRY
     return fail(GOLF_EUNSUPPORTED, "lti_frames: need M <= 38 and hop >= ring width (M=%d hop=%d)", M, hop);
+}
+
+extern "C" size_t golf_lti_frames_bwd_workspace_bytes(int B, int Tx, int F, int M, int hop, int W) {
+    if (B < 1 || Tx < 1 || F < 2 || hop < 1 || W < 1) return 0;
+    int nfr, Ty;
+    ff_geometry(Tx, F, hop, W, &nfr, &Ty);
+    if (nfr < 1) return 256;
+    return ff_bwd_plan(B, F, W, nfr, Ty).total;
+}
+
+extern "C" int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
+                                           const float* gain, const float* a, const float* window, float* g_ex,
+                                           int64_t g_ex_stride, int g_ex_len, float* g_gain, float* g_a, int B,
+                                           int Tx, int F, int M, int hop, int W, int Ty, const void* ws_fwd,
+                                           void* ws, size_t ws_bytes, void* stream) {
+    if (B < 1 || Tx < 1 || F < 2 || M < 1 || hop < 1 || W < 1)
+        return fail(GOLF_EINVAL, "lti_frames_bwd: bad size (need F >= 2)");
+    if (!gy || !ex || !gain || !a || !window || !g_ex || !g_gain || !g_a || !ws_fwd)
+        return fail(GOLF_EINVAL, "lti_frames_bwd: null pointer");
+    if (W < 2 * hop) return fail(GOLF_EINVAL, "lti_frames_bwd: window %d < 2*hop %d", W, 2 * hop);
+    if ((int64_t)Tx > (int64_t)(F - 1) * hop + 1) return fail(GOLF_EINVAL, "lti_frames_bwd: Tx exceeds (F-1)*hop+1");
+    int nfr, ty;
+    ff_geometry(Tx, F, hop, W, &nfr, &ty);
+    if (nfr < 1 || nfr > F) return fail(GOLF_EINVAL, "lti_frames_bwd: %d frames vs %d coefficient frames", nfr, F);
+    if (ty != Ty) return fail(GOLF_EINVAL, "lti_frames_bwd: Ty=%d, expected %d", Ty, ty);
+    if (g_ex_len < Tx) return fail(GOLF_EINVAL, "lti_frames_bwd: g_ex_len %d < Tx %d", g_ex_len, Tx);
+    const size_t need = ff_bwd_plan(B, F, W, nfr, Ty).total;
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "lti_frames_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", need,
+                    ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    // g_ex is written for t < min(g_ex_len, (F-1)*hop+1): zeros beyond Tx
+    int Tfull = (F - 1) * hop + 1;
+    if (Tfull > g_ex_len) Tfull = g_ex_len;
+#define GOLF_FF_TRY(w, nt)                                                                                     \
+    if (M <= (nt) && (w) <= hop)                                                                               \
+        return launch_ff_bwd<w, nt>(gy, gy_stride, ex, ex_stride, gain, a, window, g_ex, g_ex_stride, g_gain, g_a, B, \
+                                    Tx, Tfull, F, M, hop, W, Ty, nfr, (const float*)ws_fwd, (char*)ws, st);
+    GOLF_FF_TRY(8, 6)
+    GOLF_FF_TRY(16, 14)
+    GOLF_FF_TRY(24, 22)
+    GOLF_FF_TRY(32, 30)
+    GOLF_FF_TRY(40, 38)
+#undef GOLF_FF_TRY
+    return fail(GOLF_EUNSUPPORTED, "lti_frames_bwd: need M <= 38 and hop >= ring width (M=%d hop=%d)", M, hop);
 }

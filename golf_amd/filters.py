@@ -102,7 +102,8 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
 
 class LTVMinimumPhaseFilter(LTVMinimumPhaseFilterPrecise):
     """GOLF-ff end filter: per-frame LTI all-pole + windowed overlap-add
-    (reference models/filters.py:116-184).  Forward-only in this round."""
+    (reference models/filters.py:116-184); custom backward w.r.t. ex, gain and a
+    (golf_lti_frames_ola_{fwd,bwd}_f32)."""
 
     def prefetch(self, *args, **kwargs) -> None:  # the frame-wise filter has no excitation-independent phase
         return None

@@ -186,12 +186,30 @@ class _LTIFramesOLA(torch.autograd.Function):
                                              window.data_ptr(), y.data_ptr(), y.stride(0), B, Tx, F, M, hop, W, Ty,
                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_lti_frames_ola_fwd_f32")
+        ctx.save_for_backward(ex, gain, a, window, ws)  # ws holds the filtered frames the backward needs
+        ctx.geom = (hop, Tx, Ty)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        raise NotImplementedError("golf_amd: the frame-wise (GOLF-ff) filter is forward-only in this round; "
-                                  "train with LTVMinimumPhaseFilterPrecise (GOLF-ss)")
+        ex, gain, a, window, ws_fwd = ctx.saved_tensors
+        hop, Tx, Ty = ctx.geom
+        lib = _lib.load()
+        gy = _rows(gy)
+        B, Tx0 = ex.shape
+        F, M = a.shape[1], a.shape[2]
+        W = window.numel()
+        covered = min(Tx0, (F - 1) * hop + 1)
+        g_ex = torch.empty_like(ex) if covered == Tx0 else torch.zeros_like(ex)
+        g_gain = torch.empty_like(gain)
+        g_a = torch.empty_like(a)
+        ws = _workspace(lib.golf_lti_frames_bwd_workspace_bytes(B, Tx, F, M, hop, W), ex.device)
+        rc = lib.golf_lti_frames_ola_bwd_f32(gy.data_ptr(), gy.stride(0), ex.data_ptr(), ex.stride(0),
+                                             gain.data_ptr(), a.data_ptr(), window.data_ptr(), g_ex.data_ptr(),
+                                             g_ex.stride(0), Tx0, g_gain.data_ptr(), g_a.data_ptr(), B, Tx, F, M, hop,
+                                             W, Ty, ws_fwd.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_lti_frames_ola_bwd_f32")
+        return g_ex, g_gain, g_a, None, None
 
 
 def lti_frames_ola(ex, gain, a, window, hop: int) -> torch.Tensor:

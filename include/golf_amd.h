@@ -118,6 +118,21 @@ int golf_lti_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float*
                                 int B, int Tx, int F, int M, int hop, int W, int Ty,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* Custom backward of the above (what autograd computes in the reference through conv_transpose1d, lfilter, unfold,
+ * the zero pad and the gain product; closed form in oracle/golf_oracle.py::lti_frames_ola_backward, pinned by
+ * tests/golden/g15):  g_q = gy/norm;  u_f = the frame's all-pole recursion run backwards in time on window*g_q;
+ *     g_a[f,i] = -sum_k u_f[k]*y_f[k-1-i];   g_x = overlap-add of the u_f;   g_ex = g_x*G;   g_gain = up^T(g_x*ex).
+ *   ws_fwd = the forward's workspace, unmodified (it holds the filtered frames y_f);
+ *   ws     = scratch of golf_lti_frames_bwd_workspace_bytes();
+ *   g_ex (B, g_ex_len >= Tx) is written for t < min(g_ex_len, (F-1)*hop+1) (zeros past Tx); g_gain (B,F) and
+ *   g_a (B,F,M) are fully overwritten.  Requires W % ring width == 0 (the fast path of the forward). */
+size_t golf_lti_frames_bwd_workspace_bytes(int B, int Tx, int F, int M, int hop, int W);
+int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
+                                const float* gain, const float* a, const float* window, float* g_ex,
+                                int64_t g_ex_stride, int g_ex_len, float* g_gain, float* g_a, int B, int Tx, int F,
+                                int M, int hop, int W, int Ty, const void* ws_fwd, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a-8/a-9: indexed glottal-flow wavetable oscillator.
  * Replaces IndexedGlottalFlowTable.forward, models/synth.py:213-263 (table blend, phase/oversampling,

@@ -35,6 +35,7 @@ __all__ = [
     "lfilter_allpole",
     "hann_window_periodic",
     "lti_frames_ola_forward",
+    "lti_frames_ola_backward",
     "ltv_inverse_filter",
     "rc2lpc",
     "logits2biquads",
@@ -236,6 +237,64 @@ def lti_frames_ola_forward(ex, gain, a, hop: int, window: np.ndarray, centred: b
         k = hop // 2
         y = np.concatenate([y[:, 1 : k + 1][:, ::-1], y], axis=1)  # F.pad reflect (left)
     return y, norm
+
+
+def lti_frames_ola_backward(gy, ex, gain, a, hop: int, window: np.ndarray, centred: bool = True):
+    """Closed-form gradients of lti_frames_ola_forward (what autograd computes in the reference through the
+    reflect pad, conv_transpose1d, lfilter, unfold, zero pad and the gain product; pinned by tests/golden/g15):
+      g_q = gy / norm;  per frame g_yf[k] = window[k] * g_q[f*hop + k - pad]
+      u_f[k] = g_yf[k] - sum_i a_f[i] * u_f[k+1+i]                 (the all-pole recursion run backwards in time)
+      g_a[f,i] = -sum_k u_f[k] * y_f[k-1-i];   g_x = overlap-add of the u_f;   g_ex = g_x*G;   g_gain = up^T(g_x*ex)."""
+    gy = np.asarray(gy, dtype=np.float64)
+    ex = np.asarray(ex, dtype=np.float64)
+    gain = np.asarray(gain, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    W = window.shape[0]
+    pad = W // 2
+    B, F, M = a.shape
+    G = linear_upsample(gain, hop, axis=1)
+    off = 0 if centred else hop // 2
+    e = ex[:, off:]
+    T = min(e.shape[1], G.shape[1])
+    x = e[:, :T] * G[:, :T]
+    xp = np.concatenate([np.zeros((B, pad)), x, np.zeros((B, pad))], axis=1)
+    nfr = (xp.shape[1] - W) // hop + 1
+    frames = np.stack([xp[:, f * hop : f * hop + W] for f in range(nfr)], axis=1)
+    filt = lfilter_allpole(frames.reshape(B * nfr, W), a[:, :nfr].reshape(B * nfr, -1)).reshape(B, nfr, W)
+    full = (nfr - 1) * hop + W
+    Ty = full - 2 * pad
+    norm = np.zeros(full)
+    for f in range(nfr):
+        norm[f * hop : f * hop + W] += window
+    if centred:
+        g_y = gy.copy()
+    else:  # adjoint of the left reflect pad: y_out[j] = y[k-j] for j < k, y_out[k+n] = y[n]
+        k = hop // 2
+        g_y = gy[:, k:].copy()
+        for j in range(k):
+            g_y[:, k - j] += gy[:, j]
+    g_full = np.zeros((B, full))
+    g_full[:, pad : pad + Ty] = g_y / norm[pad : pad + Ty]
+    g_a = np.zeros_like(a)
+    g_xp = np.zeros_like(xp)
+    for f in range(nfr):
+        g_yf = g_full[:, f * hop : f * hop + W] * window
+        u = np.zeros((B, W + M))
+        for k in range(W - 1, -1, -1):
+            u[:, k] = g_yf[:, k] - np.einsum("bi,bi->b", a[:, f], u[:, k + 1 : k + 1 + M])
+        u = u[:, :W]
+        ypad = np.concatenate([np.zeros((B, M)), filt[:, f]], axis=1)        # ypad[M+k] = y_f[k]
+        for i in range(M):
+            g_a[:, f, i] = -np.einsum("bk,bk->b", u, ypad[:, M - 1 - i : M - 1 - i + W])
+        g_xp[:, f * hop : f * hop + W] += u
+    g_x = g_xp[:, pad : pad + T]
+    g_ex = np.zeros_like(ex)
+    g_ex[:, off : off + T] = g_x * G[:, :T]
+    gG = np.zeros_like(G)
+    gG[:, :T] = g_x * e[:, :T]
+    g_gain = _upsample_adjoint(gG, hop, F)
+    return g_ex, g_gain, g_a
 
 
 # --------------------------------------------------------------------------------------

@@ -64,6 +64,20 @@ def sample_wise_lpc(x, a):
 
 
 def lfilter(x, a_coeffs, b_coeffs, clamp=True, batching=True):
+    if x.requires_grad or a_coeffs.requires_grad:
+        # autograd-able float64 loop of the same direct-form difference equation (used only to capture the
+        # reference's gradients through its own glue; b = [1,0,...] at every call site of this path)
+        a0 = a_coeffs[:, :1]
+        an, bn = a_coeffs / a0, b_coeffs / a0
+        R, W = x.shape
+        K = an.shape[1]
+        ys = []
+        for n in range(W):
+            acc = sum(bn[:, k] * x[:, n - k] for k in range(min(K, n + 1)))
+            for k in range(1, min(K, n + 1)):
+                acc = acc - an[:, k] * ys[n - k]
+            ys.append(acc)
+        return torch.stack(ys, 1)
     xn = x.detach().double().numpy()
     an = a_coeffs.detach().double().numpy()
     bn = b_coeffs.detach().double().numpy()
@@ -432,4 +446,22 @@ y = dec(phase=AT(phase, 1), harm_oscillator_params=(AT(w, 64),), noise_generator
 d.update(phase=phase, w=w, w_hop=64, noise=noise, gain=gain, a=a, log_mag=lm, hop=hop, table=osc.table,
          room2_kernel=room2.kernel.detach(), y=y.as_tensor())
 save("g14_room_and_full_decoder", **d)
+# ----------------------------------------------------------------------------- g15 gradients of the ff filter (a-4)
+d = {}
+for tag, (B, F, hop, W, M, centred, Tx) in (("c", (2, 7, 8, 32, 4, True, None)), ("u", (2, 7, 8, 32, 4, False, None)),
+                                            ("s", (1, 6, 8, 16, 3, True, 33))):
+    _, a = smooth_lpc(B, F, M)
+    a = a.detach().clone().requires_grad_(True)
+    gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double()).requires_grad_(True)
+    Tx = Tx or (F - 1) * hop + 3
+    ex = torch.from_numpy(rng.normal(0, 1, (B, Tx)).astype(np.float32)).double().requires_grad_(True)
+    m = rf.LTVMinimumPhaseFilter(window="hanning", window_length=W, centred=centred, lpc_order=M)
+    m._kernel = m._kernel.double()
+    y = m(AT(ex, 1), AT(gain, hop), AT(a, hop)).as_tensor()
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+    (y * gy).sum().backward()
+    d.update({f"{tag}_ex": ex, f"{tag}_gain": gain, f"{tag}_a": a, f"{tag}_hop": hop, f"{tag}_W": W,
+              f"{tag}_centred": int(centred), f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_g_ex": ex.grad,
+              f"{tag}_g_gain": gain.grad, f"{tag}_g_a": a.grad})
+save("g15_ff_grads", **d)
 print("done")

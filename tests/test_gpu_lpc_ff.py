@@ -68,3 +68,63 @@ def test_ff_full_size():
     y0 = run_module(ex, gain, 0 * a, 240, 960, True)
     G = O.linear_upsample(gain, 240)[:, :47760]
     check(y0, ex[:, :47760] * G, "ff with a=0 is x*gain")
+
+
+def run_module_grad(ex, gain, a, hop, W, gy, centred=True):
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTVMinimumPhaseFilter
+
+    m = LTVMinimumPhaseFilter(window="hanning", window_length=W, centred=centred, lpc_order=a.shape[-1]).cuda()
+    x, g, aa = (dev(v).requires_grad_(True) for v in (ex, gain, a))
+    y = m(AudioTensor(x), AudioTensor(g, hop), AudioTensor(aa, hop)).as_tensor()
+    (y * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    return [t.detach().cpu().numpy() for t in (y, x.grad, g.grad, aa.grad)]
+
+
+@pytest.mark.parametrize("tag", ["c", "u", "s"])
+def test_golden_g15_grads(golden, tag):
+    """Gradients captured from the reference's own glue (autograd through its unfold / lfilter / conv_transpose1d)."""
+    g = golden("g15_ff_grads")
+    hop, W, centred = int(g[f"{tag}_hop"]), int(g[f"{tag}_W"]), bool(g[f"{tag}_centred"])
+    y, gx, gg, ga = run_module_grad(g[f"{tag}_ex"], g[f"{tag}_gain"], g[f"{tag}_a"], hop, W, g[f"{tag}_gy"], centred)
+    check(y, g[f"{tag}_y"], f"g15{tag} y")
+    check(gx, g[f"{tag}_g_ex"], f"g15{tag} g_ex")
+    check(gg, g[f"{tag}_g_gain"], f"g15{tag} g_gain")
+    check(ga, g[f"{tag}_g_a"], f"g15{tag} g_a")
+
+
+@pytest.mark.parametrize("B,F,M,hop,W,Tx", [(3, 12, 22, 240, 960, 2641), (2, 12, 22, 240, 960, 2500),
+                                            (2, 20, 12, 24, 96, 480), (1, 30, 26, 120, 480, 3481)])
+def test_ff_grads_vs_oracle(B, F, M, hop, W, Tx):
+    from oracle import golf_oracle as O
+    from test_gpu_lpc_ss import smooth_case
+
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=F + M)
+    win = torch.hann_window(W).double().numpy()
+    ref, _ = O.lti_frames_ola_forward(ex, gain, a, hop, win, centred=True)
+    gy = np.random.default_rng(3).normal(0, 1, ref.shape).astype(np.float32)
+    y, gx, gg, ga = run_module_grad(ex, gain, a, hop, W, gy)
+    rgx, rgg, rga = O.lti_frames_ola_backward(gy, ex, gain, a, hop, win, centred=True)
+    check(y, ref, "y")
+    check(gx, rgx, "g_ex")
+    check(gg, rgg, "g_gain")
+    check(ga, rga, "g_a")
+
+
+def test_ff_full_size_grads():
+    """GOLF-ff training shape (B=32, 2 s, W=960, hop 240, M=22): gradients vs the oracle on a slice of the batch."""
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32)
+    ex, gain, a = (inp[k].numpy() for k in ("noise", "gain", "a"))
+    win = torch.hann_window(960).double().numpy()
+    gy = np.random.default_rng(5).normal(0, 1, (32, 47760)).astype(np.float32)
+    y, gx, gg, ga = run_module_grad(ex, gain, a, 240, 960, gy)
+    nb = 2
+    rgx, rgg, rga = O.lti_frames_ola_backward(gy[:nb], ex[:nb], gain[:nb], a[:nb], 240, win, centred=True)
+    check(gx[:nb], rgx, "full-size g_ex")
+    check(gg[:nb], rgg, "full-size g_gain")
+    check(ga[:nb], rga, "full-size g_a")
+    assert np.all(gx[:, 47761:] == 0) and np.isfinite(gx).all() and np.isfinite(ga).all()
