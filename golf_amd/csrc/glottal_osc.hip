@@ -5,16 +5,18 @@
 // (B,21,2048) blended tables, >= 6 oversampled (B,191997) temporaries, a (B,191997,1,2) sampling
 // grid for F.grid_sample, and runs torch.cumsum in fp32 over 192k samples.  Here:
 //
-//   O1  osc_phase_scan   per utterance: exclusive prefix of the per-segment phase advance in fp64,
-//                        wrapped to [0,1).  Linear interpolation of the phase increment has a closed
-//                        form inside a segment, so only the Tp coarse samples are scanned, not the
-//                        N = (Tp-1)*hop*os+1 oversampled ones.
+//   O1  osc_phase_scan   per utterance: exclusive prefix of the per-segment phase advance.  The phase is kept
+//                        in 64-bit FIXED POINT (2^64 = one cycle): wrapping is the integer overflow, sums are
+//                        exact and associative (so the scan order cannot matter), and the per-sample work in O2
+//                        is integer adds instead of fp64 multiply/floor chains.  Linear interpolation of the
+//                        increment has a closed form inside a segment, so only the Tp coarse samples are
+//                        scanned, not the N = (Tp-1)*hop*os+1 oversampled ones.
 //   O2  osc_render       one workgroup per (utterance, control interval): the two blended table rows
 //                        of that interval are staged in LDS (2 x (L+1) floats), every oversampled
 //                        sample is then phase -> bilinear LDS lookup -> equal-energy scaling.
 //   O3  osc_decimate     strided FIR (kazane.Decimate stand-in; taps are an input) with a polyphase,
 //                        bank-conflict-free LDS tile.
-//   The running phase is exact to ~1e-13 cycles (the reference's fp32 cumsum drifts ~3e-5 cycles).
+//   The running phase is exact to ~1e-19 cycles per term (the reference's fp32 cumsum drifts ~3e-5 cycles).
 #include "common.h"
 
 namespace golf {
@@ -25,6 +27,7 @@ struct OscGeom {
     int hop_t;    // fine samples per control (table) frame = w_hop * os
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
+    int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
     size_t off_cw, off_ttot, off_pre, off_part, total;
 };
 #define OSC_SCAN_TILE 1024
@@ -36,33 +39,44 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->nint = (int)ceil_div(g->N, g->hop_t);
     size_t o = 0;
     g->ntile = (int)ceil_div(Tp, OSC_SCAN_TILE);
-    g->off_cw = o;   o = align_up(o + sizeof(double) * (size_t)B * Tp, 256);
-    g->off_ttot = o; o = align_up(o + sizeof(double) * (size_t)B * g->ntile, 256);
-    g->off_pre = o;  o = align_up(o + sizeof(float) * (size_t)B * g->N, 256);
+    g->off_cw = o;   o = align_up(o + sizeof(unsigned long long) * (size_t)B * Tp, 256);
+    g->off_ttot = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * g->ntile, 256);
+    g->pre_stride = (g->N + 3) & ~3;
+    g->off_pre = o;  o = align_up(o + sizeof(float) * (size_t)B * g->pre_stride, 256);
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
     g->total = o;
 }
 
 // ---- O1 ---------------------------------------------------------------------------------------
-// segsum_j = phase advance over coarse segment j = (P*p_j + (p_{j+1}-p_j)(P-1)/2)/os  (closed form of the
-// linearly interpolated increment).  One workgroup per (tile of 1024 coarse samples, utterance):
-//   Cloc[b][j] = frac(sum of segsums of the tile before j)   (exclusive, fp64)
-//   Ttot[b][tile] = frac(tile total)
+// Fixed-point increments (both kernels use exactly these two functions, so their phases agree bit for bit):
+//   inc_j(k) = a_j + k * d_j,  a_j = p_j/os,  d_j = (p_{j+1} - p_j)/(os*P)      [cycles per fine sample, Q0.64]
+//   inclusive phase after fine step k of coarse sample j:  C_j + (k+1) a_j + d_j k(k+1)/2
+//   segment total T_j = P a_j + d_j P(P-1)/2;   C_j = sum_{i<j} T_i   (all modulo 2^64 = modulo one cycle)
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 osc_fix_a(float p, double scale_a) {   // scale_a = 2^64 / os
+    return (u64)__double2ull_rn((double)p * scale_a);                  // p in [0, 0.5]: below 2^63
+}
+__device__ __forceinline__ u64 osc_fix_d(float p0, float p1, double scale_d) {  // scale_d = 2^64 / (os*P)
+    return (u64)__double2ll_rn(((double)p1 - (double)p0) * scale_d);   // signed, two's complement
+}
+// One workgroup per (tile of 1024 coarse samples, utterance):
+//   Cloc[b][j] = sum of the segment totals of the tile before j   (exclusive)
+//   Ttot[b][tile] = tile total
 // The render kernel adds the (<= ntile-term) prefix of Ttot itself.  Coalesced loads, wave shuffles.
-__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+__device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const double u = __shfl_up(v, off, 64);
+        const u64 u = __shfl_up(v, off, 64);
         if (lane >= off) v += u;
     }
     return v;
 }
 
 __global__ __launch_bounds__(256) void osc_phase_tile_kernel(const float* __restrict__ phase, int64_t phase_stride,
-                                                             double* __restrict__ Cloc, double* __restrict__ Ttot,
+                                                             u64* __restrict__ Cloc, u64* __restrict__ Ttot,
                                                              int Tp, int P, int os, int ntile) {
     __shared__ float ps[OSC_SCAN_TILE + 1];
-    __shared__ double wsum[4];
+    __shared__ u64 wsum[4];
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const float* pb = phase + (size_t)b * phase_stride;
@@ -72,121 +86,168 @@ __global__ __launch_bounds__(256) void osc_phase_tile_kernel(const float* __rest
         ps[u] = pb[j < Tp ? j : Tp - 1];
     }
     __syncthreads();
-    const double inv_os = 1.0 / (double)os;
-    const double half = 0.5 * (double)(P - 1);
-    double seg[4];
-    double tsum = 0.0;
+    const double scale_a = 18446744073709551616.0 / (double)os;
+    const double scale_d = scale_a / (double)P;
+    const u64 tri = (u64)P * (u64)(P - 1) / 2;
+    u64 seg[4];
+    u64 tsum = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int u = tid * 4 + r;
         const int j = j0 + u;
-        const double p0 = (double)ps[u], p1 = (double)ps[u + 1];
-        seg[r] = j < Tp - 1 ? ((double)P * p0 + (p1 - p0) * half) * inv_os : 0.0;  // segments 0..Tp-2
+        const u64 a = osc_fix_a(ps[u], scale_a), d = osc_fix_d(ps[u], ps[u + 1], scale_d);
+        seg[r] = j < Tp - 1 ? (u64)P * a + d * tri : 0;  // segments 0..Tp-2
         tsum += seg[r];
     }
-    const double incl = wave_incl_scan(tsum, lane);
+    const u64 incl = wave_incl_scan(tsum, lane);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    double base = 0.0;
+    u64 base = 0;
     for (int w = 0; w < wv; ++w) base += wsum[w];
-    double run = base + incl - tsum;  // exclusive prefix of this thread's first segment
-    double* cb = Cloc + (size_t)b * Tp;
+    u64 run = base + incl - tsum;  // exclusive prefix of this thread's first segment
+    u64* cb = Cloc + (size_t)b * Tp;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int j = j0 + tid * 4 + r;
-        if (j < Tp) cb[j] = run - floor(run);
+        if (j < Tp) cb[j] = run;
         run += seg[r];
     }
-    if (tid == 255) Ttot[(size_t)b * ntile + tile] = run - floor(run);
+    if (tid == 255) Ttot[(size_t)b * ntile + tile] = run;
 }
 
 // ---- O2 ---------------------------------------------------------------------------------------
 // MODE 0: forward render (writes fine samples);  MODE 1: backward w.r.t. table_select_weight
 // (reduces g_pre * d(pre)/d(p_row) over the interval into part[b][interval][2]).
 #define OSC_RENDER_THREADS 512  // 4 blocks/CU: the 640 blocks of the B=32 config run in one round
-template <int MODE>
+template <int MODE, int PT>  // PT = fine samples per coarse phase sample when known at compile time (0: runtime P)
 __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
-    const float* __restrict__ phase, int64_t phase_stride, const double* __restrict__ Cloc,
-    const double* __restrict__ Ttot, int ntile, const float* __restrict__ wsel, int Fw,
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc,
+    const u64* __restrict__ Ttot, int ntile, const float* __restrict__ wsel, int Fw,
     const float* __restrict__ table, int n_tab, int L, int Tp, int P, int os, int hop_t, int N, int equal_energy,
     float* __restrict__ dst, int64_t dst_stride, const float* __restrict__ g_pre, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ double toff[256];  // prefix of the tile totals (ntile <= 256 tiles = 262144 coarse samples)
+    __shared__ u64 toff[256];  // prefix of the tile totals (ntile <= 256 tiles = 262144 coarse samples)
     float* row0 = smem;
     float* row1 = smem + (L + 1);
     constexpr int NTH = OSC_RENDER_THREADS;
     const int r0 = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (tid < ntile) {
-        double acc = 0.0;
-        for (int t = 0; t < tid; ++t) acc += Ttot[(size_t)b * ntile + t];
-        toff[tid] = acc;
+    // exclusive prefix of the tile totals: one load per thread + a wave scan.  (First version: thread t summed
+    // Ttot[0..t) in a loop of dependent global loads, up to 46 serial L2 round trips at the head of every workgroup
+    // -- most of this kernel's duration.)
+    __shared__ u64 twsum[4];
+    if (tid < 256) {
+        const u64 v = tid < ntile ? Ttot[(size_t)b * ntile + tid] : 0;
+        const u64 incl = wave_incl_scan(v, tid & 63);
+        if ((tid & 63) == 63) twsum[tid >> 6] = incl;
+        toff[tid] = incl - v;
     }
-    // ---- stage rows r0, r0+1 (blended tables in MODE 0; table differences in MODE 1)
-    for (int rr = 0; rr < 2; ++rr) {
-        int k = r0 + rr;
-        if (k > Fw - 1) k = Fw - 1;
-        const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
-        int i0 = (int)idx;
-        i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
-        const float p = idx - (float)i0;
-        const float* t0 = table + (size_t)i0 * L;
-        const float* t1 = t0 + L;
-        float* row = rr ? row1 : row0;
-        for (int c = tid; c < L; c += NTH) {
-            if (MODE == 0) row[c] = t0[c] * (1.0f - p) + t1[c] * p;
-            else row[c] = t1[c] - t0[c];
+    __syncthreads();
+    if (tid < 256) {
+        u64 base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += twsum[w];
+        toff[tid] += base;
+    }
+    // ---- stage rows r0, r0+1 (blended tables in MODE 0; table differences in MODE 1).  All table loads of a batch
+    // (2 rows x 2 tables x 4 columns per thread) are issued before the first blend: clamped indices, no branches.
+    {
+        const float* t0[2];
+        float pw[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            int k = r0 + rr;
+            if (k > Fw - 1) k = Fw - 1;
+            const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+            int i0 = (int)idx;
+            i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+            pw[rr] = idx - (float)i0;
+            t0[rr] = table + (size_t)i0 * L;
         }
-        if (tid == 0) {
-            if (MODE == 0) row[L] = t0[0] * (1.0f - p) + t1[0] * p;
-            else row[L] = t1[0] - t0[0];
+        constexpr int SU = 4;
+        for (int cb0 = 0; cb0 < L + 1; cb0 += SU * NTH) {  // column L = wrap-around copy of column 0
+            float va[2][SU], vb[2][SU];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    int c = cb0 + u * NTH + tid;
+                    c = c > L ? L : c;
+                    c = c == L ? 0 : c;
+                    va[rr][u] = t0[rr][c];
+                    vb[rr][u] = t0[rr][L + c];
+                }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int c = cb0 + u * NTH + tid;
+                    const float v = MODE == 0 ? va[rr][u] * (1.0f - pw[rr]) + vb[rr][u] * pw[rr] : vb[rr][u] - va[rr][u];
+                    if (c <= L) (rr ? row1 : row0)[c] = v;
+                }
         }
     }
     __syncthreads();
     const float* pb = phase + (size_t)b * phase_stride;
-    const double* cb = Cloc + (size_t)b * Tp;
+    const u64* cb = Cloc + (size_t)b * Tp;
     const int m_lo = r0 * hop_t;
     const int m_hi = m_lo + hop_t < N ? m_lo + hop_t : N;
     const float inv_hop_t = 1.0f / (float)hop_t;
     const float inv_P = 1.0f / (float)P;
     const float inv_osf = 1.0f / (float)os;
-    const double inv_os = 1.0 / (double)os;
-    const int dj = NTH / P, dk = NTH % P;  // advance of (j,k) per NTH fine samples
-    int m = m_lo + tid;
-    int j = m / P;
-    int k = m - j * P;
+    const double scale_a = 18446744073709551616.0 / (double)os;
+    const double scale_d = scale_a / (double)P;
+    // One thread per COARSE phase sample of the interval, walking its P fine samples with two integer adds each
+    // (ph += inc; inc += d).  The first version evaluated the closed form in fp64 for every fine sample (77 VALU
+    // instructions per sample, 42 % VALU-active with the rest of the time waiting for its four loads per sample).
+    const int j_lo = m_lo / P, j_hi = (m_hi - 1) / P;  // coarse samples overlapping [m_lo, m_hi)
     float acc0 = 0.f, acc1 = 0.f;
-    for (; m < m_hi; m += NTH) {
-        // coarse sample j (clamped for the final point: k == 0 there, and d == 0 because j+1 clamps to j)
+    for (int j = j_lo + tid; j <= j_hi; j += NTH) {
+        // coarse sample j (the final point: j = Tp-1 has only k = 0, and d == 0 because j+1 clamps to j)
         const int jc = j < Tp - 1 ? j : Tp - 1;
         const int jn = jc + 1 < Tp ? jc + 1 : Tp - 1;
-        const float p0 = pb[jc];
-        const float d = (pb[jn] - p0) * inv_P;
-        const double cj = cb[jc] + toff[jc / OSC_SCAN_TILE];
-        const int kk_i = m - jc * P;
-        const double kk = (double)kk_i;
-        // inclusive cumulative phase: C_j + ((k+1) p0 + d k(k+1)/2)/os, in fp64, wrapped
-        double ph = cj + ((kk + 1.0) * (double)p0 + (double)d * (kk * (kk + 1.0) * 0.5)) * inv_os;
-        ph -= floor(ph);
-        const float c = (float)ph * (float)L;
-        int c0 = (int)c;
-        c0 = c0 > L - 1 ? L - 1 : c0;  // ph rounded up to 1.0f
-        const float cf = c - (float)c0;
-        const float rf = (float)(m - m_lo) * inv_hop_t;
-        const float a00 = row0[c0], a01 = row0[c0 + 1], a10 = row1[c0], a11 = row1[c0 + 1];
-        const float top = fmaf(cf, a01 - a00, a00);
-        const float bot = fmaf(cf, a11 - a10, a10);
-        float scale = 1.0f;
-        if (equal_energy) scale = rsqrtf(fmaf((float)kk_i, d, p0) * inv_osf);
-        if (MODE == 0) {
-            dst[(size_t)b * dst_stride + m] = fmaf(rf, bot - top, top) * scale;
-        } else {
-            const float g = g_pre[(size_t)b * N + m] * scale;
-            acc0 = fmaf(g * (1.0f - rf), top, acc0);
-            acc1 = fmaf(g * rf, bot, acc1);
+        const float p0 = pb[jc], p1 = pb[jn];
+        const float d = (p1 - p0) * inv_P;
+        u64 inc = osc_fix_a(p0, scale_a);
+        const u64 dinc = osc_fix_d(p0, p1, scale_d);
+        u64 ph = cb[jc] + toff[jc / OSC_SCAN_TILE];
+        const int mb = jc * P;
+        float o4[PT > 0 ? PT : 1];
+        const int pcount = PT > 0 ? PT : P;
+#pragma unroll
+        for (int k = 0; k < pcount; ++k) {
+            ph += inc;   // inclusive cumulative phase of fine sample mb + k
+            inc += dinc;
+            const int m = mb + k;
+            const bool in = m >= m_lo && m < m_hi;
+            // table position: (ph / 2^64) * L, from the top 32 phase bits in exact 64-bit integer arithmetic
+            const u64 pos = (ph >> 32) * (u64)L;
+            const int c0 = (int)(pos >> 32);
+            const float cf = (float)((unsigned)pos >> 8) * (1.0f / 16777216.0f);
+            const float rf = (float)(m - m_lo) * inv_hop_t;
+            const float a00 = row0[c0], a01 = row0[c0 + 1], a10 = row1[c0], a11 = row1[c0 + 1];
+            const float top = fmaf(cf, a01 - a00, a00);
+            const float bot = fmaf(cf, a11 - a10, a10);
+            float scale = 1.0f;
+            if (equal_energy) scale = rsqrtf(fmaf((float)k, d, p0) * inv_osf);
+            if (MODE == 0) {
+                const float v = fmaf(rf, bot - top, top) * scale;
+                if (PT > 0) o4[k] = v;
+                else if (in) dst[(size_t)b * dst_stride + m] = v;
+            } else if (in) {
+                const float g = g_pre[(size_t)b * N + m] * scale;
+                acc0 = fmaf(g * (1.0f - rf), top, acc0);
+                acc1 = fmaf(g * rf, bot, acc1);
+            }
         }
-        j += dj;
-        k += dk;
-        if (k >= P) { k -= P; j += 1; }
+        if (MODE == 0 && PT > 0) {
+            float* o = dst + (size_t)b * dst_stride + mb;
+            if (PT == 4 && mb >= m_lo && mb + 4 <= m_hi && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                *reinterpret_cast<float4*>(o) = make_float4(o4[0], o4[1], o4[2], o4[3]);  // one 16-byte store per thread
+            } else {
+#pragma unroll
+                for (int k = 0; k < PT; ++k)
+                    if (mb + k >= m_lo && mb + k < m_hi) o[k] = o4[k];
+            }
+        }
     }
     if (MODE == 1) {
         __syncthreads();
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
 //   4 FMAs; the LDS tile splits X_ph further by (i & 3) so that lanes (stride-4 outputs) hit consecutive banks:
 //   addr(ph, i) = (ph*4 + (i&3))*RS4 + (i>>2).  Taps sit in LDS as 4-aligned groups (broadcast ds_read_b128).
 #define OSC_TILE 1024
-__global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restrict__ pre, int N,
+__global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restrict__ pre, int N, int64_t pre_stride,
                                                            const float* __restrict__ taps, int K, int os,
                                                            float* __restrict__ out, int64_t out_stride, int Tout,
                                                            int RS4, int dmin, int ngrp) {
@@ -224,7 +285,7 @@ __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restri
     const int HS = ngrp * 4 + 8;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int o0 = blockIdx.x * OSC_TILE;
-    const float* pb = pre + (size_t)b * N;
+    const float* pb = pre + (size_t)b * pre_stride;
     const int half = (K - 1) / 2;
     const int64_t m_lo = (int64_t)(o0 + dmin) * os;
     const int span = OSC_TILE + ngrp * 4 + 4;  // polyphase indices staged per phase
@@ -419,17 +480,24 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
                     ws_bytes);
     if (g.ntile > 256) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: Tp=%d > 262144 coarse phase samples", Tp);
     hipStream_t st = (hipStream_t)stream;
-    double* Cw = (double*)((char*)ws + g.off_cw);
-    double* Ttot = (double*)((char*)ws + g.off_ttot);
+    u64* Cw = (u64*)((char*)ws + g.off_cw);
+    u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
                        g.P, os, g.ntile);
     GOLF_LAUNCH_CHECK();
     float* fine = os > 1 ? (pre ? pre : (float*)((char*)ws + g.off_pre)) : out;
-    const int64_t fine_stride = os > 1 ? g.N : out_stride;
+    // the internal oversampled buffer uses a row stride that is a multiple of 4 floats (16-byte stores / loads); a
+    // caller-provided `pre` is dense (B, N)
+    const int64_t fine_stride = os > 1 ? (pre ? (int64_t)g.N : g.pre_stride) : out_stride;
     const size_t lds = sizeof(float) * 2 * (size_t)(L + 1);
-    hipLaunchKernelGGL((osc_render_kernel<0>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase, phase_stride,
-                       (const double*)Cw, (const double*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P, os, g.hop_t,
-                       g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr);
+    if (g.P == 4)
+        hipLaunchKernelGGL((osc_render_kernel<0, 4>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase,
+                           phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P,
+                           os, g.hop_t, g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((osc_render_kernel<0, 0>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase,
+                           phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P,
+                           os, g.hop_t, g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr);
     GOLF_LAUNCH_CHECK();
     if (os > 1) {
         const int half = (K - 1) / 2;
@@ -443,7 +511,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const size_t lds3 = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8));
         if (lds3 > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: %d taps x os %d exceed LDS", K, os);
         hipLaunchKernelGGL(osc_decimate_kernel, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
-                           (const float*)fine, g.N, taps, K, os, out, out_stride, Tout, RS4, dmin, ngrp);
+                           (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin, ngrp);
         GOLF_LAUNCH_CHECK();
     }
     return GOLF_OK;
@@ -464,7 +532,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         return fail(GOLF_EWORKSPACE, "glottal_osc_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
-    const double* Cw = (const double*)((char*)ws + g.off_cw);  // still valid from the forward
+    const u64* Cw = (const u64*)((char*)ws + g.off_cw);  // still valid from the forward
     float* g_pre = (float*)((char*)ws + g.off_pre);
     float* part = (float*)((char*)ws + g.off_part);
     if (os == 4) {
@@ -493,8 +561,8 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
     }
     size_t lds = sizeof(float) * 2 * (size_t)(L + 1);
     if (lds < sizeof(float) * 2 * OSC_RENDER_THREADS) lds = sizeof(float) * 2 * OSC_RENDER_THREADS;
-    const double* Ttot = (const double*)((char*)ws + g.off_ttot);
-    hipLaunchKernelGGL((osc_render_kernel<1>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase, phase_stride,
+    const u64* Ttot = (const u64*)((char*)ws + g.off_ttot);
+    hipLaunchKernelGGL((osc_render_kernel<1, 0>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase, phase_stride,
                        Cw, Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P, os, g.hop_t, g.N, equal_energy,
                        (float*)nullptr, (int64_t)0, (const float*)g_pre, part);
     GOLF_LAUNCH_CHECK();

@@ -1,0 +1,24 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"; do
+  i=$((i+1))
+  bash $R/tools/prof_pmc.sh $R/gpurun_out/osc_pmc_$i $set -- python $R/tools/osc_case.py > $R/gpurun_out/osc_pmc_$i.log 2>&1
+done
+cd $R && python - <<'PY'
+import csv, glob, collections
+res = collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/osc_pmc_*")):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[-40:]
+            if "golf::" in k:
+                acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            res[k][c] = sum(v) / len(v)
+for k, d in res.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"    {c:28s} {v:14.0f}")
+PY
