@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gain, const float* __restrict__ a,
                                                       const float* __restrict__ S, float* __restrict__ out,
                                                       int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ,
-                                                      int NCS) {
+                                                      int NCS, const float* __restrict__ zin) {
     constexpr int TPL = quad_tpl(W, NT);
     constexpr int R = 16;
     using TL = Tile<W, R>;
@@ -205,24 +205,17 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
             const int i = r * TPL + k;
-            if (i < W) zp[i] = i < M ? w[TPL - 1 - k] : 0.f;
+            if (i < W) {
+                float v = i < M ? w[TPL - 1 - k] : 0.f;
+                // MODE 2 (refinement sweep): the chunk was re-run from the scanned state S_c, v = its true end state
+                // E_c; what the second scan needs is z_c + (E_c - S_{c+1}): the observed defect added to the
+                // zero-state response (one Parareal iteration; the boundary error becomes second order in the
+                // transition-matrix error).
+                if (MODE == 2) v += zin[((size_t)b * NCQ + c) * W + i] - S[((size_t)b * NCS + c + 1) * 64 + i];
+                zp[i] = v;
+            }
         }
     }
-}
-
-// Refinement sweep glue: z2[b][c][i] = z[b][c][i] + E[b][c][i] - S[b][c+1][i]   (c < NP)
-// With transitions Phi~ of limited (fp32) accuracy the scanned boundary states S0 are ~1e-4 off.  Re-running every
-// chunk from S0 (exactly, in-lane) gives its true end state E_c; feeding the scan z + (E_c - S0_{c+1}) makes it
-// return S1 with S1_{c+1} = Phi~_c (S1_c - S0_c) + E_c: the error is now second order in the Phi~ error
-// (one Parareal iteration; measured 1.8e-4 -> 2.3e-5 = the accuracy of a sequential fp32 recursion).
-__global__ void lpc_zfix_kernel(const float* __restrict__ z, const float* __restrict__ E, const float* __restrict__ S,
-                                float* __restrict__ z2, int B, int NP, int NC, int W) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * NP * W) return;
-    const int i = idx % W;
-    const int c = (idx / W) % NP;
-    const int b = idx / (W * NP);
-    z2[idx] = z[idx] + E[idx] - S[((size_t)b * NC + c + 1) * 64 + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -966,29 +959,26 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, s1)) return rc;
         }
         hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP);
+                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP,
+                           (const float*)nullptr);
         GOLF_LAUNCH_CHECK();
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
                        S, p.NC, p.NP);
     GOLF_LAUNCH_CHECK();
-    if (fast && p.NP > 0) {  // one refinement sweep (see lpc_zfix_kernel)
-        float* E = (float*)(ws + p.off_E);
+    if (fast && p.NP > 0) {  // one refinement sweep (see lpc_fwdq_kernel, MODE 2)
         float* z2 = (float*)(ws + p.off_z2);
         hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 2>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)S, E, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC);
-        GOLF_LAUNCH_CHECK();
-        const int nz = B * p.NP * W;
-        hipLaunchKernelGGL(lpc_zfix_kernel, dim3((unsigned)ceil_div(nz, 256)), dim3(256), 0, st, (const float*)z,
-                           (const float*)E, (const float*)S, z2, B, p.NP, p.NC, W);
+                           ex_stride, gain, a, (const float*)S, z2, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
+                           (const float*)z);
         GOLF_LAUNCH_CHECK();
         hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT,
                            (const float*)z2, S, p.NC, p.NP);
         GOLF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
-                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC);
+                       ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC, (const float*)nullptr);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
