@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): every bench line, rocprofv3 kernel traces and the
+# separate HBM-counter passes that profiles/ is built from (tools/collect_profiles.py turns the output into profiles/).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r01
+rm -rf $O; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+b() { python bench.py "$@" 2>/dev/null | tail -1; }
+b > $O/bench_golf_ss_synth.json
+b --streams 1 --no-graphs --no-cpu-baseline > $O/bench_single_stream.json
+b --workload golf-ss-train --no-cpu-baseline --steps 100 > $O/bench_train.json
+b --workload golf-ff-synth --no-cpu-baseline > $O/bench_ff.json
+b --workload golf-ff-train --no-cpu-baseline --steps 100 > $O/bench_ff_train.json
+b --workload golf-ss-decoder --no-cpu-baseline > $O/bench_decoder.json
+b --workload golf-ss-decoder-train --no-cpu-baseline --steps 100 > $O/bench_decoder_train.json
+b --batch 256 --no-cpu-baseline --steps 50 > $O/bench_b256.json
+prof() { out=$1; shift; (cd /tmp && rocprofv3 --kernel-trace -d $O/$out -- python $R/bench.py --no-cpu-baseline --steps 50 --warmup 10 "$@" > $O/$out.log 2>&1); }
+prof trace_synth
+prof trace_synth_single --streams 1 --no-graphs
+prof trace_train --workload golf-ss-train
+prof trace_decoder --workload golf-ss-decoder --streams 1 --no-graphs
+prof trace_decoder_train --workload golf-ss-decoder-train
+prof trace_ff_train --workload golf-ff-train
+for c in FETCH_SIZE WRITE_SIZE; do
+  bash tools/prof_pmc.sh $O/pmc_${c}_decoder $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/pmc_${c}_decoder.log 2>&1
+  bash tools/prof_pmc.sh $O/pmc_${c}_train $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train > $O/pmc_${c}_train.log 2>&1
+done
+ls -R $O | head -60
+du -sh $O
