@@ -56,9 +56,9 @@ SIGNATURES = {
     "golf_zero_phase_fir_kernels_f32": (_int, [_c_f32p, _c_f32p, _vp, _c_f32p, _int, _int, _vp]),
     "golf_zero_phase_fir_kernels_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _vp, _c_f32p, _int, _int, _vp]),
     "golf_ltv_fir_frames_length": (_int, [_int] * 4),
-    "golf_ltv_fir_frames_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64] + [_int] * 5 + [_vp]),
+    "golf_ltv_fir_frames_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64] + [_int] * 6 + [_vp]),
     "golf_ltv_fir_frames_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _c_f32p, _i64, _c_f32p]
-                                    + [_int] * 5 + [_vp]),
+                                    + [_int] * 6 + [_vp]),
     "golf_lti_fir_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
     "golf_lti_fir_taps_grad_workspace_bytes": (_sz, [_int] * 3),
     "golf_lti_fir_taps_grad_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _int, _vp, _sz,

@@ -114,7 +114,7 @@ __device__ __forceinline__ f32x4 fir_finish(const FirAcc& A) {
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_fwd_kernel(
     const float* __restrict__ ex, int64_t ex_stride, const float* __restrict__ kern, int KS, float* __restrict__ y,
-    int64_t y_stride, int B, int T, int nfr, int F, int N, int hop, int npass, int RS) {
+    int64_t y_stride, int B, int T, int nfr, int F, int N, int hop, int npass, int RS, int frame0) {
     extern __shared__ __attribute__((aligned(16))) float fir_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_fwd_kernel(
     wave_lds_fence();
     FirAcc A;
     fir_zero(A);
-    fir_accum(A, sig, kern + (size_t)(b * F + f) * KS, ntaps, lane);
+    fir_accum(A, sig, kern + (size_t)(b * F + f + frame0) * KS, ntaps, lane);  // output frame f uses kernel row f + frame0
     const f32x4 r = fir_finish(A);
     const BufRow yr(y + b * y_stride, nfr * hop);
     const int o = 4 * lane;
@@ -148,18 +148,19 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_fwd_kernel(
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
     const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ ex, int64_t ex_stride,
-    float* __restrict__ g_kern, int KS, int B, int T, int nfr, int F, int N, int hop, int npass, int RS) {
+    float* __restrict__ g_kern, int KS, int B, int T, int nfr, int F, int N, int hop, int npass, int RS, int frame0) {
     extern __shared__ __attribute__((aligned(16))) float fir_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int unit = blockIdx.x * FIR_WAVES + wv;
     if (unit >= B * F * npass) return;
-    const int c = unit % npass, f = (unit / npass) % F, b = unit / (npass * F);
-    const BufRow gr(g_kern + (size_t)(b * F + f) * KS, N);
+    const int c = unit % npass, fr = (unit / npass) % F, b = unit / (npass * F);
+    const int f = fr - frame0;  // output frame that used kernel row fr (rows outside [frame0, frame0+nfr) get zeros)
+    const BufRow gr(g_kern + (size_t)(b * F + fr) * KS, N);
     const int k0 = c * FIR_TILE, o = 4 * lane;
     const int lim = min(FIR_TILE, N - k0);
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (f < nfr) {  // wave-uniform
+    if (f >= 0 && f < nfr) {  // wave-uniform
         float* sig = fir_lds + wv * RS;
         const int P = (N - 1) >> 1;
         const int span = 256 + hop + 4;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
 __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
     const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ kern, int KS,
     float* __restrict__ g_ex, int64_t g_ex_stride, int B, int T, int nfr, int F, int N, int hop, int TILE,
-    int tile_lo, int ntile, int RS) {
+    int tile_lo, int ntile, int RS, int frame0) {
     extern __shared__ __attribute__((aligned(16))) float fir_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
     FirAcc A;
     fir_zero(A);
     for (int f = f_lo; f <= f_hi; ++f) {
-        const BufRow kr(kern + (size_t)(b * F + f) * KS, N);
+        const BufRow kr(kern + (size_t)(b * F + f + frame0) * KS, N);
         wave_lds_fence();
         fir_stage<true>(sig, kr, m_hi - f * hop, span, lane);
         wave_lds_fence();
@@ -563,45 +564,46 @@ int golf_zero_phase_fir_kernels_bwd_f32(const float* g_kern, const float* log_ma
     return GOLF_OK;
 }
 
-static int fir_geometry(const char* who, int B, int T, int F, int N, int hop, int KS, int* nfr_out) {
-    if (B < 1 || T < 1 || F < 1 || N < 2 || hop < 1 || KS < ((N + 3) & ~3))
-        return fail(GOLF_EINVAL, "%s: bad sizes B=%d T=%d F=%d N=%d hop=%d row_stride=%d", who, B, T, F, N, hop, KS);
+static int fir_geometry(const char* who, int B, int T, int F, int N, int hop, int KS, int frame0, int* nfr_out) {
+    if (B < 1 || T < 1 || F < 1 || N < 2 || hop < 1 || KS < ((N + 3) & ~3) || frame0 < 0 || frame0 >= F)
+        return fail(GOLF_EINVAL, "%s: bad sizes B=%d T=%d F=%d N=%d hop=%d row_stride=%d frame0=%d", who, B, T, F, N, hop,
+                    KS, frame0);
     const int P = (N - 1) / 2, span = N + hop - 1;
     if (T + 2 * P < span)
         return fail(GOLF_EINVAL, "%s: excitation (T=%d) shorter than one frame span (%d)", who, T, span - 2 * P);
     int nfr = (T + 2 * P - span) / hop + 1;
-    if (nfr > F) nfr = F;
+    if (nfr > F - frame0) nfr = F - frame0;
     *nfr_out = nfr;
     return GOLF_OK;
 }
 
 int golf_ltv_fir_frames_length(int T, int F, int N, int hop) {
     int nfr = 0;
-    if (fir_geometry("ltv_fir_frames_length", 1, T, F, N, hop, (N + 3) & ~3, &nfr)) return -1;
+    if (fir_geometry("ltv_fir_frames_length", 1, T, F, N, hop, (N + 3) & ~3, 0, &nfr)) return -1;
     return nfr * hop;
 }
 
 int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float* kern, int kern_row_stride, float* y,
-                                int64_t y_stride, int B, int T, int F, int N, int hop, void* stream) {
+                                int64_t y_stride, int B, int T, int F, int N, int hop, int frame0, void* stream) {
     if (!ex || !kern || !y) return fail(GOLF_EINVAL, "ltv_fir_frames_fwd: null pointer");
     int nfr = 0;
-    if (int rc = fir_geometry("ltv_fir_frames_fwd", B, T, F, N, hop, kern_row_stride, &nfr)) return rc;
+    if (int rc = fir_geometry("ltv_fir_frames_fwd", B, T, F, N, hop, kern_row_stride, frame0, &nfr)) return rc;
     const int npass = (hop + FIR_TILE - 1) / FIR_TILE;
     const int RS = fir_region(256 + ((N + 3) & ~3) + 4);
     const long long units = (long long)B * nfr * npass;
     hipLaunchKernelGGL(fir_frames_fwd_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
                        dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, kern,
-                       kern_row_stride, y, y_stride, B, T, nfr, F, N, hop, npass, RS);
+                       kern_row_stride, y, y_stride, B, T, nfr, F, N, hop, npass, RS, frame0);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
 
 int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
                                 const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,
-                                float* g_kern, int B, int T, int F, int N, int hop, void* stream) {
+                                float* g_kern, int B, int T, int F, int N, int hop, int frame0, void* stream) {
     if (!gy || !ex || !kern) return fail(GOLF_EINVAL, "ltv_fir_frames_bwd: null pointer");
     int nfr = 0;
-    if (int rc = fir_geometry("ltv_fir_frames_bwd", B, T, F, N, hop, kern_row_stride, &nfr)) return rc;
+    if (int rc = fir_geometry("ltv_fir_frames_bwd", B, T, F, N, hop, kern_row_stride, frame0, &nfr)) return rc;
     if (hop % 4 != 0)
         return fail(GOLF_EUNSUPPORTED, "ltv_fir_frames_bwd: hop=%d must be a multiple of 4 (the frame's gradient "
                     "samples are the packed taps of the backward kernels)", hop);
@@ -612,7 +614,7 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
         const long long units = (long long)B * F * npass;
         hipLaunchKernelGGL(fir_frames_bwd_kern_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
                            dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, ex, ex_stride,
-                           g_kern, kern_row_stride, B, T, nfr, F, N, hop, npass, RS);
+                           g_kern, kern_row_stride, B, T, nfr, F, N, hop, npass, RS, frame0);
         GOLF_LAUNCH_CHECK();
     }
     if (g_ex) {
@@ -623,7 +625,7 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
         const long long units = (long long)B * ntile;
         hipLaunchKernelGGL(fir_frames_bwd_ex_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
                            dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, kern,
-                           kern_row_stride, g_ex, g_ex_stride, B, T, nfr, F, N, hop, TILE, tile_lo, ntile, RS);
+                           kern_row_stride, g_ex, g_ex_stride, B, T, nfr, F, N, hop, TILE, tile_lo, ntile, RS, frame0);
         GOLF_LAUNCH_CHECK();
     }
     return GOLF_OK;

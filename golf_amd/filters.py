@@ -18,7 +18,8 @@ from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
 
 __all__ = ["FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
-           "LTVZeroPhaseFIRFilter", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter", "convert2samplewise"]
+           "LTVZeroPhaseFIRFilter", "LTVZeroPhaseFIRFilterPrecise", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter",
+           "convert2samplewise"]
 
 
 class FilterInterface(Controllable):
@@ -172,6 +173,24 @@ class LTVZeroPhaseFIRFilter(LTVFilterInterface):
         return AudioTensor(y)
 
 
+class LTVZeroPhaseFIRFilterPrecise(LTVZeroPhaseFIRFilter):
+    """Sample-wise variant (reference models/filters.py:286-337; what ``convert2samplewise`` swaps in): the windowed
+    kernels are linearly interpolated to sample rate before the convolution.  Same kernels underneath
+    (golf_ltv_fir_frames_* twice, rows f and f+1, blended per sample)."""
+
+    def __init__(self, window: str, n_mag: int = None):
+        super().__init__(window=window, conv_method="direct", n_mag=n_mag)
+
+    def forward(self, ex: AudioTensor, log_mag: AudioTensor) -> AudioTensor:
+        assert ex.ndim == 2, ex.shape
+        assert log_mag.ndim == 3, log_mag.shape
+        assert ex.hop_length == 1, f"excitation must be at hop 1 (got {ex.hop_length})"
+        n = 2 * (log_mag.shape[-1] - 1)
+        y = GF.zero_phase_fir_filter_precise(ex.as_tensor(), log_mag.as_tensor(),
+                                             self._window(n, ex.as_tensor().device), int(log_mag.hop_length))
+        return AudioTensor(y)
+
+
 class LTVAPZeroPhaseFIRFilter(LTVZeroPhaseFIRFilter):
     """Reference models/filters.py:387-397: same filter, sigmoid-bounded magnitudes."""
 
@@ -215,6 +234,10 @@ def convert2samplewise(config: dict) -> dict:
                 config["class_path"] = value.rsplit(".", 1)[0] + ".LTVMinimumPhaseFilterPrecise"
                 for k in ("window", "window_length", "centred"):
                     config.get("init_args", {}).pop(k, None)
+                return config
+            if ".LTVZeroPhaseFIRFilter" in value and not value.endswith("Precise"):
+                config["class_path"] = value.rsplit(".", 1)[0] + ".LTVZeroPhaseFIRFilterPrecise"
+                config.get("init_args", {}).pop("conv_method", None)
                 return config
         elif isinstance(value, dict):
             config[key] = convert2samplewise(value)

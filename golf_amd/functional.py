@@ -12,6 +12,7 @@ from . import _lib
 __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_ola", "glottal_osc",
            "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
            "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
+           "zero_phase_fir_filter_precise",
            "fir_frames_length", "lti_fir"]
 
 HAVE_TRANSITIONS = 1
@@ -334,82 +335,128 @@ def zero_phase_fir_kernels(log_mag: torch.Tensor, window: torch.Tensor) -> torch
     return kern.view(B, F, -1)[..., :N]
 
 
-class _ZeroPhaseFIR(torch.autograd.Function):
+class _ZPKernels(torch.autograd.Function):
+    """(B,F,n_mag) log magnitudes -> (B*F, row_stride) windowed zero-phase FIR rows (cosine transform on the MFMAs)."""
+
     @staticmethod
-    def forward(ctx, ex, log_mag, window, hop):
-        _lib.require_device(ex, log_mag, window)
+    def forward(ctx, log_mag, window):
+        _lib.require_device(log_mag, window)
         lib = _lib.load()
-        ex = _rows(ex)
         log_mag = log_mag.contiguous()
         window = window.contiguous()
-        B, T = ex.shape
-        if log_mag.dim() != 3 or log_mag.shape[0] != B:
-            raise _lib.GolfError(f"zero_phase_fir_filter: ex {tuple(ex.shape)} vs log_mag {tuple(log_mag.shape)}")
-        F, n_mag = log_mag.shape[1], log_mag.shape[2]
-        N = 2 * (n_mag - 1)
-        if window.numel() != N:
-            raise _lib.GolfError(f"zero_phase_fir_filter: window has {window.numel()} taps, expected {N}")
-        Ty = fir_frames_length(T, F, N, hop)
-        basis = zero_phase_fir_basis(n_mag, ex.device)
+        n_mag = log_mag.shape[2]
+        if window.numel() != 2 * (n_mag - 1):
+            raise _lib.GolfError(f"zero_phase_fir: window has {window.numel()} taps, expected {2 * (n_mag - 1)}")
+        basis = zero_phase_fir_basis(n_mag, log_mag.device)
         kern = _zp_kernels_raw(lib, log_mag, window, basis)
+        ctx.save_for_backward(log_mag, window, basis)
+        return kern
+
+    @staticmethod
+    def backward(ctx, g_kern):
+        log_mag, window, basis = ctx.saved_tensors
+        lib = _lib.load()
+        g_kern = g_kern.contiguous()
+        B, F, n_mag = log_mag.shape
+        g_lm = torch.empty_like(log_mag)
+        _lib.check(lib.golf_zero_phase_fir_kernels_bwd_f32(g_kern.data_ptr(), log_mag.data_ptr(), window.data_ptr(),
+                                                           basis.data_ptr(), g_lm.data_ptr(), B * F, n_mag,
+                                                           _lib.stream_ptr()),
+                   "golf_zero_phase_fir_kernels_bwd_f32")
+        return g_lm, None
+
+
+class _FIRFrames(torch.autograd.Function):
+    """Per-frame FIR with kernel rows kern (B*F, row_stride): output frame f uses row f + frame0."""
+
+    @staticmethod
+    def forward(ctx, ex, kern, F, N, hop, frame0):
+        _lib.require_device(ex, kern)
+        lib = _lib.load()
+        ex = _rows(ex)
+        kern = kern.contiguous()
+        B, T = ex.shape
+        if kern.shape[0] != B * F:
+            raise _lib.GolfError(f"fir_frames: {kern.shape[0]} kernel rows for B={B}, F={F}")
+        Ty = fir_frames_length(T, F - frame0, N, hop)
         y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
         _lib.check(lib.golf_ltv_fir_frames_fwd_f32(ex.data_ptr(), ex.stride(0), kern.data_ptr(), kern.shape[1],
-                                                   y.data_ptr(), y.stride(0), B, T, F, N, hop, _lib.stream_ptr()),
+                                                   y.data_ptr(), y.stride(0), B, T, F, N, hop, frame0,
+                                                   _lib.stream_ptr()),
                    "golf_ltv_fir_frames_fwd_f32")
-        ctx.save_for_backward(ex, log_mag, window, kern, basis)
-        ctx.hop = hop
+        ctx.save_for_backward(ex, kern)
+        ctx.geom = (F, N, hop, frame0)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        ex, log_mag, window, kern, basis = ctx.saved_tensors
+        ex, kern = ctx.saved_tensors
+        F, N, hop, frame0 = ctx.geom
         lib = _lib.load()
         gy = _rows(gy)
         B, T = ex.shape
-        F, n_mag = log_mag.shape[1], log_mag.shape[2]
-        N = 2 * (n_mag - 1)
-        need_ex, need_lm = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_ex, need_k = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_ex = torch.empty_like(ex) if need_ex else None
-        g_kern = torch.empty_like(kern) if need_lm else None
+        g_kern = torch.empty_like(kern) if need_k else None
         _lib.check(lib.golf_ltv_fir_frames_bwd_f32(gy.data_ptr(), gy.stride(0), ex.data_ptr(), ex.stride(0),
                                                    kern.data_ptr(), kern.shape[1],
                                                    g_ex.data_ptr() if need_ex else None,
                                                    g_ex.stride(0) if need_ex else 0,
-                                                   g_kern.data_ptr() if need_lm else None,
-                                                   B, T, F, N, ctx.hop, _lib.stream_ptr()),
+                                                   g_kern.data_ptr() if need_k else None,
+                                                   B, T, F, N, hop, frame0, _lib.stream_ptr()),
                    "golf_ltv_fir_frames_bwd_f32")
-        g_lm = None
-        if need_lm:
-            g_lm = torch.empty_like(log_mag)
-            _lib.check(lib.golf_zero_phase_fir_kernels_bwd_f32(g_kern.data_ptr(), log_mag.data_ptr(),
-                                                               window.data_ptr(), basis.data_ptr(), g_lm.data_ptr(),
-                                                               B * F, n_mag, _lib.stream_ptr()),
-                       "golf_zero_phase_fir_kernels_bwd_f32")
-        return g_ex, g_lm, None, None
+        if need_k:
+            g_kern[:, N:] = 0  # padding taps carry no gradient
+        return g_ex, g_kern, None, None, None, None
 
 
 def zero_phase_fir_filter(ex: torch.Tensor, log_mag: torch.Tensor, window: torch.Tensor, hop: int) -> torch.Tensor:
     """LTVZeroPhaseFIRFilter.forward on plain tensors: ex (B,T), log_mag (B,F,n_mag) at ``hop`` -> (B, nfr*hop);
     differentiable w.r.t. ex and log_mag."""
-    return _ZeroPhaseFIR.apply(ex, log_mag, window, hop)
+    if log_mag.dim() != 3 or log_mag.shape[0] != ex.shape[0]:
+        raise _lib.GolfError(f"zero_phase_fir_filter: ex {tuple(ex.shape)} vs log_mag {tuple(log_mag.shape)}")
+    F, n_mag = log_mag.shape[1], log_mag.shape[2]
+    kern = _ZPKernels.apply(log_mag, window)
+    return _FIRFrames.apply(ex, kern, F, 2 * (n_mag - 1), hop, 0)
+
+
+def zero_phase_fir_filter_precise(ex: torch.Tensor, log_mag: torch.Tensor, window: torch.Tensor, hop: int) -> torch.Tensor:
+    """LTVZeroPhaseFIRFilterPrecise.forward (reference models/filters.py:308-337): the kernels are linearly
+    interpolated to sample rate, y[t] = sum_k pad(ex)[t+k] * ((1-w_t) K_f[k] + w_t K_{f+1}[k]), f = t // hop,
+    w_t = (t % hop)/hop, output length min(T, (F-1)*hop+1).  Evaluated as two frame FIRs (kernel rows f and f+1 over
+    the same signal) blended per sample; the single sample t = (F-1)*hop is a dot product with the last kernel."""
+    if log_mag.dim() != 3 or log_mag.shape[0] != ex.shape[0]:
+        raise _lib.GolfError(f"zero_phase_fir_filter_precise: ex {tuple(ex.shape)} vs log_mag {tuple(log_mag.shape)}")
+    B, T = ex.shape
+    F, n_mag = log_mag.shape[1], log_mag.shape[2]
+    if F < 2:
+        raise _lib.GolfError("zero_phase_fir_filter_precise: need at least 2 frames")
+    N = 2 * (n_mag - 1)
+    P = (N - 1) // 2
+    Tfull = (F - 1) * hop + 1
+    Tout = min(T, Tfull)
+    kern = _ZPKernels.apply(log_mag, window)
+    # the samples the outputs t < Tfull can reach: ex[t + k - P], k < N  ->  indices < Tfull + N-1-P (zeros past T)
+    Tin = Tfull + N - 1 - P
+    x = ex[:, :Tin]
+    if x.shape[1] < Tin:
+        x = torch.nn.functional.pad(x, (0, Tin - x.shape[1]))
+    ya = _FIRFrames.apply(x, kern, F, N, hop, 0)[:, : (F - 1) * hop]
+    yb = _FIRFrames.apply(x, kern, F, N, hop, 1)[:, : (F - 1) * hop]
+    w = (torch.arange((F - 1) * hop, device=ex.device) % hop).to(torch.float32) / hop
+    main = ya + w * (yb - ya)
+    tail = torch.nn.functional.pad(x, (P, 0))[:, Tfull - 1: Tfull - 1 + N]  # pad(ex)[Tfull-1 + k], k < N
+    last = (tail * kern.view(B, F, -1)[:, F - 1, :N]).sum(-1, keepdim=True)
+    return torch.cat([main, last], dim=1)[:, :Tout]
 
 
 def ltv_fir_frames(ex: torch.Tensor, kernels: torch.Tensor, hop: int) -> torch.Tensor:
     """Frame-wise FIR with arbitrary per-frame kernels (B,F,N): y[b,f*hop+n] = sum_k pad(ex)[b,f*hop+n+k] *
-    kernels[b,f,k] (forward only)."""
-    _lib.require_device(ex, kernels)
-    lib = _lib.load()
-    ex = _rows(ex)
-    B, T = ex.shape
-    _, F, N = kernels.shape
+    kernels[b,f,k]; differentiable w.r.t. both."""
+    B, F, N = kernels.shape
     KS = (N + 15) // 16 * 16
-    kern = torch.zeros(B * F, KS, dtype=torch.float32, device=ex.device)
-    kern[:, :N] = kernels.reshape(B * F, N)
-    y = torch.empty(B, fir_frames_length(T, F, N, hop), dtype=torch.float32, device=ex.device)
-    _lib.check(lib.golf_ltv_fir_frames_fwd_f32(ex.data_ptr(), ex.stride(0), kern.data_ptr(), KS, y.data_ptr(),
-                                               y.stride(0), B, T, F, N, hop, _lib.stream_ptr()),
-               "golf_ltv_fir_frames_fwd_f32")
-    return y
+    kern = torch.nn.functional.pad(kernels.reshape(B * F, N), (0, KS - N))
+    return _FIRFrames.apply(ex, kern, F, N, hop, 0)
 
 
 # ------------------------------------------------------------------------------------------------

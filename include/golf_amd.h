@@ -193,14 +193,17 @@ int golf_zero_phase_fir_kernels_bwd_f32(const float* g_kern, const float* log_ma
                                         const void* basis, float* g_log_mag, int G, int n_mag, void* stream);
 
 int golf_ltv_fir_frames_length(int T, int F, int N, int hop);
-/* ex (B, >=T) stride ex_stride; kern (B*F, kern_row_stride), zero in [N, ceil4(N)); y (B, nfr*hop) stride y_stride */
+/* ex (B, >=T) stride ex_stride; kern (B*F, kern_row_stride), zero in [N, ceil4(N)); y (B, nfr*hop) stride y_stride.
+ * frame0 (normally 0): output frame f is filtered with kernel row f + frame0, nfr = min(frames in T, F - frame0) —
+ * what the sample-wise variant (LTVZeroPhaseFIRFilterPrecise, models/filters.py:286-337: kernels interpolated between
+ * frames f and f+1) needs for its second term. */
 int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float* kern, int kern_row_stride, float* y,
-                                int64_t y_stride, int B, int T, int F, int N, int hop, void* stream);
+                                int64_t y_stride, int B, int T, int F, int N, int hop, int frame0, void* stream);
 /* gy (B, nfr*hop).  g_ex (B,T) and g_kern (B*F, kern_row_stride; rows of unused frames zeroed) are fully
  * overwritten; either may be NULL to skip it.  Requires hop % 4 == 0. */
 int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
                                 const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,
-                                float* g_kern, int B, int T, int F, int N, int hop, void* stream);
+                                float* g_kern, int B, int T, int F, int N, int hop, int frame0, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f-2: LTI FIR shared by the whole batch — the room filter after the end filter.

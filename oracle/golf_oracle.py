@@ -51,6 +51,8 @@ __all__ = [
     "zero_phase_fir_kernels",
     "ltv_fir_frames_forward",
     "ltv_fir_frames_backward",
+    "ltv_fir_precise_forward",
+    "ltv_fir_precise_backward",
     "lti_acoustic_filter_forward",
     "lti_acoustic_filter_backward",
     "golf_ss_decoder",
@@ -643,6 +645,13 @@ def ltv_fir_frames_backward(gy, ex, log_mag, window, hop: int):
         for n in range(hop):
             g_xp[:, f * hop + n : f * hop + n + N] += g[:, n : n + 1] * kernel[:, f]
     g_ex = g_xp[:, pad : pad + T]
+    return g_ex, _zero_phase_kernel_adjoint(g_kernel, log_mag, window)
+
+
+def _zero_phase_kernel_adjoint(g_kernel, log_mag, window):
+    """d/d log_mag of zero_phase_fir_kernels: adjoint of window * fftshift * irfft, times exp(log_mag)."""
+    n_mag = log_mag.shape[-1]
+    N = 2 * (n_mag - 1)
     g_fir = np.fft.ifftshift(g_kernel * window, axes=-1)                      # adjoint of fftshift (N even: same roll)
     # irfft: fir[n] = (1/N) * sum_k c_k mag[k] cos(2 pi k n / N), c_0 = c_{N/2} = 1, else 2
     n = np.arange(N)
@@ -650,8 +659,46 @@ def ltv_fir_frames_backward(gy, ex, log_mag, window, hop: int):
     c = np.full(n_mag, 2.0)
     c[0] = c[-1] = 1.0
     basis = c[:, None] * np.cos(2 * np.pi * k[:, None] * n[None, :] / N) / N  # (n_mag, N)
-    g_mag = g_fir @ basis.T
-    return g_ex, g_mag * np.exp(log_mag)
+    return (g_fir @ basis.T) * np.exp(log_mag)
+
+
+def ltv_fir_precise_forward(ex, kernel, hop: int) -> np.ndarray:
+    """models/filters.py:308-337 LTVZeroPhaseFIRFilterPrecise.forward after the kernel is built: the (B,F,N) kernels
+    are linearly upsampled to sample rate (reduce_hop_length), the excitation is padded by (N-1)//2 left and
+    N-1-(N-1)//2 right and unfolded sample by sample; y[t] = <pad(ex)[t:t+N], K[t]>, length min(T, (F-1)*hop+1)."""
+    ex = np.asarray(ex, dtype=np.float64)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    B, T = ex.shape
+    _, F, N = kernel.shape
+    K = linear_upsample(kernel, hop, axis=1)                       # (B, (F-1)*hop+1, N)
+    Tout = min(T, K.shape[1])
+    pl = (N - 1) // 2
+    xp = np.pad(ex, ((0, 0), (pl, N - 1 - pl)))
+    win = np.lib.stride_tricks.sliding_window_view(xp, N, axis=1)  # (B, T, N)
+    return np.einsum("btk,btk->bt", win[:, :Tout], K[:, :Tout])
+
+
+def ltv_fir_precise_backward(gy, ex, log_mag, window, hop: int):
+    gy = np.asarray(gy, dtype=np.float64)
+    ex = np.asarray(ex, dtype=np.float64)
+    log_mag = np.asarray(log_mag, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    B, T = ex.shape
+    F = log_mag.shape[1]
+    kernel = zero_phase_fir_kernels(log_mag, window)
+    N = kernel.shape[-1]
+    K = linear_upsample(kernel, hop, axis=1)
+    Tout = min(T, K.shape[1])
+    pl = (N - 1) // 2
+    xp = np.pad(ex, ((0, 0), (pl, N - 1 - pl)))
+    win = np.lib.stride_tricks.sliding_window_view(xp, N, axis=1)
+    gK = np.zeros_like(K)
+    gK[:, :Tout] = gy[:, :Tout, None] * win[:, :Tout]
+    g_kernel = _upsample_adjoint(gK, hop, F)
+    g_xp = np.zeros_like(xp)
+    for t in range(Tout):
+        g_xp[:, t : t + N] += gy[:, t : t + 1] * K[:, t]
+    return g_xp[:, pl : pl + T], _zero_phase_kernel_adjoint(g_kernel, log_mag, window)
 
 
 # --------------------------------------------------------------------------------------

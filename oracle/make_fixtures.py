@@ -464,4 +464,17 @@ for tag, (B, F, hop, W, M, centred, Tx) in (("c", (2, 7, 8, 32, 4, True, None)),
               f"{tag}_centred": int(centred), f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_g_ex": ex.grad,
               f"{tag}_g_gain": gain.grad, f"{tag}_g_a": a.grad})
 save("g15_ff_grads", **d)
+# ----------------------------------------------------------------------------- g16 sample-wise zero-phase FIR filter
+# LTVZeroPhaseFIRFilterPrecise.forward (filters.py:308-337) in float64, with autograd gradients
+d = {}
+for tag, (B, T, F, hop, n_mag) in (("a", (2, 57, 8, 8, 9)), ("b", (2, 40, 9, 8, 9)), ("c", (1, 150, 6, 24, 17))):
+    flt = rf.LTVZeroPhaseFIRFilterPrecise(window="hanning", n_mag=n_mag)
+    ex = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32)).double().requires_grad_(True)
+    lm = torch.from_numpy(rng.normal(-1, 0.7, (B, F, n_mag)).astype(np.float32)).double().requires_grad_(True)
+    y = flt(AT(ex, 1), AT(lm, hop)).as_tensor()
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+    (y * gy).sum().backward()
+    d.update({f"{tag}_ex": ex, f"{tag}_log_mag": lm, f"{tag}_hop": hop, f"{tag}_y": y, f"{tag}_gy": gy,
+              f"{tag}_g_ex": ex.grad, f"{tag}_g_log_mag": lm.grad})
+save("g16_zero_phase_fir_precise", **d)
 print("done")

@@ -155,3 +155,43 @@ def test_generic_frames_match_torch_conv():
         for n in range(hop):
             ref[:, f * hop + n] = (xp[:, f * hop + n: f * hop + n + N] * kern[:, f]).sum(-1)
     check(y, ref, "generic frames", 1e-5)
+
+
+def run_precise(ex, log_mag, hop, gy=None):
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTVZeroPhaseFIRFilterPrecise
+
+    m = LTVZeroPhaseFIRFilterPrecise(window="hanning", n_mag=log_mag.shape[-1]).cuda()
+    x, lm = dev(ex, gy is not None), dev(log_mag, gy is not None)
+    yt = m(AudioTensor(x), AudioTensor(lm, hop)).as_tensor()
+    if gy is None:
+        return yt.detach().cpu().numpy()
+    (yt * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    return yt.detach().cpu().numpy(), x.grad.cpu().numpy(), lm.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_golden_g16_precise(golden, tag):
+    """LTVZeroPhaseFIRFilterPrecise (kernels interpolated to sample rate) against the reference's own run."""
+    g = golden("g16_zero_phase_fir_precise")
+    y, gx, glm = run_precise(g[f"{tag}_ex"], g[f"{tag}_log_mag"], int(g[f"{tag}_hop"]), gy=g[f"{tag}_gy"])
+    check(y, g[f"{tag}_y"], f"g16{tag} y", 1e-5)
+    check(gx, g[f"{tag}_g_ex"], f"g16{tag} g_ex", 1e-5)
+    check(glm, g[f"{tag}_g_log_mag"], f"g16{tag} g_log_mag", 1e-5)
+
+
+@pytest.mark.parametrize("B,T,F,n_mag,hop", [(2, 2500, 11, 65, 240), (2, 1000, 6, 256, 240), (1, 700, 30, 17, 24)])
+def test_precise_vs_oracle(B, T, F, n_mag, hop):
+    from oracle import golf_oracle as O
+
+    ex, lm = case(B, T, F, n_mag, seed=T)
+    win = np_window("hanning", 2 * (n_mag - 1))
+    ref = O.ltv_fir_precise_forward(ex, O.zero_phase_fir_kernels(lm, win), hop)
+    gy = np.random.default_rng(9).normal(0, 1, ref.shape).astype(np.float32)
+    y, gx, glm = run_precise(ex, lm, hop, gy=gy)
+    assert y.shape == ref.shape
+    check(y, ref, "precise fwd", 1e-5)
+    rgx, rglm = O.ltv_fir_precise_backward(gy, ex, lm, win, hop)
+    check(gx, rgx, "precise g_ex", 2e-5)
+    check(glm, rglm, "precise g_log_mag", 2e-5)
