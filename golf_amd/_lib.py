@@ -38,6 +38,8 @@ SIGNATURES = {
     "golf_ltv_allpole_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64,
                                         _c_f32p, _c_f32p] + [_int] * 5 + [_vp, _sz, _vp]),
     "golf_ltv_inverse_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _i64] + [_int] * 5 + [_vp]),
+    "golf_ltv_inverse_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _i64, _c_f32p] + [_int] * 5
+                                 + [_vp]),
     "golf_lti_frames_workspace_bytes": (_sz, [_int] * 6),
     "golf_lti_frames_ola_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 7
                                     + [_vp, _sz, _vp]),

@@ -882,6 +882,65 @@ __global__ void lpc_inverse_kernel(const float* __restrict__ y, int64_t y_stride
     e[(size_t)b * e_stride + t] = acc;
 }
 
+// Backward of the analysis filter e[t] = y[t] + sum_i A[t,i] y[t-1-i]  (A = up(a)):
+//   g_y[t]   = g_e[t] + sum_i A[t+1+i, i] g_e[t+1+i]
+//   g_a[f,i] = sum_t hat_f(t) g_e[t] y[t-1-i]      (hat_f = the interpolation weights of frame f: up^T)
+__global__ void lpc_inverse_bwd_y_kernel(const float* __restrict__ ge, int64_t ge_stride, const float* __restrict__ a,
+                                         float* __restrict__ gy, int64_t gy_stride, int B, int T, int F, int M,
+                                         int hop) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * T) return;
+    const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
+    const float* gb = ge + (size_t)b * ge_stride;
+    float acc = gb[t];
+    for (int i = 0; i < M; ++i) {
+        const int u = t + 1 + i;
+        if (u >= T) break;
+        int f = F >= 2 ? u / hop : 0;
+        if (F >= 2 && f > F - 2) f = F - 2;
+        const float w = (float)(u - f * hop) / (float)hop;
+        const float* pa0 = a + ((size_t)b * F + f) * M;
+        const float* pa1 = F >= 2 ? pa0 + M : pa0;
+        acc = fmaf(fmaf(w, pa1[i] - pa0[i], pa0[i]), gb[u], acc);
+    }
+    gy[(size_t)b * gy_stride + t] = acc;
+}
+
+// one wave per (b, f): lanes stride over the (at most 2*hop+1) samples whose interpolation touches frame f
+__global__ __launch_bounds__(64) void lpc_inverse_bwd_a_kernel(const float* __restrict__ ge, int64_t ge_stride,
+                                                               const float* __restrict__ y, int64_t y_stride,
+                                                               float* __restrict__ g_a, int T, int F, int M, int hop) {
+    const int f = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float* gb = ge + (size_t)b * ge_stride;
+    const float* yb = y + (size_t)b * y_stride;
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    // samples t with segment index s(t) = min(t / hop, F-2): weight (1-w) on frame s, w on frame s+1
+    int t_lo = (f - 1) * hop, t_hi = (f + 1) * hop;  // [t_lo, t_hi)
+    if (f == F - 1) t_hi = T;                        // the clamped tail belongs to segment F-2
+    if (t_lo < 0) t_lo = 0;
+    if (t_hi > T) t_hi = T;
+    const float inv_hop = 1.0f / (float)hop;
+    for (int t = t_lo + lane; t < t_hi; t += 64) {
+        int sgm = F >= 2 ? t / hop : 0;
+        if (F >= 2 && sgm > F - 2) sgm = F - 2;
+        const float w = F >= 2 ? (float)(t - sgm * hop) * inv_hop : 0.f;
+        const float wt = sgm == f ? 1.0f - w : (sgm == f - 1 ? w : 0.f);
+        const float gv = gb[t] * wt;
+        for (int i = 0; i < M; ++i) {
+            if (t - 1 - i < 0) break;
+            acc[i] = fmaf(gv, yb[t - 1 - i], acc[i]);
+        }
+    }
+    for (int i = 0; i < M; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) g_a[((size_t)b * F + f) * M + i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
@@ -1134,5 +1193,27 @@ extern "C" int golf_ltv_inverse_f32(const float* y, int64_t y_stride, const floa
     hipLaunchKernelGGL(lpc_inverse_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, y,
                        y_stride, a, e, e_stride, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_ltv_inverse_bwd_f32(const float* g_e, int64_t g_e_stride, const float* y, int64_t y_stride,
+                                        const float* a, float* g_y, int64_t g_y_stride, float* g_a, int B, int T,
+                                        int F, int M, int hop, void* stream) {
+    if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
+    if (!g_e || !y || !a) return fail(GOLF_EINVAL, "ltv_inverse_bwd: null pointer");
+    if (g_e_stride < T || y_stride < T || (g_y && g_y_stride < T))
+        return fail(GOLF_EINVAL, "ltv_inverse_bwd: row stride < T");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_y) {
+        const int64_t n = (int64_t)B * T;
+        hipLaunchKernelGGL(lpc_inverse_bwd_y_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, g_e,
+                           g_e_stride, a, g_y, g_y_stride, B, T, F, M, hop);
+        GOLF_LAUNCH_CHECK();
+    }
+    if (g_a) {
+        hipLaunchKernelGGL(lpc_inverse_bwd_a_kernel, dim3((unsigned)F, B), dim3(64), 0, st, g_e, g_e_stride, y,
+                           y_stride, g_a, T, F, M, hop);
+        GOLF_LAUNCH_CHECK();
+    }
     return GOLF_OK;
 }

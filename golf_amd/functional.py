@@ -140,20 +140,45 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference))
 
 
+class _LTVInverse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, a, hop):
+        _lib.require_device(y, a)
+        lib = _lib.load()
+        y = _rows(y)
+        a = a.contiguous()
+        B, Ty = y.shape
+        F, M = a.shape[1], a.shape[2]
+        T = ss_output_length(Ty, F, hop)
+        e = torch.empty(B, T, dtype=torch.float32, device=y.device)
+        rc = lib.golf_ltv_inverse_f32(y.data_ptr(), y.stride(0), a.data_ptr(), e.data_ptr(), e.stride(0), B, T, F, M,
+                                      hop, _lib.stream_ptr())
+        _lib.check(rc, "golf_ltv_inverse_f32")
+        ctx.save_for_backward(y, a)
+        ctx.geom = (hop, T)
+        return e
+
+    @staticmethod
+    def backward(ctx, g_e):
+        y, a = ctx.saved_tensors
+        hop, T = ctx.geom
+        lib = _lib.load()
+        g_e = _rows(g_e)
+        B, Ty = y.shape
+        F, M = a.shape[1], a.shape[2]
+        need_y, need_a = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_y = (torch.empty_like(y) if Ty == T else torch.zeros_like(y)) if need_y else None
+        g_a = torch.empty_like(a) if need_a else None
+        rc = lib.golf_ltv_inverse_bwd_f32(g_e.data_ptr(), g_e.stride(0), y.data_ptr(), y.stride(0), a.data_ptr(),
+                                          g_y.data_ptr() if need_y else None, g_y.stride(0) if need_y else 0,
+                                          g_a.data_ptr() if need_a else None, B, T, F, M, hop, _lib.stream_ptr())
+        _lib.check(rc, "golf_ltv_inverse_bwd_f32")
+        return g_y, g_a, None
+
+
 def ltv_inverse(y: torch.Tensor, a: torch.Tensor, hop: int) -> torch.Tensor:
-    """e[t] = y[t] + sum_i up(a)[t,i] y[t-1-i] (analysis filter; forward only)."""
-    _lib.require_device(y, a)
-    lib = _lib.load()
-    y = _rows(y)
-    a = a.contiguous()
-    B, Ty = y.shape
-    F, M = a.shape[1], a.shape[2]
-    T = ss_output_length(Ty, F, hop)
-    e = torch.empty(B, T, dtype=torch.float32, device=y.device)
-    rc = lib.golf_ltv_inverse_f32(y.data_ptr(), y.stride(0), a.data_ptr(), e.data_ptr(), e.stride(0), B, T, F, M, hop,
-                                  _lib.stream_ptr())
-    _lib.check(rc, "golf_ltv_inverse_f32")
-    return e
+    """e[t] = y[t] + sum_i up(a)[t,i] y[t-1-i] (analysis filter); differentiable w.r.t. y and a."""
+    return _LTVInverse.apply(y, a, hop)
 
 
 # ------------------------------------------------------------------------------------------------

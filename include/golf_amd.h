@@ -99,6 +99,12 @@ int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, const float* y,
  * Replaces LTVMinimumPhaseFilter.reverse -> fir_filt, models/filters.py:186-195, utils.py:433-441. */
 int golf_ltv_inverse_f32(const float* y, int64_t y_stride, const float* a, float* e, int64_t e_stride,
                          int B, int T, int F, int M, int hop, void* stream);
+/* Its backward (autograd through fir_filt's unfold + matmul in the reference; used when a decoder is trained with
+ * `inverse_target`, ltng/vocoder.py:192-200):  g_y[t] = g_e[t] + sum_i A[t+1+i,i] g_e[t+1+i],
+ * g_a[f,i] = up^T(g_e[t] * y[t-1-i]).  Either output may be NULL. */
+int golf_ltv_inverse_bwd_f32(const float* g_e, int64_t g_e_stride, const float* y, int64_t y_stride, const float* a,
+                             float* g_y, int64_t g_y_stride, float* g_a, int B, int T, int F, int M, int hop,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a-4: frame-wise LTI all-pole + windowed overlap-add — GOLF-ff end filter.

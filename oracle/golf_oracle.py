@@ -37,6 +37,7 @@ __all__ = [
     "lti_frames_ola_forward",
     "lti_frames_ola_backward",
     "ltv_inverse_filter",
+    "ltv_inverse_backward",
     "rc2lpc",
     "logits2biquads",
     "biquads2lpc",
@@ -316,6 +317,27 @@ def ltv_inverse_filter(y, a, hop: int) -> np.ndarray:
     for i in range(M):
         e += A[:, :, i] * ypad[:, M - 1 - i : M - 1 - i + T]
     return e
+
+
+def ltv_inverse_backward(g_e, y, a, hop: int):
+    """Closed-form gradients of ltv_inverse_filter w.r.t. y and a (autograd through fir_filt's unfold + matmul and
+    F.interpolate in the reference; pinned by tests/golden/g17)."""
+    g_e = np.asarray(g_e, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    B, F, M = a.shape
+    A = linear_upsample(a, hop, axis=1)
+    T = min(y.shape[1], A.shape[1])
+    A = A[:, :T]
+    ypad = np.concatenate([np.zeros((B, M)), y[:, :T]], axis=1)
+    g_y = np.zeros_like(y)
+    g_y[:, :T] = g_e
+    gA = np.zeros((B, (F - 1) * hop + 1, M))
+    for i in range(M):
+        prod = A[:, :, i] * g_e                     # contributes to y[t-1-i]
+        g_y[:, : T - 1 - i] += prod[:, 1 + i :] if T - 1 - i > 0 else 0
+        gA[:, :T, i] = g_e * ypad[:, M - 1 - i : M - 1 - i + T]
+    return g_y, _upsample_adjoint(gA, hop, F)
 
 
 # --------------------------------------------------------------------------------------

@@ -477,4 +477,20 @@ for tag, (B, T, F, hop, n_mag) in (("a", (2, 57, 8, 8, 9)), ("b", (2, 40, 9, 8, 
     d.update({f"{tag}_ex": ex, f"{tag}_log_mag": lm, f"{tag}_hop": hop, f"{tag}_y": y, f"{tag}_gy": gy,
               f"{tag}_g_ex": ex.grad, f"{tag}_g_log_mag": lm.grad})
 save("g16_zero_phase_fir_precise", **d)
+# ----------------------------------------------------------------------------- g17 gradients of reverse() (a-5)
+mff = rf.LTVMinimumPhaseFilter(window="hanning", window_length=32, lpc_order=4)
+d = {}
+for tag, (B, F, hop, M, Ty) in (("a", (2, 6, 8, 4, 48)), ("b", (2, 5, 24, 22, 97))):
+    _, a = smooth_lpc(B, F, M)
+    a = a.detach().clone().requires_grad_(True)
+    gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+    ex = torch.from_numpy(rng.normal(0, 1, (B, Ty)).astype(np.float32)).double()
+    tgt = torch.from_numpy(rng.normal(0, 1, (B, Ty)).astype(np.float32)).double().requires_grad_(True)
+    _, e = mff.reverse(AT(ex, 1), AT(tgt, 1), AT(gain, hop), AT(a, hop))
+    e = e.as_tensor()
+    ge = torch.from_numpy(rng.normal(0, 1, tuple(e.shape)).astype(np.float32)).double()
+    (e * ge).sum().backward()
+    d.update({f"{tag}_target": tgt, f"{tag}_a": a, f"{tag}_hop": hop, f"{tag}_e": e, f"{tag}_g_e": ge,
+              f"{tag}_g_target": tgt.grad, f"{tag}_g_a": a.grad})
+save("g17_reverse_grads", **d)
 print("done")
