@@ -18,6 +18,7 @@
 //                        bank-conflict-free LDS tile.
 //   The running phase is exact to ~1e-19 cycles per term (the reference's fp32 cumsum drifts ~3e-5 cycles).
 #include "common.h"
+#include <algorithm>
 
 namespace golf {
 
@@ -453,6 +454,182 @@ static int osc_check(int B, int Tp, int phase_hop, int Fw, int w_hop, int n_tab,
     return GOLF_OK;
 }
 
+
+// =============================================================================================
+// Harmonic oscillator bank (the source of the DDSP / NHV / WORLD / MLSA / SawSing / PULF
+// baselines).  Replaces HarmonicOscillator.forward, models/synth.py:403-446, and what its subclasses feed it
+// (AdditiveSynthesizer :449-468, SawToothOscillator :486-504, AdditivePulseTrain :526-547):
+//     out[t] = sum_{h=1..H} [h * p(t) < 0.5] * amp(t,h) * sin(2 pi h Phi(t)),   Phi = inclusive cumsum of p = up(phase)
+//     amp(t,h) = up(A)[t,h] * up(tscale)[t] * hscale[h]      (each factor optional)
+// The reference materialises (B,T,H) tensors (0.95 GB each at B=32, T=48000, H=155) for the harmonic phases, their
+// cumsum, the mask, the amplitudes and the sines.  Here one thread owns one output sample: the phase comes from the
+// same exact fixed-point prefix as the wavetable oscillator (h * Phi wraps exactly in 64-bit integers), sin(h theta)
+// follows by a rotation recurrence that is re-anchored from the exact phase every HARM_ANCHOR harmonics, and the
+// frame-rate amplitude rows the block needs are staged in LDS.
+// =============================================================================================
+constexpr int HARM_THREADS = 256;
+constexpr int HARM_ANCHOR = 32;
+
+struct HarmSample {
+    u64 Phi;     // inclusive phase, Q0.64 cycles
+    float p;     // instantaneous increment up(phase)[t]  (cycles per sample)
+};
+__device__ __forceinline__ HarmSample harm_sample(const float* __restrict__ pb, const u64* __restrict__ cb,
+                                                  const u64* toff, int t, int Tp, int P, double scale_a,
+                                                  double scale_d) {
+    const int j = t / P, k = t - j * P;
+    const int jc = j < Tp - 1 ? j : Tp - 1;
+    const int jn = jc + 1 < Tp ? jc + 1 : Tp - 1;
+    const float p0 = pb[jc], p1 = pb[jn];
+    const u64 a = osc_fix_a(p0, scale_a), d = osc_fix_d(p0, p1, scale_d);
+    HarmSample r;
+    r.Phi = cb[jc] + toff[jc / OSC_SCAN_TILE] + (u64)(k + 1) * a + d * ((u64)k * (u64)(k + 1) / 2);
+    r.p = fmaf((float)k, (p1 - p0) / (float)P, p0);
+    return r;
+}
+// sin and cos of 2*pi*(x / 2^64)
+__device__ __forceinline__ void harm_sincos(u64 x, float& s, float& c) {
+    const float rev = (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);  // top 24 bits: exact in fp32, [0,1)
+    sincospif(2.0f * rev, &s, &c);
+}
+
+// MODE 0: forward, one block per 256 consecutive output samples.
+// MODE 1: gradient w.r.t. the amplitude rows, one block per (utterance, amplitude frame f): every sample whose
+//         interpolation touches frame f is visited (threads stride over them), per harmonic a wave reduction + one LDS
+//         add per wave; no atomics on global memory, deterministic.
+template <int MODE>
+__global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
+    int ntile, int Tp, int P, const float* __restrict__ amp, int Fa, int amp_hop, const float* __restrict__ tscale,
+    int Fs, int ts_hop, const float* __restrict__ hscale, int H, float* __restrict__ out, int64_t out_stride,
+    const float* __restrict__ g_out, int64_t g_out_stride, float* __restrict__ g_amp, int Tout, int nrows_lds) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    __shared__ u64 toff[256];
+    __shared__ u64 twsum[4];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    {   // exclusive prefix of the phase tile totals (as in osc_render_kernel)
+        const u64 v = tid < ntile ? Ttot[(size_t)b * ntile + tid] : 0;
+        const u64 incl = wave_incl_scan(v, tid & 63);
+        if ((tid & 63) == 63) twsum[tid >> 6] = incl;
+        toff[tid] = incl - v;
+        __syncthreads();
+        u64 base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += twsum[w];
+        toff[tid] += base;
+    }
+    float* hs = hsm;                 // [H] per-harmonic scale
+    float* rows = hsm + ((H + 3) & ~3);  // MODE 0: [nrows_lds][H] amplitude rows; MODE 1: [H] gradient sums
+    for (int h = tid; h < H; h += HARM_THREADS) hs[h] = hscale ? hscale[h] : 1.0f;
+    const float* pb = phase + (size_t)b * phase_stride;
+    const u64* cb = Cloc + (size_t)b * Tp;
+    const double scale_a = 18446744073709551616.0, scale_d = scale_a / (double)P;
+    const float inv_ah = 1.0f / (float)amp_hop, inv_sh = 1.0f / (float)ts_hop;
+
+    int t_lo, t_hi, row_lo = 0;
+    if (MODE == 0) {
+        t_lo = blockIdx.x * HARM_THREADS;
+        t_hi = min(t_lo + HARM_THREADS, Tout);
+        if (amp) {  // stage the amplitude rows this block interpolates between
+            row_lo = Fa >= 2 ? min(t_lo / amp_hop, Fa - 2) : 0;
+            const float* ab = amp + ((size_t)b * Fa + row_lo) * H;
+            const int nr = min(nrows_lds, Fa - row_lo);
+            for (int e = tid; e < nr * H; e += HARM_THREADS) rows[e] = ab[e];
+        }
+    } else {
+        const int f = blockIdx.x;
+        t_lo = max((f - 1) * amp_hop, 0);
+        t_hi = f == Fa - 1 ? Tout : min((f + 1) * amp_hop, Tout);
+        for (int h = tid; h < H; h += HARM_THREADS) rows[h] = 0.f;
+    }
+    __syncthreads();
+
+    for (int t = t_lo + tid; t < ((t_hi - t_lo + HARM_THREADS - 1) / HARM_THREADS) * HARM_THREADS + t_lo;
+         t += HARM_THREADS) {
+        const bool live = t < t_hi;
+        const int tc = live ? t : t_hi - 1;
+        const HarmSample sm = harm_sample(pb, cb, toff, tc, Tp, P, scale_a, scale_d);
+        // amplitude interpolation position
+        int fa = 0;
+        float wa = 0.f;
+        if (Fa >= 2) { fa = min(tc / amp_hop, Fa - 2); wa = (float)(tc - fa * amp_hop) * inv_ah; }
+        float ts = 1.0f;
+        if (tscale) {
+            int fs = 0;
+            float ws = 0.f;
+            if (Fs >= 2) { fs = min(tc / ts_hop, Fs - 2); ws = (float)(tc - fs * ts_hop) * inv_sh; }
+            const float s0 = tscale[(size_t)b * Fs + fs], s1 = tscale[(size_t)b * Fs + (Fs >= 2 ? fs + 1 : fs)];
+            ts = fmaf(ws, s1 - s0, s0);
+        }
+        // harmonics below Nyquist: h * p < 0.5 (evaluated as the reference does, in fp32 on h * p)
+        float gscale = 0.f;   // MODE 1: gy * tscale * hat weight of this block's frame
+        if (MODE == 1) {
+            const int f = blockIdx.x;
+            const float wt = fa == f ? 1.0f - wa : (fa == f - 1 ? wa : 0.f);
+            gscale = live ? g_out[(size_t)b * g_out_stride + tc] * ts * wt : 0.f;
+        }
+        float rs, rc;  // rotation by theta = 2 pi Phi
+        harm_sincos(sm.Phi, rs, rc);
+        float s = 0.f, c = 1.0f, acc = 0.f;
+        const float* r0 = rows + (size_t)(fa - row_lo) * H;
+        for (int h = 1; h <= H; ++h) {
+            if (((h - 1) % HARM_ANCHOR) == 0) harm_sincos((u64)h * sm.Phi, s, c);  // exact re-anchor
+            else {
+                const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
+                s = sn;
+                c = cn;
+            }
+            const bool below = (float)h * sm.p < 0.5f;
+            if (MODE == 0) {
+                float a = hs[h - 1];
+                if (amp) a *= fmaf(wa, r0[H + h - 1] - r0[h - 1], r0[h - 1]);
+                acc = below ? fmaf(a, s, acc) : acc;
+            } else {
+                float v = below ? gscale * hs[h - 1] * s : 0.f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if ((tid & 63) == 0) atomicAdd(&rows[h - 1], v);  // LDS, 4 waves per block
+            }
+        }
+        if (MODE == 0 && live) out[(size_t)b * out_stride + t] = acc * ts;
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int h = tid; h < H; h += HARM_THREADS) g_amp[((size_t)b * Fa + blockIdx.x) * H + h] = rows[h];
+    }
+}
+
+struct HarmGeom {
+    int P, N, ntile, nrows;
+    size_t off_cw, off_ttot, total;
+};
+static int harm_geom(int B, int Tp, int phase_hop, int amp_hop, HarmGeom* g) {
+    g->P = phase_hop;
+    g->N = phase_hop > 1 ? (Tp - 1) * phase_hop + 1 : Tp;
+    g->ntile = (int)ceil_div(Tp, OSC_SCAN_TILE);
+    g->nrows = HARM_THREADS / (amp_hop > 0 ? amp_hop : 1) + 3;
+    size_t o = 0;
+    g->off_cw = o;   o = align_up(o + sizeof(u64) * (size_t)B * Tp, 256);
+    g->off_ttot = o; o = align_up(o + sizeof(u64) * (size_t)B * g->ntile, 256);
+    g->total = o;
+    return 0;
+}
+static int harm_check(const char* who, const float* phase, int B, int Tp, int phase_hop, const float* amp, int Fa,
+                      int amp_hop, const float* tscale, int Fs, int ts_hop, int H, int Tout, const HarmGeom& g) {
+    if (!phase || B < 1 || Tp < 1 || phase_hop < 1 || H < 1 || H > 4096)
+        return fail(GOLF_EINVAL, "%s: bad size (B=%d Tp=%d phase_hop=%d H=%d)", who, B, Tp, phase_hop, H);
+    if ((amp && (Fa < 1 || amp_hop < 1)) || (tscale && (Fs < 1 || ts_hop < 1)))
+        return fail(GOLF_EINVAL, "%s: bad amplitude / scale geometry", who);
+    int expect = g.N;
+    if (amp) expect = std::min(expect, amp_hop > 1 ? (Fa - 1) * amp_hop + 1 : Fa);
+    if (tscale) expect = std::min(expect, ts_hop > 1 ? (Fs - 1) * ts_hop + 1 : Fs);
+    if (Tout != expect) return fail(GOLF_EINVAL, "%s: Tout=%d, expected %d", who, Tout, expect);
+    if (g.ntile > 256) return fail(GOLF_EUNSUPPORTED, "%s: Tp=%d > 262144 coarse phase samples", who, Tp);
+    if (amp && (size_t)(g.nrows + 1) * H * sizeof(float) > 60 * 1024)
+        return fail(GOLF_EUNSUPPORTED, "%s: amplitude hop %d too fine for %d harmonics (LDS staging); pass amplitudes "
+                    "at a coarser hop or fold them into tscale/hscale", who, amp_hop, H);
+    return GOLF_OK;
+}
+
 }  // namespace golf
 
 using namespace golf;
@@ -568,6 +745,67 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(osc_wsel_reduce_kernel, dim3((unsigned)ceil_div(B * Fw, 256)), dim3(256), 0, st,
                        (const float*)part, g_wsel, B, Fw, g.nint, n_tab);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop) {
+    if (B < 1 || Tp < 1 || phase_hop < 1) return 0;
+    HarmGeom g;
+    harm_geom(B, Tp, phase_hop, 1, &g);
+    return g.total;
+}
+
+extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                                         const float* amp, int Fa, int amp_hop, const float* tscale, int Fs,
+                                         int ts_hop, const float* hscale, int H, float* out, int64_t out_stride, int B,
+                                         int Tout, void* ws, size_t ws_bytes, void* stream) {
+    HarmGeom g;
+    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp ? amp_hop : HARM_THREADS, &g);
+    if (int rc = harm_check("harmonic_osc_fwd", phase, B, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs, ts_hop, H, Tout, g))
+        return rc;
+    if (!out || out_stride < Tout || phase_stride < Tp) return fail(GOLF_EINVAL, "harmonic_osc_fwd: bad output / stride");
+    if (!ws || ws_bytes < g.total || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "harmonic_osc_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
+                    ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    u64* Cw = (u64*)((char*)ws + g.off_cw);
+    u64* Ttot = (u64*)((char*)ws + g.off_ttot);
+    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
+                       g.P, 1, g.ntile);
+    GOLF_LAUNCH_CHECK();
+    const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H);
+    hipLaunchKernelGGL((harm_kernel<0>), dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
+                       phase, phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, amp, amp ? Fa : 1,
+                       amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, (const float*)nullptr,
+                       (int64_t)0, (float*)nullptr, Tout, g.nrows);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_stride, const float* phase,
+                                             int64_t phase_stride, int Tp, int phase_hop, int Fa, int amp_hop,
+                                             const float* tscale, int Fs, int ts_hop, const float* hscale, int H,
+                                             float* g_amp, int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
+    HarmGeom g;
+    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp_hop > 0 ? amp_hop : 1, &g);
+    if (int rc = harm_check("harmonic_osc_bwd_amp", phase, B, Tp, phase_hop, g_amp, Fa, amp_hop, tscale, Fs, ts_hop, H,
+                            Tout, g))
+        return rc;
+    if (!g_out || !g_amp || g_out_stride < Tout) return fail(GOLF_EINVAL, "harmonic_osc_bwd_amp: bad pointer / stride");
+    if (!ws || ws_bytes < g.total || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "harmonic_osc_bwd_amp: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
+                    ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    u64* Cw = (u64*)((char*)ws + g.off_cw);   // recomputed: the backward does not rely on the forward's scratch
+    u64* Ttot = (u64*)((char*)ws + g.off_ttot);
+    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
+                       g.P, 1, g.ntile);
+    GOLF_LAUNCH_CHECK();
+    const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)H);
+    hipLaunchKernelGGL((harm_kernel<1>), dim3((unsigned)Fa, B), dim3(HARM_THREADS), lds, st, phase, phase_stride,
+                       (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, (const float*)nullptr, Fa, amp_hop, tscale,
+                       Fs, ts_hop, hscale, H, (float*)nullptr, (int64_t)0, g_out, g_out_stride, g_amp, Tout, 1);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -13,7 +13,7 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
            "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
            "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
            "zero_phase_fir_filter_precise",
-           "fir_frames_length", "lti_fir"]
+           "fir_frames_length", "lti_fir", "harmonic_osc"]
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
@@ -530,3 +530,70 @@ def lti_fir(ex: torch.Tensor, taps: torch.Tensor, lead: int) -> torch.Tensor:
     """y[b,t] = sum_n taps[n] * ex[b, t-lead+n] (zero outside the signal); taps.numel() % 4 == 0; differentiable
     w.r.t. both arguments."""
     return _LTIFIR.apply(ex, taps, lead)
+
+
+# ------------------------------------------------------------------------------------------------
+# harmonic oscillator bank (reference models/synth.py:403-547)
+# ------------------------------------------------------------------------------------------------
+def _up_len(n: int, hop: int) -> int:
+    return (n - 1) * hop + 1 if hop > 1 else n
+
+
+class _HarmonicOsc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop):
+        _lib.require_device(phase, amp, tscale, hscale)
+        lib = _lib.load()
+        phase = _rows(phase)
+        B, Tp = phase.shape
+        Tout = _up_len(Tp, phase_hop)
+        Fa = Fs = 1
+        if amp is not None:
+            amp = amp.contiguous()
+            if amp.dim() != 3 or amp.shape[0] != B or amp.shape[2] != H:
+                raise _lib.GolfError(f"harmonic_osc: amplitudes {tuple(amp.shape)} for B={B}, H={H}")
+            Fa = amp.shape[1]
+            Tout = min(Tout, _up_len(Fa, amp_hop))
+        if tscale is not None:
+            tscale = tscale.contiguous()
+            Fs = tscale.shape[1]
+            Tout = min(Tout, _up_len(Fs, ts_hop))
+        if hscale is not None:
+            hscale = hscale.contiguous()
+        out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
+        ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop), phase.device)
+        rc = lib.golf_harmonic_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, _lib.ptr(amp), Fa, amp_hop,
+                                           _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(),
+                                           out.stride(0), B, Tout, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_harmonic_osc_fwd_f32")
+        ctx.save_for_backward(phase, tscale, hscale)
+        ctx.geom = (H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, amp is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        phase, tscale, hscale = ctx.saved_tensors
+        H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = ctx.geom
+        if any(ctx.needs_input_grad[i] for i in (0, 2, 3)):
+            raise NotImplementedError("golf_amd: the harmonic oscillator is differentiable w.r.t. the amplitudes only "
+                                      "(phase and the per-sample / per-harmonic scales are data)")
+        g_amp = None
+        if has_amp and ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            g_out = _rows(g_out)
+            B, Tp = phase.shape
+            g_amp = torch.empty(B, Fa, H, dtype=torch.float32, device=phase.device)
+            ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop), phase.device)
+            rc = lib.golf_harmonic_osc_bwd_amp_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(),
+                                                   phase.stride(0), Tp, phase_hop, Fa, amp_hop, _lib.ptr(tscale), Fs,
+                                                   ts_hop, _lib.ptr(hscale), H, g_amp.data_ptr(), B, Tout,
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "golf_harmonic_osc_bwd_amp_f32")
+        return None, g_amp, None, None, None, None, None, None
+
+
+def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, tscale=None, ts_hop: int = 1,
+                 hscale=None) -> torch.Tensor:
+    """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h] * sin(2 pi h cumsum(p)[t]),
+    p = up(phase); differentiable w.r.t. ``amp``."""
+    return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop)

@@ -19,7 +19,8 @@ from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import get_transformed_lf, get_transformed_lf_v2
 
 __all__ = ["OscillatorInterface", "GlottalFlowTable", "IndexedGlottalFlowTable",
-           "DownsampledIndexedGlottalFlowTable", "Decimate", "get_downsampler"]
+           "DownsampledIndexedGlottalFlowTable", "Decimate", "get_downsampler", "HarmonicOscillator",
+           "AdditiveSynthesizer", "V1AdditiveSynthesizer", "SawToothOscillator", "AdditivePulseTrain"]
 
 
 class Decimate(nn.Module):
@@ -150,3 +151,88 @@ class DownsampledIndexedGlottalFlowTable(IndexedGlottalFlowTable):
                 ),
             ),
         )
+
+
+# ---------------------------------------------------------------------------------------------
+# harmonic oscillator bank (reference models/synth.py:403-547): the sources of the DDSP / NHV / WORLD / MLSA /
+# SawSing / PULF baselines.  One fused kernel (golf_harmonic_osc_{fwd,bwd_amp}_f32): the reference's (B,T,H)
+# phase / mask / amplitude / sine tensors are never formed.
+# ---------------------------------------------------------------------------------------------
+class HarmonicOscillator(OscillatorInterface):
+    """out = sum_h sin(2 pi cumsum(h * up(phase))) * amplitudes[..., h], harmonics at or above Nyquist muted."""
+
+    def _run(self, phase: AudioTensor, num_harmonics: int, amplitudes: AudioTensor = None, tscale: AudioTensor = None,
+             hscale: Tensor = None, initial_phase=None, phase_offset=None) -> AudioTensor:
+        assert phase.ndim == 2, phase.shape
+        if initial_phase is not None or phase_offset is not None:
+            raise NotImplementedError("golf_amd: initial_phase / phase_offset are not supported by the fused harmonic "
+                                      "oscillator (no shipped config passes them)")
+        if self.check_ranges:
+            assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
+        y = GF.harmonic_osc(phase.as_tensor(), num_harmonics, phase_hop=int(phase.hop_length),
+                            amp=None if amplitudes is None else amplitudes.as_tensor(),
+                            amp_hop=1 if amplitudes is None else int(amplitudes.hop_length),
+                            tscale=None if tscale is None else tscale.as_tensor(),
+                            ts_hop=1 if tscale is None else int(tscale.hop_length), hscale=hscale)
+        return AudioTensor(y)
+
+    def forward(self, phase: AudioTensor, amplitudes: AudioTensor, initial_phase=None, phase_offset=None) -> AudioTensor:
+        return self._run(phase, amplitudes.shape[-1], amplitudes, initial_phase=initial_phase,
+                         phase_offset=phase_offset)
+
+
+def _sqrt_two_phase(phase: AudioTensor) -> AudioTensor:
+    """rsqrt(0.5 / phase): the equal-energy factor of the reference (synth.py:465-466, 543-544), at the phase's hop."""
+    return phase.new_tensor(torch.rsqrt(0.5 / phase.as_tensor()))
+
+
+class AdditiveSynthesizer(HarmonicOscillator):
+    def __init__(self, num_harmonics: int = 150, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.ctrl = wrap_ctrl_fn(
+            split_size=(1, num_harmonics),
+            trsfm_fn=lambda log_gain, amplitudes_logits: (torch.exp(log_gain) * torch.sigmoid(amplitudes_logits),))
+
+    def forward(self, phase: AudioTensor, amplitudes: AudioTensor, **kwargs) -> AudioTensor:
+        scale = _sqrt_two_phase(phase)
+        if phase.hop_length == 1:
+            # amplitudes are upsampled to the sample rate and multiplied point-wise: the factor can ride along as a
+            # per-sample scale instead of materialising (B, T, H)
+            return self._run(phase, amplitudes.shape[-1], amplitudes, tscale=scale, **kwargs)
+        # coarser phase: the reference forms the product at the finer of the two hops and upsamples that
+        return self._run(phase, amplitudes.shape[-1], amplitudes * torch.unsqueeze(scale, -1), **kwargs)
+
+
+class V1AdditiveSynthesizer(HarmonicOscillator):
+    def __init__(self, num_harmonics: int = 150, **kwargs) -> None:
+        super().__init__(**kwargs)
+
+        def normalised(log_gain, amplitudes_logits):
+            s = torch.sigmoid(amplitudes_logits.as_tensor())
+            return (torch.exp(log_gain) * amplitudes_logits.new_tensor(s / s.sum(-1, keepdim=True)),)
+
+        self.ctrl = wrap_ctrl_fn(split_size=(1, num_harmonics), trsfm_fn=normalised)
+
+
+class SawToothOscillator(HarmonicOscillator):
+    """Band-limited sawtooth: harmonic h with amplitude 1/h (the reference's ``gain`` argument is unused there too)."""
+
+    def __init__(self, num_harmonics: int, gain: float = 0.4, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.gain = gain
+        self.register_buffer("amplitudes", 1 / torch.arange(1, num_harmonics + 1))
+
+    def forward(self, phase: AudioTensor, initial_phase=None, phase_offset=None, **kwargs) -> AudioTensor:
+        return self._run(phase, self.amplitudes.numel(), hscale=self.amplitudes, initial_phase=initial_phase,
+                         phase_offset=phase_offset)
+
+
+class AdditivePulseTrain(HarmonicOscillator):
+    def __init__(self, num_harmonics: int = 155, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.num_harmonics = num_harmonics
+
+    def forward(self, phase: AudioTensor, initial_phase=None, phase_offset=None, **kwargs) -> AudioTensor:
+        # all harmonics share rsqrt(0.5/phase) (at the phase's hop, linearly upsampled like any amplitude)
+        return self._run(phase, self.num_harmonics, tscale=_sqrt_two_phase(phase), initial_phase=initial_phase,
+                         phase_offset=phase_offset)

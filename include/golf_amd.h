@@ -226,6 +226,28 @@ size_t golf_lti_fir_taps_grad_workspace_bytes(int B, int T, int ntaps);
 int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, float* g_taps,
                                int ntaps, int lead, int B, int T, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a-11: harmonic oscillator bank — the source of the DDSP / NHV / WORLD / MLSA / SawSing / PULF baselines.
+ * Replaces HarmonicOscillator.forward, models/synth.py:403-446, and what AdditiveSynthesizer (:449-468),
+ * SawToothOscillator (:486-504) and AdditivePulseTrain (:526-547) feed it:
+ *     p = up(phase)  [cycles/sample, linear upsampling from phase_hop];   Phi = inclusive cumsum of p
+ *     out[t] = sum_{h=1..H} [h*p(t) < 0.5] * amp(t,h) * sin(2 pi h Phi(t))
+ *     amp(t,h) = up(A)[t,h] * up(tscale)[t] * hscale[h];  A (B,Fa,H) at amp_hop, tscale (B,Fs) at ts_hop, hscale (H):
+ *     each may be NULL (= 1).  Tout = min of the upsampled lengths ((n-1)*hop+1) of phase and the given factors.
+ *   The (B,T,H) tensors of the reference are never formed; the phase is exact (64-bit fixed point, as in the
+ *   wavetable oscillator), sin(h theta) by a rotation recurrence re-anchored from the exact phase every 32 harmonics.
+ * Backward w.r.t. A only (the phase is data in every shipped config): g_amp (B,Fa,H) fully overwritten.
+ * ------------------------------------------------------------------------------------------- */
+size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop);
+int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                              const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
+                              const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
+                              void* ws, size_t ws_bytes, void* stream);
+int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_stride, const float* phase, int64_t phase_stride,
+                                  int Tp, int phase_hop, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
+                                  const float* hscale, int H, float* g_amp, int B, int Tout,
+                                  void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ __all__ = [
     "lti_acoustic_filter_forward",
     "lti_acoustic_filter_backward",
     "golf_ss_decoder",
+    "harmonic_oscillator_forward",
+    "harmonic_oscillator_backward_amp",
 ]
 
 
@@ -770,3 +772,38 @@ def golf_ss_decoder(phase, phase_hop, weight, weight_hop, table, noise, log_mag,
     if room_kernel is not None:
         y = lti_acoustic_filter_forward(y, room_kernel)
     return src, y
+
+
+# --------------------------------------------------------------------------------------
+# a-11  harmonic oscillator bank (DDSP / NHV / WORLD / MLSA / SawSing / PULF baselines)
+# --------------------------------------------------------------------------------------
+def _harmonic_terms(phase, phase_hop, n_harm, n_out):
+    up = linear_upsample(np.asarray(phase, dtype=np.float64), phase_hop, axis=1)[:, :n_out]   # cycles / sample
+    h = np.arange(1, n_harm + 1, dtype=np.float64)
+    inst = np.cumsum(up, axis=1)[:, :, None] * h                         # cumsum(h * up) = h * cumsum(up)
+    mask = (up[:, :, None] * h) < 0.5                                    # anti-aliasing: synth.py:440
+    return np.sin(2.0 * np.pi * inst), mask
+
+
+def harmonic_oscillator_forward(phase, phase_hop: int, amplitudes, amp_hop: int) -> np.ndarray:
+    """HarmonicOscillator.forward, models/synth.py:403-446 (initial_phase = phase_offset = None):
+    harmonic h runs at h * up(phase) cycles per sample, phase = inclusive cumsum, amplitudes (B,Fa,H) at ``amp_hop``
+    are linearly upsampled, zeroed where h * up(phase) >= 0.5, out[t] = sum_h sin(2 pi phase_h[t]) * amp[t,h];
+    length = min((Tp-1)*phase_hop+1, (Fa-1)*amp_hop+1)  (mixed-hop truncation, utils.py:230-232)."""
+    amplitudes = np.asarray(amplitudes, dtype=np.float64)
+    A = linear_upsample(amplitudes, amp_hop, axis=1)
+    N = (np.asarray(phase).shape[1] - 1) * phase_hop + 1 if phase_hop > 1 else np.asarray(phase).shape[1]
+    n_out = min(N, A.shape[1])
+    sines, mask = _harmonic_terms(phase, phase_hop, amplitudes.shape[-1], n_out)
+    return np.einsum("bth,bth->bt", sines * mask, A[:, :n_out])
+
+
+def harmonic_oscillator_backward_amp(gy, phase, phase_hop: int, amplitudes_shape, amp_hop: int) -> np.ndarray:
+    """d/d amplitudes of harmonic_oscillator_forward (the phase is data)."""
+    gy = np.asarray(gy, dtype=np.float64)
+    B, Fa, H = amplitudes_shape
+    n_out = gy.shape[1]
+    sines, mask = _harmonic_terms(phase, phase_hop, H, n_out)
+    gA = np.zeros((B, (Fa - 1) * amp_hop + 1 if amp_hop > 1 else Fa, H))
+    gA[:, :n_out] = gy[:, :, None] * sines * mask
+    return _upsample_adjoint(gA, amp_hop, Fa)

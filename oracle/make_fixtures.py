@@ -493,4 +493,33 @@ for tag, (B, F, hop, M, Ty) in (("a", (2, 6, 8, 4, 48)), ("b", (2, 5, 24, 22, 97
     d.update({f"{tag}_target": tgt, f"{tag}_a": a, f"{tag}_hop": hop, f"{tag}_e": e, f"{tag}_g_e": ge,
               f"{tag}_g_target": tgt.grad, f"{tag}_g_a": a.grad})
 save("g17_reverse_grads", **d)
+# ----------------------------------------------------------------------------- g18 harmonic oscillator bank (a-11)
+# HarmonicOscillator / AdditiveSynthesizer / SawToothOscillator / AdditivePulseTrain (synth.py:403-547).  The reference
+# cumsums in float32 (synth.py:426-427): dyadic phase increments make that exact for these short signals, and
+# power-of-two hops keep the interpolated h*phase exact too, so that harmonics sitting exactly AT Nyquist (h*p == 0.5)
+# are masked identically by every implementation instead of by the rounding of one particular interpolation routine.
+d = {}
+H = 6
+for tag, (B, Tp, ph, Fa, ah) in (("t", (2, 97, 1, 7, 16)), ("r", (2, 7, 16, 4, 32)), ("q", (1, 25, 4, 3, 32))):
+    phase = dyadic((B, Tp), 10, 0.01, 0.12)
+    # float32 throughout: the reference casts the harmonic phases to float32 (synth.py:427), a float64 amplitude
+    # tensor does not even type-check in its matmul
+    amp = torch.from_numpy(rng.uniform(0, 1, (B, Fa, H)).astype(np.float32)).requires_grad_(True)
+    y = rs.HarmonicOscillator()(AT(phase, ph), AT(amp, ah)).as_tensor()
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
+    (y * gy).sum().backward()
+    d.update({f"{tag}_phase": phase, f"{tag}_phase_hop": ph, f"{tag}_amp": amp, f"{tag}_amp_hop": ah, f"{tag}_y": y,
+              f"{tag}_gy": gy, f"{tag}_g_amp": amp.grad})
+    d[f"{tag}_additive"] = rs.AdditiveSynthesizer(num_harmonics=H)(AT(phase, ph), AT(amp.detach(), ah)).as_tensor()
+    d[f"{tag}_saw"] = rs.SawToothOscillator(num_harmonics=H)(AT(phase, ph)).as_tensor()
+    d[f"{tag}_pulse"] = rs.AdditivePulseTrain(num_harmonics=H)(AT(phase, ph)).as_tensor()
+add_syn = rs.AdditiveSynthesizer(num_harmonics=H)
+(split, trsfm) = add_syn.ctrl(lambda s_, t_: (s_, t_))((), ())
+lg = torch.from_numpy(rng.normal(-1, 0.3, (2, 7)).astype(np.float32))
+lo = torch.from_numpy(rng.normal(0, 1, (2, 7, H)).astype(np.float32))
+(amp_c,) = trsfm[0](AT(lg, 16), AT(lo, 16))
+# (V1AdditiveSynthesizer's transform calls .sum() on the AudioTensor, which models.utils.LegacyAudioTensor lacks: it
+# cannot be captured with the submodule absent)
+d.update(ctrl_log_gain=lg, ctrl_logits=lo, ctrl_amp=amp_c.as_tensor(), ctrl_split=np.array(split[0]))
+save("g18_harmonic_oscillators", **d)
 print("done")

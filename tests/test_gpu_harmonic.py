@@ -1,0 +1,87 @@
+"""GPU parity of the harmonic oscillator bank (golf_harmonic_osc_*; reference models/synth.py:403-547): golden vectors
+from the reference's own float32 run (g18), the float64 oracle at the size the baselines use, gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x, grad=False):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda().requires_grad_(grad)
+
+
+def check(y, ref, what, tol):
+    y = np.asarray(y)
+    emax, el2 = rel_err(y, ref)
+    print(f"{what}: rel-max {emax:.3e} rel-l2 {el2:.3e}")
+    assert np.isfinite(y).all()
+    assert emax <= tol and el2 <= tol, (what, emax, el2)
+
+
+@pytest.mark.parametrize("tag", ["t", "r", "q"])
+def test_golden_g18(golden, tag):
+    from golf_amd.audiotensor import AudioTensor as AT
+    from golf_amd import synth as S
+
+    g = golden("g18_harmonic_oscillators")
+    ph, ah = int(g[f"{tag}_phase_hop"]), int(g[f"{tag}_amp_hop"])
+    phase, amp = dev(g[f"{tag}_phase"]), dev(g[f"{tag}_amp"], True)
+    H = amp.shape[-1]
+    y = S.HarmonicOscillator().cuda()(AT(phase, ph), AT(amp, ah))
+    assert y.hop_length == 1
+    yt = y.as_tensor()
+    (yt * dev(g[f"{tag}_gy"])).sum().backward()
+    # the reference itself runs this in float32 (cumsum, sin): 2e-5 is its own accuracy here
+    check(yt.detach().cpu().numpy(), g[f"{tag}_y"], f"g18{tag} harmonic", 3e-5)
+    check(amp.grad.cpu().numpy(), g[f"{tag}_g_amp"], f"g18{tag} g_amp", 3e-5)
+    add = S.AdditiveSynthesizer(num_harmonics=H).cuda()(AT(phase, ph), AT(amp.detach(), ah)).as_tensor()
+    check(add.cpu().numpy(), g[f"{tag}_additive"], f"g18{tag} additive", 3e-5)
+    saw = S.SawToothOscillator(num_harmonics=H).cuda()(AT(phase, ph)).as_tensor()
+    check(saw.cpu().numpy(), g[f"{tag}_saw"], f"g18{tag} sawtooth", 3e-5)
+    pulse = S.AdditivePulseTrain(num_harmonics=H).cuda()(AT(phase, ph)).as_tensor()
+    check(pulse.cpu().numpy(), g[f"{tag}_pulse"], f"g18{tag} pulse train", 3e-5)
+
+
+def test_ctrl_transforms(golden):
+    from golf_amd.audiotensor import AudioTensor as AT
+    from golf_amd import synth as S
+
+    g = golden("g18_harmonic_oscillators")
+    H = g["ctrl_logits"].shape[-1]
+    m = S.AdditiveSynthesizer(num_harmonics=H)
+    (split, trsfm) = m.ctrl(lambda s_, t_: (s_, t_))((), ())
+    assert tuple(split[0]) == tuple(g["ctrl_split"])
+    (amp,) = trsfm[0](AT(torch.as_tensor(g["ctrl_log_gain"]), 16), AT(torch.as_tensor(g["ctrl_logits"]), 16))
+    np.testing.assert_allclose(amp.as_tensor().numpy(), g["ctrl_amp"], rtol=1e-6, atol=1e-7)
+    v1 = S.V1AdditiveSynthesizer(num_harmonics=H)
+    (_, t1) = v1.ctrl(lambda s_, t_: (s_, t_))((), ())
+    (a1,) = t1[0](AT(torch.as_tensor(g["ctrl_log_gain"]), 16), AT(torch.as_tensor(g["ctrl_logits"]), 16))
+    sg = torch.sigmoid(torch.as_tensor(g["ctrl_logits"]))
+    ref = torch.exp(torch.as_tensor(g["ctrl_log_gain"]))[..., None] * sg / sg.sum(-1, keepdim=True)
+    np.testing.assert_allclose(a1.as_tensor().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,Tp,ph,Fa,ah,H", [(4, 48000, 1, 201, 240, 155), (2, 401, 120, 201, 240, 150),
+                                             (3, 5000, 1, 40, 128, 31), (2, 3000, 1, 1, 1, 5)])
+def test_vs_oracle(B, Tp, ph, Fa, ah, H):
+    """DDSP-style shapes: 2 s @ 24 kHz, 155 harmonics, amplitudes at hop 240; f0 from 80 to 1000 Hz so that the
+    Nyquist mask cuts the upper harmonics of the high voices."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(H + Tp)
+    f0 = rng.uniform(80, 1000, (B, 1)) * (1 + 0.03 * np.sin(np.linspace(0, 20, Tp))[None])
+    phase = (f0 / 24000).astype(np.float32)
+    amp = (rng.uniform(0, 1, (B, Fa, H)) / np.arange(1, H + 1)).astype(np.float32)
+    ref = O.harmonic_oscillator_forward(phase, ph, amp, ah)
+    gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+    a = dev(amp, True)
+    y = GF.harmonic_osc(dev(phase), H, phase_hop=ph, amp=a, amp_hop=ah)
+    assert tuple(y.shape) == ref.shape
+    (y * dev(gy)).sum().backward()
+    check(y.detach().cpu().numpy(), ref, f"harmonic fwd B{B} Tp{Tp} H{H}", 2e-5)
+    rga = O.harmonic_oscillator_backward_amp(gy, phase, ph, amp.shape, ah)
+    check(a.grad.cpu().numpy(), rga, "harmonic g_amp", 2e-5)
