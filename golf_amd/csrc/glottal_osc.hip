@@ -493,16 +493,12 @@ __device__ __forceinline__ void harm_sincos(u64 x, float& s, float& c) {
     sincospif(2.0f * rev, &s, &c);
 }
 
-// MODE 0: forward, one block per 256 consecutive output samples.
-// MODE 1: gradient w.r.t. the amplitude rows, one block per (utterance, amplitude frame f): every sample whose
-//         interpolation touches frame f is visited (threads stride over them), per harmonic a wave reduction + one LDS
-//         add per wave; no atomics on global memory, deterministic.
-template <int MODE>
+// Forward: one block per 256 consecutive output samples.
 __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
     int ntile, int Tp, int P, const float* __restrict__ amp, int Fa, int amp_hop, const float* __restrict__ tscale,
-    int Fs, int ts_hop, const float* __restrict__ hscale, int H, float* __restrict__ out, int64_t out_stride,
-    const float* __restrict__ g_out, int64_t g_out_stride, float* __restrict__ g_amp, int Tout, int nrows_lds) {
+    int Fs, int ts_hop, const float* __restrict__ hscale, int H, float* __restrict__ out, int64_t out_stride, int Tout,
+    int nrows_lds) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     __shared__ u64 toff[256];
     __shared__ u64 twsum[4];
@@ -517,92 +513,153 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
         for (int w = 0; w < (tid >> 6); ++w) base += twsum[w];
         toff[tid] += base;
     }
-    float* hs = hsm;                 // [H] per-harmonic scale
-    float* rows = hsm + ((H + 3) & ~3);  // MODE 0: [nrows_lds][H] amplitude rows; MODE 1: [H] gradient sums
+    float* hs = hsm;                     // [H] per-harmonic scale
+    float* rows = hsm + ((H + 3) & ~3);  // [nrows_lds][H] amplitude rows
     for (int h = tid; h < H; h += HARM_THREADS) hs[h] = hscale ? hscale[h] : 1.0f;
     const float* pb = phase + (size_t)b * phase_stride;
     const u64* cb = Cloc + (size_t)b * Tp;
     const double scale_a = 18446744073709551616.0, scale_d = scale_a / (double)P;
     const float inv_ah = 1.0f / (float)amp_hop, inv_sh = 1.0f / (float)ts_hop;
-
-    int t_lo, t_hi, row_lo = 0;
-    if (MODE == 0) {
-        t_lo = blockIdx.x * HARM_THREADS;
-        t_hi = min(t_lo + HARM_THREADS, Tout);
-        if (amp) {  // stage the amplitude rows this block interpolates between
-            row_lo = Fa >= 2 ? min(t_lo / amp_hop, Fa - 2) : 0;
-            const float* ab = amp + ((size_t)b * Fa + row_lo) * H;
-            const int nr = min(nrows_lds, Fa - row_lo);
-            for (int e = tid; e < nr * H; e += HARM_THREADS) rows[e] = ab[e];
-        }
-    } else {
-        const int f = blockIdx.x;
-        t_lo = max((f - 1) * amp_hop, 0);
-        t_hi = f == Fa - 1 ? Tout : min((f + 1) * amp_hop, Tout);
-        for (int h = tid; h < H; h += HARM_THREADS) rows[h] = 0.f;
+    const int t_lo = blockIdx.x * HARM_THREADS;
+    int row_lo = 0;
+    if (amp) {  // stage the amplitude rows this block interpolates between
+        row_lo = Fa >= 2 ? min(t_lo / amp_hop, Fa - 2) : 0;
+        const float* ab = amp + ((size_t)b * Fa + row_lo) * H;
+        const int nr = min(nrows_lds, Fa - row_lo);
+        for (int e = tid; e < nr * H; e += HARM_THREADS) rows[e] = ab[e];
     }
     __syncthreads();
-
-    for (int t = t_lo + tid; t < ((t_hi - t_lo + HARM_THREADS - 1) / HARM_THREADS) * HARM_THREADS + t_lo;
-         t += HARM_THREADS) {
-        const bool live = t < t_hi;
-        const int tc = live ? t : t_hi - 1;
-        const HarmSample sm = harm_sample(pb, cb, toff, tc, Tp, P, scale_a, scale_d);
-        // amplitude interpolation position
-        int fa = 0;
-        float wa = 0.f;
-        if (Fa >= 2) { fa = min(tc / amp_hop, Fa - 2); wa = (float)(tc - fa * amp_hop) * inv_ah; }
-        float ts = 1.0f;
-        if (tscale) {
-            int fs = 0;
-            float ws = 0.f;
-            if (Fs >= 2) { fs = min(tc / ts_hop, Fs - 2); ws = (float)(tc - fs * ts_hop) * inv_sh; }
-            const float s0 = tscale[(size_t)b * Fs + fs], s1 = tscale[(size_t)b * Fs + (Fs >= 2 ? fs + 1 : fs)];
-            ts = fmaf(ws, s1 - s0, s0);
+    const int t = t_lo + tid;
+    if (t >= Tout) return;
+    const HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+    int fa = 0;
+    float wa = 0.f;
+    if (Fa >= 2) { fa = min(t / amp_hop, Fa - 2); wa = (float)(t - fa * amp_hop) * inv_ah; }
+    float ts = 1.0f;
+    if (tscale) {
+        int fs = 0;
+        float ws = 0.f;
+        if (Fs >= 2) { fs = min(t / ts_hop, Fs - 2); ws = (float)(t - fs * ts_hop) * inv_sh; }
+        const float s0 = tscale[(size_t)b * Fs + fs], s1 = tscale[(size_t)b * Fs + (Fs >= 2 ? fs + 1 : fs)];
+        ts = fmaf(ws, s1 - s0, s0);
+    }
+    float rs, rc;  // rotation by theta = 2 pi Phi
+    harm_sincos(sm.Phi, rs, rc);
+    float s = 0.f, c = 1.0f, acc = 0.f;
+    const float* r0 = rows + (size_t)(fa - row_lo) * H;
+    for (int h = 1; h <= H; ++h) {
+        if (((h - 1) % HARM_ANCHOR) == 0) harm_sincos((u64)h * sm.Phi, s, c);  // exact re-anchor
+        else {
+            const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
+            s = sn;
+            c = cn;
         }
         // harmonics below Nyquist: h * p < 0.5 (evaluated as the reference does, in fp32 on h * p)
-        float gscale = 0.f;   // MODE 1: gy * tscale * hat weight of this block's frame
-        if (MODE == 1) {
-            const int f = blockIdx.x;
-            const float wt = fa == f ? 1.0f - wa : (fa == f - 1 ? wa : 0.f);
-            gscale = live ? g_out[(size_t)b * g_out_stride + tc] * ts * wt : 0.f;
+        float a = hs[h - 1];
+        if (amp) a *= fmaf(wa, r0[H + h - 1] - r0[h - 1], r0[h - 1]);
+        acc = (float)h * sm.p < 0.5f ? fmaf(a, s, acc) : acc;
+    }
+    out[(size_t)b * out_stride + t] = acc * ts;
+}
+
+// Gradient w.r.t. the amplitude rows.  One wave per (utterance, amplitude segment sg): every sample of the segment is
+// visited ONCE and feeds both rows it interpolates between (row sg with 1-w, row sg+1 with w).  Harmonics are
+// processed in chunks of HARM_ANCHOR = 32 (one exact re-anchor per sample and chunk): a lane keeps 2 x 32 running sums
+// in registers over its samples (stride 64) and only at the end of the chunk are they reduced across the wave -- the
+// first version reduced every harmonic of every 64 samples across lanes (930 cross-lane operations per 64 samples) and
+// visited each sample from both of its rows: 617 us at B=32, H=155.  Partial sums part[b][sg][2][H] are combined by
+// harm_bwd_combine_kernel (deterministic, no atomics).
+__global__ __launch_bounds__(64) void harm_bwd_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
+    int ntile, int Tp, int P, int Fa, int amp_hop, const float* __restrict__ tscale, int Fs, int ts_hop,
+    const float* __restrict__ hscale, int H, const float* __restrict__ g_out, int64_t g_out_stride,
+    float* __restrict__ part, int nseg, int Tout) {
+    __shared__ u64 toff[256];
+    const int lane = threadIdx.x, sg = blockIdx.x, b = blockIdx.y;
+    {   // exclusive prefix of the phase tile totals, 4 passes of one wave
+        u64 carry = 0;
+        for (int base = 0; base < 256; base += 64) {
+            const int i = base + lane;
+            const u64 v = i < ntile ? Ttot[(size_t)b * ntile + i] : 0;
+            const u64 incl = wave_incl_scan(v, lane);
+            toff[i] = carry + incl - v;
+            carry += __shfl(incl, 63);
         }
-        float rs, rc;  // rotation by theta = 2 pi Phi
-        harm_sincos(sm.Phi, rs, rc);
-        float s = 0.f, c = 1.0f, acc = 0.f;
-        const float* r0 = rows + (size_t)(fa - row_lo) * H;
-        for (int h = 1; h <= H; ++h) {
-            if (((h - 1) % HARM_ANCHOR) == 0) harm_sincos((u64)h * sm.Phi, s, c);  // exact re-anchor
-            else {
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const float* pb = phase + (size_t)b * phase_stride;
+    const u64* cb = Cloc + (size_t)b * Tp;
+    const double scale_a = 18446744073709551616.0, scale_d = scale_a / (double)P;
+    const float inv_ah = 1.0f / (float)amp_hop, inv_sh = 1.0f / (float)ts_hop;
+    // samples of segment sg: [sg*hop, (sg+1)*hop), the last segment also owns the clamped tail
+    const int t_lo = sg * amp_hop;
+    const int t_hi = sg == nseg - 1 ? Tout : min((sg + 1) * amp_hop, Tout);
+    float* p0 = part + (((size_t)b * nseg + sg) * 2) * H;
+    float* p1 = p0 + H;
+    for (int h0 = 1; h0 <= H; h0 += HARM_ANCHOR) {
+        float a0[HARM_ANCHOR], a1[HARM_ANCHOR];
+#pragma unroll
+        for (int i = 0; i < HARM_ANCHOR; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+        for (int t = t_lo + lane; t < t_hi; t += 64) {
+            const HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+            const float wa = Fa >= 2 ? (float)(t - t_lo) * inv_ah : 0.f;
+            float ts = 1.0f;
+            if (tscale) {
+                int fs = 0;
+                float ws = 0.f;
+                if (Fs >= 2) { fs = min(t / ts_hop, Fs - 2); ws = (float)(t - fs * ts_hop) * inv_sh; }
+                const float s0 = tscale[(size_t)b * Fs + fs], s1 = tscale[(size_t)b * Fs + (Fs >= 2 ? fs + 1 : fs)];
+                ts = fmaf(ws, s1 - s0, s0);
+            }
+            const float g = g_out[(size_t)b * g_out_stride + t] * ts;
+            const float g0 = g * (1.0f - wa), g1 = g * wa;
+            float rs, rc, s, c;
+            harm_sincos(sm.Phi, rs, rc);
+            harm_sincos((u64)h0 * sm.Phi, s, c);
+#pragma unroll
+            for (int i = 0; i < HARM_ANCHOR; ++i) {
+                const int h = h0 + i;
+                const float v = (h <= H && (float)h * sm.p < 0.5f) ? s : 0.f;
+                a0[i] = fmaf(g0, v, a0[i]);
+                a1[i] = fmaf(g1, v, a1[i]);
                 const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
                 s = sn;
                 c = cn;
             }
-            const bool below = (float)h * sm.p < 0.5f;
-            if (MODE == 0) {
-                float a = hs[h - 1];
-                if (amp) a *= fmaf(wa, r0[H + h - 1] - r0[h - 1], r0[h - 1]);
-                acc = below ? fmaf(a, s, acc) : acc;
-            } else {
-                float v = below ? gscale * hs[h - 1] * s : 0.f;
+        }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if ((tid & 63) == 0) atomicAdd(&rows[h - 1], v);  // LDS, 4 waves per block
+        for (int i = 0; i < HARM_ANCHOR; ++i) {
+            float v0 = a0[i], v1 = a1[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off); }
+            const int h = h0 + i;
+            if (lane == 0 && h <= H) {
+                const float hsv = hscale ? hscale[h - 1] : 1.0f;
+                p0[h - 1] = v0 * hsv;
+                p1[h - 1] = v1 * hsv;
             }
         }
-        if (MODE == 0 && live) out[(size_t)b * out_stride + t] = acc * ts;
     }
-    if (MODE == 1) {
-        __syncthreads();
-        for (int h = tid; h < H; h += HARM_THREADS) g_amp[((size_t)b * Fa + blockIdx.x) * H + h] = rows[h];
-    }
+}
+
+// g_amp[b][f][h] = part[b][f][0][h] (segment f, weight 1-w) + part[b][f-1][1][h] (segment f-1, weight w)
+__global__ void harm_bwd_combine_kernel(const float* __restrict__ part, float* __restrict__ g_amp, int B, int Fa, int H,
+                                        int nseg) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Fa * H) return;
+    const int h = idx % H, f = (idx / H) % Fa, b = idx / (H * Fa);
+    float v = 0.f;
+    if (f < nseg) v += part[(((size_t)b * nseg + f) * 2 + 0) * H + h];
+    if (f >= 1) v += part[(((size_t)b * nseg + f - 1) * 2 + 1) * H + h];
+    g_amp[idx] = v;
 }
 
 struct HarmGeom {
     int P, N, ntile, nrows;
-    size_t off_cw, off_ttot, total;
+    size_t off_cw, off_ttot, off_part, total;
 };
-static int harm_geom(int B, int Tp, int phase_hop, int amp_hop, HarmGeom* g) {
+static int harm_geom(int B, int Tp, int phase_hop, int amp_hop, HarmGeom* g, int Fa = 0, int H = 0) {
     g->P = phase_hop;
     g->N = phase_hop > 1 ? (Tp - 1) * phase_hop + 1 : Tp;
     g->ntile = (int)ceil_div(Tp, OSC_SCAN_TILE);
@@ -610,6 +667,7 @@ static int harm_geom(int B, int Tp, int phase_hop, int amp_hop, HarmGeom* g) {
     size_t o = 0;
     g->off_cw = o;   o = align_up(o + sizeof(u64) * (size_t)B * Tp, 256);
     g->off_ttot = o; o = align_up(o + sizeof(u64) * (size_t)B * g->ntile, 256);
+    g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * (Fa > 1 ? Fa - 1 : 1) * 2 * H, 256);
     g->total = o;
     return 0;
 }
@@ -749,10 +807,10 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
     return GOLF_OK;
 }
 
-extern "C" size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop) {
-    if (B < 1 || Tp < 1 || phase_hop < 1) return 0;
+extern "C" size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fa, int H) {
+    if (B < 1 || Tp < 1 || phase_hop < 1 || Fa < 0 || H < 1) return 0;
     HarmGeom g;
-    harm_geom(B, Tp, phase_hop, 1, &g);
+    harm_geom(B, Tp, phase_hop, 1, &g, Fa, H);
     return g.total;
 }
 
@@ -761,7 +819,8 @@ extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_strid
                                          int ts_hop, const float* hscale, int H, float* out, int64_t out_stride, int B,
                                          int Tout, void* ws, size_t ws_bytes, void* stream) {
     HarmGeom g;
-    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp ? amp_hop : HARM_THREADS, &g);
+    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp ? amp_hop : HARM_THREADS, &g,
+              amp ? Fa : 0, H > 0 ? H : 1);
     if (int rc = harm_check("harmonic_osc_fwd", phase, B, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs, ts_hop, H, Tout, g))
         return rc;
     if (!out || out_stride < Tout || phase_stride < Tp) return fail(GOLF_EINVAL, "harmonic_osc_fwd: bad output / stride");
@@ -775,10 +834,9 @@ extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_strid
                        g.P, 1, g.ntile);
     GOLF_LAUNCH_CHECK();
     const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H);
-    hipLaunchKernelGGL((harm_kernel<0>), dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
+    hipLaunchKernelGGL(harm_kernel, dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
                        phase, phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, amp, amp ? Fa : 1,
-                       amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, (const float*)nullptr,
-                       (int64_t)0, (float*)nullptr, Tout, g.nrows);
+                       amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, Tout, g.nrows);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -788,7 +846,8 @@ extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_s
                                              const float* tscale, int Fs, int ts_hop, const float* hscale, int H,
                                              float* g_amp, int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
     HarmGeom g;
-    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp_hop > 0 ? amp_hop : 1, &g);
+    harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp_hop > 0 ? amp_hop : 1, &g, Fa,
+              H > 0 ? H : 1);
     if (int rc = harm_check("harmonic_osc_bwd_amp", phase, B, Tp, phase_hop, g_amp, Fa, amp_hop, tscale, Fs, ts_hop, H,
                             Tout, g))
         return rc;
@@ -799,13 +858,18 @@ extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_s
     hipStream_t st = (hipStream_t)stream;
     u64* Cw = (u64*)((char*)ws + g.off_cw);   // recomputed: the backward does not rely on the forward's scratch
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
+    float* part = (float*)((char*)ws + g.off_part);
     hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
                        g.P, 1, g.ntile);
     GOLF_LAUNCH_CHECK();
-    const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)H);
-    hipLaunchKernelGGL((harm_kernel<1>), dim3((unsigned)Fa, B), dim3(HARM_THREADS), lds, st, phase, phase_stride,
-                       (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, (const float*)nullptr, Fa, amp_hop, tscale,
-                       Fs, ts_hop, hscale, H, (float*)nullptr, (int64_t)0, g_out, g_out_stride, g_amp, Tout, 1);
+    const int nseg = Fa > 1 ? Fa - 1 : 1;
+    hipLaunchKernelGGL(harm_bwd_kernel, dim3((unsigned)nseg, B), dim3(64), 0, st, phase, phase_stride, (const u64*)Cw,
+                       (const u64*)Ttot, g.ntile, Tp, g.P, Fa, amp_hop, tscale, Fs, ts_hop, hscale, H, g_out,
+                       g_out_stride, part, nseg, Tout);
+    GOLF_LAUNCH_CHECK();
+    const int n = B * Fa * H;
+    hipLaunchKernelGGL(harm_bwd_combine_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)part,
+                       g_amp, B, Fa, H, nseg);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -561,7 +561,8 @@ class _HarmonicOsc(torch.autograd.Function):
         if hscale is not None:
             hscale = hscale.contiguous()
         out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
-        ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop), phase.device)
+        ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa if amp is not None else 0, H),
+                        phase.device)
         rc = lib.golf_harmonic_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, _lib.ptr(amp), Fa, amp_hop,
                                            _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(),
                                            out.stride(0), B, Tout, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
@@ -583,7 +584,7 @@ class _HarmonicOsc(torch.autograd.Function):
             g_out = _rows(g_out)
             B, Tp = phase.shape
             g_amp = torch.empty(B, Fa, H, dtype=torch.float32, device=phase.device)
-            ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop), phase.device)
+            ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa, H), phase.device)
             rc = lib.golf_harmonic_osc_bwd_amp_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(),
                                                    phase.stride(0), Tp, phase_hop, Fa, amp_hop, _lib.ptr(tscale), Fs,
                                                    ts_hop, _lib.ptr(hscale), H, g_amp.data_ptr(), B, Tout,

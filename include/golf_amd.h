@@ -238,7 +238,8 @@ int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* 
  *   wavetable oscillator), sin(h theta) by a rotation recurrence re-anchored from the exact phase every 32 harmonics.
  * Backward w.r.t. A only (the phase is data in every shipped config): g_amp (B,Fa,H) fully overwritten.
  * ------------------------------------------------------------------------------------------- */
-size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop);
+/* Fa = amplitude frames (0 if amp is NULL); sized for the forward and the backward */
+size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fa, int H);
 int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                               const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                               const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
