@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--single-device", action="store_true",
                     help="dev: map every rank to cuda:0 (control-flow dry run of the N>1 path on a 1-GPU box)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the audio (N>1)")
+    ap.add_argument("--fp64-transitions", action="store_true",
+                    help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
                     help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
     return ap.parse_args()
@@ -75,7 +77,7 @@ def build_modules(device):
     return osc, ss, ff
 
 
-def make_step(workload, inp, osc, ss, ff):
+def make_step(workload, inp, osc, ss, ff, fast=True):
     """Returns (step_fn, samples_per_step, stage_fns) working on plain tensors (module internals)."""
     from golf_amd import functional as GF
 
@@ -92,7 +94,7 @@ def make_step(workload, inp, osc, ss, ff):
 
     if workload == "golf-ss-synth":
         def step():
-            return GF.ltv_allpole_ss(source(), gain, a, hop)
+            return GF.ltv_allpole_ss(source(), gain, a, hop, fast_inference=fast)
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)
@@ -242,7 +244,7 @@ def main():
     inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
            for k, v in shard_inputs(inp_all, rank, world).items()}
     osc, ss, ff = build_modules(device)
-    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff)
+    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff, fast=not args.fp64_transitions)
     do_gather = world > 1 and not args.no_gather
     gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(max(1, args.streams))] if do_gather else None
     pipelined = args.gather_mode == "pipelined"
