@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
-                             "golf-ss-decoder", "golf-ss-decoder-train"],
+                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
                          "and the room filter)")
@@ -123,6 +123,20 @@ def make_step(workload, inp, osc, ss, ff, fast=True):
                 t.grad = None
             y.backward(gy)
             return y
+    elif workload == "ddsp-decoder":  # cfg/ae/decoder/ddsp.yaml: 155-harmonic additive synth + filtered noise + room
+        from golf_amd.synthetic import make_harmonic_amplitudes
+
+        lm, rk = inp["log_mag"], inp["room_kernel"]
+        fir_win = torch.hann_window(2 * (lm.shape[-1] - 1), device=phase.device)
+        K = rk.numel()
+        room_taps = torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)])
+        amps = make_harmonic_amplitudes(B, a.shape[1] + 1, 155, device=phase.device)
+        tscale = torch.rsqrt(0.5 / phase)
+
+        def step():
+            h = GF.harmonic_osc(phase, 155, 1, amps, hop, tscale, 1)
+            nz = GF.zero_phase_fir_filter(noise[:, : h.shape[1]], lm, fir_win, hop)
+            return GF.lti_fir(h[:, : nz.shape[1]] + nz, room_taps, K)
     elif workload == "golf-ff-synth":
         win = ff._window
 
@@ -241,6 +255,8 @@ def main():
 
     B = args.batch
     inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
+    if args.workload == "ddsp-decoder":
+        assert world == 1, "ddsp-decoder is a single-GPU side benchmark"
     inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
            for k, v in shard_inputs(inp_all, rank, world).items()}
     osc, ss, ff = build_modules(device)
@@ -351,7 +367,9 @@ def main():
         # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
         path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8,
                       "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
-                      "golf-ff-train": 16.4 + 16.8}
+                      "golf-ff-train": 16.4 + 16.8,
+                      # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
+                      "ddsp-decoder": 10.6 + 12.27 + 8.0}
         step_us = event_time_us(step)
         traffic = None
         try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed

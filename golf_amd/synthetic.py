@@ -85,3 +85,38 @@ def make_decoder(noise_filter: bool = True, room_filter: bool = True, injected_n
         end_filter=end,
         room_filter=LTIAcousticFilter(length=128, conv_method="direct") if room_filter else None,
         subtract_harmonics=False)
+
+
+def make_ddsp_decoder(num_harmonics: int = 155, injected_noise: torch.Tensor = None):
+    """The DDSP baseline decoder as cfg/ae/decoder/ddsp.yaml instantiates it: additive synthesiser + filtered noise
+    + room filter, from this package's drop-in classes."""
+    from .audiotensor import AudioTensor
+    from .ctrl import PassThrough
+    from .filters import LTIAcousticFilter, LTVZeroPhaseFIRFilter
+    from .noise import NoiseInterface, StandardNormalNoise
+    from .sf import HarmonicPlusNoiseSynth
+    from .synth import AdditiveSynthesizer
+
+    if injected_noise is not None:
+        class _Fixed(NoiseInterface):
+            def forward(self, ref, *args, **kwargs):
+                return AudioTensor(injected_noise[:, : ref.shape[1]])
+
+        gen = _Fixed()
+    else:
+        gen = StandardNormalNoise()
+    return HarmonicPlusNoiseSynth(
+        harm_oscillator=AdditiveSynthesizer(num_harmonics=num_harmonics), noise_generator=gen,
+        harm_filter=PassThrough(), noise_filter=LTVZeroPhaseFIRFilter(window="hanning", n_mag=256),
+        end_filter=LTIAcousticFilter(length=128, conv_method="fft"))
+
+
+def make_harmonic_amplitudes(B: int, F: int, num_harmonics: int = 155, seed: int = 2434, device="cpu"):
+    """Smooth synthetic harmonic amplitudes (B,F,H) as AdditiveSynthesizer.ctrl produces them:
+    exp(log_gain) * sigmoid(logits), with a 1/h spectral tilt and a slow random walk per frame."""
+    g = torch.Generator().manual_seed(seed + 1)
+    tilt = -torch.log(torch.arange(1, num_harmonics + 1, dtype=torch.float32))
+    logits = tilt + torch.cumsum(0.05 * torch.randn(B, F, num_harmonics, generator=g), 1) \
+        + 0.5 * torch.randn(B, 1, num_harmonics, generator=g)
+    log_gain = -3 + torch.cumsum(0.05 * torch.randn(B, F, 1, generator=g), 1)
+    return (torch.exp(log_gain) * torch.sigmoid(logits)).to(device)

@@ -223,3 +223,34 @@ def test_full_size_decoder_vs_oracle():
     emax, el2 = rel_err(y[:nb].detach().cpu().numpy(), ref)
     print("full-size decoder", emax, el2)
     assert emax < 1e-4 and el2 < 1e-4
+
+
+def test_ddsp_decoder_vs_oracle():
+    """cfg/ae/decoder/ddsp.yaml (HarmonicPlusNoiseSynth: AdditiveSynthesizer(155) + LTVZeroPhaseFIRFilter noise +
+    LTIAcousticFilter) assembled from the drop-in classes, against the float64 oracle composition."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synthetic import make_ddsp_decoder, make_harmonic_amplitudes, make_inputs
+    from oracle import golf_oracle as O
+
+    B, H = 3, 155
+    inp = make_inputs(B=B, T=24000, device="cuda", with_noise_filter=True)
+    amps = make_harmonic_amplitudes(B, 101, H, device="cuda")
+    dec = make_ddsp_decoder(H, injected_noise=inp["noise"]).cuda()
+    with torch.no_grad():
+        dec.end_filter.kernel.copy_(inp["room_kernel"])
+    split_sizes, _, keys = dec.split_sizes_and_trsfms
+    assert split_sizes == ((1, 155), (), (), (256,), ()) and sum(sum(s) for s in split_sizes) == 412
+    y = dec(phase=AudioTensor(inp["phase"]), harm_oscillator_params=(AudioTensor(amps, 240),),
+            noise_generator_params=(), harm_filter_params=(), noise_filter_params=(AudioTensor(inp["log_mag"], 240),))
+    y = y.as_tensor().detach().cpu().numpy()
+    c = lambda t: t.double().cpu().numpy()
+    phase = c(inp["phase"])
+    harm = O.harmonic_oscillator_forward(phase, 1, c(amps) , 240) * np.sqrt(2 * phase[:, :24000])
+    win = torch.hann_window(510, dtype=torch.float64).numpy()
+    nz = O.ltv_fir_frames_forward(c(inp["noise"])[:, : harm.shape[1]], O.zero_phase_fir_kernels(c(inp["log_mag"]), win), 240)
+    n = min(harm.shape[1], nz.shape[1])
+    ref = O.lti_acoustic_filter_forward(harm[:, :n] + nz[:, :n], c(inp["room_kernel"]))
+    assert y.shape == ref.shape
+    emax, el2 = rel_err(y, ref)
+    print("ddsp decoder", emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4
