@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--single-device", action="store_true",
                     help="dev: map every rank to cuda:0 (control-flow dry run of the N>1 path on a 1-GPU box)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the audio (N>1)")
+    ap.add_argument("--overlap-transitions", action="store_true",
+                    help="golf-ss-decoder: start the (excitation-independent) transition kernel on a side stream at the "
+                         "top of the step so that it overlaps the oscillator and the noise filter")
     ap.add_argument("--fp64-transitions", action="store_true",
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
@@ -77,7 +80,7 @@ def build_modules(device):
     return osc, ss, ff
 
 
-def make_step(workload, inp, osc, ss, ff, fast=True):
+def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
     """Returns (step_fn, samples_per_step, stage_fns) working on plain tensors (module internals)."""
     from golf_amd import functional as GF
 
@@ -112,10 +115,11 @@ def make_step(workload, inp, osc, ss, ff, fast=True):
             room_taps = torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)])
 
         def step():
+            prep = GF.ltv_allpole_prepare(a, hop, 47760, overlap=True, fast=True) if (overlap and not train) else None
             o = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True)
             nz = GF.zero_phase_fir_filter(noise[:, : o.shape[1]], lm, fir_win, hop)
             src = o[:, : nz.shape[1]] + nz
-            y = GF.ltv_allpole_ss(src, gain, a, hop)
+            y = GF.ltv_allpole_ss(src, gain, a, hop, prepared=prep)
             if not train:
                 return GF.lti_fir(y, room_taps, K)
             y = GF.lti_fir(y, torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)]), K)
@@ -260,7 +264,8 @@ def main():
     inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
            for k, v in shard_inputs(inp_all, rank, world).items()}
     osc, ss, ff = build_modules(device)
-    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff, fast=not args.fp64_transitions)
+    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff, fast=not args.fp64_transitions,
+                                     overlap=args.overlap_transitions)
     do_gather = world > 1 and not args.no_gather
     gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(max(1, args.streams))] if do_gather else None
     pipelined = args.gather_mode == "pipelined"
@@ -270,7 +275,7 @@ def main():
     # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
     # (9 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
     S = max(1, args.streams)
-    use_graphs = (not args.no_graphs) and not args.workload.endswith("train")  # autograd is issued eagerly
+    use_graphs = not args.no_graphs  # training steps (forward + custom backward) are captured whole, like inference
     graphs, outs = [], []
     if use_graphs:
         for i in range(S):

@@ -35,17 +35,20 @@ class PreparedTransitions:
     """Handle returned by ltv_allpole_prepare: the workspace with the transition matrices in flight on the side
     stream, plus the shape key they are valid for."""
 
-    def __init__(self, ws, key, stream, a):
-        self.ws, self.key, self.stream, self.a = ws, key, stream, a
+    def __init__(self, ws, key, stream, a, fast=False):
+        self.ws, self.key, self.stream, self.a, self.fast = ws, key, stream, a, fast
 
 
-def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False) -> PreparedTransitions:
+def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False,
+                        fast: bool = False) -> PreparedTransitions:
     """Compute the transition matrices for coefficients ``a`` (B,F,M) and output length ``T`` ahead of the
     excitation; pass the handle to ltv_allpole_ss(..., prepared=handle) (e.g. to filter several signals with the
     same coefficients, or to start the most expensive, excitation-independent phase early).
     ``overlap=True`` launches on a second HIP stream that the forward joins right before its boundary scan.
-    Measured on MI355X at B=32 this does NOT pay: the transition kernel already occupies every SIMD, so whatever
-    runs beside it slows down by as much as is saved — hence off by default."""
+    Measured on MI355X at B=32 this does NOT pay with the fp64 matrices: that kernel occupies most SIMDs, so whatever
+    runs beside it slows down by as much as is saved — hence off by default.
+    ``fast=True`` computes the fp32 matrices of the inference path (the forward then runs its refinement sweep; such a
+    handle must not be used when gradients are needed)."""
     _lib.require_device(a)
     lib = _lib.load()
     a = a.detach().contiguous()
@@ -58,10 +61,10 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
         side.wait_stream(cur)  # `a` (and the fresh workspace) are ordered after the current stream's work
         ws.record_stream(side)
         a.record_stream(side)
-    rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(), 0,
-                                              (side or cur).cuda_stream)
+    rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
+                                              FAST_TRANSITIONS if fast else 0, (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
-    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a)
+    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a, fast)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -94,8 +97,11 @@ class _LTVAllPoleSS(torch.autograd.Function):
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
         side, flags = None, 0
         needs_grad = any(ctx.needs_input_grad[:3])
-        if prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version):
+        if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version)
+                and not (prepared.fast and needs_grad)):
             ws, flags, side = prepared.ws, HAVE_TRANSITIONS, prepared.stream
+            if prepared.fast:
+                flags |= FAST_TRANSITIONS
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
             if not needs_grad and fast_inference:
