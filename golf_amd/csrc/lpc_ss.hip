@@ -767,9 +767,15 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     __builtin_amdgcn_wave_barrier();
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     const int len4 = (len + 3) & ~3;
-    if (k < NT) {
-        const float* yk = ys + 63 - k;  // yk[t] = y[ts + t - 1 - k]
-        for (int t = 0; t < len4; t += 4) {
+    // Lanes kk = 0..NT-1 own one tap each, lane NT the gain: with NT + 1 <= 32 the two halves of the wave take the
+    // two halves of the segment (first version: 23 of 64 lanes busy for the whole segment, 27 us).
+    const bool split = NT + 1 <= 32;
+    const int half = split ? k >> 5 : 0, kk = split ? k & 31 : k;
+    const int tmid = split ? ((len4 / 4 + 1) / 2) * 4 : len4;
+    const int tb = half ? tmid : 0, te = half ? len4 : tmid;
+    if (kk < NT) {
+        const float* yk = ys + 63 - kk;  // yk[t] = y[ts + t - 1 - kk]
+        for (int t = tb; t < te; t += 4) {
             const float4 gv = *reinterpret_cast<const float4*>(gs + t);
             const float n = (float)(nbase + t);
             const float y0 = yk[t], y1 = yk[t + 1], y2 = yk[t + 2], y3 = yk[t + 3];
@@ -778,11 +784,8 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
             a1 = fmaf(gv.x * n, y0, a1);          b1 = fmaf(gv.y * (n + 1.f), y1, b1);
             a1 = fmaf(gv.z * (n + 2.f), y2, a1);  b1 = fmaf(gv.w * (n + 3.f), y3, b1);
         }
-        float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
-        pp[k] = -(a0 + b0);
-        pp[W + k] = -(a1 + b1);
-    } else if (k == NT) {
-        for (int t = 0; t < len4; t += 4) {
+    } else if (kk == NT) {
+        for (int t = tb; t < te; t += 4) {
             const float4 gv = *reinterpret_cast<const float4*>(ge + t);
             const float n = (float)(nbase + t);
             a0 += gv.x + gv.z;
@@ -790,12 +793,24 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
             a1 = fmaf(gv.x, n, a1);          b1 = fmaf(gv.y, n + 1.f, b1);
             a1 = fmaf(gv.z, n + 2.f, a1);    b1 = fmaf(gv.w, n + 3.f, b1);
         }
-        pg[((size_t)b * NSEG + sg) * 2 + 0] = a0 + b0;
-        pg[((size_t)b * NSEG + sg) * 2 + 1] = a1 + b1;
+    }
+    float v0 = a0 + b0, v1 = a1 + b1;
+    if (split) {
+        v0 += __shfl_down(v0, 32);
+        v1 += __shfl_down(v1, 32);
+    }
+    if (half == 0) {
+        if (kk < NT) {
+            float* pp = pa + ((size_t)b * NSEG + sg) * 2 * W;
+            pp[kk] = -v0;
+            pp[W + kk] = -v1;
+        } else if (kk == NT) {
+            pg[((size_t)b * NSEG + sg) * 2 + 0] = v0;
+            pg[((size_t)b * NSEG + sg) * 2 + 1] = v1;
+        }
     }
 }
 
-// B4: per-segment partial sums -> frame-rate gradients (adjoint of the hat interpolation).
 __global__ void lpc_grad_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pg,
                                        float* __restrict__ g_a, float* __restrict__ g_gain, int B, int F, int M,
                                        int W, int hop, int seg, int NSEG) {
