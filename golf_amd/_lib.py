@@ -46,6 +46,8 @@ SIGNATURES = {
     "golf_lti_frames_bwd_workspace_bytes": (_sz, [_int] * 6),
     "golf_lti_frames_ola_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int,
                                            _c_f32p, _c_f32p] + [_int] * 7 + [_vp, _vp, _sz, _vp]),
+    "golf_biquad_frames_ola_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 9
+                                       + [_vp, _sz, _vp]),
     "golf_glottal_osc_workspace_bytes": (_sz, [_int] * 7),
     "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
                                         _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),

@@ -203,11 +203,10 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
 }
 
 __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restrict__ window, float* __restrict__ y,
-                              int64_t y_stride, int B, int Ty, int hop, int Wl, int nfr) {
+                              int64_t y_stride, int B, int Ty, int hop, int Wl, int nfr, int pad) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * Ty) return;
     const int b = (int)(idx / Ty), n = (int)(idx - (int64_t)b * Ty);
-    const int pad = Wl / 2;
     const int m = n + pad;          // position in the padded signal
     int fhi = m / hop;              // k = m - f*hop >= 0
     if (fhi > nfr - 1) fhi = nfr - 1;
@@ -222,6 +221,120 @@ __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restr
         norm += wk;
     }
     y[(size_t)b * y_stride + n] = acc / norm;
+}
+
+// ---- cascade of second-order sections ---------------------------------------------------------
+// BatchSecondOrderLPCSynth.forward, models/lpc.py:94-131: every frame runs through K all-pole biquads
+// 1/(a0 + a1 z^-1 + a2 z^-2) one after the other.  A cascade is a pipeline: section k can work on sample m while section
+// k+1 works on sample m-1.  Here the pipeline is laid ACROSS LANES: a frame owns a 16-lane DPP row, lane k is section
+// k, and at step n it filters sample n-k, taking its input from lane k-1's output of the previous step (row_shr:1).
+// The loop-carried dependency is one DPP move + one FMA (the state part  -a1*s1 - a2*s2  does not wait for the
+// input), against K dependent sections per sample if one lane ran the whole cascade, or the 6-FMA + 2-DPP reduction
+// chain of the direct form (ff_framesq_kernel).  4 frames per wave; frames are staged in LDS (gain applied) and the
+// last section's outputs collected there for a coalesced write-out.
+constexpr int BQ_ROW = 16;   // lanes per frame (K <= 16)
+constexpr int BQ_FPW = 64 / BQ_ROW;
+#define DPP_ROW_SHR1 0x111
+__global__ __launch_bounds__(64) void ff_biquad_frames_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                              const float* __restrict__ gain,
+                                                              const float* __restrict__ bq, float* __restrict__ wf,
+                                                              int Tx, int F, int K, int hop, int Wl, int pad, int nfr,
+                                                              int gain_mode, int WS, int XS) {
+    extern __shared__ __attribute__((aligned(16))) float bq_lds[];
+    float* xin = bq_lds;                      // [XS]: union of the wave's frames
+    float* yout = bq_lds + XS;                // [BQ_FPW][WS]
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const int slot = lane >> 4, k = lane & 15;
+    const int f0 = blockIdx.x * BQ_FPW;
+    const BufRow xrow(ex + (size_t)b * ex_stride, Tx);
+    const float* gb = gain + (size_t)b * F;
+    const float inv_hop = 1.0f / (float)hop;
+    // ---- stage the input: the wave's BQ_FPW consecutive frames overlap (hop apart), so their union
+    // [f0*hop - pad, f0*hop - pad + (BQ_FPW-1)*hop + Wl) is staged ONCE, gain applied; frame s starts at s*hop.
+    // (per-frame gain mode scales a frame as a whole, which the section of lane 0 does: its g carries the gain.)
+    // Eight elements per lane at a time, every load unconditional (clamped index, mask applied to the value): a guarded
+    // loop made hipcc wait for each of its loads in turn (145 us for this kernel instead of 40).
+    {
+        const int tb = f0 * hop - pad;
+        for (int i0 = 0; i0 < XS; i0 += 8 * 64) {
+            float xv[8], ga[8], gd[8];
+            int nn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = tb + i0 + u * 64 + lane;
+                xv[u] = xrow.ld(max(t, -1));
+                int ft = max(t, 0) / hop;
+                ft = max(min(ft, F - 2), 0);
+                nn[u] = t - ft * hop;
+                ga[u] = gain_mode == 0 ? gb[ft] : 1.f;
+                gd[u] = gain_mode == 0 ? gb[min(ft + 1, F - 1)] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 64 + lane;
+                const float G = gain_mode == 1 ? 1.f : fmaf((float)nn[u], (gd[u] - ga[u]) * inv_hop, ga[u]);
+                if (i < XS) xin[i] = xv[u] * G;
+            }
+        }
+    }
+    // ---- this lane's section
+    const int f = f0 + slot;
+    float a1 = 0.f, a2 = 0.f, g = 1.f;
+    if (k < K && f < nfr) {
+        const float* c = bq + (((size_t)b * F + f) * K + k) * 3;
+        const float ia0 = 1.0f / c[0];
+        g = ia0 * ((gain_mode == 1 && k == 0) ? gb[f] : 1.0f);
+        a1 = c[1] * ia0;
+        a2 = c[2] * ia0;
+    }
+    wave_lds_fence();
+    const float* xs = xin + slot * hop;      // frame `slot` of this wave inside the staged union
+    float* ys = yout + slot * WS + BQ_ROW;   // ys[m], m in [-(K-1), Wl + 3]
+    float s1 = 0.f, s2 = 0.f, outp = 0.f;   // outp = this lane's output of the previous step
+    const int nsteps = Wl + K - 1;
+    const bool first = k == 0, last = k == K - 1;
+    // four steps of the pipeline on the inputs x4; the last section's outputs go to ys[n0 - (K-1) ...]
+    auto steps4 = [&](const float4 x4, int n0) {
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        float yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p = fmaf(-a1, s1, -a2 * s2);          // does not depend on this step's input
+            // the shift is executed by ALL lanes (a DPP read from a lane that sits out of a branch returns the old
+            // value): select afterwards.  bound_ctrl: lane 0 of a row reads 0.
+            const float sh = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, outp), DPP_ROW_SHR1, 0xF, 0xF, true));
+            const float in = first ? xv[j] : sh;
+            const float y = fmaf(g, in, p);
+            s2 = s1;
+            s1 = y;
+            outp = y;
+            yv[j] = y;
+        }
+        if (last) {  // yout rows carry BQ_ROW floats of slack in front: the pipeline's fill outputs land there
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ys[n0 + j - (K - 1)] = yv[j];
+        }
+    };
+    // lane 0 of the row reads its next four input samples (zeros past the frame: the tail is staged as 0) one block of
+    // steps AHEAD, into the other of two register quads: the LDS latency stays off the recursion's critical path
+    const float4* xs4 = reinterpret_cast<const float4*>(xs);
+    const int nblk4 = (nsteps + 3) / 4, last4 = (XS - slot * hop) / 4 - 1;
+    float4 xa = xs4[0], xb;
+    for (int q = 0; q < nblk4; q += 2) {
+        xb = xs4[min(q + 1, last4)];
+        steps4(xa, 4 * q);
+        xa = xs4[min(q + 2, last4)];
+        if (q + 1 < nblk4) steps4(xb, 4 * q + 4);
+    }
+    wave_lds_fence();
+    // ---- coalesced write-out of the filtered frames
+    for (int s_ = 0; s_ < BQ_FPW; ++s_) {
+        const int fo = f0 + s_;
+        if (fo >= nfr) break;
+        float* o = wf + ((size_t)b * nfr + fo) * Wl;
+        for (int i = lane; i < Wl; i += 64) o[i] = yout[s_ * WS + BQ_ROW + i];
+    }
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------
@@ -410,7 +523,7 @@ static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, cons
     GOLF_LAUNCH_CHECK();
     const int64_t n = (int64_t)B * Ty;
     hipLaunchKernelGGL(ff_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)wf, window, y,
-                       y_stride, B, Ty, hop, Wl, nfr);
+                       y_stride, B, Ty, hop, Wl, nfr, Wl / 2);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -507,4 +620,39 @@ extern "C" int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, c
     GOLF_FF_TRY(40, 38)
 #undef GOLF_FF_TRY
     return fail(GOLF_EUNSUPPORTED, "lti_frames_bwd: need M <= 38 and hop >= ring width (M=%d hop=%d)", M, hop);
+}
+
+extern "C" int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float* gain,
+                                              const float* biquads, const float* window, float* y, int64_t y_stride,
+                                              int B, int Tx, int F, int K, int hop, int W, int pad, int gain_mode,
+                                              int Ty, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 1 || Tx < 1 || F < 1 || K < 1 || hop < 1 || W < 1 || pad < 0 || (gain_mode != 0 && gain_mode != 1))
+        return fail(GOLF_EINVAL, "biquad_frames: bad size / mode");
+    if (gain_mode == 0 && F < 2) return fail(GOLF_EINVAL, "biquad_frames: interpolated gain needs F >= 2");
+    if (!ex || !gain || !biquads || !window || !y) return fail(GOLF_EINVAL, "biquad_frames: null pointer");
+    if (K > BQ_ROW) return fail(GOLF_EUNSUPPORTED, "biquad_frames: %d sections > %d (one DPP row per frame)", K, BQ_ROW);
+    if (hop % 4 != 0) return fail(GOLF_EUNSUPPORTED, "biquad_frames: hop=%d must be a multiple of 4", hop);
+    if (Tx + 2 * pad < W) return fail(GOLF_EINVAL, "biquad_frames: signal shorter than one frame");
+    const int nfr = (Tx + 2 * pad - W) / hop + 1;
+    const int ty = (nfr - 1) * hop + W - 2 * pad;
+    if (nfr > F) return fail(GOLF_EINVAL, "biquad_frames: %d frames vs %d coefficient frames", nfr, F);
+    if (ty != Ty || ty < 1) return fail(GOLF_EINVAL, "biquad_frames: Ty=%d, expected %d", Ty, ty);
+    if (ex_stride < Tx || y_stride < Ty) return fail(GOLF_EINVAL, "biquad_frames: row stride too small");
+    const size_t need = align_up(sizeof(float) * (size_t)B * nfr * W, 256);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "biquad_frames: workspace needs %zu bytes, 256-aligned (got %zu)", need, ws_bytes);
+    const int WS = ((W + 3) & ~3) + 2 * BQ_ROW;
+    const int XS = (((BQ_FPW - 1) * hop + W + 2 * BQ_ROW + 8) + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)XS + (size_t)BQ_FPW * WS);
+    if (lds > 60 * 1024) return fail(GOLF_EUNSUPPORTED, "biquad_frames: window %d too long for the LDS staging", W);
+    hipStream_t st = (hipStream_t)stream;
+    float* wf = (float*)ws;
+    hipLaunchKernelGGL(ff_biquad_frames_kernel, dim3((unsigned)ceil_div(nfr, BQ_FPW), B), dim3(64), lds, st, ex,
+                       ex_stride, gain, biquads, wf, Tx, F, K, hop, W, pad, nfr, gain_mode, WS, XS);
+    GOLF_LAUNCH_CHECK();
+    const int64_t n = (int64_t)B * Ty;
+    hipLaunchKernelGGL(ff_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)wf, window, y,
+                       y_stride, B, Ty, hop, W, nfr, pad);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
 }

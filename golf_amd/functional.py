@@ -13,7 +13,7 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
            "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
            "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
            "zero_phase_fir_filter_precise",
-           "fir_frames_length", "lti_fir", "harmonic_osc"]
+           "fir_frames_length", "lti_fir", "harmonic_osc", "biquad_frames_ola"]
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
@@ -604,3 +604,37 @@ def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, 
     """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h] * sin(2 pi h cumsum(p)[t]),
     p = up(phase); differentiable w.r.t. ``amp``."""
     return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop)
+
+
+# ------------------------------------------------------------------------------------------------
+# frame-wise all-pole synthesis as a cascade of biquads (reference models/lpc.py:94-131)
+# ------------------------------------------------------------------------------------------------
+def biquad_frames_ola(ex: torch.Tensor, gain: torch.Tensor, biquads: torch.Tensor, window: torch.Tensor, hop: int,
+                      pad: int = None, frame_gain: bool = True) -> torch.Tensor:
+    """ex (B,Tx), gain (B,F), biquads (B,F,K,3) -> (B,Ty): every frame through its K sections 1/(a0+a1 z^-1+a2 z^-2),
+    windowed overlap-add.  ``pad`` defaults to (W-hop)//2 and ``frame_gain`` to True (BatchSecondOrderLPCSynth);
+    pad = W//2, frame_gain=False is LTVMinimumPhaseFilter's convention.  Inference only (no backward): train through
+    the direct form (biquads2lpc + lti_frames_ola)."""
+    _lib.require_device(ex, gain, biquads, window)
+    if any(t.requires_grad for t in (ex, gain, biquads)) and torch.is_grad_enabled():
+        raise NotImplementedError("golf_amd: the cascaded-biquad kernel is forward-only; use biquads2lpc + "
+                                  "lti_frames_ola (LTVMinimumPhaseFilter) when gradients are needed")
+    lib = _lib.load()
+    ex = _rows(ex)
+    gain, biquads, window = gain.contiguous(), biquads.contiguous(), window.contiguous()
+    B, Tx0 = ex.shape
+    F, K = biquads.shape[1], biquads.shape[2]
+    W = window.numel()
+    pad = (W - hop) // 2 if pad is None else pad
+    Tx = Tx0 if frame_gain else min(Tx0, (F - 1) * hop + 1)
+    nfr = (Tx + 2 * pad - W) // hop + 1
+    if nfr < 1 or nfr > F:
+        raise _lib.GolfError(f"biquad_frames_ola: {nfr} frames for {F} coefficient frames")
+    Ty = (nfr - 1) * hop + W - 2 * pad
+    y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
+    ws = _workspace(B * nfr * W * 4 + 256, ex.device)
+    rc = lib.golf_biquad_frames_ola_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), biquads.data_ptr(),
+                                            window.data_ptr(), y.data_ptr(), y.stride(0), B, Tx, F, K, hop, W, pad,
+                                            1 if frame_gain else 0, Ty, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "golf_biquad_frames_ola_fwd_f32")
+    return y

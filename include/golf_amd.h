@@ -139,6 +139,18 @@ int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, const float*
                                 int M, int hop, int W, int Ty, const void* ws_fwd, void* ws, size_t ws_bytes,
                                 void* stream);
 
+/* a-6: the same frame-wise synthesis with the all-pole filter given as a CASCADE of K second-order sections.
+ * Replaces BatchSecondOrderLPCSynth.forward, models/lpc.py:94-131 (pad, unfold, K successive torchaudio lfilter calls
+ * with a = biquads[...,k,:] and b = [1,0,0], windowed overlap-add, normalisation).
+ *   biquads (B,F,K,3) = (a0,a1,a2) per section, K <= 16;  frames of W samples every hop of the signal zero-padded by
+ *   `pad` on both sides (the reference class uses (W-hop)/2; LTVMinimumPhaseFilter's convention is W/2);
+ *   gain_mode 1: frame f is scaled by gain[b,f] (the reference class); 0: ex is multiplied by up(gain) first.
+ *   nfr = (Tx + 2*pad - W)/hop + 1 <= F,  Ty = (nfr-1)*hop + W - 2*pad;  ws: golf_lti_frames_workspace_bytes(). */
+int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* biquads,
+                                   const float* window, float* y, int64_t y_stride, int B, int Tx, int F, int K,
+                                   int hop, int W, int pad, int gain_mode, int Ty, void* ws, size_t ws_bytes,
+                                   void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a-8/a-9: indexed glottal-flow wavetable oscillator.
  * Replaces IndexedGlottalFlowTable.forward, models/synth.py:213-263 (table blend, phase/oversampling,

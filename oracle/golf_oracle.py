@@ -57,6 +57,7 @@ __all__ = [
     "lti_acoustic_filter_forward",
     "lti_acoustic_filter_backward",
     "golf_ss_decoder",
+    "biquad_frames_ola_forward",
     "harmonic_oscillator_forward",
     "harmonic_oscillator_backward_amp",
 ]
@@ -807,3 +808,48 @@ def harmonic_oscillator_backward_amp(gy, phase, phase_hop: int, amplitudes_shape
     gA = np.zeros((B, (Fa - 1) * amp_hop + 1 if amp_hop > 1 else Fa, H))
     gA[:, :n_out] = gy[:, :, None] * sines * mask
     return _upsample_adjoint(gA, amp_hop, Fa)
+
+
+# --------------------------------------------------------------------------------------
+# a-6  frame-wise all-pole synthesis as a CASCADE of second-order sections
+# --------------------------------------------------------------------------------------
+def biquad_frames_ola_forward(ex, gain, biquads, hop: int, window: np.ndarray, pad: int | None = None,
+                              frame_gain: bool = True):
+    """BatchSecondOrderLPCSynth.forward, models/lpc.py:94-131: zero-pad by (W-hop)//2, unfold into frames of W every
+    hop, scale frame f by gain[b,f], run it through the K sections 1/(a0 + a1 z^-1 + a2 z^-2) one after the other
+    (torchaudio lfilter with b = [1,0,0], zero state), windowed overlap-add normalised by the overlap-add of the window.
+    ``frame_gain=False`` / ``pad=W//2`` give the conventions of LTVMinimumPhaseFilter (gain interpolated to sample rate
+    before framing) for the same cascade."""
+    ex = np.asarray(ex, dtype=np.float64)
+    gain = np.asarray(gain, dtype=np.float64)
+    bq = np.asarray(biquads, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    W = window.shape[0]
+    pad = (W - hop) // 2 if pad is None else pad
+    B = ex.shape[0]
+    if frame_gain:
+        x = ex
+    else:
+        G = linear_upsample(gain, hop, axis=1)
+        T = min(ex.shape[1], G.shape[1])
+        x = ex[:, :T] * G[:, :T]
+    xp = np.pad(x, ((0, 0), (pad, pad)))
+    nfr = (xp.shape[1] - W) // hop + 1
+    assert nfr <= bq.shape[1]
+    full = (nfr - 1) * hop + W
+    acc = np.zeros((B, full))
+    norm = np.zeros(full)
+    K = bq.shape[2]
+    for f in range(nfr):
+        v = xp[:, f * hop : f * hop + W].copy()
+        if frame_gain:
+            v *= gain[:, f : f + 1]
+        for k in range(K):
+            a0, a1, a2 = bq[:, f, k, 0], bq[:, f, k, 1], bq[:, f, k, 2]
+            y = np.zeros((B, W + 2))
+            for n in range(W):
+                y[:, n + 2] = (v[:, n] - a1 * y[:, n + 1] - a2 * y[:, n]) / a0
+            v = y[:, 2:]
+        acc[:, f * hop : f * hop + W] += v * window
+        norm[f * hop : f * hop + W] += window
+    return acc[:, pad : full - pad] / norm[pad : full - pad]

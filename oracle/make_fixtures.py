@@ -522,4 +522,19 @@ lo = torch.from_numpy(rng.normal(0, 1, (2, 7, H)).astype(np.float32))
 # cannot be captured with the submodule absent)
 d.update(ctrl_log_gain=lg, ctrl_logits=lo, ctrl_amp=amp_c.as_tensor(), ctrl_split=np.array(split[0]))
 save("g18_harmonic_oscillators", **d)
+# ----------------------------------------------------------------------------- g19 cascaded-biquad frame synthesis (a-6)
+# BatchSecondOrderLPCSynth.forward (models/lpc.py:94-131): the reference's statement of the cascaded-biquad all-pole
+# filter; biquads from its own get_logits2biquads("coef").
+import models.lpc as rlpc
+d = {}
+for tag, (B, F, K, hop, W, T) in (("a", (2, 9, 3, 8, 32, 64)), ("b", (1, 6, 5, 16, 48, 80))):
+    logits = torch.from_numpy(rng.normal(0, 1, (B, F, K, 2)).astype(np.float32)).double()
+    bq = ru.get_logits2biquads("coef", 0.95)(logits)                      # (B,F,K,3), a0 = 1
+    gain = torch.exp(torch.from_numpy(rng.normal(-1, 0.3, (B, F)).astype(np.float32)).double())
+    ex = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32)).double()
+    syn = rlpc.BatchSecondOrderLPCSynth(hop_length=hop, window_size=W, window="hanning").double()
+    y = syn(ex, gain, bq)
+    d.update({f"{tag}_ex": ex, f"{tag}_gain": gain, f"{tag}_biquads": bq, f"{tag}_hop": hop, f"{tag}_W": W, f"{tag}_y": y,
+              f"{tag}_lpc": ru.biquads2lpc(bq)})
+save("g19_biquad_cascade", **d)
 print("done")
