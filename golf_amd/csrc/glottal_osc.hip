@@ -531,8 +531,8 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
         for (int w = 0; w < (tid >> 6); ++w) base += twsum[w];
         toff[tid] += base;
     }
-    float* hs = hsm;                     // [H] per-harmonic scale
-    float* rows = hsm + ((H + 3) & ~3);  // [nrows_lds][H] amplitude rows
+    float* hs = hsm;                     // [H] per-harmonic scale (used directly when there is no amplitude tensor)
+    float* rows = hsm + ((H + 3) & ~3);  // [nrows_lds][H] amplitude rows, per-harmonic scale already folded in
     for (int h = tid; h < H; h += HARM_THREADS) hs[h] = hscale ? hscale[h] : 1.0f;
     const float* pb = phase + (size_t)b * phase_stride;
     const u64* cb = Cloc + (size_t)b * Tp;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
         row_lo = Fa >= 2 ? min(t_lo / amp_hop, Fa - 2) : 0;
         const float* ab = amp + ((size_t)b * Fa + row_lo) * H;
         const int nr = min(nrows_lds, Fa - row_lo);
-        for (int e = tid; e < nr * H; e += HARM_THREADS) rows[e] = ab[e];
+        for (int e = tid; e < nr * H; e += HARM_THREADS) rows[e] = ab[e] * (hscale ? hscale[e % H] : 1.0f);
     }
     __syncthreads();
     const int t = t_lo + tid;
@@ -561,21 +561,31 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
         const float s0 = tscale[(size_t)b * Fs + fs], s1 = tscale[(size_t)b * Fs + (Fs >= 2 ? fs + 1 : fs)];
         ts = fmaf(ws, s1 - s0, s0);
     }
+    // number of harmonics below Nyquist for this sample: the largest hl with (float)h * p < 0.5 for all h <= hl,
+    // found from the quotient and corrected by the very comparison the reference makes (synth.py:440)
+    int hl = sm.p > 0.f ? (int)fminf(0.5f / sm.p, (float)H) : H;
+    while (hl < H && (float)(hl + 1) * sm.p < 0.5f) ++hl;
+    while (hl > 0 && !((float)hl * sm.p < 0.5f)) --hl;
     float rs, rc;  // rotation by theta = 2 pi Phi
     harm_sincos(sm.Phi, rs, rc);
-    float s = 0.f, c = 1.0f, acc = 0.f;
-    const float* r0 = rows + (size_t)(fa - row_lo) * H;
-    for (int h = 1; h <= H; ++h) {
-        if (((h - 1) % HARM_ANCHOR) == 0) harm_sincos((u64)h * sm.Phi, s, c);  // exact re-anchor
-        else {
-            const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
-            s = sn;
-            c = cn;
+    float acc = 0.f;
+    const float* r0 = amp ? rows + (size_t)(fa - row_lo) * H : hs;
+    const float* r1 = amp ? r0 + H : hs;
+    for (int h0 = 1; h0 <= H; h0 += HARM_ANCHOR) {   // blocks of 32 harmonics, fully unrolled, exact re-anchor each
+        float s, c;
+        harm_sincos((u64)h0 * sm.Phi, s, c);
+#pragma unroll
+        for (int i = 0; i < HARM_ANCHOR; ++i) {
+            const int h = h0 + i;
+            if (h <= H) {  // uniform
+                const float a0 = r0[h - 1];
+                const float a = fmaf(wa, r1[h - 1] - a0, a0);
+                acc = h <= hl ? fmaf(a, s, acc) : acc;
+                const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
+                s = sn;
+                c = cn;
+            }
         }
-        // harmonics below Nyquist: h * p < 0.5 (evaluated as the reference does, in fp32 on h * p)
-        float a = hs[h - 1];
-        if (amp) a *= fmaf(wa, r0[H + h - 1] - r0[h - 1], r0[h - 1]);
-        acc = (float)h * sm.p < 0.5f ? fmaf(a, s, acc) : acc;
     }
     out[(size_t)b * out_stride + t] = acc * ts;
 }
