@@ -9,12 +9,8 @@ import rocpd_summary
 
 for f in glob.glob(os.path.join(SRC, "bench_*.json")):
     shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
-for d in glob.glob(os.path.join(SRC, "trace_*")):
-    if not os.path.isdir(d):
-        continue
-    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-    if dbs:
-        rocpd_summary.main(dbs[0], os.path.join(DST, "r01_" + os.path.basename(d).replace("trace_", "") + "_kernel_stats.csv"))
+for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh
+    shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
 
 def counters(tag):
     out = collections.defaultdict(dict)
@@ -39,4 +35,30 @@ json.dump({"batch": 32, "workload": "golf-ss-decoder (inference) + golf-ss-decod
                      "per-launch averages; hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH doubled per "
                      "MI355X_MICROARCH.md gfx950 note: exact for wide coalesced reads, an upper bound for narrow ones)",
            "kernels": kern}, open(os.path.join(DST, "r01_hbm_traffic.json"), "w"), indent=1)
+
+# ---- SQ counters -> per-kernel utilisation figures
+sq = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(SRC, "sq_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "golf::" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in acc.items():
+        sq[k][c] = round(sum(v) / len(v))
+N_XCD, N_SIMD = 8, 1024
+for k, d in sq.items():
+    if "GRBM_GUI_ACTIVE" in d and "SQ_ACTIVE_INST_VALU" in d:
+        cyc = d["GRBM_GUI_ACTIVE"] / N_XCD                      # elapsed shader-clock cycles of the launch
+        d["valu_busy_frac"] = round(d["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * N_SIMD), 4)   # 4 cycles per wave64 VALU op
+    if "SQ_WAVE_CYCLES" in d and "SQ_WAIT_INST_ANY" in d and d["SQ_WAVE_CYCLES"]:
+        d["wave_wait_frac"] = round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4)
+    if "SQ_LDS_IDX_ACTIVE" in d and "GRBM_GUI_ACTIVE" in d:
+        d["lds_busy_frac"] = round(d["SQ_LDS_IDX_ACTIVE"] / (d["GRBM_GUI_ACTIVE"] / N_XCD * 256), 4)   # 256 CUs
+if sq:
+    json.dump({"batch": 32, "method": "rocprofv3 --kernel-trace --pmc <4 counters> (separate passes, tools/prof_pmc.sh) on the "
+               "eager single-stream golf-ss-decoder and golf-ss-decoder-train steps; per-launch averages. valu_busy_frac = "
+               "4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); wave_wait_frac = SQ_WAIT_INST_ANY / "
+               "SQ_WAVE_CYCLES; lds_busy_frac = SQ_LDS_IDX_ACTIVE / (cycles * 256 CUs)",
+               "kernels": dict(sq)}, open(os.path.join(DST, "r01_sq_counters.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))

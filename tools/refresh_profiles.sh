@@ -26,5 +26,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
   bash tools/prof_pmc.sh $O/pmc_${c}_decoder $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/pmc_${c}_decoder.log 2>&1
   bash tools/prof_pmc.sh $O/pmc_${c}_train $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train > $O/pmc_${c}_train.log 2>&1
 done
+# SQ counters (separate passes, kernel-trace only) on the eager single-stream decoder and training steps
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  bash tools/prof_pmc.sh $O/sq_${i}_decoder $set -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/sq_${i}_decoder.log 2>&1
+  bash tools/prof_pmc.sh $O/sq_${i}_train $set -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train --streams 1 --no-graphs > $O/sq_${i}_train.log 2>&1
+done
+# keep the merge-back small: summarise the rocpd databases here, drop them and the per-dispatch traces of the counter passes
+for d in $O/trace_*; do
+  [ -d "$d" ] || continue
+  db=$(find $d -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py $db $O/$(basename $d | sed 's/trace_//')_kernel_stats.csv
+  rm -rf $d
+done
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 ls -R $O | head -60
 du -sh $O
