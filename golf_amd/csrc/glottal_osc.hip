@@ -201,6 +201,7 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
     // (ph += inc; inc += d).  The first version evaluated the closed form in fp64 for every fine sample (77 VALU
     // instructions per sample, 42 % VALU-active with the rest of the time waiting for its four loads per sample).
     const int j_lo = m_lo / P, j_hi = (m_hi - 1) / P;  // coarse samples overlapping [m_lo, m_hi)
+    const int lshift = (L & (L - 1)) == 0 ? 31 - __clz(L) : -1;  // log2(L) for power-of-two tables
     float acc0 = 0.f, acc1 = 0.f;
     for (int j = j_lo + tid; j <= j_hi; j += NTH) {
         // coarse sample j (the final point: j = Tp-1 has only k = 0, and d == 0 because j+1 clamps to j)
@@ -220,10 +221,18 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
             inc += dinc;
             const int m = mb + k;
             const bool in = m >= m_lo && m < m_hi;
-            // table position: (ph / 2^64) * L, from the top 32 phase bits in exact 64-bit integer arithmetic
-            const u64 pos = (ph >> 32) * (u64)L;
-            const int c0 = (int)(pos >> 32);
-            const float cf = (float)((unsigned)pos >> 8) * (1.0f / 16777216.0f);
+            // table position: (ph / 2^64) * L from the top 32 phase bits, exact; a power-of-two table needs no multiply
+            const unsigned hi = (unsigned)(ph >> 32);
+            int c0;
+            float cf;
+            if (lshift >= 0) {
+                c0 = (int)(hi >> (32 - lshift));
+                cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+            } else {
+                const u64 pos = (u64)hi * (u64)L;
+                c0 = (int)(pos >> 32);
+                cf = (float)((unsigned)pos >> 8) * (1.0f / 16777216.0f);
+            }
             const float rf = (float)(m - m_lo) * inv_hop_t;
             const float a00 = row0[c0], a01 = row0[c0 + 1], a10 = row1[c0], a11 = row1[c0 + 1];
             const float top = fmaf(cf, a01 - a00, a00);
@@ -275,10 +284,12 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
 //   4 FMAs; the LDS tile splits X_ph further by (i & 3) so that lanes (stride-4 outputs) hit consecutive banks:
 //   addr(ph, i) = (ph*4 + (i&3))*RS4 + (i>>2).  Taps sit in LDS as 4-aligned groups (broadcast ds_read_b128).
 #define OSC_TILE 1024
+template <int OST>  // OST > 0: oversampling factor known at compile time (index arithmetic becomes shifts); 0: runtime
 __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restrict__ pre, int N, int64_t pre_stride,
-                                                           const float* __restrict__ taps, int K, int os,
+                                                           const float* __restrict__ taps, int K, int os_rt,
                                                            float* __restrict__ out, int64_t out_stride, int Tout,
                                                            int RS4, int dmin, int ngrp) {
+    const int os = OST > 0 ? OST : os_rt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: X = smem[0 .. os*4*RS4), H = 16-aligned after it: H[ph][ngrp*4 + 4] (3 leading zeros + taps + zero tail)
     float* X = smem;
@@ -773,8 +784,14 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int hoff = (os * 4 * RS4 + 3) & ~3;
         const size_t lds3 = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8));
         if (lds3 > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: %d taps x os %d exceed LDS", K, os);
-        hipLaunchKernelGGL(osc_decimate_kernel, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
-                           (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin, ngrp);
+        if (os == 4)
+            hipLaunchKernelGGL(osc_decimate_kernel<4>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
+                               (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
+                               ngrp);
+        else
+            hipLaunchKernelGGL(osc_decimate_kernel<0>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
+                               (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
+                               ngrp);
         GOLF_LAUNCH_CHECK();
     }
     return GOLF_OK;
