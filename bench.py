@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--overlap-transitions", action="store_true",
                     help="golf-ss-decoder: start the (excitation-independent) transition kernel on a side stream at the "
                          "top of the step so that it overlaps the oscillator and the noise filter")
+    ap.add_argument("--fork-transitions", action="store_true",
+                    help="run the transition kernel on a side stream beside the zero-state pass (fork/join inside the step)")
     ap.add_argument("--fp64-transitions", action="store_true",
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
@@ -254,6 +256,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    if args.fork_transitions:
+        import golf_amd.functional as _GF
+
+        _GF.FORK_TRANSITIONS = True
     from golf_amd.dist import shard_inputs, gather_audio, gather_audio_async
     from golf_amd.synthetic import make_inputs
 

@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void osc_phase_tile_kernel(const float* __rest
 // MODE 0: forward render (writes fine samples);  MODE 1: backward w.r.t. table_select_weight
 // (reduces g_pre * d(pre)/d(p_row) over the interval into part[b][interval][2]).
 #define OSC_RENDER_THREADS 512  // 4 blocks/CU: the 640 blocks of the B=32 config run in one round
-template <int MODE, int PT>  // PT = fine samples per coarse phase sample when known at compile time (0: runtime P)
+// PT = fine samples per coarse phase sample when known at compile time (0: runtime P).  FLAGS >= 0: the table length
+// is a power of two and equal_energy == FLAGS, both known at compile time -- as runtime flags they were wave-uniform
+// branches around every fine sample, which kept hipcc from overlapping the LDS lookups of one sample with the
+// arithmetic of the previous one (75 -> ~45 instructions per fine sample).
+template <int MODE, int PT, int FLAGS = -1>
 __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc,
     const u64* __restrict__ Ttot, int ntile, const float* __restrict__ wsel, int Fw,
@@ -201,7 +205,8 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
     // (ph += inc; inc += d).  The first version evaluated the closed form in fp64 for every fine sample (77 VALU
     // instructions per sample, 42 % VALU-active with the rest of the time waiting for its four loads per sample).
     const int j_lo = m_lo / P, j_hi = (m_hi - 1) / P;  // coarse samples overlapping [m_lo, m_hi)
-    const int lshift = (L & (L - 1)) == 0 ? 31 - __clz(L) : -1;  // log2(L) for power-of-two tables
+    const int lshift = (FLAGS >= 0 || (L & (L - 1)) == 0) ? 31 - __clz(L) : -1;  // log2(L) for power-of-two tables
+    const bool ee = FLAGS >= 0 ? FLAGS == 1 : equal_energy != 0;
     float acc0 = 0.f, acc1 = 0.f;
     for (int j = j_lo + tid; j <= j_hi; j += NTH) {
         // coarse sample j (the final point: j = Tp-1 has only k = 0, and d == 0 because j+1 clamps to j)
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
             const unsigned hi = (unsigned)(ph >> 32);
             int c0;
             float cf;
-            if (lshift >= 0) {
+            if (FLAGS >= 0 || lshift >= 0) {
                 c0 = (int)(hi >> (32 - lshift));
                 cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
             } else {
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
             const float top = fmaf(cf, a01 - a00, a00);
             const float bot = fmaf(cf, a11 - a10, a10);
             float scale = 1.0f;
-            if (equal_energy) scale = rsqrtf(fmaf((float)k, d, p0) * inv_osf);
+            if (ee) scale = rsqrtf(fmaf((float)k, d, p0) * inv_osf);
             if (MODE == 0) {
                 const float v = fmaf(rf, bot - top, top) * scale;
                 if (PT > 0) o4[k] = v;
@@ -288,7 +293,7 @@ template <int OST>  // OST > 0: oversampling factor known at compile time (index
 __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restrict__ pre, int N, int64_t pre_stride,
                                                            const float* __restrict__ taps, int K, int os_rt,
                                                            float* __restrict__ out, int64_t out_stride, int Tout,
-                                                           int RS4, int dmin, int ngrp) {
+                                                           int RS4, int dmin, int ngrp, int vec4) {
     const int os = OST > 0 ? OST : os_rt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: X = smem[0 .. os*4*RS4), H = 16-aligned after it: H[ph][ngrp*4 + 4] (3 leading zeros + taps + zero tail)
@@ -302,7 +307,31 @@ __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restri
     const int half = (K - 1) / 2;
     const int64_t m_lo = (int64_t)(o0 + dmin) * os;
     const int span = OSC_TILE + ngrp * 4 + 4;  // polyphase indices staged per phase
-    {
+    if (OST == 4 && vec4 && m_lo >= 0 && m_lo + 4 * (int64_t)span <= N) {
+        // fill of an interior tile (all but the first and last of an utterance), os = 4, 16-byte aligned rows: one
+        // 16-byte load brings the four polyphase components of a coarse index (m_lo is a multiple of 4), so the index
+        // arithmetic is paid once per 4 elements: ~4 loads per thread instead of ~17 (the fill was about as many VALU
+        // instructions as the FIR itself).  No masks at all here: with `cond ? v : 0` in front of the LDS stores
+        // hipcc turns the selects into branches and sinks (and splits) the loads into them.
+        // (__builtin_amdgcn_raw_buffer_load_b128 is miscompiled by this hipcc: it emits buffer_load_dword and
+        // splats the one dword over the four components -- hence plain loads.)
+        const float4* src = reinterpret_cast<const float4*>(pb + m_lo);
+        auto put = [&](int i, const float4& q) {
+            float* xp = X + (i & 3) * RS4 + (i >> 2);
+            xp[0 * 4 * RS4] = q.x;
+            xp[1 * 4 * RS4] = q.y;
+            xp[2 * 4 * RS4] = q.z;
+            xp[3 * 4 * RS4] = q.w;
+        };
+        // span >= OSC_TILE = 4 x 256: four unconditional batches, then the few groups that are left
+        static_assert(OSC_TILE == 4 * 256, "fill assumes 4 full batches");
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[u * 256 + tid];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) put(u * 256 + tid, v[u]);
+        for (int i = OSC_TILE + tid; i < span; i += 256) put(i, src[i]);
+    } else {
         // fill: 8 bounds-checked loads per thread in flight at a time (a guarded `cond ? pb[m] : 0` made hipcc branch
         // and wait for every one of the ~17 loads per thread in turn: most of this kernel's former 18.9 us)
         const BufRow prow(pb, N);
@@ -764,10 +793,17 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     // caller-provided `pre` is dense (B, N)
     const int64_t fine_stride = os > 1 ? (pre ? (int64_t)g.N : g.pre_stride) : out_stride;
     const size_t lds = sizeof(float) * 2 * (size_t)(L + 1);
-    if (g.P == 4)
-        hipLaunchKernelGGL((osc_render_kernel<0, 4>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase,
-                           phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P,
-                           os, g.hop_t, g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr);
+    const bool pow2 = (L & (L - 1)) == 0 && L >= 2;
+#define GOLF_RENDER(KERNEL)                                                                                            \
+    hipLaunchKernelGGL(KERNEL, dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase, phase_stride,               \
+                       (const u64*)Cw, (const u64*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P, os, g.hop_t,    \
+                       g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr)
+    if (g.P == 4 && pow2 && equal_energy)
+        GOLF_RENDER((osc_render_kernel<0, 4, 1>));
+    else if (g.P == 4 && pow2)
+        GOLF_RENDER((osc_render_kernel<0, 4, 0>));
+    else if (g.P == 4)
+        GOLF_RENDER((osc_render_kernel<0, 4>));
     else
         hipLaunchKernelGGL((osc_render_kernel<0, 0>), dim3(g.nint, B), dim3(OSC_RENDER_THREADS), lds, st, phase,
                            phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, wsel, Fw, table, n_tab, L, Tp, g.P,
@@ -784,14 +820,15 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int hoff = (os * 4 * RS4 + 3) & ~3;
         const size_t lds3 = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8));
         if (lds3 > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: %d taps x os %d exceed LDS", K, os);
+        const int vec4 = (fine_stride % 4 == 0 && ((uintptr_t)fine & 15) == 0) ? 1 : 0;
         if (os == 4)
             hipLaunchKernelGGL(osc_decimate_kernel<4>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
                                (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp);
+                               ngrp, vec4);
         else
             hipLaunchKernelGGL(osc_decimate_kernel<0>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
                                (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp);
+                               ngrp, vec4);
         GOLF_LAUNCH_CHECK();
     }
     return GOLF_OK;

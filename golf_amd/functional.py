@@ -17,6 +17,7 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
+FORK_TRANSITIONS = False  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
 
 
@@ -106,6 +107,11 @@ class _LTVAllPoleSS(torch.autograd.Function):
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
             if not needs_grad and fast_inference:
                 flags = FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
+            if FORK_TRANSITIONS:
+                # the transition kernel (needs only `a`) and the zero-state pass (needs `ex`) are independent: the
+                # library forks the former onto a side stream and joins before the boundary scan
+                side = _side_stream(ex.device)
+                ws.record_stream(side)
         rc = lib.golf_ltv_allpole_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), a.data_ptr(), y.data_ptr(),
                                           y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
                                           side.cuda_stream if side is not None else 0, _lib.stream_ptr())
