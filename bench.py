@@ -21,6 +21,7 @@ Extra objects on the JSON line (contract §4):
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -43,10 +44,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
-                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder"],
+                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
-                         "and the room filter)")
+                         "and the room filter); golf-ss-train-step (BASELINE config 5, use --batch 64): one optimisation "
+                         "step of the autoencoder of cfg/ae/vctk.yaml -- U-Net/LSTM encoder and multi-scale spectral "
+                         "loss in stock PyTorch (MIOpen, rocFFT) around the HIP decoder, Adam(1e-4), grad-clip 0.5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight: the K steps are issued round-robin on this many HIP streams")
@@ -143,6 +146,34 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
             h = GF.harmonic_osc(phase, 155, 1, amps, hop, tscale, 1)
             nz = GF.zero_phase_fir_filter(noise[:, : h.shape[1]], lm, fir_win, hop)
             return GF.lti_fir(h[:, : nz.shape[1]] + nz, room_taps, K)
+    elif workload == "golf-ss-train-step":
+        # BASELINE configs[4] / cfg/ae/vctk.yaml: encoder(x, f0) -> golf-precise decoder -> MSSLoss(509, 1021, 2053)
+        # -> backward -> clip 0.5 -> Adam(1e-4).  Steps depend on each other through the weights: one stream, eager.
+        from golf_amd.ae import VoiceAutoEncoder, train_step
+        from golf_amd.loss import MSSLoss
+        from golf_amd.synthetic import make_decoder
+
+        torch.manual_seed(2434)
+        model = VoiceAutoEncoder(
+            decoder=make_decoder(), criterion=MSSLoss([509, 1021, 2053], alpha=1.0, window="hanning", center=True),
+            encoder_class_path="models.enc.VocoderParameterEncoderInterface",
+            encoder_init_args=dict(f0_min=60.0, f0_max=1000.0, backbone_type="models.unet.UNetEncoder", n_fft=1024,
+                                   hop_length=240, channels=[32, 64, 128, 256], strides=[4, 4, 4, 4],
+                                   lstm_hidden_size=256, num_layers=3, dropout=0.1, learn_voicing=False,
+                                   learn_f0=False),
+            sample_rate=SR, detach_f0=True, detach_voicing=True, train_with_true_f0=True).to(phase.device)
+        with torch.no_grad():  # the reference starts out_linear at exactly 0 (constant decoder parameters); a small
+            model.encoder.backbone.out_linear.weight.normal_(0, 0.02)  # random head makes them vary like a trained one
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        f0 = phase * SR
+        f0[:, : SR // 5] = 0  # an unvoiced stretch (driven at a random frequency, ltng/ae.py:97-101)
+        ph = torch.cumsum(phase.double(), 1)
+        x = sum(torch.sin(2 * math.pi * h * ph) / h for h in range(1, 9)).float() * 0.05 + 0.005 * noise
+        uv = torch.empty(B, 1, device=phase.device).uniform_(50, 500)
+
+        def step():
+            return train_step(model, opt, (x, f0), clip=0.5, unvoiced_f0=uv, return_output=True)[1]
     elif workload == "golf-ff-synth":
         win = ff._window
 
@@ -264,6 +295,9 @@ def main():
     from golf_amd.synthetic import make_inputs
 
     B = args.batch
+    if args.workload == "golf-ss-train-step":  # the optimiser couples consecutive steps: no batches in flight
+        args.streams, args.no_graphs, args.no_cpu_baseline = 1, True, True
+        assert world == 1, "golf-ss-train-step is a single-GPU side benchmark (DDP of the encoder is stock PyTorch)"
     inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
     if args.workload == "ddsp-decoder":
         assert world == 1, "ddsp-decoder is a single-GPU side benchmark"
@@ -378,7 +412,7 @@ def main():
         # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
         path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8,
                       "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
-                      "golf-ff-train": 16.4 + 16.8,
+                      "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
                       # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
                       "ddsp-decoder": 10.6 + 12.27 + 8.0}
         step_us = event_time_us(step)

@@ -18,7 +18,9 @@ provide them:
 * ``torchaudio.functional.lfilter``       := scipy.signal.lfilter per row (float64, independent witness).
 * ``kazane.Decimate``                     := recorder: stores its input (the pre-decimation signal),
   returns x[..., ::q].  kazane's taps are unknown => decimation parity is unpinned.
-* ``torch_fftconv``, ``diffsptk``, ``torchaudio.transforms``, ``pyworld`` := inert placeholders
+* ``torchaudio.transforms.Spectrogram``   := |torch.stft|^power with torchaudio's documented arguments and defaults
+  (only g20 — encoder / loss — ever calls it).
+* ``torch_fftconv``, ``diffsptk``, ``pyworld`` := inert placeholders
   (only needed so that ``import models.filters`` succeeds; never on the measured path).
 
 Every array written is an input or an output of reference code — no reference source text.
@@ -90,6 +92,27 @@ class _Dummy(nn.Module):
         super().__init__()
 
 
+class Spectrogram(nn.Module):
+    """torchaudio.transforms.Spectrogram as documented: win_length = n_fft, hop = win_length // 2, periodic Hann,
+    power 2, centre-padded by reflection, one-sided, unnormalised; ``window`` is a registered buffer."""
+
+    def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, window_fn=torch.hann_window, power=2.0,
+                 normalized=False, wkwargs=None, center=True, pad_mode="reflect", onesided=True):
+        super().__init__()
+        assert pad == 0 and not normalized and onesided
+        self.n_fft = n_fft
+        self.win_length = n_fft if win_length is None else win_length
+        self.hop_length = self.win_length // 2 if hop_length is None else hop_length
+        self.power, self.center, self.pad_mode = power, center, pad_mode
+        self.register_buffer("window", window_fn(self.win_length, **(wkwargs or {})))
+
+    def forward(self, x):
+        x = x.as_tensor() if hasattr(x, "as_tensor") else x
+        z = torch.stft(x, self.n_fft, self.hop_length, self.win_length, self.window.to(x.dtype), center=self.center,
+                       pad_mode=self.pad_mode, normalized=False, onesided=True, return_complex=True)
+        return z.abs() if self.power == 1 else z.abs().pow(self.power)
+
+
 class Decimate(nn.Module):
     last_input = None
 
@@ -107,7 +130,7 @@ _mod("pyworld", dio=lambda *a, **k: None)
 _mod("torchlpc", sample_wise_lpc=sample_wise_lpc)
 _mod("torchaudio")
 _mod("torchaudio.functional", lfilter=lfilter, melscale_fbanks=lambda *a, **k: None)
-_mod("torchaudio.transforms", Spectrogram=_Dummy, InverseSpectrogram=_Dummy)
+_mod("torchaudio.transforms", Spectrogram=Spectrogram, InverseSpectrogram=_Dummy)
 _mod("torch_fftconv")
 _mod("torch_fftconv.functional", fft_conv1d=torch.nn.functional.conv1d)
 _mod("diffsptk", MLSA=_Dummy, MelCepstralAnalysis=_Dummy, MelGeneralizedCepstrumToSpectrum=_Dummy,
@@ -537,4 +560,52 @@ for tag, (B, F, K, hop, W, T) in (("a", (2, 9, 3, 8, 32, 64)), ("b", (1, 6, 5, 1
     d.update({f"{tag}_ex": ex, f"{tag}_gain": gain, f"{tag}_biquads": bq, f"{tag}_hop": hop, f"{tag}_W": W, f"{tag}_y": y,
               f"{tag}_lpc": ru.biquads2lpc(bq)})
 save("g19_biquad_cascade", **d)
+# ----------------------------------------------------------------------------- g20 encoder, encoder interface, loss (f-3)
+# UNetEncoder.forward (models/unet.py:86-224), VocoderParameterEncoderInterface (models/enc.py:33-100) on the toy
+# GOLF-ss decoder of g14, MSSLoss (loss/spec.py:32-67).  float32 like the reference runs them.
+_mod("models.lru", LRU=_Dummy)
+import models.enc as renc  # noqa: E402
+import models.unet as runet  # noqa: E402,F401
+import loss.spec as rloss  # noqa: E402
+
+torch.manual_seed(20)
+d = {}
+enc_args = dict(n_fft=64, hop_length=16, channels=[4, 8], strides=[2, 2], lstm_hidden_size=8, num_layers=2)
+iface = renc.VocoderParameterEncoderInterface(
+    backbone_type="models.unet.UNetEncoder", learn_voicing=True, learn_f0=True, f0_min=60.0, f0_max=1000.0,
+    split_sizes=dec.split_sizes_and_trsfms[0], trsfms=dec.split_sizes_and_trsfms[1],
+    args_keys=dec.split_sizes_and_trsfms[2], **enc_args).float()
+with torch.no_grad():
+    iface.backbone.out_linear.weight.normal_(0, 0.3)
+    iface.backbone.out_linear.bias.normal_(0, 0.1)
+d["split_sizes"] = np.array([s for g_ in iface.split_sizes for s in g_])
+d["group_lengths"] = np.array([len(g_) for g_ in iface.split_sizes])
+d["args_keys"] = np.array(list(iface.args_keys))
+for k, v in iface.state_dict().items():
+    d["state0/" + k] = v.clone()
+xs = [torch.from_numpy(rng.normal(0, 0.3, (3, 400)).astype(np.float32)) for _ in range(3)]
+f0s = [torch.from_numpy(rng.uniform(80, 300, (3, 400)).astype(np.float32)) for _ in range(3)]
+iface.train()
+for i in range(2):          # two training-mode calls: running extrema and BatchNorm statistics evolve
+    d[f"h_train{i}"] = iface.backbone(AT(xs[i], 1), f0=AT(f0s[i], 1)).as_tensor()
+iface.eval()
+d["h_eval"] = iface.backbone(AT(xs[2], 1), f0=AT(f0s[2], 1)).as_tensor()
+params = iface(AT(xs[2], 1), f0=AT(f0s[2], 1))
+for k, v in params.items():
+    for j, t in enumerate(v if isinstance(v, tuple) else (v,)):
+        d[f"param/{k}/{j}"] = t.as_tensor()
+        d[f"param_hop/{k}/{j}"] = t.hop_length
+for k, v in iface.state_dict().items():
+    if "running" in k or "log_spec" in k or "num_batches" in k:
+        d["state1/" + k] = v.clone()
+d.update({f"x{i}": xs[i] for i in range(3)})
+d.update({f"f0_{i}": f0s[i] for i in range(3)})
+crit = rloss.MSSLoss([61, 127, 251], alpha=1.0, window="hanning", center=True)
+pred = torch.from_numpy(rng.normal(0, 0.3, (2, 1500)).astype(np.float32)).requires_grad_(True)
+true = torch.from_numpy(rng.normal(0, 0.3, (2, 1500)).astype(np.float32))
+val = crit(pred, true)
+val.backward()
+d.update(loss_pred=pred, loss_true=true, loss_value=val, loss_g_pred=pred.grad,
+         loss_hops=np.array([l_.spec.hop_length for l_ in crit.losses]))
+save("g20_encoder_and_loss", **d)
 print("done")

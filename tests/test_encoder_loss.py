@@ -1,0 +1,179 @@
+"""Encoder, encoder interface, spectral loss and the training step against the reference's own
+run (tests/golden/g20; models/unet.py:86-224, models/enc.py:33-100, loss/spec.py:11-67).  Stock-PyTorch modules, so the
+parity part runs on the CPU; the GPU test runs the whole training step on the HIP decoder."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+ENC_ARGS = dict(n_fft=64, hop_length=16, channels=[4, 8], strides=[2, 2], lstm_hidden_size=8, num_layers=2)
+
+
+def toy_decoder():
+    """The toy GOLF-ss decoder of g14 (same split sizes as the reference object g20's interface was built from)."""
+    from golf_amd.filters import LTIAcousticFilter, LTVMinimumPhaseFilterPrecise, LTVZeroPhaseFIRFilter
+    from golf_amd.noise import StandardNormalNoise
+    from golf_amd.sf import SourceFilterSynth
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    return SourceFilterSynth(
+        harm_oscillator=IndexedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                                align_peak=True, lf_v2=True, points=16, oversampling=1,
+                                                equal_energy=True),
+        noise_generator=StandardNormalNoise(), noise_filter=LTVZeroPhaseFIRFilter(window="hanning", n_mag=9),
+        end_filter=LTVMinimumPhaseFilterPrecise(lpc_order=6), room_filter=LTIAcousticFilter(length=8),
+        subtract_harmonics=False)
+
+
+def make_iface():
+    from golf_amd.enc import VocoderParameterEncoderInterface
+
+    split_sizes, trsfms, args_keys = toy_decoder().split_sizes_and_trsfms
+    # the reference's YAML path resolves to this package's class
+    return VocoderParameterEncoderInterface(backbone_type="models.unet.UNetEncoder", learn_voicing=True, learn_f0=True,
+                                            f0_min=60.0, f0_max=1000.0, split_sizes=split_sizes, trsfms=trsfms,
+                                            args_keys=args_keys, **ENC_ARGS)
+
+
+def close(y, ref, what, tol=2e-5):
+    emax, el2 = rel_err(np.asarray(y), np.asarray(ref))
+    print(f"{what}: rel-max {emax:.2e} rel-l2 {el2:.2e}")
+    assert emax <= tol and el2 <= tol, (what, emax, el2)
+
+
+def test_encoder_matches_reference_g20(golden):
+    from golf_amd.audiotensor import AudioTensor
+
+    g = golden("g20_encoder_and_loss")
+    iface = make_iface()
+    assert [s for grp in iface.split_sizes for s in grp] == list(g["split_sizes"])
+    assert [len(grp) for grp in iface.split_sizes] == list(g["group_lengths"])
+    assert list(iface.args_keys) == [str(k) for k in g["args_keys"]]
+    state0 = {k[len("state0/"):]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("state0/")}
+    assert set(state0) == set(iface.state_dict())          # the reference's checkpoint keys, exactly
+    iface.load_state_dict(state0)
+    x = [torch.from_numpy(g[f"x{i}"]) for i in range(3)]
+    f0 = [torch.from_numpy(g[f"f0_{i}"]) for i in range(3)]
+    iface.train()
+    for i in range(2):
+        h = iface.backbone(AudioTensor(x[i]), f0=AudioTensor(f0[i]))
+        assert h.hop_length == 16
+        close(h.as_tensor().detach(), g[f"h_train{i}"], f"h_train{i}")
+    iface.eval()
+    close(iface.backbone(AudioTensor(x[2]), f0=AudioTensor(f0[2])).as_tensor().detach(), g["h_eval"], "h_eval")
+    sd = iface.state_dict()
+    for k in g.files:                                       # running extrema and BatchNorm statistics evolved alike
+        if k.startswith("state1/"):
+            np.testing.assert_allclose(sd[k[len("state1/"):]].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    params = iface(AudioTensor(x[2]), f0=AudioTensor(f0[2]))
+    seen = 0
+    for key, val in params.items():
+        for j, t in enumerate(val if isinstance(val, tuple) else (val,)):
+            close(t.as_tensor().detach(), g[f"param/{key}/{j}"], f"param {key}[{j}]")
+            assert t.hop_length == int(g[f"param_hop/{key}/{j}"])
+            seen += 1
+    assert seen == sum(1 for k in g.files if k.startswith("param/"))
+
+
+def test_out_linear_starts_at_zero():
+    """Training starts from the decoder's neutral parameters (models/enc.py:26-27)."""
+    iface = make_iface()
+    assert float(iface.backbone.out_linear.weight.detach().abs().max()) == 0.0
+    assert float(iface.backbone.out_linear.bias.detach().abs().max()) == 0.0
+
+
+def test_mss_loss_matches_reference_g20(golden):
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.loss import MSSLoss
+
+    g = golden("g20_encoder_and_loss")
+    crit = MSSLoss([61, 127, 251], alpha=1.0, window="hanning", center=True)
+    assert [l.spec.hop_length for l in crit.losses] == list(g["loss_hops"])
+    pred = torch.from_numpy(g["loss_pred"]).requires_grad_(True)
+    val = crit(pred, torch.from_numpy(g["loss_true"]))
+    val.backward()
+    np.testing.assert_allclose(float(val), float(g["loss_value"]), rtol=2e-6)
+    close(pred.grad, g["loss_g_pred"], "d loss / d pred", 1e-4)
+    # AudioTensor in -> AudioTensor out (the reference's step calls .as_tensor() on it, ltng/ae.py:116-118)
+    val2 = crit(AudioTensor(pred.detach()), AudioTensor(torch.from_numpy(g["loss_true"])))
+    assert float(val2.as_tensor()) == pytest.approx(float(val), rel=1e-6)
+
+
+def test_spectrogram_is_the_dft():
+    """The restated front end against a direct DFT of reflect-padded, windowed frames (float64)."""
+    from golf_amd.loss import Spectrogram
+
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, (2, 300))
+    n_fft, hop = 61, 15
+    for power in (1, 2.0):
+        s = Spectrogram(n_fft=n_fft, hop_length=hop, power=power).double()
+        s.window = torch.hann_window(n_fft, dtype=torch.float64)
+        got = s(torch.from_numpy(x)).numpy()
+        xp = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        nfr = 1 + (xp.shape[1] - n_fft) // hop
+        w = torch.hann_window(n_fft, dtype=torch.float64).numpy()
+        k = np.arange(n_fft // 2 + 1)[:, None] * np.arange(n_fft)[None, :]
+        dft = np.exp(-2j * np.pi * k / n_fft)
+        ref = np.stack([np.abs(dft @ (xp[:, f * hop: f * hop + n_fft] * w).T).T for f in range(nfr)], -1) ** power
+        assert got.shape == ref.shape == (2, n_fft // 2 + 1, nfr)
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
+
+
+def _autoencoder(decoder, hop, n_fft, n_ffts, **enc_over):
+    from golf_amd.ae import VoiceAutoEncoder
+    from golf_amd.loss import MSSLoss
+
+    enc_args = dict(f0_min=60.0, f0_max=1000.0, backbone_type="models.unet.UNetEncoder", n_fft=n_fft, hop_length=hop,
+                    channels=[4, 8], strides=[2, 2], lstm_hidden_size=8, num_layers=2, dropout=0.0,
+                    learn_voicing=False, learn_f0=False)
+    enc_args.update(enc_over)
+    return VoiceAutoEncoder(decoder=decoder, criterion=MSSLoss(n_ffts, alpha=1.0, window="hanning", center=True),
+                            encoder_class_path="models.enc.VocoderParameterEncoderInterface",
+                            encoder_init_args=enc_args, sample_rate=24000, detach_f0=True, detach_voicing=True,
+                            train_with_true_f0=True)
+
+
+def test_autoencoder_wiring_cpu():
+    """Encoder head sized by the decoder's control protocol; vctk.yaml's encoder has out_channels = 343."""
+    from golf_amd.synthetic import make_decoder
+
+    model = _autoencoder(make_decoder(), hop=240, n_fft=1024, n_ffts=[509, 1021, 2053], channels=[32, 64, 128, 256],
+                         strides=[4, 4, 4, 4], lstm_hidden_size=256, num_layers=3, dropout=0.1)
+    assert model.encoder.backbone.out_linear.out_features == 343
+    assert model.encoder.args_keys == ("harm_oscillator_params", "noise_generator_params", "noise_filter_params",
+                                       "end_filter_params", "room_filter_params")
+    assert model.encoder.backbone.lstm.input_size == 2 * 256 + 1
+    keys = set(model.state_dict())
+    assert {"encoder.backbone.out_linear.weight", "encoder.backbone.cnns.12.weight", "decoder.room_filter.kernel",
+            "criterion.losses.2.spec.window", "encoder.backbone.log_spec_max"} <= keys
+
+
+@pytest.mark.gpu
+def test_training_step_runs_and_learns():
+    """Config-5 step at toy size on the HIP decoder: loss -> backward through the custom backward kernels -> gradient
+    clipping 0.5 -> Adam(1e-4); finite gradients reach the encoder, and repeating the step on one batch lowers the loss."""
+    from golf_amd.ae import train_step
+    from golf_amd.synthetic import make_decoder
+
+    torch.manual_seed(0)
+    B, T, hop = 4, 4800, 240
+    model = _autoencoder(make_decoder(), hop=hop, n_fft=256, n_ffts=[127, 251, 509]).cuda()
+    with torch.no_grad():
+        model.encoder.backbone.out_linear.weight.normal_(0, 0.02)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    t = torch.arange(T, device="cuda") / 24000
+    f0 = (120 + 40 * torch.rand(B, 1, device="cuda")) * (1 + 0.03 * torch.sin(2 * np.pi * 5.5 * t))[None]
+    f0[:, :600] = 0                                            # an unvoiced stretch
+    x = 0.1 * torch.sin(2 * np.pi * torch.cumsum(f0 / 24000, 1)) + 0.01 * torch.randn(B, T, device="cuda")
+    uv = torch.full((B, 1), 200.0, device="cuda")
+    model.train()
+    losses = [float(train_step(model, opt, (x, f0), clip=0.5, unvoiced_f0=uv)) for _ in range(25)]
+    print("losses", [round(v, 3) for v in losses[::6]])
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    g = [p.grad for p in model.encoder.parameters() if p.grad is not None]
+    assert g and all(torch.isfinite(v).all() for v in g)
+    total = torch.sqrt(sum((v.float() ** 2).sum() for v in g))
+    assert float(total) <= 0.5 * 1.001                         # clipped

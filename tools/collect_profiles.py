@@ -9,6 +9,8 @@ import rocpd_summary
 
 for f in glob.glob(os.path.join(SRC, "bench_*.json")):
     shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
+if os.path.exists(os.path.join(SRC, "train_step_profile.json")):
+    shutil.copy(os.path.join(SRC, "train_step_profile.json"), os.path.join(DST, "r01_train_step_profile.json"))
 for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh
     shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
 
