@@ -94,9 +94,8 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
     table = osc.table
     B = phase.shape[0]
 
-    def source():
-        o = GF.glottal_osc(phase, wsel, table, taps, 1, w_hop, 4, True)
-        return o + noise[:, : o.shape[1]]
+    def source():   # oscillator + noise: the sum is fused into the oscillator's decimation kernel
+        return GF.glottal_osc(phase, wsel, table, taps, 1, w_hop, 4, True, add=noise)
 
     t_ss = min(phase.shape[1], (a.shape[1] - 1) * hop + 1)
 
@@ -121,9 +120,8 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
 
         def step():
             prep = GF.ltv_allpole_prepare(a, hop, 47760, overlap=True, fast=True) if (overlap and not train) else None
-            o = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True)
-            nz = GF.zero_phase_fir_filter(noise[:, : o.shape[1]], lm, fir_win, hop)
-            src = o[:, : nz.shape[1]] + nz
+            nz = GF.zero_phase_fir_filter(noise, lm, fir_win, hop)
+            src = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True, add=nz)[:, : nz.shape[1]]
             y = GF.ltv_allpole_ss(src, gain, a, hop, prepared=prep)
             if not train:
                 return GF.lti_fir(y, room_taps, K)
@@ -185,8 +183,8 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
         gy = torch.randn(B, 47760, device=phase.device)
 
         def step():
-            o = GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True)
-            y = GF.lti_frames_ola(o + noise[:, : o.shape[1]], gain_g, a_g, win, hop)
+            y = GF.lti_frames_ola(GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True, add=noise), gain_g, a_g,
+                                  win, hop)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y
@@ -197,8 +195,8 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
         gy = torch.randn(B, 47761, device=phase.device)
 
         def step():
-            o = GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True)
-            y = GF.ltv_allpole_ss(o + noise[:, : o.shape[1]], gain_g, a_g, hop)
+            y = GF.ltv_allpole_ss(GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True, add=noise), gain_g, a_g,
+                                  hop)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y

@@ -293,7 +293,9 @@ template <int OST>  // OST > 0: oversampling factor known at compile time (index
 __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restrict__ pre, int N, int64_t pre_stride,
                                                            const float* __restrict__ taps, int K, int os_rt,
                                                            float* __restrict__ out, int64_t out_stride, int Tout,
-                                                           int RS4, int dmin, int ngrp, int vec4) {
+                                                           int RS4, int dmin, int ngrp, int vec4,
+                                                           const float* __restrict__ addend, int64_t addend_stride,
+                                                           int Tadd) {
     const int os = OST > 0 ? OST : os_rt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: X = smem[0 .. os*4*RS4), H = 16-aligned after it: H[ph][ngrp*4 + 4] (3 leading zeros + taps + zero tail)
@@ -361,6 +363,11 @@ __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restri
     }
     __syncthreads();
     const int u = tid;  // outputs o0 + 4u .. 4u+3
+    // optional fused `+ addend` (the decoder's harm_osc + noise, models/sf.py:53): loads issued before the FIR so they
+    // are free; a null addend is a zero-length descriptor, which reads 0 without touching memory -- no branch
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+    const float ad0 = arow.ld(o0 + 4 * u), ad1 = arow.ld(o0 + 4 * u + 1), ad2 = arow.ld(o0 + 4 * u + 2),
+                ad3 = arow.ld(o0 + 4 * u + 3);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int ph = 0; ph < os; ++ph) {
         const float* Xp = X + (size_t)ph * 4 * RS4 + u;
@@ -387,10 +394,10 @@ __global__ __launch_bounds__(256) void osc_decimate_kernel(const float* __restri
     }
     const int o = o0 + 4 * u;
     float* ob = out + (size_t)b * out_stride;
-    if (o < Tout) ob[o] = acc0;
-    if (o + 1 < Tout) ob[o + 1] = acc1;
-    if (o + 2 < Tout) ob[o + 2] = acc2;
-    if (o + 3 < Tout) ob[o + 3] = acc3;
+    if (o < Tout) ob[o] = acc0 + ad0;
+    if (o + 1 < Tout) ob[o + 1] = acc1 + ad1;
+    if (o + 2 < Tout) ob[o + 2] = acc2 + ad2;
+    if (o + 3 < Tout) ob[o + 3] = acc3 + ad3;
 }
 
 // transpose of the decimator: g_pre[m] = sum_o taps[m - o*os + half] * g_out[o]
@@ -770,7 +777,8 @@ extern "C" size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop,
 extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                         const float* wsel, int Fw, int w_hop, const float* table, int n_tab, int L,
                                         int os, int equal_energy, const float* taps, int K, float* pre, float* out,
-                                        int64_t out_stride, int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
+                                        int64_t out_stride, int B, int Tout, void* ws, size_t ws_bytes, void* stream,
+                                        const float* addend, int64_t addend_stride, int Tadd) {
     if (int rc = osc_check(B, Tp, phase_hop, Fw, w_hop, n_tab, L, os, K, taps)) return rc;
     if (!phase || !wsel || !table || !out) return fail(GOLF_EINVAL, "glottal_osc_fwd: null pointer");
     OscGeom g;
@@ -778,6 +786,8 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     const int tout = os > 1 ? (g.N - 1) / os + 1 : g.N;
     if (Tout != tout) return fail(GOLF_EINVAL, "glottal_osc_fwd: Tout=%d, expected %d", Tout, tout);
     if (phase_stride < Tp || out_stride < Tout) return fail(GOLF_EINVAL, "glottal_osc_fwd: row stride too small");
+    if (addend && (os <= 1 || Tadd < 0 || addend_stride < Tadd))
+        return fail(GOLF_EINVAL, "glottal_osc_fwd: the fused addend needs oversampling > 1 and addend_stride >= Tadd >= 0");
     if (!ws || ws_bytes < g.total || ((uintptr_t)ws & 255))
         return fail(GOLF_EWORKSPACE, "glottal_osc_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
@@ -824,11 +834,11 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         if (os == 4)
             hipLaunchKernelGGL(osc_decimate_kernel<4>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
                                (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp, vec4);
+                               ngrp, vec4, addend, addend_stride, Tadd);
         else
             hipLaunchKernelGGL(osc_decimate_kernel<0>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
                                (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp, vec4);
+                               ngrp, vec4, addend, addend_stride, Tadd);
         GOLF_LAUNCH_CHECK();
     }
     return GOLF_OK;

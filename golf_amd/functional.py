@@ -265,8 +265,12 @@ def osc_lengths(Tp: int, phase_hop: int, os: int):
 
 class _GlottalOsc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, phase, wsel, table, taps, phase_hop, w_hop, os, equal_energy, want_pre):
+    def forward(ctx, phase, wsel, table, taps, phase_hop, w_hop, os, equal_energy, want_pre, add=None):
         _lib.require_device(phase, wsel, table, taps)
+        if add is not None:
+            assert os > 1 and add.ndim == 2 and add.shape[0] == phase.shape[0]
+            _lib.require_device(add)
+            add = _rows(add.float())
         if phase.requires_grad or table.requires_grad:
             raise NotImplementedError("golf_amd: the glottal oscillator backward covers table_select_weight only "
                                       "(phase / trainable tables are not differentiable in this round)")
@@ -288,9 +292,11 @@ class _GlottalOsc(torch.autograd.Function):
         rc = lib.golf_glottal_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, wsel.data_ptr(), Fw, w_hop,
                                           table.data_ptr(), n_tab, L, os, int(bool(equal_energy)), _lib.ptr(taps), K,
                                           _lib.ptr(pre), out.data_ptr(), out.stride(0), B, Tout, ws.data_ptr(),
-                                          ws.numel(), _lib.stream_ptr())
+                                          ws.numel(), _lib.stream_ptr(), _lib.ptr(add),
+                                          0 if add is None else add.stride(0), 0 if add is None else add.shape[1])
         _lib.check(rc, "golf_glottal_osc_fwd_f32")
         ctx.cfg = (phase_hop, w_hop, os, bool(equal_energy))
+        ctx.add_len = None if add is None else add.shape[1]
         ctx.save_for_backward(phase, wsel, table, taps if taps is not None else phase.new_empty(0), ws)
         ctx.mark_non_differentiable(*([pre] if pre is not None else []))
         return (out, pre) if pre is not None else (out, None)
@@ -311,14 +317,26 @@ class _GlottalOsc(torch.autograd.Function):
                                                int(eq), _lib.ptr(taps) if K else 0, K, g_w.data_ptr(), B,
                                                g_out.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_glottal_osc_bwd_wsel_f32")
-        return None, g_w, None, None, None, None, None, None, None
+        g_add = None
+        if ctx.add_len is not None and ctx.needs_input_grad[9]:   # out[:, :Tadd] += add
+            n = min(ctx.add_len, g_out.shape[1])
+            g_add = g_out[:, :n] if n == ctx.add_len else torch.nn.functional.pad(g_out, (0, ctx.add_len - n))
+        return None, g_w, None, None, None, None, None, None, None, g_add
 
 
 def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampling: int = 1,
-                equal_energy: bool = False, return_pre: bool = False):
-    """Indexed glottal-flow wavetable oscillator (see include/golf_amd.h golf_glottal_osc_fwd_f32)."""
+                equal_energy: bool = False, return_pre: bool = False, add=None):
+    """Indexed glottal-flow wavetable oscillator (see include/golf_amd.h golf_glottal_osc_fwd_f32).
+    ``add`` (B, Tadd), oversampling > 1: fused ``out[:, :Tadd] += add`` (differentiable w.r.t. ``add``); the caller
+    truncates to the common length as AudioTensor addition would."""
+    if add is not None and oversampling <= 1:   # no decimator to fuse into
+        out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
+                                     bool(equal_energy), bool(return_pre))
+        n = min(out.shape[1], add.shape[1])
+        out = torch.cat([out[:, :n] + add[:, :n], out[:, n:]], 1)
+        return (out, pre) if return_pre else out
     out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
-                                 bool(equal_energy), bool(return_pre))
+                                 bool(equal_energy), bool(return_pre), add)
     return (out, pre) if return_pre else out
 
 

@@ -37,15 +37,24 @@ class SourceFilterSynth(Synth):
                 and hasattr(self.harm_oscillator, "output_length")):
             # overlap the filter's excitation-independent phase with the oscillator (second HIP stream)
             self.end_filter.prefetch(*end_filter_params, n_samples=self.harm_oscillator.output_length(phase))
-        harm_osc = self.harm_oscillator(phase, *harm_oscillator_params)
-        if voicing is not None:
-            if self.check_ranges:
-                assert torch.all(voicing >= 0) and torch.all(voicing <= 1)
-            harm_osc = harm_osc * F.threshold(voicing, 0.5, 0)
-        src = harm_osc + self.noise_filter(self.noise_generator(harm_osc, *noise_generator_params),
-                                           *noise_filter_params)
-        if self.subtract_harmonics:
-            src = src - self.noise_filter(harm_osc, *noise_filter_params)
+        if (voicing is None and not self.subtract_harmonics
+                and getattr(self.harm_oscillator, "supports_fused_add", False)):
+            # src = harm_osc + noise_filter(noise): the noise branch needs the oscillator output only for its shape,
+            # so it runs first and the sum is fused into the oscillator's last kernel
+            n = self.harm_oscillator.output_length(phase)
+            ref = AudioTensor(phase.as_tensor().new_empty((phase.shape[0], n)))   # shape/device carrier, never read
+            nz = self.noise_filter(self.noise_generator(ref, *noise_generator_params), *noise_filter_params)
+            src = self.harm_oscillator(phase, *harm_oscillator_params, add=nz)
+        else:
+            harm_osc = self.harm_oscillator(phase, *harm_oscillator_params)
+            if voicing is not None:
+                if self.check_ranges:
+                    assert torch.all(voicing >= 0) and torch.all(voicing <= 1)
+                harm_osc = harm_osc * F.threshold(voicing, 0.5, 0)
+            src = harm_osc + self.noise_filter(self.noise_generator(harm_osc, *noise_generator_params),
+                                               *noise_filter_params)
+            if self.subtract_harmonics:
+                src = src - self.noise_filter(harm_osc, *noise_filter_params)
         if target is not None:
             return self.end_filter.reverse(src, target, *end_filter_params)
         return self.room_filter(self.end_filter(src, *end_filter_params))

@@ -106,8 +106,10 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
         """Number of samples forward() will return for this phase input."""
         return GF.osc_lengths(phase.shape[1], phase.hop_length, self.oversampling)[1]
 
+    supports_fused_add = True   # forward(..., add=x) returns oscillator + x (hop 1), truncated to the shorter
+
     def forward(self, phase: AudioTensor, table_select_weight: AudioTensor, phase_offset: AudioTensor = None,
-                return_pre: bool = False) -> AudioTensor:
+                return_pre: bool = False, add: AudioTensor = None) -> AudioTensor:
         assert phase.ndim == 2, phase.shape
         assert table_select_weight.dim() == 2
         if phase_offset is not None:
@@ -118,7 +120,11 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
         taps = self.decimater.taps if self.oversampling > 1 else None
         res = GF.glottal_osc(phase.as_tensor(), table_select_weight.as_tensor(), self.table, taps,
                              phase_hop=phase.hop_length, w_hop=table_select_weight.hop_length,
-                             oversampling=self.oversampling, equal_energy=self.equal_energy, return_pre=return_pre)
+                             oversampling=self.oversampling, equal_energy=self.equal_energy, return_pre=return_pre,
+                             add=None if add is None else add.as_tensor())
+        if add is not None:   # what AudioTensor addition of two hop-1 signals does: truncate to the shorter
+            assert add.hop_length == 1 and not return_pre
+            return AudioTensor(res[:, : min(res.shape[1], add.shape[1])])
         if return_pre:
             return AudioTensor(res[0]), res[1]
         return AudioTensor(res)

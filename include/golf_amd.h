@@ -161,8 +161,11 @@ int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const flo
  *   pre (B,N) (optional, may be NULL) = the signal handed to the decimator;
  *   out (B,Tout): os==1 -> out = pre (Tout = N); os>1 -> strided FIR with `taps` (K odd),
  *   Tout = (N-1)/os + 1.
- *   The running phase is accumulated in fp64 and wrapped (more accurate than the reference's fp32
- *   cumsum; parity is against the float64 oracle). */
+ *   The running phase is accumulated exactly (64-bit fixed point; the reference uses an fp32
+ *   cumsum; parity is against the float64 oracle).
+ *   addend (B, Tadd rows of stride addend_stride; optional, may be NULL; os > 1 only): out[b,o] += addend[b,o] for
+ *   o < Tadd — the `harm_osc + noise_filter(noise)` of SourceFilterSynth.forward, models/sf.py:53-56, fused into the
+ *   decimator's epilogue (one full-tensor round trip and one launch less per step). */
 size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fw, int w_hop, int L, int os);
 
 int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
@@ -170,7 +173,8 @@ int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, i
                              const float* table, int n_tab, int L,
                              int os, int equal_energy, const float* taps, int K,
                              float* pre, float* out, int64_t out_stride, int B, int Tout,
-                             void* ws, size_t ws_bytes, void* stream);
+                             void* ws, size_t ws_bytes, void* stream,
+                             const float* addend, int64_t addend_stride, int Tadd);
 
 /* Backward w.r.t. table_select_weight only (phase is data in GOLF training: train_with_true_f0,
  * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = the forward's workspace. */

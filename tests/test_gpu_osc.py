@@ -124,3 +124,54 @@ def test_osc_backward_wsel(os_, eq):
             wm[b, k] -= eps
             ref[b, k] = (f(wp) - f(wm)) / (2 * eps)
     check(got, ref, f"g_wsel os{os_}", 2e-3)
+
+
+@pytest.mark.parametrize("Tadd_delta", [0, -37, 11])
+def test_fused_addend(Tadd_delta):
+    """``glottal_osc(..., add=x)`` (harm_osc + noise fused into the decimator's epilogue, models/sf.py:53) is bit-identical
+    to the separate addition on the common length, leaves the oscillator alone beyond it, and passes gradients through to
+    both the addend and table_select_weight."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    rng = np.random.default_rng(11)
+    B, Tp, w_hop = 3, 2500, 240
+    phase = dev((rng.uniform(100, 300, (B, 1)) / 24000 * np.ones((1, Tp))).astype(np.float32))
+    w = dev(rng.uniform(0.05, 0.95, (B, 12)).astype(np.float32))
+    m = IndexedGlottalFlowTable(table_size=20, lf_v2=True, points=256, oversampling=4, equal_energy=True).cuda()
+    plain = GF.glottal_osc(phase, w, m.table, m.decimater.taps, 1, w_hop, 4, True)
+    Tout = plain.shape[1]
+    Tadd = Tout + Tadd_delta
+    x = dev(rng.normal(0, 1, (B, Tadd)).astype(np.float32))
+    n = min(Tout, Tadd)
+    # a non-contiguous addend view (row stride > Tadd) goes through as is
+    xw = torch.zeros(B, Tadd + 5, device="cuda")
+    xw[:, :Tadd] = x
+    for xa in (x, xw[:, :Tadd]):
+        wg, xg = w.clone().requires_grad_(True), xa.detach().clone().requires_grad_(True)
+        fused = GF.glottal_osc(phase, wg, m.table, m.decimater.taps, 1, w_hop, 4, True, add=xg)
+        assert fused.shape == plain.shape
+        assert torch.equal(fused[:, :n], plain[:, :n] + x[:, :n])
+        assert torch.equal(fused[:, n:], plain[:, n:])
+        gy = dev(rng.normal(0, 1, (B, Tout)).astype(np.float32))
+        (fused * gy).sum().backward()
+        w2 = w.clone().requires_grad_(True)
+        (GF.glottal_osc(phase, w2, m.table, m.decimater.taps, 1, w_hop, 4, True) * gy).sum().backward()
+        assert torch.equal(wg.grad, w2.grad)
+        ref = torch.zeros(B, Tadd, device="cuda")
+        ref[:, :n] = gy[:, :n]
+        assert torch.equal(xg.grad, ref)
+
+
+def test_fused_addend_module_truncates_like_audiotensor_addition():
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    m = IndexedGlottalFlowTable(table_size=20, lf_v2=True, points=256, oversampling=4, equal_energy=True).cuda()
+    phase = AudioTensor(torch.full((2, 1000), 0.01, device="cuda"))
+    w = AudioTensor(torch.full((2, 5), 0.4, device="cuda"), 240)
+    nz = AudioTensor(torch.randn(2, 900, device="cuda"))
+    sep = m(phase, w) + nz
+    fused = m(phase, w, add=nz)
+    assert fused.hop_length == 1 and fused.shape == sep.shape == (2, 900)
+    assert torch.equal(fused.as_tensor(), sep.as_tensor())
