@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
-                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step"],
+                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step", "osc-only", "lpc-ss-fast"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
                          "and the room filter); golf-ss-train-step (BASELINE config 5, use --batch 64): one optimisation "
@@ -105,6 +105,12 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)
+    elif workload == "lpc-ss-fast":   # the inference filter alone (diagnostic: its share of the pipelined step)
+        def step():
+            return GF.ltv_allpole_ss(noise, gain, a, hop, fast_inference=True)
+    elif workload == "osc-only":      # the source alone (diagnostic)
+        def step():
+            return source()
     elif workload in ("golf-ss-decoder", "golf-ss-decoder-train"):
         lm, rk = inp["log_mag"], inp["room_kernel"]
         fir_win = torch.hann_window(2 * (lm.shape[-1] - 1), device=phase.device)
@@ -408,7 +414,7 @@ def main():
         alg_bytes = bytes_per_sample * samples
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
         # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
-        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "golf-ss-train": 16.4 + 16.8,
+        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0, "golf-ss-train": 16.4 + 16.8,
                       "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
                       "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
                       # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
