@@ -65,12 +65,22 @@ __device__ __forceinline__ u64 osc_fix_d(float p0, float p1, double scale_d) {  
 //   Cloc[b][j] = sum of the segment totals of the tile before j   (exclusive)
 //   Ttot[b][tile] = tile total
 // The render kernel adds the (<= ntile-term) prefix of Ttot itself.  Coalesced loads, wave shuffles.
-__device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const u64 u = __shfl_up(v, off, 64);
-        if (lane >= off) v += u;
-    }
+// Inclusive wave scan of 64-bit integers on the DPP network: row_shr 1/2/4/8 inside each row of 16 lanes (lanes without
+// a source read 0), then row_bcast15 / row_bcast31 across rows -- 6 steps of two moves + one 64-bit add.  (__shfl_up
+// goes through ds_bpermute: ~60 instructions and 12 serial LDS-crossbar round trips per scan.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_add_u64(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xF, true);
+    return v + (((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
+}
+__device__ __forceinline__ u64 wave_incl_scan(u64 v, int /*lane*/) {
+    v = dpp_add_u64<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_add_u64<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_add_u64<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_add_u64<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_add_u64<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u64<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
