@@ -32,7 +32,8 @@ class Spectrogram(nn.Module):
     def __init__(self, n_fft: int = 400, win_length: Optional[int] = None, hop_length: Optional[int] = None,
                  pad: int = 0, window_fn: Callable[..., torch.Tensor] = torch.hann_window,
                  power: Optional[float] = 2.0, normalized: bool = False, wkwargs: Optional[dict] = None,
-                 center: bool = True, pad_mode: str = "reflect", onesided: bool = True):
+                 center: bool = True, pad_mode: str = "reflect", onesided: bool = True,
+                 return_complex: Optional[bool] = None):  # (deprecated torchaudio argument, saved in old configs)
         super().__init__()
         if normalized:
             raise NotImplementedError("Spectrogram(normalized=True) is not used by any GOLF config")
