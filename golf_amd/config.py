@@ -82,7 +82,10 @@ def build_model(config: Union[str, Mapping]):
     file (cfg/ae/decoder/*.yaml: top-level ``decoder:``) yields the decoder."""
     cfg = load_yaml(config) if isinstance(config, str) else config
     if "model" in cfg:
-        return instantiate(cfg["model"])
+        model = cfg["model"]
+        if "class_path" not in model and "decoder" in model:   # ckpts/ismir23/*: a Lightning module of ltng/vocoder.py
+            return instantiate(model["decoder"])                # (control plane) around the decoder: build the decoder
+        return instantiate(model)
     if "decoder" in cfg:
         return instantiate(cfg["decoder"])
     return instantiate(cfg)

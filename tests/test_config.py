@@ -122,7 +122,11 @@ REF = "/root/reference"
 GOLF_FILES = ["cfg/ae/decoder/golf.yaml", "cfg/ae/decoder/golf-precise.yaml", "cfg/ae/decoder/golf-v1.yaml",
               "cfg/ae/decoder/ddsp.yaml", "ckpts/interspeech24/golf-ss/config.yaml",
               "ckpts/interspeech24/golf-ff/config.yaml", "ckpts/interspeech24/golf-v1/config.yaml",
-              "ckpts/interspeech24/ddsp/config.yaml"]
+              "ckpts/interspeech24/ddsp/config.yaml"] + [f"ckpts/ismir23/{m}_{v}/config.yaml"
+                                                         for m in ("glottal_d", "ddsp", "pulse", "sawsing")
+                                                         for v in ("f1", "m1")]
+ISMIR_SPLITS = {"glottal_d": ((64,), (), (1, 22), (1, 22), ()), "ddsp": ((1, 150), (), (), (80,), ()),
+                "pulse": ((), (), (1, 26), (1, 22), ()), "sawsing": ((), (), (256,), (80,), ())}
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
@@ -134,6 +138,9 @@ def test_shipped_golf_configs_instantiate(rel):
 
     model = build_model(os.path.join(REF, rel))
     dec = getattr(model, "decoder", model)
+    if "ismir23" in rel:   # ISMIR'23 models: the decoder of each (the Lightning module around it is control plane)
+        assert dec.split_sizes_and_trsfms[0] == ISMIR_SPLITS[rel.split("/")[2].rsplit("_", 1)[0]]
+        return
     total = sum(s for grp in dec.split_sizes_and_trsfms[0] for s in grp)
     assert total == (412 if "ddsp" in rel else 343)
     if hasattr(model, "encoder"):
@@ -196,3 +203,76 @@ def test_yaml_built_golf_v1_and_golf_ff_decoders_vs_oracle():
         emax, el2 = rel_err(y, ref)
         print(type(dec).__name__, "vs oracle", emax, el2)
         assert emax < 1e-4 and el2 < 1e-4
+
+
+GLOTTAL_D = """
+decoder:
+  class_path: models.hpn.HarmonicPlusNoiseSynth
+  init_args:
+    harm_oscillator:
+      class_path: models.synth.DownsampledIndexedGlottalFlowTable
+      init_args: {hop_rate: 10, in_channels: 64, table_size: 100, table_type: derivative,
+                  normalize_method: constant_power, align_peak: true, trainable: false, min_R_d: 0.3, max_R_d: 2.7,
+                  T_0: 5.0, n_iter_eps: 5, n_iter_a: 100, points: 2048}
+    noise_generator: {class_path: models.noise.StandardNormalNoise}
+    harm_filter:
+      class_path: models.filters.LTVMinimumPhaseFilter
+      init_args: {window: hanning, window_length: 480, centred: false, lpc_order: 22, lpc_parameterisation: coef,
+                  max_abs_value: 0.99}
+    noise_filter:
+      class_path: models.filters.LTVMinimumPhaseFilter
+      init_args: {window: hanning, window_length: 480, centred: false, lpc_order: 22, lpc_parameterisation: coef,
+                  max_abs_value: 0.99}
+    end_filter: {class_path: models.ctrl.PassThrough}
+"""
+
+
+@pytest.mark.gpu
+def test_yaml_built_ismir23_glottal_decoder_vs_oracle():
+    """The ISMIR'23 GOLF decoder (ckpts/ismir23/glottal_d_*: LF-v1 wavetable without oversampling, two frame-wise LPC
+    filters with a 480-sample window, ``centred: false``, biquad ("coef") parameterisation) through the encoder-side
+    control transforms, against the float64 oracle composition."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.config import build_model
+    from golf_amd.noise import NoiseInterface
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    B, T, hop = 2, 12000, 240
+    inp = make_inputs(B=B, T=T, device="cuda")
+    F = T // hop
+    g = torch.Generator().manual_seed(5)
+    dec = build_model(GLOTTAL_D).cuda()
+
+    class Fixed(NoiseInterface):
+        def forward(self, ref, *args, **kwargs):
+            return AudioTensor(inp["noise"][:, : ref.shape[1]])
+
+    dec.noise_generator = Fixed()
+    split_sizes, trsfms, keys = dec.split_sizes_and_trsfms
+    assert split_sizes == ((64,), (), (1, 22), (1, 22), ())
+    # per-utterance spread of the biquad logits: 0.2 keeps the poles where an ORDER-22 DIRECT FORM is well conditioned in
+    # fp32 (the reference runs the same fp32 direct form): measured rel-max 4e-7 / 1.7e-5 / 2e-3 at spread 0.1 / 0.25 / 0.5
+    SPREAD = 0.2
+    # filter parameters through the modules' own control transforms (log-gain, 11 x 2 biquad logits -> direct form)
+    params = []
+    for k in range(2):
+        lg = AudioTensor((torch.randn(B, F, generator=g) * 0.1 - 2).cuda(), hop)
+        lo = AudioTensor((torch.cumsum(torch.randn(B, F, 22, generator=g) * 0.03, 1) + torch.randn(B, 1, 22, generator=g) * SPREAD).cuda(), hop)
+        params.append(trsfms[2 + k](lg, lo))
+    y = dec(phase=AudioTensor(inp["phase"]), harm_oscillator_params=(AudioTensor(inp["wsel"][:, : T // 2400 + 1], 2400),),
+            noise_generator_params=(), harm_filter_params=params[0], noise_filter_params=params[1])
+    y = y.as_tensor().detach().cpu().numpy()
+    c = lambda t: t.double().cpu().numpy()
+    osc = dec.harm_oscillator
+    src = O.indexed_glottal_forward(c(inp["phase"]), 1, c(inp["wsel"][:, : T // 2400 + 1]), 2400, c(osc.table), 1, False)["out"]
+    win = torch.hann_window(480, dtype=torch.float64).numpy()
+    ga = [(c(p[0].as_tensor()), c(p[1].as_tensor())) for p in params]
+    harm = O.lti_frames_ola_forward(src, ga[0][0], ga[0][1], hop, win, centred=False)[0]
+    nz = O.lti_frames_ola_forward(c(inp["noise"])[:, : src.shape[1]], ga[1][0], ga[1][1], hop, win, centred=False)[0]
+    n = min(harm.shape[1], nz.shape[1])
+    ref = harm[:, :n] + nz[:, :n]
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    emax, el2 = rel_err(y, ref)
+    print("ISMIR'23 glottal_d decoder vs oracle", emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4
