@@ -64,6 +64,8 @@ def parse():
                          "top of the step so that it overlaps the oscillator and the noise filter")
     ap.add_argument("--fork-transitions", action="store_true",
                     help="run the transition kernel on a side stream beside the zero-state pass (fork/join inside the step)")
+    ap.add_argument("--split-p1", action="store_true",
+                    help="diagnostic: transition kernel and zero-state pass as two launches instead of the fused one")
     ap.add_argument("--fp64-transitions", action="store_true",
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
@@ -295,6 +297,10 @@ def main():
         import golf_amd.functional as _GF
 
         _GF.FORK_TRANSITIONS = True
+    if args.split_p1:
+        import golf_amd.functional as _GF
+
+        _GF.SPLIT_P1 = True
     from golf_amd.dist import shard_inputs, gather_audio, gather_audio_async
     from golf_amd.synthetic import make_inputs
 

@@ -96,19 +96,18 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
 //   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
 //   MODE 1 (P3) : initial state S[(b*NCS+c)*64 + i], writes y[b][t]
 //   MODE 2      : initial state S[(b*NCS+c)*64 + i], chunks c < NCQ=NP, final state -> out (refinement sweep)
+// The body is a device function of ONE wave (its LDS tiles are passed in, its only synchronisation is the wave-level
+// LDS fence) so that it can also run as one of the four independent waves of lpc_p1fz_kernel's workgroups.
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ ex, int64_t ex_stride,
-                                                      const float* __restrict__ gain, const float* __restrict__ a,
-                                                      const float* __restrict__ S, float* __restrict__ out,
-                                                      int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ,
-                                                      int NCS, const float* __restrict__ zin) {
+__device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t ex_stride,
+                                          const float* __restrict__ gain, const float* __restrict__ a,
+                                          const float* __restrict__ S, float* __restrict__ out, int64_t y_stride, int T,
+                                          int F, int M, int hop, int L, int NCQ, int NCS,
+                                          const float* __restrict__ zin, float* __restrict__ xt,
+                                          float* __restrict__ yt, int b, int cg, int lane) {
     constexpr int TPL = quad_tpl(W, NT);
     constexpr int R = 16;
     using TL = Tile<W, R>;
-    __shared__ float xt[TL::SIZE];
-    __shared__ float yt[TL::SIZE];
-    const int b = blockIdx.y, cg = blockIdx.x;
-    const int lane = threadIdx.x;
     const int lq = lane / W, lr = lane % W;
     const int row = lane >> 2, r = lane & 3;
     const int c0 = cg * R;
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
         const int tw = c0 * L + blk * W;  // block start of the wave's first chunk
         if (tw >= T) break;               // wave-uniform: nothing left for any lane
         TL::scatter(xt, nx, lq, lr);
-        __syncthreads();
+        wave_lds_fence();
         float xin[W];
         TL::rows_load(xin, xt, row);
         TL::fetch(nx, xrow, tw + W, L, lq, lr);  // prefetch next block (past the end: hardware returns 0)
@@ -193,12 +192,12 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
-            __syncthreads();
+            wave_lds_fence();
             float o[TL::ITS];
             TL::gather(o, yt, lq, lr);
             TL::store(o, yrow, tw, L, lq, lr);
         }
-        __syncthreads();
+        wave_lds_fence();
     }
     if (MODE != 1 && mine) {
         float* zp = out + ((size_t)b * NCQ + c) * W;
@@ -216,6 +215,19 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
             }
         }
     }
+}
+
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                      const float* __restrict__ gain, const float* __restrict__ a,
+                                                      const float* __restrict__ S, float* __restrict__ out,
+                                                      int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ,
+                                                      int NCS, const float* __restrict__ zin) {
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    fwdq_body<W, NT, MODE>(ex, ex_stride, gain, a, S, out, y_stride, T, F, M, hop, L, NCQ, NCS, zin, xt, yt,
+                           blockIdx.y, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,25 +335,30 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 template <int W, int NT>
-__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
-                                                               int F, int M, int hop, int L, int NP, int nq) {
+struct P1fGeom {
+    static constexpr int KT = 4;
+    static constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
+    static constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
+    static constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
+    static constexpr int CPP0 = (16384 / 4) / (NT * LDT);  // chunks staged per copy-out pass: <= 16 KB per wave
+    static constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
+    static constexpr int TILE_FLOATS = P1F_WPB * CPP * NT * LDT;
+};
+template <int W, int NT>
+__device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
+                                         int L, int NP, int nq, float* __restrict__ tile_all, int blk_id) {
     // Workgroups of P1F_WPB = 4 independent waves: there are fewer waves than SIMDs (637 for B=32) and every wave is
     // FMA-issue bound, so two waves sharing a SIMD double the kernel.  With single-wave workgroups the dispatcher's
     // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
     // puts one wave on each SIMD of its CU.
-    constexpr int KT = 4;
-    constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
-    constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
+    using G = P1fGeom<W, NT>;
+    constexpr int KT = G::KT, NG = G::NG, CPW = G::CPW, LDT = G::LDT, CPP = G::CPP;
     constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
-    constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
-    constexpr int CPP0 = (16384 / 4) / (NT * LDT);          // chunks staged per copy-out pass: <= 16 KB per wave
-    constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
-    __shared__ __attribute__((aligned(16))) float tile_all[P1F_WPB * CPP * NT * LDT];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* tile = tile_all + wv * (CPP * NT * LDT);
     const int cl = lane / NG, grp = lane - cl * NG;
-    const int q0 = (blockIdx.x * P1F_WPB + wv) * CPW;
+    const int q0 = (blk_id * P1F_WPB + wv) * CPW;
     if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
@@ -427,6 +444,74 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __re
             const int rowi = e / RW4, c4 = e - rowi * RW4;
             dst[e] = *reinterpret_cast<const float4*>(tile + (size_t)rowi * LDT + c4 * 4);
         }
+    }
+}
+
+template <int W, int NT>
+__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
+                                                               int F, int M, int hop, int L, int NP, int nq) {
+    __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
+    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x);
+}
+
+// `upw` zero-state units (16 chunks of one utterance each) per wave, one after the other: the host picks upw so that the
+// fused grid has no more workgroups than the device has CUs -- an extra workgroup would share the SIMDs of a CU whose
+// transition waves are issue-bound.
+template <int W, int NT>
+__device__ __forceinline__ void p1z_units(const float* __restrict__ ex, int64_t ex_stride,
+                                          const float* __restrict__ gain, const float* __restrict__ a,
+                                          float* __restrict__ z, int T, int F, int M, int hop, int L, int NP, int ncg,
+                                          int B, int upw, int zblk, float (*xt)[Tile<W, 16>::SIZE]) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int u = 0; u < upw; ++u) {
+        const int unit = (zblk * 4 + wv) * upw + u;
+        if (unit >= ncg * B) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+        fwdq_body<W, NT, 0>(ex, ex_stride, gain, a, nullptr, z, 0, T, F, M, hop, L, NP, NP, nullptr, xt[wv], nullptr,
+                            unit / ncg, unit - (unit / ncg) * ncg, threadIdx.x & 63);
+        wave_lds_fence();
+    }
+}
+
+// Horizontal fusion of the two kernels that open the inference forward and do not depend on each other: the fp32
+// transition matrices (needs only `a`; 637 issue-bound waves, one per SIMD of 160 CUs) and the zero-state pass P1z
+// (416 light waves).  Workgroups [0, nblk_f) run p1f_body, the rest run four P1z units as four independent waves, so
+// P1z uses the CUs the transition kernel leaves idle instead of a launch of its own after it.  (Forking P1z onto a
+// second stream instead costs more in event record/wait than it hides: DESIGN.md.)
+template <int W, int NT>
+__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                                const float* __restrict__ gain,
+                                                                const float* __restrict__ a, float* __restrict__ z,
+                                                                float* __restrict__ PhiT, int T, int F, int M, int hop,
+                                                                int L, int NP, int nq, int nblk_f, int ncg, int B,
+                                                                int upw) {
+    using TL = Tile<W, 16>;
+    __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
+    __shared__ float xt[P1F_WPB][TL::SIZE];
+    if ((int)blockIdx.x < nblk_f) {
+        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x);
+    } else {
+        p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_f, xt);
+    }
+}
+
+// The same fusion for the training path: fp64 transition trajectories (800 waves) beside the zero-state pass.
+template <int W, int NT, int KT>
+__global__ __launch_bounds__(256) void lpc_p1hz_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                       const float* __restrict__ gain, const float* __restrict__ a,
+                                                       float* __restrict__ z, float* __restrict__ Phi,
+                                                       float* __restrict__ PhiT, int T, int F, int M, int hop, int L,
+                                                       int NP, int nq, int nblk_h, int ncg, int B, int upw) {
+    using TL = Tile<W, 16>;
+    __shared__ float xt[4][TL::SIZE];
+    if ((int)blockIdx.x < nblk_h) {
+        constexpr int NG = (NT + KT - 1) / KT;
+        const int nqb = (nq + 63) / 64;
+        const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int qblk = unit / NG, grp = unit - qblk * NG;
+        if (qblk >= nqb) return;
+        p1_hom_body<W, NT, KT, double>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
+    } else {
+        p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_h, xt);
     }
 }
 
@@ -1023,6 +1108,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     constexpr int D = 8;
     const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
     ForkJoin fork, join;
+    bool fused_p1 = false;
     if (p.NP > 0) {
         if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
             hipStream_t s1 = st;
@@ -1030,12 +1116,51 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                 if (fork.record_and_wait(st, side)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream fork failed");
                 s1 = side;
             }
-            if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, s1)) return rc;
+            if (!side && !(flags & GOLF_SS_SPLIT_P1)) {   // transitions + zero-state pass in one launch
+                const int nq = B * p.NP, ncg = (int)ceil_div(p.NP, 16);
+                const int64_t nunit = (int64_t)ncg * B;
+                static const int n_cu = [] {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) != hipSuccess ||
+                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+                        n = 256;
+                    return n;
+                }();
+                if (fast) {
+                    const int nblk_f = (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
+                    int upw = 1;
+                    while (upw < 4 && nblk_f + ceil_div(nunit, 4 * upw) > n_cu) ++upw;
+                    const int nblk_z = (int)ceil_div(nunit, 4 * upw);
+                    hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
+                                       0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
+                                       B, upw);
+                    GOLF_LAUNCH_CHECK();
+                } else {
+                    constexpr int KT = 3, NG = (NT + KT - 1) / KT;
+                    float* Phi = (float*)(ws + p.off_phi);
+                    const int nblk_h = (int)ceil_div(ceil_div(nq, 64) * NG, 4);
+                    int upw = 1;
+                    while (upw < 4 && nblk_h + ceil_div(nunit, 4 * upw) > n_cu) ++upw;
+                    const int nblk_z = (int)ceil_div(nunit, 4 * upw);
+                    hipLaunchKernelGGL((lpc_p1hz_kernel<W, NT, KT>), dim3((unsigned)(nblk_h + nblk_z)), dim3(256), 0, st,
+                                       ex, ex_stride, gain, a, z, Phi, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_h, ncg, B,
+                                       upw);
+                    GOLF_LAUNCH_CHECK();
+                    hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
+                                       (const float*)Phi, PhiT, nq);
+                    GOLF_LAUNCH_CHECK();
+                }
+                fused_p1 = true;
+            } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, s1)) {
+                return rc;
+            }
         }
-        hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP,
-                           (const float*)nullptr);
-        GOLF_LAUNCH_CHECK();
+        if (!fused_p1) {
+            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
+                               ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP,
+                               (const float*)nullptr);
+            GOLF_LAUNCH_CHECK();
+        }
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,

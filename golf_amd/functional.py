@@ -17,7 +17,8 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
-FORK_TRANSITIONS = False  # set True to run the transition kernel beside the zero-state pass (streams)
+FORK_TRANSITIONS = False
+SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
 
 
@@ -107,6 +108,8 @@ class _LTVAllPoleSS(torch.autograd.Function):
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
             if not needs_grad and fast_inference:
                 flags = FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
+            if SPLIT_P1:
+                flags |= 4                # GOLF_SS_SPLIT_P1 (diagnostic): two launches instead of the fused one
             if FORK_TRANSITIONS:
                 # the transition kernel (needs only `a`) and the zero-state pass (needs `ex`) are independent: the
                 # library forks the former onto a side stream and joins before the boundary scan

@@ -74,6 +74,9 @@ size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
  *                with HAVE_TRANSITIONS the forward joins it (event wait) right before the boundary scan. */
 #define GOLF_SS_HAVE_TRANSITIONS 1
 #define GOLF_SS_FAST_TRANSITIONS 2
+/*          GOLF_SS_SPLIT_P1  (diagnostic) launch the fp32 transition kernel and the zero-state pass separately instead
+ *                of as one horizontally fused kernel (the default with FAST and without HAVE / side_stream). */
+#define GOLF_SS_SPLIT_P1 4
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);
