@@ -171,6 +171,10 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
         with torch.no_grad():  # the reference starts out_linear at exactly 0 (constant decoder parameters); a small
             model.encoder.backbone.out_linear.weight.normal_(0, 0.02)  # random head makes them vary like a trained one
         model.train()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # one process per GPU, gradients all-reduced by DDP over RCCL
+            from golf_amd.ae import data_parallel
+
+            model = data_parallel(model, device_ids=[phase.device.index])
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
         f0 = phase * SR
         f0[:, : SR // 5] = 0  # an unvoiced stretch (driven at a random frequency, ltng/ae.py:97-101)
@@ -307,7 +311,7 @@ def main():
     B = args.batch
     if args.workload == "golf-ss-train-step":  # the optimiser couples consecutive steps: no batches in flight
         args.streams, args.no_graphs, args.no_cpu_baseline = 1, True, True
-        assert world == 1, "golf-ss-train-step is a single-GPU side benchmark (DDP of the encoder is stock PyTorch)"
+        args.no_gather = True   # N > 1: the exchange of this workload is DDP's gradient all-reduce, not an audio gather
     inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
     if args.workload == "ddsp-decoder":
         assert world == 1, "ddsp-decoder is a single-GPU side benchmark"
@@ -410,6 +414,10 @@ def main():
     value = world * samples / (elapsed / args.steps)
 
     result = None
+    collective_step = world > 1 and args.workload == "golf-ss-train-step"   # DDP: every rank must take every step
+    if rank != 0 and collective_step:
+        device_kernel_times(step)
+        event_time_us(step)
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live
         ktimes = device_kernel_times(step)
