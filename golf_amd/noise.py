@@ -13,11 +13,18 @@ __all__ = ["NoiseInterface", "StandardNormalNoise", "UniformNoise", "SignFlipNoi
 
 
 class NoiseInterface(Controllable):
+    # False: forward() takes only shape / dtype / device from ``ref``.  SourceFilterSynth then generates the noise before
+    # the oscillator has run and fuses the sum into the oscillator's last kernel; generators that read the values of
+    # ``ref`` keep the default and the reference's order of operations.
+    uses_reference_values = True
+
     def forward(self, ref: AudioTensor, *args, **kwargs) -> AudioTensor:
         raise NotImplementedError
 
 
 class StandardNormalNoise(NoiseInterface):
+    uses_reference_values = False
+
     def forward(self, ref: AudioTensor, *args, **kwargs) -> AudioTensor:
         return torch.randn_like(ref)
 
@@ -25,12 +32,16 @@ class StandardNormalNoise(NoiseInterface):
 class UniformNoise(NoiseInterface):
     """Zero-mean unit-variance uniform noise on [-sqrt(3), sqrt(3))."""
 
+    uses_reference_values = False
+
     def forward(self, ref: AudioTensor, *args, **kwargs) -> AudioTensor:
         return (torch.rand_like(ref) - 0.5) * (2 * math.sqrt(3))
 
 
 class SignFlipNoise(NoiseInterface):
     """+s, -s, +s, ... with one random sign s per row."""
+
+    uses_reference_values = False
 
     def forward(self, ref: AudioTensor, *args, **kwargs) -> AudioTensor:
         data = ref.as_tensor()

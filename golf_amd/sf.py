@@ -38,7 +38,8 @@ class SourceFilterSynth(Synth):
             # overlap the filter's excitation-independent phase with the oscillator (second HIP stream)
             self.end_filter.prefetch(*end_filter_params, n_samples=self.harm_oscillator.output_length(phase))
         if (voicing is None and not self.subtract_harmonics
-                and getattr(self.harm_oscillator, "supports_fused_add", False)):
+                and getattr(self.harm_oscillator, "supports_fused_add", False)
+                and not getattr(self.noise_generator, "uses_reference_values", True)):
             # src = harm_osc + noise_filter(noise): the noise branch needs the oscillator output only for its shape,
             # so it runs first and the sum is fused into the oscillator's last kernel
             n = self.harm_oscillator.output_length(phase)

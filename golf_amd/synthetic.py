@@ -67,6 +67,8 @@ def make_decoder(noise_filter: bool = True, room_filter: bool = True, injected_n
 
     if injected_noise is not None:
         class _Fixed(NoiseInterface):
+            uses_reference_values = False
+
             def forward(self, ref, *args, **kwargs):
                 return AudioTensor(injected_noise[:, : ref.shape[1]])
 
@@ -99,6 +101,8 @@ def make_ddsp_decoder(num_harmonics: int = 155, injected_noise: torch.Tensor = N
 
     if injected_noise is not None:
         class _Fixed(NoiseInterface):
+            uses_reference_values = False
+
             def forward(self, ref, *args, **kwargs):
                 return AudioTensor(injected_noise[:, : ref.shape[1]])
 
