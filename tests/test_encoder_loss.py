@@ -177,3 +177,101 @@ def test_training_step_runs_and_learns():
     assert g and all(torch.isfinite(v).all() for v in g)
     total = torch.sqrt(sum((v.float() ** 2).sum() for v in g))
     assert float(total) <= 0.5 * 1.001                         # clipped
+
+
+# ---- data-parallel training step (config 5 at N > 1): DistributedDataParallel over gloo, world size 2, on the CPU.
+# The HIP decoder cannot run here, so a small PyTorch decoder speaking the same control protocol stands in for it: what
+# is under test is the wrapper (golf_amd.ae.data_parallel + train_step), i.e. that gradients are averaged across ranks.
+def _toy_autoencoder():
+    import torch.nn as nn
+
+    from golf_amd.ae import VoiceAutoEncoder
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.ctrl import Controllable, Synth, wrap_ctrl_fn
+    from golf_amd.loss import MSSLoss
+
+    class ToyOsc(Controllable):
+        def __init__(self):
+            super().__init__()
+            self.scale = nn.Parameter(torch.tensor(0.1))
+            self.ctrl = wrap_ctrl_fn(split_size=(1, 3), trsfm_fn=lambda g, h: (g.new_tensor(torch.exp(g.as_tensor())), h))
+
+        def forward(self, phase, gain, harm):
+            ph = torch.cumsum(phase.as_tensor(), 1) * (2 * np.pi)
+            g = gain.reduce_hop_length().as_tensor()
+            a = harm.reduce_hop_length().as_tensor()
+            n = min(ph.shape[1], g.shape[1])
+            sig = sum(a[:, :n, k] * torch.sin((k + 1) * ph[:, :n]) for k in range(3))
+            return AudioTensor(self.scale * g[:, :n] * sig)
+
+    class ToyDecoder(Synth):
+        def __init__(self):
+            super().__init__()
+            self.osc = ToyOsc()
+
+        def forward(self, phase, osc_params, **_):
+            return self.osc(phase, *osc_params)
+
+    torch.manual_seed(3)
+    model = VoiceAutoEncoder(
+        decoder=ToyDecoder(), criterion=MSSLoss([61, 127], alpha=1.0, window="hanning", center=True),
+        encoder_class_path="models.enc.VocoderParameterEncoderInterface",
+        encoder_init_args=dict(backbone_type="models.unet.UNetEncoder", n_fft=64, hop_length=16, channels=[4, 8],
+                               strides=[2, 2], lstm_hidden_size=8, num_layers=1, learn_voicing=False, learn_f0=False),
+        sample_rate=8000, train_with_true_f0=True)
+    with torch.no_grad():
+        model.encoder.backbone.out_linear.weight.normal_(0, 0.1)
+    return model
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from golf_amd.ae import data_parallel, train_step
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _toy_autoencoder()                       # same seed on every rank; DDP broadcasts rank 0's weights anyway
+    ddp = data_parallel(model)
+    opt = torch.optim.Adam(ddp.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(100 + rank)    # every rank its own shard of the batch
+    x = 0.1 * torch.randn(3, 800, generator=g)
+    f0 = 100 + 100 * torch.rand(3, 1, generator=g) * torch.ones(1, 800)
+    uv = torch.full((3, 1), 150.0)
+    before = [p.detach().clone() for p in model.parameters()]
+    losses = [float(train_step(ddp, opt, (x, f0), clip=0.5, unvoiced_f0=uv)) for _ in range(3)]
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered)            # averaged gradients -> identical weights
+    moved = any(not torch.equal(b, p.detach()) for b, p in zip(before, model.parameters()))
+    if rank == 0:
+        q.put((same, moved, losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_gloo_world2():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, moved, losses = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same, "ranks diverged: gradients were not averaged"
+    assert moved and all(np.isfinite(losses))
