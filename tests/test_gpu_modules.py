@@ -254,3 +254,37 @@ def test_ddsp_decoder_vs_oracle():
     emax, el2 = rel_err(y, ref)
     print("ddsp decoder", emax, el2)
     assert emax < 1e-4 and el2 < 1e-4
+
+
+def test_replay_pipeline_matches_eager():
+    """golf_amd.pipeline.ReplayPipeline (hipGraph replay of the whole decoder, 4 slots on 4 streams) returns bit for bit
+    what eager calls return, also after the static inputs of a slot were refilled."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.pipeline import ReplayPipeline
+    from golf_amd.synthetic import make_decoder, make_inputs
+
+    B = 4
+    base = make_inputs(B=B, T=12000, device="cuda", with_noise_filter=True)
+    dec = make_decoder(noise_filter=True, room_filter=True, injected_noise=base["noise"]).cuda()
+
+    def fn(inp):
+        return dec(phase=AudioTensor(inp["phase"]), harm_oscillator_params=(AudioTensor(inp["wsel"], base["w_hop"]),),
+                   noise_generator_params=(), noise_filter_params=(AudioTensor(inp["log_mag"], 240),),
+                   end_filter_params=(AudioTensor(inp["gain"], 240), AudioTensor(inp["a"], 240))).as_tensor()
+
+    keys = ("phase", "wsel", "log_mag", "gain", "a")
+    pipe = ReplayPipeline(fn, lambda: {k: base[k].clone() for k in keys}, n_slots=4)
+    variants = []
+    for k in range(6):   # six different batches through four slots: every slot is reused at least once
+        v = {"phase": base["phase"] * (1 + 0.01 * k), "wsel": (base["wsel"] + 0.03 * k).clamp(0, 1),
+             "log_mag": base["log_mag"] - 0.1 * k, "gain": base["gain"] * (1 + 0.05 * k), "a": base["a"]}
+        variants.append(v)
+    outs = []
+    for v in variants:
+        slot = pipe.slots[pipe._next]
+        slot.load(**v)
+        s = pipe.submit()
+        s.stream.synchronize()
+        outs.append(s.output.clone())
+    for v, y in zip(variants, outs):
+        assert torch.equal(y, fn(v))
