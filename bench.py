@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
-                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step", "osc-only", "lpc-ss-fast"],
+                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step", "osc-only", "lpc-ss-fast", "golf-ss-decoder-logits"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
                          "and the room filter); golf-ss-train-step (BASELINE config 5, use --batch 64): one optimisation "
@@ -152,6 +152,31 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
             h = GF.harmonic_osc(phase, 155, 1, amps, hop, tscale, 1)
             nz = GF.zero_phase_fir_filter(noise[:, : h.shape[1]], lm, fir_win, hop)
             return GF.lti_fir(h[:, : nz.shape[1]] + nz, room_taps, K)
+    elif workload == "golf-ss-decoder-logits":
+        # the decoder as the autoencoder drives it: encoder output (B, 200, 343) -> control transforms (.ctrl of every
+        # module: table-selection network, exp gain, logits -> reflection -> direct-form coefficients) -> golf-precise
+        # decoder, through the drop-in modules (AudioTensor protocol included)
+        from golf_amd.audiotensor import AudioTensor
+        from golf_amd.synthetic import make_decoder
+
+        dec = make_decoder(injected_noise=noise).to(phase.device).eval()
+        with torch.no_grad():
+            dec.room_filter.kernel.copy_(inp["room_kernel"])
+        split_sizes, trsfms, keys = dec.split_sizes_and_trsfms
+        flat = [n for grp in split_sizes for n in grp]
+        torch.manual_seed(2434)
+        h = torch.randn(B, a.shape[1], sum(flat), device=phase.device) * 0.3
+        h[..., 64 + 256] -= 3.0   # log-gain channel
+        ph = AudioTensor(phase)
+
+        @torch.no_grad()
+        def step():
+            pieces = [AudioTensor(t.squeeze(2) if t.shape[2] == 1 else t, hop) for t in torch.split(h, flat, dim=2)]
+            params, i = {}, 0
+            for key, grp, fn in zip(keys, split_sizes, trsfms):
+                params[key] = fn(*pieces[i:i + len(grp)])
+                i += len(grp)
+            return dec(phase=ph, **params).as_tensor()
     elif workload == "golf-ss-train-step":
         # BASELINE configs[4] / cfg/ae/vctk.yaml: encoder(x, f0) -> golf-precise decoder -> MSSLoss(509, 1021, 2053)
         # -> backward -> clip 0.5 -> Adam(1e-4).  Steps depend on each other through the weights: one stream, eager.
@@ -313,6 +338,8 @@ def main():
         args.streams, args.no_graphs, args.no_cpu_baseline = 1, True, True
         args.no_gather = True   # N > 1: the exchange of this workload is DDP's gradient all-reduce, not an audio gather
     inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
+    if args.workload == "golf-ss-decoder-logits":
+        assert world == 1, "golf-ss-decoder-logits is a single-GPU side benchmark"
     if args.workload == "ddsp-decoder":
         assert world == 1, "ddsp-decoder is a single-GPU side benchmark"
     inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
@@ -429,7 +456,8 @@ def main():
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
         # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
         path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0, "golf-ss-train": 16.4 + 16.8,
-                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
+                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-logits": 16.4 + 12.27 + 8.0,
+                      "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
                       "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
                       # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
                       "ddsp-decoder": 10.6 + 12.27 + 8.0}

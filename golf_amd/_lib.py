@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgolf_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip")
+SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip", "ctrl.hip")
 
 _c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -48,6 +48,8 @@ SIGNATURES = {
                                            _c_f32p, _c_f32p] + [_int] * 7 + [_vp, _vp, _sz, _vp]),
     "golf_biquad_frames_ola_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 9
                                        + [_vp, _sz, _vp]),
+    "golf_rc2lpc_fwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
+    "golf_rc2lpc_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
     "golf_glottal_osc_workspace_bytes": (_sz, [_int] * 7),
     "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
                                         _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _i64,

@@ -1,0 +1,127 @@
+// Frame-rate control transform of the LPC filters: logits -> reflection coefficients -> direct-form
+// coefficients.  Replaces, for tensors on the GPU, the reference's
+//     rc2lpc(tanh(logits) * max_abs_value)          models/filters.py:91-97, models/utils.py:581-593
+// which is a Python loop of M-1 Levinson step-up iterations, each a cat / flip / mul / add on (B,F,n) tensors: ~100
+// tiny dependent kernels, measured 270 us as a hipGraph and 620 us eager for the GOLF decoder's controls at B=32 --
+// three to seven times the whole synthesis step they feed.  Here: one thread per frame, the polynomial in LDS
+// (column per lane, conflict-free), 253 FMAs per frame; the backward re-runs the step-up to the stage it needs and
+// applies the adjoint of one iteration at a time (M^3/6 FMAs per frame, still nothing).
+#include "common.h"
+
+namespace golf {
+
+constexpr int RC_THREADS = 64;
+constexpr int RC_MAX_ORDER = 64;
+
+// poly (length n+1, poly[0] = 1) -> poly of stage n+1 in place:  new[i] = ext[i] + k * ext[n+1-i],  ext = [poly, 0]
+__device__ __forceinline__ void step_up(float* p, int stride, int n, float k) {
+    // pairs (i, n+1-i) are updated together so that the update is in place
+    const int len = n + 2;
+    p[(n + 1) * stride] = 0.f;
+    for (int i = 0; i < len / 2; ++i) {
+        const float u = p[i * stride], v = p[(n + 1 - i) * stride];
+        p[i * stride] = fmaf(k, v, u);
+        p[(n + 1 - i) * stride] = fmaf(k, u, v);
+    }
+    if (len & 1) {  // the middle element pairs with itself
+        const int m = len / 2;
+        const float u = p[m * stride];
+        p[m * stride] = fmaf(k, u, u);
+    }
+}
+
+__global__ __launch_bounds__(RC_THREADS) void rc2lpc_fwd_kernel(const float* __restrict__ logits, float* __restrict__ a,
+                                                                int64_t N, int M, float max_abs, int apply_tanh) {
+    extern __shared__ float smem[];   // [M+1][RC_THREADS]
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + lane;
+    if (row >= N) return;
+    float* p = smem + lane;
+    const float* lg = logits + row * M;
+    auto refl = [&](int i) { return apply_tanh ? tanhf(lg[i]) * max_abs : lg[i]; };
+    p[0] = 1.f;
+    p[RC_THREADS] = refl(0);
+    for (int n = 1; n < M; ++n) step_up(p, RC_THREADS, n, refl(n));
+    float* out = a + row * M;
+    for (int i = 0; i < M; ++i) out[i] = p[(i + 1) * RC_THREADS];
+}
+
+// g_logits from g_a.  For n = M-1 .. 1: rebuild poly_{n} (the input of iteration n), then
+//   g_k_n = sum_i g_new[i] * ext[n+1-i];   g_ext[i] = g_new[i] + k_n * g_new[n+1-i];   g_poly = g_ext[0..n]
+__global__ __launch_bounds__(RC_THREADS) void rc2lpc_bwd_kernel(const float* __restrict__ logits,
+                                                                const float* __restrict__ g_a,
+                                                                float* __restrict__ g_logits, int64_t N, int M,
+                                                                float max_abs, int apply_tanh) {
+    extern __shared__ float smem[];   // poly [M+1][T], grad [M+1][T], refl [M][T]
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + lane;
+    if (row >= N) return;
+    float* p = smem + lane;
+    float* g = smem + (size_t)(M + 1) * RC_THREADS + lane;
+    float* k = smem + (size_t)2 * (M + 1) * RC_THREADS + lane;
+    const float* lg = logits + row * M;
+    for (int i = 0; i < M; ++i) k[i * RC_THREADS] = apply_tanh ? tanhf(lg[i]) * max_abs : lg[i];
+    const float* ga = g_a + row * M;
+    g[0] = 0.f;                       // poly[0] = 1 is a constant
+    for (int i = 0; i < M; ++i) g[(i + 1) * RC_THREADS] = ga[i];
+    float* gl = g_logits + row * M;
+    for (int n = M - 1; n >= 1; --n) {
+        // poly of stage n (length n+1): re-run the step-up from the start
+        p[0] = 1.f;
+        p[RC_THREADS] = k[0];
+        for (int j = 1; j < n; ++j) step_up(p, RC_THREADS, j, k[j * RC_THREADS]);
+        p[(n + 1) * RC_THREADS] = 0.f;                       // ext = [poly, 0]
+        const float kn = k[n * RC_THREADS];
+        float gk = 0.f;
+        for (int i = 0; i <= n + 1; ++i) gk = fmaf(g[i * RC_THREADS], p[(n + 1 - i) * RC_THREADS], gk);
+        // g_ext[i] = g_new[i] + kn * g_new[n+1-i], in place over pairs
+        const int len = n + 2;
+        for (int i = 0; i < len / 2; ++i) {
+            const float u = g[i * RC_THREADS], v = g[(n + 1 - i) * RC_THREADS];
+            g[i * RC_THREADS] = fmaf(kn, v, u);
+            g[(n + 1 - i) * RC_THREADS] = fmaf(kn, u, v);
+        }
+        if (len & 1) {
+            const int m = len / 2;
+            const float u = g[m * RC_THREADS];
+            g[m * RC_THREADS] = fmaf(kn, u, u);
+        }
+        // g_ext[n+1] belongs to the appended zero: dropped
+        const float d = apply_tanh ? max_abs * (1.f - (kn / max_abs) * (kn / max_abs)) : 1.f;
+        gl[n] = gk * d;
+    }
+    const float k0 = k[0];
+    gl[0] = g[RC_THREADS] * (apply_tanh ? max_abs * (1.f - (k0 / max_abs) * (k0 / max_abs)) : 1.f);
+}
+
+static int rc_check(const char* who, const void* x, const void* y, int64_t N, int M, float max_abs) {
+    if (!x || !y) return fail(GOLF_EINVAL, "%s: null pointer", who);
+    if (N < 1 || M < 1 || M > RC_MAX_ORDER) return fail(GOLF_EINVAL, "%s: bad size (N=%lld, order %d, max %d)", who, (long long)N, M, RC_MAX_ORDER);
+    if (!(max_abs > 0.f)) return fail(GOLF_EINVAL, "%s: max_abs must be positive", who);
+    return GOLF_OK;
+}
+
+}  // namespace golf
+
+using namespace golf;
+
+extern "C" int golf_rc2lpc_fwd_f32(const float* logits, float* a, int64_t N, int M, float max_abs, int apply_tanh,
+                                   void* stream) {
+    if (int rc = rc_check("rc2lpc_fwd", logits, a, N, M, max_abs)) return rc;
+    const size_t lds = sizeof(float) * (size_t)(M + 1) * RC_THREADS;
+    hipLaunchKernelGGL(rc2lpc_fwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS), lds,
+                       (hipStream_t)stream, logits, a, N, M, max_abs, apply_tanh);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_rc2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits, int64_t N, int M,
+                                   float max_abs, int apply_tanh, void* stream) {
+    if (int rc = rc_check("rc2lpc_bwd", logits, g_a, N, M, max_abs)) return rc;
+    if (!g_logits) return fail(GOLF_EINVAL, "rc2lpc_bwd: null pointer");
+    const size_t lds = sizeof(float) * (size_t)(3 * M + 2) * RC_THREADS;
+    hipLaunchKernelGGL(rc2lpc_bwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS), lds,
+                       (hipStream_t)stream, logits, g_a, g_logits, N, M, max_abs, apply_tanh);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}

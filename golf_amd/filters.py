@@ -60,7 +60,9 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
             num_logits = lpc_order
         elif lpc_parameterisation == "rc2lpc":
             def logits2lpc(logits: Tensor) -> Tensor:
-                return rc2lpc(torch.tanh(logits) * max_abs_value)
+                if logits.is_cuda and logits.shape[-1] <= 64:   # one fused kernel instead of ~100 tiny ones
+                    return GF.rc2lpc_logits(logits, max_abs_value)
+                return rc2lpc(torch.tanh(logits) * max_abs_value)   # host-side protocol logic (CPU tensors)
 
             num_logits = lpc_order
         elif lpc_parameterisation == "lsp2lpc":

@@ -258,6 +258,47 @@ def lti_frames_ola(ex, gain, a, window, hop: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# control transform of the LPC filters: logits -> direct-form coefficients (reference models/utils.py:581-593)
+# ------------------------------------------------------------------------------------------------
+class _RC2LPC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, max_abs, apply_tanh):
+        _lib.require_device(logits)
+        lib = _lib.load()
+        x = logits.float().contiguous()
+        M = x.shape[-1]
+        N = x.numel() // M
+        a = torch.empty_like(x)
+        _lib.check(lib.golf_rc2lpc_fwd_f32(x.data_ptr(), a.data_ptr(), N, M, float(max_abs), int(apply_tanh),
+                                           _lib.stream_ptr()), "golf_rc2lpc_fwd_f32")
+        ctx.cfg = (float(max_abs), int(apply_tanh))
+        ctx.save_for_backward(x)
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        (x,) = ctx.saved_tensors
+        max_abs, apply_tanh = ctx.cfg
+        lib = _lib.load()
+        M = x.shape[-1]
+        g = g_a.float().contiguous()
+        out = torch.empty_like(x)
+        _lib.check(lib.golf_rc2lpc_bwd_f32(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel() // M, M, max_abs,
+                                           apply_tanh, _lib.stream_ptr()), "golf_rc2lpc_bwd_f32")
+        return out, None, None
+
+
+def rc2lpc_logits(logits: torch.Tensor, max_abs: float = 1.0) -> torch.Tensor:
+    """``rc2lpc(tanh(logits) * max_abs)`` (..., M) -> (..., M) as ONE kernel (forward and backward)."""
+    return _RC2LPC.apply(logits, float(max_abs), True)
+
+
+def rc2lpc(rc: torch.Tensor) -> torch.Tensor:
+    """Levinson step-up of given reflection coefficients (..., M) -> a_1..a_M, one kernel, differentiable."""
+    return _RC2LPC.apply(rc, 1.0, False)
+
+
+# ------------------------------------------------------------------------------------------------
 def osc_lengths(Tp: int, phase_hop: int, os: int):
     """(N oversampled length, Tout)."""
     P = phase_hop * os

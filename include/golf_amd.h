@@ -155,6 +155,18 @@ int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const flo
                                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a-2: control transform of the LPC filters, logits -> direct-form coefficients.
+ * Replaces rc2lpc(tanh(logits) * max_abs_value), models/filters.py:91-97 + models/utils.py:581-593 (a Python loop of
+ * M-1 Levinson step-up iterations A_n = [A_{n-1}, 0] + k_n * flip([A_{n-1}, 0]), ~100 tiny kernels) by one kernel.
+ *   logits (N, M) with N = B*F frames, contiguous;  a (N, M) = a_1..a_M;  M <= 64;
+ *   apply_tanh != 0: k = tanh(logits) * max_abs;  0: k = logits (reflection coefficients given directly).
+ * Backward: g_logits (N, M) from g_a (N, M) (the adjoint of the step-up, through the tanh when apply_tanh). */
+int golf_rc2lpc_fwd_f32(const float* logits, float* a, int64_t N, int M, float max_abs, int apply_tanh,
+                        void* stream);
+int golf_rc2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits, int64_t N, int M, float max_abs,
+                        int apply_tanh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a-8/a-9: indexed glottal-flow wavetable oscillator.
  * Replaces IndexedGlottalFlowTable.forward, models/synth.py:213-263 (table blend, phase/oversampling,
  * linear upsample, fp32 cumsum, %1, GlottalFlowTable.generate = F.grid_sample bilinear

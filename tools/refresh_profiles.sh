@@ -16,6 +16,7 @@ b --workload golf-ss-decoder --no-cpu-baseline > $O/bench_decoder.json
 b --workload golf-ss-decoder-train --no-cpu-baseline --steps 100 > $O/bench_decoder_train.json
 b --batch 256 --no-cpu-baseline --steps 50 > $O/bench_b256.json
 b --workload ddsp-decoder --no-cpu-baseline > $O/bench_ddsp_decoder.json
+b --workload golf-ss-decoder-logits --no-cpu-baseline > $O/bench_decoder_logits.json
 b --fp64-transitions --no-cpu-baseline > $O/bench_fp64_transitions.json
 b --workload golf-ss-train-step --batch 64 --steps 20 --warmup 5 > $O/bench_train_step.json
 python tools/train_step_profile.py 64 > $O/train_step_profile.json 2>/dev/null
