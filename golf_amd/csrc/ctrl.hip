@@ -94,6 +94,102 @@ __global__ __launch_bounds__(RC_THREADS) void rc2lpc_bwd_kernel(const float* __r
     gl[0] = g[RC_THREADS] * (apply_tanh ? max_abs * (1.f - (k0 / max_abs) * (k0 / max_abs)) : 1.f);
 }
 
+// Register versions for orders up to 32: the polynomial lives in MP+1 registers and every loop is unrolled (orders below
+// MP are padded with k = 0, which leaves the polynomial unchanged).  The LDS version above is latency-bound on its ~1000
+// dependent LDS accesses per frame (14 us for 6400 frames of order 22); this one is ~300 straight-line FMAs.
+template <int MP>
+__device__ __forceinline__ void step_up_reg(float (&p)[MP + 1], int n, float k) {   // n compile-time after unrolling
+#pragma unroll
+    for (int i = 0; i < MP / 2 + 1; ++i) {
+        const int j = n + 1 - i;
+        if (i < j) {
+            const float u = p[i], v = j <= n ? p[j] : 0.f;
+            p[i] = fmaf(k, v, u);
+            p[j] = fmaf(k, u, v);
+        } else if (i == j) {
+            p[i] = fmaf(k, p[i], p[i]);
+        }
+    }
+}
+
+template <int MP>
+__global__ __launch_bounds__(RC_THREADS) void rc2lpc_fwd_reg_kernel(const float* __restrict__ logits,
+                                                                    float* __restrict__ a, int64_t N, int M,
+                                                                    float max_abs, int apply_tanh) {
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + threadIdx.x;
+    if (row >= N) return;
+    const float* lg = logits + row * M;
+    float k[MP], p[MP + 1];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const float v = i < M ? lg[i] : 0.f;
+        k[i] = apply_tanh ? tanhf(v) * max_abs : v;
+    }
+    p[0] = 1.f;
+    p[1] = k[0];
+#pragma unroll
+    for (int i = 2; i <= MP; ++i) p[i] = 0.f;
+#pragma unroll
+    for (int n = 1; n < MP; ++n) step_up_reg<MP>(p, n, k[n]);
+    float* out = a + row * M;
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+        if (i < M) out[i] = p[i + 1];
+}
+
+template <int MP>
+__global__ __launch_bounds__(RC_THREADS) void rc2lpc_bwd_reg_kernel(const float* __restrict__ logits,
+                                                                    const float* __restrict__ g_a,
+                                                                    float* __restrict__ g_logits, int64_t N, int M,
+                                                                    float max_abs, int apply_tanh) {
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + threadIdx.x;
+    if (row >= N) return;
+    const float* lg = logits + row * M;
+    const float* ga = g_a + row * M;
+    float k[MP], g[MP + 1], gk[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const float v = i < M ? lg[i] : 0.f;
+        k[i] = apply_tanh ? tanhf(v) * max_abs : v;
+        g[i + 1] = i < M ? ga[i] : 0.f;
+    }
+    g[0] = 0.f;
+#pragma unroll
+    for (int n = MP - 1; n >= 1; --n) {
+        float p[MP + 1];   // poly of stage n, rebuilt
+        p[0] = 1.f;
+        p[1] = k[0];
+#pragma unroll
+        for (int i = 2; i <= MP; ++i) p[i] = 0.f;
+#pragma unroll
+        for (int j = 1; j < n; ++j) step_up_reg<MP>(p, j, k[j]);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 1; i <= n + 1; ++i) acc = fmaf(g[i], p[n + 1 - i], acc);   // ext[n+1] = 0 kills the i = 0 term
+        gk[n] = acc;
+        const float kn = k[n];
+#pragma unroll
+        for (int i = 0; i < MP / 2 + 1; ++i) {
+            const int j = n + 1 - i;
+            if (i < j) {
+                const float u = g[i], v = g[j];
+                g[i] = fmaf(kn, v, u);
+                g[j] = fmaf(kn, u, v);
+            } else if (i == j) {
+                g[i] = fmaf(kn, g[i], g[i]);
+            }
+        }
+    }
+    gk[0] = g[1];
+    float* gl = g_logits + row * M;
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+        if (i < M) {
+            const float t = k[i] / max_abs;
+            gl[i] = gk[i] * (apply_tanh ? max_abs * (1.f - t * t) : 1.f);
+        }
+}
+
 static int rc_check(const char* who, const void* x, const void* y, int64_t N, int M, float max_abs) {
     if (!x || !y) return fail(GOLF_EINVAL, "%s: null pointer", who);
     if (N < 1 || M < 1 || M > RC_MAX_ORDER) return fail(GOLF_EINVAL, "%s: bad size (N=%lld, order %d, max %d)", who, (long long)N, M, RC_MAX_ORDER);
@@ -108,9 +204,19 @@ using namespace golf;
 extern "C" int golf_rc2lpc_fwd_f32(const float* logits, float* a, int64_t N, int M, float max_abs, int apply_tanh,
                                    void* stream) {
     if (int rc = rc_check("rc2lpc_fwd", logits, a, N, M, max_abs)) return rc;
-    const size_t lds = sizeof(float) * (size_t)(M + 1) * RC_THREADS;
-    hipLaunchKernelGGL(rc2lpc_fwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS), lds,
-                       (hipStream_t)stream, logits, a, N, M, max_abs, apply_tanh);
+    const dim3 grid((unsigned)ceil_div(N, RC_THREADS)), block(RC_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 8)
+        hipLaunchKernelGGL(rc2lpc_fwd_reg_kernel<8>, grid, block, 0, st, logits, a, N, M, max_abs, apply_tanh);
+    else if (M <= 16)
+        hipLaunchKernelGGL(rc2lpc_fwd_reg_kernel<16>, grid, block, 0, st, logits, a, N, M, max_abs, apply_tanh);
+    else if (M <= 24)
+        hipLaunchKernelGGL(rc2lpc_fwd_reg_kernel<24>, grid, block, 0, st, logits, a, N, M, max_abs, apply_tanh);
+    else if (M <= 32)
+        hipLaunchKernelGGL(rc2lpc_fwd_reg_kernel<32>, grid, block, 0, st, logits, a, N, M, max_abs, apply_tanh);
+    else
+        hipLaunchKernelGGL(rc2lpc_fwd_kernel, grid, block, sizeof(float) * (size_t)(M + 1) * RC_THREADS, st, logits, a,
+                           N, M, max_abs, apply_tanh);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -119,9 +225,17 @@ extern "C" int golf_rc2lpc_bwd_f32(const float* logits, const float* g_a, float*
                                    float max_abs, int apply_tanh, void* stream) {
     if (int rc = rc_check("rc2lpc_bwd", logits, g_a, N, M, max_abs)) return rc;
     if (!g_logits) return fail(GOLF_EINVAL, "rc2lpc_bwd: null pointer");
-    const size_t lds = sizeof(float) * (size_t)(3 * M + 2) * RC_THREADS;
-    hipLaunchKernelGGL(rc2lpc_bwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS), lds,
-                       (hipStream_t)stream, logits, g_a, g_logits, N, M, max_abs, apply_tanh);
+    const dim3 grid((unsigned)ceil_div(N, RC_THREADS)), block(RC_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 8)
+        hipLaunchKernelGGL(rc2lpc_bwd_reg_kernel<8>, grid, block, 0, st, logits, g_a, g_logits, N, M, max_abs, apply_tanh);
+    else if (M <= 16)
+        hipLaunchKernelGGL(rc2lpc_bwd_reg_kernel<16>, grid, block, 0, st, logits, g_a, g_logits, N, M, max_abs, apply_tanh);
+    else if (M <= 24)
+        hipLaunchKernelGGL(rc2lpc_bwd_reg_kernel<24>, grid, block, 0, st, logits, g_a, g_logits, N, M, max_abs, apply_tanh);
+    else
+        hipLaunchKernelGGL(rc2lpc_bwd_kernel, grid, block, sizeof(float) * (size_t)(3 * M + 2) * RC_THREADS, st, logits,
+                           g_a, g_logits, N, M, max_abs, apply_tanh);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -32,3 +32,5 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 n = sum(e.count for e in prof.key_averages()); tt = sum(e.device_time_total for e in prof.key_averages())
 print("kernels per call:", n/10, "device us per call:", tt/10)
+for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:16]:
+    print("%7.1f us x%4.1f  %s" % (e.device_time_total / 10, e.count / 10, e.key[:100]))
