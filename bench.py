@@ -200,7 +200,7 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
             from golf_amd.ae import data_parallel
 
             model = data_parallel(model, device_ids=[phase.device.index])
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)   # same update, one kernel per parameter group
         f0 = phase * SR
         f0[:, : SR // 5] = 0  # an unvoiced stretch (driven at a random frequency, ltng/ae.py:97-101)
         ph = torch.cumsum(phase.double(), 1)

@@ -7,7 +7,8 @@ LayerNorm -> out_linear.  Stock PyTorch (MIOpen convolutions / LSTM, rocFFT).  M
 reference's, so its checkpoints load: ``spectrogram.window``, ``cnns.{0,1,4,5,...}``, ``lstm.*``, ``norm.*``,
 ``out_linear.*``, ``log_spec_min``, ``log_spec_max``.
 
-One deliberate difference: the running extrema of the log spectrogram are updated ON THE DEVICE
+Two deliberate differences: the convolution stack is kept in channels-last memory format (layout only), and the
+running extrema of the log spectrogram are updated ON THE DEVICE
 (``torch.minimum`` into the buffers) — the reference reads them back with ``.item()`` every training step
 (models/unet.py:207-209), a host sync per step that would also break hipGraph capture.  Values are identical.
 """
@@ -41,7 +42,9 @@ class UNetEncoder(BackboneModelInterface):
             stages += [nn.Conv2d(c_in, c_out, (2 * s + 1, 3), padding=(s, 1)), nn.BatchNorm2d(c_out), nn.ReLU(),
                        nn.MaxPool2d((s, 1), stride=(s, 1))]
             c_in = c_out
-        self.cnns = nn.Sequential(*stages)
+        # NHWC weights: MIOpen's fp32 implicit-GEMM convolutions are NHWC kernels; with NCHW tensors it transposes around
+        # every call (measured on the config-5 step, B=64: 68.0 -> 60.4 ms).  Shapes, values and state_dict are unchanged.
+        self.cnns = nn.Sequential(*stages).to(memory_format=torch.channels_last)
         flat = (n_fft // 2 + 1) // reduce(lambda p, q: p * q, strides) * c_in
         self.lstm = nn.LSTM(flat + (1 if f0_conditioning else 0), lstm_hidden_size, batch_first=True,
                             bidirectional=True, **lstm_kwargs)
