@@ -71,7 +71,9 @@ def load_yaml(path_or_text: str) -> dict:
 
     import yaml
 
-    if "\n" not in path_or_text and os.path.exists(path_or_text):
+    if "\n" not in path_or_text:
+        if not os.path.exists(path_or_text):
+            raise FileNotFoundError(f"golf_amd.config: no such config file: {path_or_text}")
         with open(path_or_text) as f:
             return _interpolate(yaml.safe_load(f))
     return _interpolate(yaml.safe_load(path_or_text))

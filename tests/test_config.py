@@ -276,3 +276,23 @@ def test_yaml_built_ismir23_glottal_decoder_vs_oracle():
     emax, el2 = rel_err(y, ref)
     print("ISMIR'23 glottal_d decoder vs oracle", emax, el2)
     assert emax < 1e-4 and el2 < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["golf-ff", "golf-ss"])
+def test_rtf_harness_on_one_clip(which):
+    """BASELINE configs[0] — the reference's test_rtf.py protocol (one 2 s clip, f0 at hop sr // 200 so that the
+    oscillator gets its phase at hop 120, analysis then synthesis, drop fastest/slowest) on a model built from YAML."""
+    from golf_amd.rtf import run
+
+    from golf_amd.config import load_yaml
+
+    cfg = load_yaml(MODEL)
+    if which == "golf-ss":
+        cfg["model"]["init_args"]["decoder"]["init_args"]["end_filter"] = {
+            "class_path": "models.filters.LTVMinimumPhaseFilterPrecise",
+            "init_args": {"lpc_order": 22, "lpc_parameterisation": "rc2lpc"}}
+    r = run(cfg, num=5, duration=2.0)
+    print(which, {k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
+    assert r["duration"] == 2.0 and 47000 < r["samples_out"] <= 48000
+    assert 0 < r["synthesis_rtf"] < 0.05 and 0 < r["analysis_rtf"] < 0.5   # far below real time on an MI355X
