@@ -25,27 +25,43 @@ def DUMMY_SPLIT_TRSFM(split_sizes, trsfm_fns):
     return split_sizes, trsfm_fns
 
 
-def wrap_ctrl_fn(split_size: Tuple[int, ...] = (), trsfm_fn: TRSFM_TYPE = lambda *x: ()):
-    """Build a ``.ctrl`` closure: appends (split_size, trsfm_fn) and defers to the continuation."""
+class _CtrlStep:
+    """One link of the fold.  ``step(next_fn)`` is a function of the (split sizes, transforms) gathered so far that
+    appends this module's pair and hands the longer tuples to ``next_fn`` — the calling convention the reference's
+    modules use, so links of both code bases chain."""
 
-    def ctrl_fn(next_fn):
-        def split_and_trsfm(split_sizes, trsfm_fns):
-            return next_fn(tuple(split_sizes) + (split_size,), tuple(trsfm_fns) + (trsfm_fn,))
+    __slots__ = ("split_size", "trsfm_fn")
 
-        return split_and_trsfm
+    def __init__(self, split_size: Tuple[int, ...], trsfm_fn: TRSFM_TYPE):
+        self.split_size = tuple(split_size)
+        self.trsfm_fn = trsfm_fn
 
-    return ctrl_fn
+    def __call__(self, next_fn):
+        mine = (self.split_size, self.trsfm_fn)
+        return lambda sizes, fns: next_fn((*sizes, mine[0]), (*fns, mine[1]))
+
+
+def _no_params(*_):
+    return ()
+
+
+def wrap_ctrl_fn(split_size: Tuple[int, ...] = (), trsfm_fn: TRSFM_TYPE = _no_params):
+    """The ``.ctrl`` attribute of a module that consumes ``split_size`` encoder channels (one tensor per entry) and
+    turns them into its parameters with ``trsfm_fn``."""
+    return _CtrlStep(split_size, trsfm_fn)
 
 
 def default_ctrl_fn(next_fn):
     """A module that consumes no channels (reference models/ctrl.py:20-29)."""
-    return wrap_ctrl_fn()(next_fn)
+    return _CtrlStep((), _no_params)(next_fn)
 
 
 class Controllable(torch.nn.Module):
+    """Base of every DSP module: consumes nothing unless it overrides ``ctrl``."""
+
     def __init__(self):
         super().__init__()
-        self.ctrl = wrap_ctrl_fn()
+        self.ctrl = _CtrlStep((), _no_params)
 
 
 class PassThrough(Controllable):
@@ -56,10 +72,10 @@ class PassThrough(Controllable):
 class Synth(torch.nn.Module):
     @property
     def split_sizes_and_trsfms(self):
-        children = [(name, m) for name, m in self.named_children() if isinstance(m, Controllable)]
-        fn = DUMMY_SPLIT_TRSFM
-        for _, m in reversed(children):  # innermost continuation = last child
-            fn = m.ctrl(fn)
-        split_sizes, trsfm_fns = fn((), ())
-        keys = tuple(name + "_params" for name, _ in children)
-        return split_sizes, trsfm_fns, keys
+        """(split_sizes, trsfm_fns, arg_keys) of the Controllable children, in attribute-assignment order."""
+        links = [(name, module.ctrl) for name, module in self.named_children() if isinstance(module, Controllable)]
+        chain = DUMMY_SPLIT_TRSFM
+        for _, link in links[::-1]:   # built back to front: the first child's link runs first
+            chain = link(chain)
+        sizes, fns = chain((), ())
+        return sizes, fns, tuple(f"{name}_params" for name, _ in links)
