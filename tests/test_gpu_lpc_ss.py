@@ -241,3 +241,41 @@ def test_reverse_grads_full_size():
         print("reverse full", what, emax, el2)
         assert emax < 2e-5 and el2 < 2e-5
     assert np.all(gy[:, 47761:] == 0)
+
+
+def test_random_shape_sweep():
+    """40 random shapes (batch, frames, order, hop, ragged excitation length) through both forward paths — the fused
+    transition + zero-state launch picks its grid from the shape and the device's CU count — and through the backward."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(20240928)
+    hops = [8, 16, 24, 32, 40, 48, 64, 80, 120, 128, 240, 256]
+    worst = 0.0
+    for case in range(40):
+        hop = int(rng.choice(hops))
+        widths = [w for w in (8, 16, 24, 32, 40) if hop % w == 0]
+        max_m = {8: 6, 16: 14, 24: 22, 32: 30, 40: 38}[max(widths)]
+        M = int(rng.integers(1, max_m + 1))
+        B = int(rng.integers(1, 6))
+        F = int(rng.integers(2, max(3, 2000 // hop)))
+        full = (F - 1) * hop + 1
+        Tx = int(rng.integers(max(1, full - 2 * hop), full + hop))     # shorter and longer than the parameter span
+        ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=case)
+        ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+        for fast in (True, False):
+            y = run_fwd(ex, gain, a, hop, fast=fast)
+            assert y.shape == ref.shape, (case, y.shape, ref.shape)
+            emax, el2 = rel_err(y, ref)
+            worst = max(worst, emax)
+            assert emax <= TOL and el2 <= TOL, (case, B, F, M, hop, Tx, fast, emax, el2)
+        if case % 4 == 0:   # gradients on every fourth shape
+            gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+            t = [dev(v).requires_grad_(True) for v in (ex, gain, a)]
+            (GF.ltv_allpole_ss(t[0], t[1], t[2], hop) * dev(gy)).sum().backward()
+            refs = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+            for name, got, want in zip(("g_ex", "g_gain", "g_a"), t, refs):
+                g = got.grad.cpu().numpy()
+                emax, el2 = rel_err(g[:, : want.shape[1]] if name == "g_ex" else g, want)
+                assert emax <= 2e-4 and el2 <= 2e-4, (case, name, B, F, M, hop, Tx, emax, el2)
+    print("random sweep worst forward rel-max", worst)
