@@ -175,3 +175,36 @@ def test_fused_addend_module_truncates_like_audiotensor_addition():
     fused = m(phase, w, add=nz)
     assert fused.hop_length == 1 and fused.shape == sep.shape == (2, 900)
     assert torch.equal(fused.as_tensor(), sep.as_tensor())
+
+
+def test_random_configuration_sweep():
+    """30 random oscillator configurations — oversampling 1..4, phase hops incl. non-powers of two, table lengths that
+    are and are not powers of two, table counts, ragged control grids — i.e. every render / decimate variant the
+    launcher can pick, against the float64 oracle."""
+    from golf_amd.synth import Decimate
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for case in range(30):
+        os_ = int(rng.choice([1, 2, 3, 4]))
+        ph_hop = int(rng.choice([1, 1, 1, 2, 3, 5, 16, 120]))
+        Tp = int(rng.integers(3, 2500 // ph_hop + 4))
+        L = int(rng.choice([64, 100, 256, 2048]))
+        n_tab = int(rng.integers(2, 12))
+        w_hop = int(rng.choice([ph_hop * k for k in (1, 2, 7, 20, 200)]))
+        B = int(rng.integers(1, 4))
+        eq = bool(rng.integers(0, 2))
+        f0 = rng.uniform(80, 400, (B, 1)) * (1 + 0.03 * np.sin(2 * np.pi * 5.5 * np.arange(Tp) * ph_hop / 24000))
+        phase = (f0 / 24000).astype(np.float32)
+        Fw = (Tp - 1) * ph_hop // w_hop + 2
+        w = rng.uniform(0, 1, (B, Fw)).astype(np.float32)
+        table = rng.normal(0, 1, (n_tab, L)).astype(np.float32)
+        taps = Decimate(os_).taps.numpy() if os_ > 1 else None
+        ref = O.indexed_glottal_forward(phase, ph_hop, w, w_hop, table, os_, eq, decim_taps=taps)
+        out = osc(phase, ph_hop, w, w_hop, table, os_, eq, taps)
+        assert out.shape == ref["out"].shape, (case, out.shape, ref["out"].shape)
+        emax, el2 = rel_err(out, ref["out"])
+        worst = max(worst, emax)
+        assert emax <= 1e-4 and el2 <= 1e-4, (case, B, Tp, ph_hop, w_hop, os_, L, n_tab, eq, emax, el2)
+    print("random oscillator sweep worst rel-max", worst)
