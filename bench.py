@@ -354,7 +354,7 @@ def main():
     # ---- execution mode: S independent batches in flight.  The serial phases of the filter occupy a few dozen
     # waves for tens of microseconds (the boundary scan: B waves), so one batch leaves most of the chip idle;
     # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
-    # (9 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
+    # (8 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
     S = max(1, args.streams)
     use_graphs = not args.no_graphs  # training steps (forward + custom backward) are captured whole, like inference
     graphs, outs = [], []
