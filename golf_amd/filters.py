@@ -17,7 +17,7 @@ from .audiotensor import AudioTensor
 from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
 
-__all__ = ["FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
+__all__ = ["LTVCepFilter", "FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
            "LTVZeroPhaseFIRFilter", "LTVZeroPhaseFIRFilterPrecise", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter",
            "convert2samplewise"]
 
@@ -225,6 +225,57 @@ class LTIAcousticFilter(FilterInterface):
     @property
     def impulse_response(self) -> Tensor:
         return torch.cat([self.kernel, torch.ones(1, device=self.kernel.device)]).flip(0)
+
+
+class LTVCepFilter(LTVFilterInterface):
+    """Cepstral harmonic filter of the NHV baseline (reference models/filters.py:559-623; cfg/ae/decoder/nhv.yaml):
+    ``filter_order + 1`` cepstral coefficients per frame -> log-magnitude response (even extension + FFT) -> zero- or
+    minimum-phase frequency response (the minimum phase is minus the Hilbert transform of the log magnitude) -> applied
+    in the STFT domain (two-sided STFT with ``window``, multiply, inverse STFT).
+
+    Stock PyTorch on rocFFT: a frequency-domain baseline filter, not part of the GOLF path; here so that the shipped NHV
+    decoder builds and runs on this package.  The reference takes the transforms from torchaudio (third party); the same
+    torch.stft / torch.istft calls are made directly."""
+
+    def __init__(self, filter_order: int, n_fft: int, window: str, hop_length: int, phase: str = "zero", **kwargs):
+        super().__init__()
+        if n_fft % 2 or phase not in ("zero", "min"):
+            raise ValueError("LTVCepFilter: n_fft must be even and phase 'zero' or 'min'")
+        # saved configs spell out the transform defaults (ckpts/interspeech24/nhv/config.yaml); anything else is refused
+        defaults = {"win_length": None, "pad": 0, "normalized": False, "wkwargs": None, "pad_mode": "reflect"}
+        odd = {k: v for k, v in kwargs.items() if k not in defaults or (v != defaults[k] and not (k == "win_length" and v == n_fft))}
+        if odd:
+            raise NotImplementedError(f"LTVCepFilter: unsupported transform arguments {odd}")
+        self.n_fft, self.filter_order, self.hop_length, self.phase = n_fft, filter_order, hop_length, phase
+        self.register_buffer("_window", get_window_fn(window)(n_fft).float(), persistent=False)
+        self.ctrl = wrap_ctrl_fn(split_size=(filter_order + 1,), trsfm_fn=lambda x: (x,))
+
+    def frequency_response(self, ceps: Tensor) -> Tensor:
+        """(B, F, order + 1) cepstra -> (B, n_fft, F) complex (or real, phase 'zero') two-sided response."""
+        n = self.n_fft
+        half = torch.nn.functional.pad(ceps, (0, n // 2 - self.filter_order))          # c_0 .. c_{n/2}
+        sym = torch.cat([half, half[..., 1:-1].flip(-1)], dim=-1)                       # even extension, length n
+        log_mag = torch.fft.fft(sym, dim=-1).real
+        if self.phase == "zero":
+            return torch.exp(log_mag).transpose(-1, -2)
+        # analytic signal of the log magnitude along frequency: its imaginary part is the Hilbert transform
+        weights = log_mag.new_zeros(n)
+        weights[0] = weights[n // 2] = 1
+        weights[1: n // 2] = 2
+        analytic = torch.fft.ifft(torch.fft.fft(log_mag, dim=-1) * weights, dim=-1)
+        return torch.exp(torch.complex(log_mag, -analytic.imag)).transpose(-1, -2)
+
+    def forward(self, ex: AudioTensor, ceps: AudioTensor, **kwargs) -> AudioTensor:
+        assert ceps.hop_length == self.hop_length
+        x = ex.as_tensor()
+        H = self.frequency_response(ceps.as_tensor())
+        X = torch.stft(x, self.n_fft, self.hop_length, self.n_fft, self._window, center=True, pad_mode="reflect",
+                       normalized=False, onesided=False, return_complex=True)
+        frames = min(X.shape[-1], H.shape[-1])
+        Y = X[..., :frames] * H[..., :frames]
+        y = torch.istft(Y, self.n_fft, self.hop_length, self.n_fft, self._window, center=True, normalized=False,
+                        onesided=False, return_complex=False)
+        return AudioTensor(y)
 
 
 def convert2samplewise(config: dict) -> dict:

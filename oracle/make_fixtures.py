@@ -18,8 +18,8 @@ provide them:
 * ``torchaudio.functional.lfilter``       := scipy.signal.lfilter per row (float64, independent witness).
 * ``kazane.Decimate``                     := recorder: stores its input (the pre-decimation signal),
   returns x[..., ::q].  kazane's taps are unknown => decimation parity is unpinned.
-* ``torchaudio.transforms.Spectrogram``   := |torch.stft|^power with torchaudio's documented arguments and defaults
-  (only g20 — encoder / loss — ever calls it).
+* ``torchaudio.transforms.Spectrogram`` / ``InverseSpectrogram`` := torch.stft / torch.istft with torchaudio's
+  documented arguments and defaults (only g20 — encoder / loss — and g21 — cepstral filter — ever call them).
 * ``torch_fftconv``, ``diffsptk``, ``pyworld`` := inert placeholders
   (only needed so that ``import models.filters`` succeeds; never on the measured path).
 
@@ -94,23 +94,44 @@ class _Dummy(nn.Module):
 
 class Spectrogram(nn.Module):
     """torchaudio.transforms.Spectrogram as documented: win_length = n_fft, hop = win_length // 2, periodic Hann,
-    power 2, centre-padded by reflection, one-sided, unnormalised; ``window`` is a registered buffer."""
+    power 2 (None: complex STFT), centre-padded by reflection, unnormalised; ``window`` is a registered buffer."""
 
     def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, window_fn=torch.hann_window, power=2.0,
                  normalized=False, wkwargs=None, center=True, pad_mode="reflect", onesided=True):
         super().__init__()
-        assert pad == 0 and not normalized and onesided
+        assert pad == 0 and not normalized
         self.n_fft = n_fft
         self.win_length = n_fft if win_length is None else win_length
         self.hop_length = self.win_length // 2 if hop_length is None else hop_length
-        self.power, self.center, self.pad_mode = power, center, pad_mode
+        self.power, self.center, self.pad_mode, self.onesided = power, center, pad_mode, onesided
         self.register_buffer("window", window_fn(self.win_length, **(wkwargs or {})))
 
     def forward(self, x):
         x = x.as_tensor() if hasattr(x, "as_tensor") else x
         z = torch.stft(x, self.n_fft, self.hop_length, self.win_length, self.window.to(x.dtype), center=self.center,
-                       pad_mode=self.pad_mode, normalized=False, onesided=True, return_complex=True)
+                       pad_mode=self.pad_mode, normalized=False, onesided=self.onesided, return_complex=True)
+        if self.power is None:
+            return z
         return z.abs() if self.power == 1 else z.abs().pow(self.power)
+
+
+class InverseSpectrogram(nn.Module):
+    """torchaudio.transforms.InverseSpectrogram as documented (torch.istft with the same window conventions)."""
+
+    def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, window_fn=torch.hann_window,
+                 normalized=False, wkwargs=None, center=True, pad_mode="reflect", onesided=True):
+        super().__init__()
+        assert pad == 0 and not normalized
+        self.n_fft = n_fft
+        self.win_length = n_fft if win_length is None else win_length
+        self.hop_length = self.win_length // 2 if hop_length is None else hop_length
+        self.center, self.onesided = center, onesided
+        self.register_buffer("window", window_fn(self.win_length, **(wkwargs or {})))
+
+    def forward(self, z, length=None):
+        return torch.istft(z, self.n_fft, self.hop_length, self.win_length, self.window.to(z.real.dtype),
+                           center=self.center, normalized=False, onesided=self.onesided, length=length,
+                           return_complex=False)
 
 
 class Decimate(nn.Module):
@@ -130,7 +151,7 @@ _mod("pyworld", dio=lambda *a, **k: None)
 _mod("torchlpc", sample_wise_lpc=sample_wise_lpc)
 _mod("torchaudio")
 _mod("torchaudio.functional", lfilter=lfilter, melscale_fbanks=lambda *a, **k: None)
-_mod("torchaudio.transforms", Spectrogram=Spectrogram, InverseSpectrogram=_Dummy)
+_mod("torchaudio.transforms", Spectrogram=Spectrogram, InverseSpectrogram=InverseSpectrogram)
 _mod("torch_fftconv")
 _mod("torch_fftconv.functional", fft_conv1d=torch.nn.functional.conv1d)
 _mod("diffsptk", MLSA=_Dummy, MelCepstralAnalysis=_Dummy, MelGeneralizedCepstrumToSpectrum=_Dummy,
@@ -608,4 +629,18 @@ val.backward()
 d.update(loss_pred=pred, loss_true=true, loss_value=val, loss_g_pred=pred.grad,
          loss_hops=np.array([l_.spec.hop_length for l_ in crit.losses]))
 save("g20_encoder_and_loss", **d)
+# ----------------------------------------------------------------------------- g21 cepstral filter of the NHV baseline
+# LTVCepFilter.forward (models/filters.py:559-623), both phase modes, with gradients (float64)
+d = {}
+for tag, phase_mode in (("zero", "zero"), ("min", "min")):
+    flt = rf.LTVCepFilter(filter_order=24, n_fft=128, window="hanning", hop_length=32, phase=phase_mode).double()
+    ex = torch.from_numpy(rng.normal(0, 1, (2, 640)).astype(np.float32)).double().requires_grad_(True)
+    ceps = torch.from_numpy((rng.normal(0, 0.2, (2, 21, 25)) / (1 + np.arange(25))).astype(np.float32)).double()
+    ceps.requires_grad_(True)
+    y = flt(AT(ex, 1), AT(ceps, 32)).as_tensor()
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+    (y * gy).sum().backward()
+    d.update({f"{tag}_ex": ex, f"{tag}_ceps": ceps, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_g_ex": ex.grad,
+              f"{tag}_g_ceps": ceps.grad})
+save("g21_cep_filter", **d)
 print("done")

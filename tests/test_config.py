@@ -122,7 +122,8 @@ REF = "/root/reference"
 GOLF_FILES = ["cfg/ae/decoder/golf.yaml", "cfg/ae/decoder/golf-precise.yaml", "cfg/ae/decoder/golf-v1.yaml",
               "cfg/ae/decoder/ddsp.yaml", "ckpts/interspeech24/golf-ss/config.yaml",
               "ckpts/interspeech24/golf-ff/config.yaml", "ckpts/interspeech24/golf-v1/config.yaml",
-              "ckpts/interspeech24/ddsp/config.yaml"] + [f"ckpts/ismir23/{m}_{v}/config.yaml"
+              "ckpts/interspeech24/ddsp/config.yaml", "cfg/ae/decoder/nhv.yaml",
+              "ckpts/interspeech24/nhv/config.yaml"] + [f"ckpts/ismir23/{m}_{v}/config.yaml"
                                                          for m in ("glottal_d", "ddsp", "pulse", "sawsing")
                                                          for v in ("f1", "m1")]
 ISMIR_SPLITS = {"glottal_d": ((64,), (), (1, 22), (1, 22), ()), "ddsp": ((1, 150), (), (), (80,), ()),
@@ -132,7 +133,7 @@ ISMIR_SPLITS = {"glottal_d": ((64,), (), (1, 22), (1, 22), ()), "ddsp": ((1, 150
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
 @pytest.mark.parametrize("rel", GOLF_FILES)
 def test_shipped_golf_configs_instantiate(rel):
-    """Every GOLF / DDSP config the reference ships builds unchanged (the MLSA / NHV / WORLD baselines need diffsptk
+    """Every GOLF / DDSP / NHV config the reference ships builds unchanged (the MLSA / WORLD baselines need diffsptk
     filters that are out of scope and raise NotImplementedError, see test_unknown_class_is_reported)."""
     from golf_amd.config import build_model
 
@@ -142,7 +143,7 @@ def test_shipped_golf_configs_instantiate(rel):
         assert dec.split_sizes_and_trsfms[0] == ISMIR_SPLITS[rel.split("/")[2].rsplit("_", 1)[0]]
         return
     total = sum(s for grp in dec.split_sizes_and_trsfms[0] for s in grp)
-    assert total == (412 if "ddsp" in rel else 343)
+    assert total == (412 if "ddsp" in rel else 497 if "nhv" in rel else 343)   # nhv: 241 cepstra + 256 magnitudes
     if hasattr(model, "encoder"):
         assert model.encoder.backbone.out_linear.out_features == total
 
@@ -296,3 +297,64 @@ def test_rtf_harness_on_one_clip(which):
     print(which, {k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()})
     assert r["duration"] == 2.0 and 47000 < r["samples_out"] <= 48000
     assert 0 < r["synthesis_rtf"] < 0.05 and 0 < r["analysis_rtf"] < 0.5   # far below real time on an MI355X
+
+
+@pytest.mark.parametrize("mode", ["zero", "min"])
+def test_cep_filter_matches_reference_g21(golden, mode):
+    """LTVCepFilter (the NHV baseline's harmonic filter, models/filters.py:559-623; stock PyTorch here as there) against
+    the reference's own run in float64: output and both gradients."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import LTVCepFilter
+
+    g = golden("g21_cep_filter")
+    flt = LTVCepFilter(filter_order=24, n_fft=128, window="hanning", hop_length=32, phase=mode).double()
+    ex = torch.from_numpy(g[f"{mode}_ex"]).requires_grad_(True)
+    ceps = torch.from_numpy(g[f"{mode}_ceps"]).requires_grad_(True)
+    y = flt(AudioTensor(ex), AudioTensor(ceps, 32)).as_tensor()
+    assert y.shape == g[f"{mode}_y"].shape
+    (y * torch.from_numpy(g[f"{mode}_gy"])).sum().backward()
+    for what, got, want in (("y", y.detach(), g[f"{mode}_y"]), ("g_ex", ex.grad, g[f"{mode}_g_ex"]),
+                            ("g_ceps", ceps.grad, g[f"{mode}_g_ceps"])):
+        emax, el2 = rel_err(got.numpy(), want)
+        print("g21", mode, what, emax, el2)
+        assert emax < 1e-9 and el2 < 1e-9
+
+
+@pytest.mark.gpu
+def test_nhv_decoder_runs_on_gpu():
+    """cfg/ae/decoder/nhv.yaml in this test's own YAML: additive pulse train (HIP) -> cepstral filter (rocFFT) + filtered
+    noise (HIP) -> room filter (HIP); the cepstral branch is checked against its float64 CPU evaluation."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.config import build_model
+
+    text = """
+decoder:
+  class_path: models.hpn.HarmonicPlusNoiseSynth
+  init_args:
+    harm_oscillator: {class_path: models.synth.AdditivePulseTrain, init_args: {num_harmonics: 155}}
+    noise_generator: {class_path: models.noise.StandardNormalNoise}
+    noise_filter: {class_path: models.filters.LTVZeroPhaseFIRFilter, init_args: {window: hanning, n_mag: 256}}
+    harm_filter:
+      class_path: models.filters.LTVCepFilter
+      init_args: {n_fft: 1024, window: "${decoder.init_args.noise_filter.init_args.window}", filter_order: 240,
+                  hop_length: 240, phase: min}
+    end_filter: {class_path: models.filters.LTIAcousticFilter, init_args: {length: 128, conv_method: fft}}
+"""
+    dec = build_model(text).cuda()
+    assert dec.split_sizes_and_trsfms[0] == ((), (), (241,), (256,), ())
+    B, T, F = 2, 12000, 51
+    gen = torch.Generator().manual_seed(8)
+    phase = AudioTensor((torch.rand(B, 1, generator=gen) * 0.01 + 0.004).expand(B, T).contiguous().cuda())
+    ceps = AudioTensor((torch.randn(B, F, 241, generator=gen) * 0.05 / (1 + torch.arange(241))).cuda(), 240)
+    lm = AudioTensor((torch.randn(B, F, 256, generator=gen) * 0.3 - 4).cuda(), 240)
+    y = dec(phase=phase, harm_oscillator_params=(), noise_generator_params=(), harm_filter_params=(ceps,),
+            noise_filter_params=(lm,)).as_tensor()
+    assert y.shape[0] == B and abs(y.shape[1] - T) <= 240 and torch.isfinite(y).all()
+    # the cepstral branch alone, GPU float32 vs CPU float64
+    src = dec.harm_oscillator(phase)
+    got = dec.harm_filter(src, ceps).as_tensor().cpu().numpy()
+    ref_filter = type(dec.harm_filter)(filter_order=240, n_fft=1024, window="hanning", hop_length=240, phase="min").double()
+    ref = ref_filter(AudioTensor(src.as_tensor().double().cpu()), AudioTensor(ceps.as_tensor().double().cpu(), 240))
+    emax, el2 = rel_err(got, ref.as_tensor().numpy())
+    print("nhv cepstral branch gpu vs cpu64", emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4
