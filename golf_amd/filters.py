@@ -17,7 +17,7 @@ from .audiotensor import AudioTensor
 from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
 
-__all__ = ["LTVCepFilter", "FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
+__all__ = ["LTVCepFilter", "DiffWorldSPFilter", "melscale_fbanks", "FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
            "LTVZeroPhaseFIRFilter", "LTVZeroPhaseFIRFilterPrecise", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter",
            "convert2samplewise"]
 
@@ -275,6 +275,48 @@ class LTVCepFilter(LTVFilterInterface):
         Y = X[..., :frames] * H[..., :frames]
         y = torch.istft(Y, self.n_fft, self.hop_length, self.n_fft, self._window, center=True, normalized=False,
                         onesided=False, return_complex=False)
+        return AudioTensor(y)
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int, norm=None,
+                    mel_scale: str = "htk") -> Tensor:
+    """Triangular mel filterbank (n_freqs, n_mels) — the published definition torchaudio.functional.melscale_fbanks
+    implements (third party, absent here): HTK mel scale m = 2595 log10(1 + f / 700), n_mels + 2 equally spaced mel
+    points, triangles between neighbouring points evaluated on linspace(0, sample_rate // 2, n_freqs)."""
+    if mel_scale != "htk" or norm is not None:
+        raise NotImplementedError("melscale_fbanks: only mel_scale='htk', norm=None (what the shipped configs use)")
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
+    to_mel = lambda f: 2595.0 * torch.log10(1.0 + torch.as_tensor(f, dtype=torch.float64) / 700.0)
+    pts = 700.0 * (10.0 ** (torch.linspace(float(to_mel(f_min)), float(to_mel(f_max)), n_mels + 2,
+                                           dtype=torch.float64) / 2595.0) - 1.0)
+    width = pts[1:] - pts[:-1]
+    slope = pts.unsqueeze(0) - freqs.unsqueeze(1)                       # (n_freqs, n_mels + 2)
+    rising, falling = -slope[:, :-2] / width[:-1], slope[:, 2:] / width[1:]
+    return torch.clamp(torch.minimum(rising, falling), min=0).float()
+
+
+class DiffWorldSPFilter(LTVFilterInterface):
+    """Spectral-envelope filter of the WORLD baseline (reference models/filters.py:717-760; cfg/ae/decoder/world.yaml): a
+    mel spectral envelope per frame -> linear magnitudes through the rectified pseudo-inverse of a mel filterbank ->
+    sqrt -> applied as a zero-phase gain in the STFT domain.  Stock PyTorch (rocFFT), like the reference."""
+
+    def __init__(self, n_mels: int, n_fft: int, hop_length: int, f_min: float, f_max: float, center: bool = True,
+                 window: str = "hanning", **kwargs):
+        super().__init__()
+        fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, **kwargs)
+        self.register_buffer("fb", torch.linalg.pinv(fb).relu(), persistent=False)      # (n_mels, n_fft // 2 + 1)
+        self.register_buffer("_window", get_window_fn(window)(n_fft).float(), persistent=False)
+        self.n_fft, self.hop_length, self.center = n_fft, hop_length, center
+        self.ctrl = wrap_ctrl_fn(split_size=(n_mels,), trsfm_fn=lambda x: (torch.exp(x),))
+
+    def forward(self, ex: AudioTensor, mel_sp: AudioTensor) -> AudioTensor:
+        assert mel_sp.hop_length == self.hop_length
+        gain = torch.sqrt(mel_sp.as_tensor() @ self.fb).transpose(1, 2)                  # (B, bins, F)
+        X = torch.stft(ex.as_tensor(), self.n_fft, self.hop_length, self.n_fft, self._window, center=self.center,
+                       pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        frames = min(X.shape[-1], gain.shape[-1])
+        y = torch.istft(X[..., :frames] * gain[..., :frames], self.n_fft, self.hop_length, self.n_fft, self._window,
+                        center=self.center, normalized=False, onesided=True, return_complex=False)
         return AudioTensor(y)
 
 

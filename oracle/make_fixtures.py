@@ -150,7 +150,20 @@ class Decimate(nn.Module):
 _mod("pyworld", dio=lambda *a, **k: None)
 _mod("torchlpc", sample_wise_lpc=sample_wise_lpc)
 _mod("torchaudio")
-_mod("torchaudio.functional", lfilter=lfilter, melscale_fbanks=lambda *a, **k: None)
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    """torchaudio.functional.melscale_fbanks as published (HTK scale, no normalisation): triangular filters between
+    n_mels + 2 points equally spaced in mel, on linspace(0, sample_rate // 2, n_freqs)."""
+    assert norm is None and mel_scale == "htk"
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    f_pts = 700.0 * (10.0 ** (np.linspace(mel(f_min), mel(f_max), n_mels + 2) / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
+    return torch.from_numpy(fb).float()
+
+
+_mod("torchaudio.functional", lfilter=lfilter, melscale_fbanks=melscale_fbanks)
 _mod("torchaudio.transforms", Spectrogram=Spectrogram, InverseSpectrogram=InverseSpectrogram)
 _mod("torch_fftconv")
 _mod("torch_fftconv.functional", fft_conv1d=torch.nn.functional.conv1d)
@@ -643,4 +656,18 @@ for tag, phase_mode in (("zero", "zero"), ("min", "min")):
     d.update({f"{tag}_ex": ex, f"{tag}_ceps": ceps, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_g_ex": ex.grad,
               f"{tag}_g_ceps": ceps.grad})
 save("g21_cep_filter", **d)
+# ----------------------------------------------------------------------------- g22 spectral-envelope filter (WORLD baseline)
+# DiffWorldSPFilter.forward (models/filters.py:717-760): the reference's glue (pinv().relu() of the filterbank, sqrt, STFT
+# gain); the filterbank itself comes from the restated torchaudio formula above.
+flt = rf.DiffWorldSPFilter(n_mels=12, n_fft=128, hop_length=32, f_min=0.0, f_max=4000.0, center=True, window="hanning",
+                           sample_rate=8000, norm=None, mel_scale="htk")
+ex = torch.from_numpy(rng.normal(0, 1, (2, 640)).astype(np.float32)).requires_grad_(True)
+logmel = torch.from_numpy(rng.normal(-1, 0.5, (2, 21, 12)).astype(np.float32)).requires_grad_(True)
+(split, trs) = flt.ctrl(lambda s_, t_: (s_, t_))((), ())
+(mel_sp,) = trs[0](AT(logmel, 32))
+y = flt(AT(ex, 1), mel_sp).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
+(y * gy).sum().backward()
+save("g22_world_sp_filter", ex=ex, logmel=logmel, y=y, gy=gy, g_ex=ex.grad, g_logmel=logmel.grad, inv_fb=flt.fb,
+     split=np.array(split[0]))
 print("done")

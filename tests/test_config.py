@@ -123,7 +123,8 @@ GOLF_FILES = ["cfg/ae/decoder/golf.yaml", "cfg/ae/decoder/golf-precise.yaml", "c
               "cfg/ae/decoder/ddsp.yaml", "ckpts/interspeech24/golf-ss/config.yaml",
               "ckpts/interspeech24/golf-ff/config.yaml", "ckpts/interspeech24/golf-v1/config.yaml",
               "ckpts/interspeech24/ddsp/config.yaml", "cfg/ae/decoder/nhv.yaml",
-              "ckpts/interspeech24/nhv/config.yaml"] + [f"ckpts/ismir23/{m}_{v}/config.yaml"
+              "ckpts/interspeech24/nhv/config.yaml", "cfg/ae/decoder/world.yaml",
+              "ckpts/interspeech24/world/config.yaml"] + [f"ckpts/ismir23/{m}_{v}/config.yaml"
                                                          for m in ("glottal_d", "ddsp", "pulse", "sawsing")
                                                          for v in ("f1", "m1")]
 ISMIR_SPLITS = {"glottal_d": ((64,), (), (1, 22), (1, 22), ()), "ddsp": ((1, 150), (), (), (80,), ()),
@@ -133,8 +134,8 @@ ISMIR_SPLITS = {"glottal_d": ((64,), (), (1, 22), (1, 22), ()), "ddsp": ((1, 150
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
 @pytest.mark.parametrize("rel", GOLF_FILES)
 def test_shipped_golf_configs_instantiate(rel):
-    """Every GOLF / DDSP / NHV config the reference ships builds unchanged (the MLSA / WORLD baselines need diffsptk
-    filters that are out of scope and raise NotImplementedError, see test_unknown_class_is_reported)."""
+    """Every GOLF / DDSP / NHV / WORLD config the reference ships builds unchanged (the MLSA baseline needs diffsptk's
+    MLSA filter, which is out of scope and raises NotImplementedError, see test_unknown_class_is_reported)."""
     from golf_amd.config import build_model
 
     model = build_model(os.path.join(REF, rel))
@@ -143,7 +144,8 @@ def test_shipped_golf_configs_instantiate(rel):
         assert dec.split_sizes_and_trsfms[0] == ISMIR_SPLITS[rel.split("/")[2].rsplit("_", 1)[0]]
         return
     total = sum(s for grp in dec.split_sizes_and_trsfms[0] for s in grp)
-    assert total == (412 if "ddsp" in rel else 497 if "nhv" in rel else 343)   # nhv: 241 cepstra + 256 magnitudes
+    # nhv: 241 cepstra + 256 magnitudes; world: 256 magnitudes + 80 mel bands
+    assert total == (412 if "ddsp" in rel else 497 if "nhv" in rel else 336 if "world" in rel else 343)
     if hasattr(model, "encoder"):
         assert model.encoder.backbone.out_linear.out_features == total
 
@@ -358,3 +360,29 @@ decoder:
     emax, el2 = rel_err(got, ref.as_tensor().numpy())
     print("nhv cepstral branch gpu vs cpu64", emax, el2)
     assert emax < 1e-4 and el2 < 1e-4
+
+
+def test_world_sp_filter_matches_reference_g22(golden):
+    """DiffWorldSPFilter (WORLD baseline, models/filters.py:717-760) against the reference's own run: the rectified
+    pseudo-inverse filterbank, the output and both gradients (float32 like the reference)."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.filters import DiffWorldSPFilter
+
+    g = golden("g22_world_sp_filter")
+    flt = DiffWorldSPFilter(n_mels=12, n_fft=128, hop_length=32, f_min=0.0, f_max=4000.0, center=True, window="hanning",
+                            sample_rate=8000, norm=None, mel_scale="htk")
+    np.testing.assert_allclose(flt.fb.numpy(), g["inv_fb"], rtol=1e-4, atol=1e-5)
+    (split, trs) = flt.ctrl(lambda s_, t_: (s_, t_))((), ())
+    assert tuple(split[0]) == tuple(g["split"])
+    ex = torch.from_numpy(g["ex"]).requires_grad_(True)
+    logmel = torch.from_numpy(g["logmel"]).requires_grad_(True)
+    (mel_sp,) = trs[0](AudioTensor(logmel, 32))
+    y = flt(AudioTensor(ex), mel_sp).as_tensor()
+    (y * torch.from_numpy(g["gy"])).sum().backward()
+    for what, got, want in (("y", y.detach(), g["y"]), ("g_ex", ex.grad, g["g_ex"])):
+        emax, el2 = rel_err(got.numpy(), want)
+        print("g22", what, emax, el2)
+        assert emax < 2e-5 and el2 < 2e-5
+    # the reference's own gradient w.r.t. the envelope is NaN here: relu(pinv(fb)) leaves frequency bins with zero
+    # gain and d sqrt(0) is infinite.  Same formula, same NaNs — reproduced, not "fixed".
+    assert np.isnan(g["g_logmel"]).all() and torch.isnan(logmel.grad).all()
