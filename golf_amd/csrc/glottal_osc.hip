@@ -127,6 +127,47 @@ __global__ __launch_bounds__(256) void osc_phase_tile_kernel(const float* __rest
     if (tid == 255) Ttot[(size_t)b * ntile + tile] = run;
 }
 
+// Long inputs (more than 256 tiles = 262144 coarse phase samples, e.g. > 10.9 s of audio with a per-sample phase): the
+// consumers keep the tile prefix in a 256-entry LDS array, so for longer inputs the prefix is folded into Cloc itself --
+// Ttot becomes its own exclusive prefix, every Cloc[j] gets its tile's offset added, Ttot is cleared -- and the
+// consumers' LDS prefix is all zeros (they clamp the tile index).  Two light extra passes, only on this path.
+__global__ __launch_bounds__(64) void osc_long_prefix_kernel(u64* __restrict__ Ttot, int ntile) {
+    u64* t = Ttot + (size_t)blockIdx.x * ntile;
+    const int lane = threadIdx.x;
+    u64 carry = 0;
+    for (int base = 0; base < ntile; base += 64) {
+        const int i = base + lane;
+        const u64 v = i < ntile ? t[i] : 0;
+        const u64 incl = wave_incl_scan(v, lane);
+        if (i < ntile) t[i] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+}
+__global__ void osc_long_add_kernel(u64* __restrict__ Cloc, const u64* __restrict__ Toff, int Tp, int ntile, int B) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * Tp) return;
+    const int b = (int)(idx / Tp), j = (int)(idx - (int64_t)b * Tp);
+    Cloc[idx] += Toff[(size_t)b * ntile + j / OSC_SCAN_TILE];
+}
+
+// phase tile scan of every utterance (+ the long-input passes): Cloc, Ttot as every consumer expects them
+static int launch_phase_tiles(const float* phase, int64_t phase_stride, u64* Cw, u64* Ttot, int Tp, int P, int os,
+                              int ntile, int B, hipStream_t st) {
+    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp, P, os,
+                       ntile);
+    GOLF_LAUNCH_CHECK();
+    if (ntile > 256) {
+        hipLaunchKernelGGL(osc_long_prefix_kernel, dim3(B), dim3(64), 0, st, Ttot, ntile);
+        GOLF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(osc_long_add_kernel, dim3((unsigned)ceil_div((int64_t)B * Tp, 256)), dim3(256), 0, st, Cw,
+                           (const u64*)Ttot, Tp, ntile, B);
+        GOLF_LAUNCH_CHECK();
+        hipError_t e = hipMemsetAsync(Ttot, 0, sizeof(u64) * (size_t)B * ntile, st);
+        if (e != hipSuccess) return fail((int)e, "phase scan: memset failed: %s", hipGetErrorString(e));
+    }
+    return GOLF_OK;
+}
+
 // ---- O2 ---------------------------------------------------------------------------------------
 // MODE 0: forward render (writes fine samples);  MODE 1: backward w.r.t. table_select_weight
 // (reduces g_pre * d(pre)/d(p_row) over the interval into part[b][interval][2]).
@@ -226,7 +267,7 @@ __global__ __launch_bounds__(OSC_RENDER_THREADS) void osc_render_kernel(
         const float d = (p1 - p0) * inv_P;
         u64 inc = osc_fix_a(p0, scale_a);
         const u64 dinc = osc_fix_d(p0, p1, scale_d);
-        u64 ph = cb[jc] + toff[jc / OSC_SCAN_TILE];
+        u64 ph = cb[jc] + toff[min(jc / OSC_SCAN_TILE, 255)];   // > 256 tiles: prefix already in cb, toff = 0
         const int mb = jc * P;
         float o4[PT > 0 ? PT : 1];
         const int pcount = PT > 0 ? PT : P;
@@ -558,7 +599,7 @@ __device__ __forceinline__ HarmSample harm_sample(const float* __restrict__ pb, 
     const float p0 = pb[jc], p1 = pb[jn];
     const u64 a = osc_fix_a(p0, scale_a), d = osc_fix_d(p0, p1, scale_d);
     HarmSample r;
-    r.Phi = cb[jc] + toff[jc / OSC_SCAN_TILE] + (u64)(k + 1) * a + d * ((u64)k * (u64)(k + 1) / 2);
+    r.Phi = cb[jc] + toff[min(jc / OSC_SCAN_TILE, 255)] + (u64)(k + 1) * a + d * ((u64)k * (u64)(k + 1) / 2);
     r.p = fmaf((float)k, (p1 - p0) / (float)P, p0);
     return r;
 }
@@ -766,7 +807,6 @@ static int harm_check(const char* who, const float* phase, int B, int Tp, int ph
     if (amp) expect = std::min(expect, amp_hop > 1 ? (Fa - 1) * amp_hop + 1 : Fa);
     if (tscale) expect = std::min(expect, ts_hop > 1 ? (Fs - 1) * ts_hop + 1 : Fs);
     if (Tout != expect) return fail(GOLF_EINVAL, "%s: Tout=%d, expected %d", who, Tout, expect);
-    if (g.ntile > 256) return fail(GOLF_EUNSUPPORTED, "%s: Tp=%d > 262144 coarse phase samples", who, Tp);
     if (amp && (size_t)(g.nrows + 1) * H * sizeof(float) > 60 * 1024)
         return fail(GOLF_EUNSUPPORTED, "%s: amplitude hop %d too fine for %d harmonics (LDS staging); pass amplitudes "
                     "at a coarser hop or fold them into tscale/hscale", who, amp_hop, H);
@@ -801,13 +841,10 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     if (!ws || ws_bytes < g.total || ((uintptr_t)ws & 255))
         return fail(GOLF_EWORKSPACE, "glottal_osc_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
-    if (g.ntile > 256) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: Tp=%d > 262144 coarse phase samples", Tp);
     hipStream_t st = (hipStream_t)stream;
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
-    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
-                       g.P, os, g.ntile);
-    GOLF_LAUNCH_CHECK();
+    if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, os, g.ntile, B, st)) return rc;
     float* fine = os > 1 ? (pre ? pre : (float*)((char*)ws + g.off_pre)) : out;
     // the internal oversampled buffer uses a row stride that is a multiple of 4 floats (16-byte stores / loads); a
     // caller-provided `pre` is dense (B, N)
@@ -932,9 +969,7 @@ extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_strid
     hipStream_t st = (hipStream_t)stream;
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
-    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
-                       g.P, 1, g.ntile);
-    GOLF_LAUNCH_CHECK();
+    if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, 1, g.ntile, B, st)) return rc;
     const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H);
     hipLaunchKernelGGL(harm_kernel, dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
                        phase, phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, amp, amp ? Fa : 1,
@@ -961,9 +996,7 @@ extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_s
     u64* Cw = (u64*)((char*)ws + g.off_cw);   // recomputed: the backward does not rely on the forward's scratch
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     float* part = (float*)((char*)ws + g.off_part);
-    hipLaunchKernelGGL(osc_phase_tile_kernel, dim3(g.ntile, B), dim3(256), 0, st, phase, phase_stride, Cw, Ttot, Tp,
-                       g.P, 1, g.ntile);
-    GOLF_LAUNCH_CHECK();
+    if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, 1, g.ntile, B, st)) return rc;
     const int nseg = Fa > 1 ? Fa - 1 : 1;
     hipLaunchKernelGGL(harm_bwd_kernel, dim3((unsigned)nseg, B), dim3(64), 0, st, phase, phase_stride, (const u64*)Cw,
                        (const u64*)Ttot, g.ntile, Tp, g.P, Fa, amp_hop, tscale, Fs, ts_hop, hscale, H, g_out,

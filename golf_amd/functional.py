@@ -72,7 +72,12 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
 def _rows(t: torch.Tensor) -> torch.Tensor:
     """2-D tensor with unit inner stride (row stride may exceed the width)."""
     assert t.ndim == 2
-    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+    if t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    if t.shape[0] == 1 and t.stride(1) == 1:
+        # a single row may carry any row stride (0 after numpy's [None]) and still count as contiguous
+        return t.as_strided(t.shape, (t.shape[1], 1))
+    return t.contiguous()
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:

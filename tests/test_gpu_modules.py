@@ -288,3 +288,30 @@ def test_replay_pipeline_matches_eager():
         outs.append(s.output.clone())
     for v, y in zip(variants, outs):
         assert torch.equal(y, fn(v))
+
+
+def test_long_utterance_decoder_vs_oracle():
+    """One 12.5 s utterance through the whole golf-precise decoder (293 phase-scan tiles, 1250 LPC chunks) against the
+    float64 oracle: nothing in the path is sized for 2 s clips."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synthetic import make_decoder, make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=1, T=300_000, device="cuda", with_noise_filter=True)
+    dec = make_decoder(noise_filter=True, room_filter=True, injected_noise=inp["noise"]).cuda()
+    with torch.no_grad():
+        dec.room_filter.kernel.copy_(inp["room_kernel"])
+    y = dec(phase=AudioTensor(inp["phase"]), harm_oscillator_params=(AudioTensor(inp["wsel"], inp["w_hop"]),),
+            noise_generator_params=(), noise_filter_params=(AudioTensor(inp["log_mag"], 240),),
+            end_filter_params=(AudioTensor(inp["gain"], 240), AudioTensor(inp["a"], 240))).as_tensor()
+    c = lambda k: inp[k].double().cpu().numpy()
+    osc = dec.harm_oscillator
+    win = torch.hann_window(510, dtype=torch.float64).numpy()
+    _, ref = O.golf_ss_decoder(c("phase"), 1, c("wsel"), inp["w_hop"], osc.table.double().cpu().numpy(), c("noise"),
+                               c("log_mag"), win, c("gain"), c("a"), 240,
+                               room_kernel=inp["room_kernel"].double().cpu().numpy(), oversampling=4,
+                               equal_energy=True, decim_taps=osc.decimater.kernel.double().cpu().numpy().ravel())
+    assert y.shape == ref.shape
+    emax, el2 = rel_err(y.detach().cpu().numpy(), ref)
+    print("12.5 s decoder", y.shape, emax, el2)
+    assert emax < 1e-4 and el2 < 1e-4

@@ -208,3 +208,44 @@ def test_random_configuration_sweep():
         worst = max(worst, emax)
         assert emax <= 1e-4 and el2 <= 1e-4, (case, B, Tp, ph_hop, w_hop, os_, L, n_tab, eq, emax, el2)
     print("random oscillator sweep worst rel-max", worst)
+
+
+def test_long_input_beyond_256_tiles():
+    """12.5 s with a per-sample phase = 300 000 coarse phase samples = 293 scan tiles: more than the 256-entry LDS tile
+    prefix of the render / harmonic kernels holds, so the prefix is folded into the per-sample array by two extra passes.
+    Forward (wavetable and harmonic oscillators) against the float64 oracle, and the table-selection gradient against the
+    same computation split in two halves is not possible (phase accumulates) — so against a float64 finite difference."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(5)
+    B, Tp, w_hop = 1, 300_000, 2400
+    t = np.arange(Tp) / 24000
+    phase = ((170 + 40 * np.sin(2 * np.pi * 0.3 * t)) / 24000).astype(np.float32)[None]
+    w = rng.uniform(0, 1, (B, Tp // w_hop + 2)).astype(np.float32)
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=True)
+    table, taps = m.table.numpy(), m.decimater.taps.numpy()
+    ref = O.indexed_glottal_forward(phase, 1, w, w_hop, table, 4, True, decim_taps=taps)["out"]
+    out = osc(phase, 1, w, w_hop, table, 4, True, taps)
+    assert out.shape == ref.shape == (1, Tp)
+    check(out, ref, "long wavetable oscillator (293 tiles)")
+    check(out[:, -48000:], ref[:, -48000:], "  its last 2 s (phase accumulated over 12.5 s)")
+    # harmonic bank on the same phase track
+    amps = rng.uniform(0, 1, (B, Tp // 240 + 1, 8)).astype(np.float32)
+    href = O.harmonic_oscillator_forward(phase, 1, amps, 240)
+    hout = GF.harmonic_osc(dev(phase), 8, 1, dev(amps), 240).cpu().numpy()
+    assert hout.shape == href.shape
+    check(hout, href, "long harmonic oscillator", 2e-4)
+    # gradient w.r.t. the table selection on the long input: finite difference of the oracle on two control points
+    wt = dev(w).requires_grad_(True)
+    gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+    (GF.glottal_osc(dev(phase), wt, dev(table), dev(taps), 1, w_hop, 4, True) * dev(gy)).sum().backward()
+    got = wt.grad.cpu().numpy()
+    f = lambda ww: (O.indexed_glottal_forward(phase, 1, ww, w_hop, table, 4, True, decim_taps=taps)["out"] * gy).sum()
+    for k in (3, 120):
+        wp, wm = w.astype(np.float64).copy(), w.astype(np.float64).copy()
+        wp[0, k] += 1e-4
+        wm[0, k] -= 1e-4
+        fd = (f(wp) - f(wm)) / 2e-4
+        assert abs(got[0, k] - fd) <= 5e-3 * max(1.0, abs(fd)), (k, got[0, k], fd)
