@@ -195,3 +195,39 @@ def test_precise_vs_oracle(B, T, F, n_mag, hop):
     rgx, rglm = O.ltv_fir_precise_backward(gy, ex, lm, win, hop)
     check(gx, rgx, "precise g_ex", 2e-5)
     check(glm, rglm, "precise g_log_mag", 2e-5)
+
+
+def test_random_shape_sweep():
+    """30 random shapes of the zero-phase FIR noise filter (bins, hop, frames, excitation length, batch): forward and
+    both gradients against the float64 oracle."""
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(404)
+    worst = 0.0
+    done = 0
+    for trial in range(40):
+        n_mag = int(rng.choice([5, 9, 17, 33, 65, 129, 256, 257]))
+        hop = int(rng.choice([4, 8, 24, 60, 240, 256]))
+        B = int(rng.integers(1, 4))
+        F = int(rng.integers(2, 25))
+        N = 2 * (n_mag - 1)
+        T = int(rng.integers(max(N, hop) + 1, (F + 2) * hop + N))
+        ex, lm = case(B, T, F, n_mag, seed=1000 + trial)
+        win = np_window("hanning", N)
+        try:
+            ref = O.ltv_fir_frames_forward(ex, O.zero_phase_fir_kernels(lm, win), hop)
+        except (AssertionError, ValueError):
+            continue                                  # a shape the reference's unfold rejects
+        if ref.shape[1] == 0:
+            continue
+        gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+        y, gx, glm = run_module(ex, lm, hop, gy=gy)
+        assert y.shape == ref.shape, (trial, y.shape, ref.shape)
+        rgx, rglm = O.ltv_fir_frames_backward(gy, ex, lm, win, hop)
+        for what, got, want, tol in (("y", y, ref, 1e-5), ("g_ex", gx, rgx, 3e-5), ("g_log_mag", glm, rglm, 3e-5)):
+            emax, el2 = rel_err(got, want)
+            worst = max(worst, emax)
+            assert emax <= tol and el2 <= tol, (trial, what, B, T, F, n_mag, hop, emax, el2)
+        done += 1
+    print("random FIR sweep:", done, "shapes, worst rel-max", worst)
+    assert done >= 20
