@@ -85,3 +85,40 @@ def test_vs_oracle(B, Tp, ph, Fa, ah, H):
     check(y.detach().cpu().numpy(), ref, f"harmonic fwd B{B} Tp{Tp} H{H}", 2e-5)
     rga = O.harmonic_oscillator_backward_amp(gy, phase, ph, amp.shape, ah)
     check(a.grad.cpu().numpy(), rga, "harmonic g_amp", 2e-5)
+
+
+def test_random_shape_sweep():
+    """25 random harmonic-bank shapes (harmonic count incl. non-multiples of the 32-harmonic anchor block, phase and
+    amplitude hops, very high voices that the Nyquist mask cuts to a few harmonics): forward + amplitude gradient."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(99)
+    worst = 0.0
+    for trial in range(25):
+        H = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 100, 155]))
+        ph = int(rng.choice([1, 1, 2, 5, 60]))
+        ah = int(rng.choice([k for k in (8, 16, 64, 120, 240) if k % ph == 0 or ph == 1] or [ph * 4]))
+        if ah % ph:
+            ah = ph * 4
+        B = int(rng.integers(1, 4))
+        Tp = int(rng.integers(3, 3000 // ph + 4))
+        n_out = (Tp - 1) * ph + 1
+        Fa = n_out // ah + 2
+        f0 = rng.uniform(60, 4000, (B, 1)) * (1 + 0.02 * np.sin(np.linspace(0, 9, Tp))[None])
+        phase = (f0 / 24000).astype(np.float32)
+        amp = (rng.uniform(0, 1, (B, Fa, H)) / np.arange(1, H + 1)).astype(np.float32)
+        ref = O.harmonic_oscillator_forward(phase, ph, amp, ah)
+        gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+        a = dev(amp, True)
+        y = GF.harmonic_osc(dev(phase), H, ph, a, ah)
+        assert tuple(y.shape) == ref.shape, (trial, y.shape, ref.shape)
+        (y * dev(gy)).sum().backward()
+        emax, el2 = rel_err(y.detach().cpu().numpy(), ref)
+        # samples whose (float32) harmonic frequency sits exactly at Nyquist may flip the mask: tolerate by max-norm
+        assert emax <= 2e-4 and el2 <= 2e-4, (trial, B, Tp, ph, ah, H, emax, el2)
+        worst = max(worst, emax)
+        gref = O.harmonic_oscillator_backward_amp(gy, phase, ph, amp.shape, ah)
+        gmax, gl2 = rel_err(a.grad.cpu().numpy(), gref)
+        assert gmax <= 3e-4 and gl2 <= 3e-4, (trial, "g_amp", B, Tp, ph, ah, H, gmax, gl2)
+    print("random harmonic sweep worst forward rel-max", worst)
