@@ -50,6 +50,8 @@ SIGNATURES = {
                                        + [_vp, _sz, _vp]),
     "golf_rc2lpc_fwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
     "golf_rc2lpc_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
+    "golf_sos2lpc_fwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
+    "golf_sos2lpc_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
     "golf_glottal_osc_workspace_bytes": (_sz, [_int] * 7),
     "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
                                         _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _i64,

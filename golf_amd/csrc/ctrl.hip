@@ -190,6 +190,118 @@ __global__ __launch_bounds__(RC_THREADS) void rc2lpc_bwd_reg_kernel(const float*
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Biquad parameterisations of the ISMIR'23 configs ("coef", "conj", "real"; models/utils.py:487-525) followed by the
+// product of the K second-order sections into direct form (biquads2lpc / coeff_product, models/utils.py:444-484: a tree
+// of grouped conv1d calls).  In PyTorch ops that is 112 kernels, 630 us eager / 243 us as a hipGraph for ONE filter at
+// B=32 -- and the ISMIR GOLF decoder has two.  One thread per frame, polynomial in LDS.
+//   rep 0 "coef": a1 = 2 rho tanh(l0);            a2 = ((2 - |a1|) rho tanh(l1) + |a1|) / 2
+//   rep 1 "conj": r = rho sigmoid(l0);            a1 = -2 r tanh(l1);   a2 = r^2
+//   rep 2 "real": z = rho tanh(l);                a1 = -(z0 + z1);      a2 = z0 z1
+struct Sos { float a1, a2; };
+__device__ __forceinline__ Sos sos_from_logits(float l0, float l1, float rho, int rep) {
+    Sos s;
+    if (rep == 0) {
+        s.a1 = 2.f * rho * tanhf(l0);
+        const float m = fabsf(s.a1);
+        s.a2 = 0.5f * ((2.f - m) * tanhf(l1) * rho + m);
+    } else if (rep == 1) {
+        const float r = rho / (1.f + expf(-l0));
+        s.a1 = -2.f * r * tanhf(l1);
+        s.a2 = r * r;
+    } else {
+        const float z0 = rho * tanhf(l0), z1 = rho * tanhf(l1);
+        s.a1 = -(z0 + z1);
+        s.a2 = z0 * z1;
+    }
+    return s;
+}
+// (g_a1, g_a2) -> (g_l0, g_l1)
+__device__ __forceinline__ void sos_backward(float l0, float l1, float rho, int rep, float g1, float g2, float& gl0,
+                                             float& gl1) {
+    if (rep == 0) {
+        const float t0 = tanhf(l0), t1 = tanhf(l1);
+        const float a1 = 2.f * rho * t0, m = fabsf(a1);
+        const float sgn = a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f);
+        const float da2_da1 = 0.5f * sgn * (1.f - t1 * rho);
+        gl0 = (g1 + g2 * da2_da1) * 2.f * rho * (1.f - t0 * t0);
+        gl1 = g2 * 0.5f * (2.f - m) * rho * (1.f - t1 * t1);
+    } else if (rep == 1) {
+        const float sg = 1.f / (1.f + expf(-l0)), r = rho * sg, t1 = tanhf(l1);
+        const float dr = rho * sg * (1.f - sg);
+        gl0 = (g1 * (-2.f * t1) + g2 * 2.f * r) * dr;
+        gl1 = g1 * (-2.f * r) * (1.f - t1 * t1);
+    } else {
+        const float t0 = tanhf(l0), t1 = tanhf(l1);
+        const float z0 = rho * t0, z1 = rho * t1;
+        gl0 = (-g1 + g2 * z1) * rho * (1.f - t0 * t0);
+        gl1 = (-g1 + g2 * z0) * rho * (1.f - t1 * t1);
+    }
+}
+// poly (length n+1) times (1 + a1 z^-1 + a2 z^-2), in place, length n+3
+__device__ __forceinline__ void mul_sos(float* p, int stride, int n, Sos s) {
+    p[(n + 1) * stride] = 0.f;
+    p[(n + 2) * stride] = 0.f;
+    for (int i = n + 2; i >= 1; --i) {
+        const float pm1 = p[(i - 1) * stride], pm2 = i >= 2 ? p[(i - 2) * stride] : 0.f;
+        p[i * stride] = fmaf(s.a2, pm2, fmaf(s.a1, pm1, p[i * stride]));
+    }
+}
+
+__global__ __launch_bounds__(RC_THREADS) void sos2lpc_fwd_kernel(const float* __restrict__ logits, float* __restrict__ a,
+                                                                 int64_t N, int K, float rho, int rep) {
+    extern __shared__ float smem[];   // [2K+1][RC_THREADS]
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + lane;
+    if (row >= N) return;
+    float* p = smem + lane;
+    const float* lg = logits + row * 2 * K;
+    p[0] = 1.f;
+    for (int k = 0; k < K; ++k) mul_sos(p, RC_THREADS, 2 * k, sos_from_logits(lg[2 * k], lg[2 * k + 1], rho, rep));
+    float* out = a + row * 2 * K;
+    for (int i = 0; i < 2 * K; ++i) out[i] = p[(i + 1) * RC_THREADS];
+}
+
+// Sections are applied in index order, so going backwards: rebuild the product of sections 0..k-1, take the two
+// correlations for (g_a1, g_a2), pull the gradient back through section k.
+__global__ __launch_bounds__(RC_THREADS) void sos2lpc_bwd_kernel(const float* __restrict__ logits,
+                                                                 const float* __restrict__ g_a,
+                                                                 float* __restrict__ g_logits, int64_t N, int K,
+                                                                 float rho, int rep) {
+    extern __shared__ float smem[];   // poly [2K+1][T], grad [2K+3][T]
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * RC_THREADS + lane;
+    if (row >= N) return;
+    const int M = 2 * K;
+    float* p = smem + lane;
+    float* g = smem + (size_t)(M + 1) * RC_THREADS + lane;
+    const float* lg = logits + row * M;
+    const float* ga = g_a + row * M;
+    g[0] = 0.f;
+    for (int i = 0; i < M; ++i) g[(i + 1) * RC_THREADS] = ga[i];
+    g[(M + 1) * RC_THREADS] = 0.f;
+    g[(M + 2) * RC_THREADS] = 0.f;
+    float* gl = g_logits + row * M;
+    for (int k = K - 1; k >= 0; --k) {
+        p[0] = 1.f;
+        for (int j = 0; j < k; ++j) mul_sos(p, RC_THREADS, 2 * j, sos_from_logits(lg[2 * j], lg[2 * j + 1], rho, rep));
+        const int n = 2 * k;                       // degree of the product so far; new poly has degree n + 2
+        const Sos s = sos_from_logits(lg[2 * k], lg[2 * k + 1], rho, rep);
+        float g1 = 0.f, g2 = 0.f;
+        for (int i = 1; i <= n + 2; ++i) {
+            if (i - 1 <= n) g1 = fmaf(g[i * RC_THREADS], p[(i - 1) * RC_THREADS], g1);
+            if (i >= 2) g2 = fmaf(g[i * RC_THREADS], p[(i - 2) * RC_THREADS], g2);
+        }
+        // g_prev[i] = g_new[i] + a1 g_new[i+1] + a2 g_new[i+2], ascending in place (reads run ahead of writes)
+        for (int i = 0; i <= n; ++i)
+            g[i * RC_THREADS] = fmaf(s.a2, g[(i + 2) * RC_THREADS], fmaf(s.a1, g[(i + 1) * RC_THREADS], g[i * RC_THREADS]));
+        float gl0, gl1;
+        sos_backward(lg[2 * k], lg[2 * k + 1], rho, rep, g1, g2, gl0, gl1);
+        gl[2 * k] = gl0;
+        gl[2 * k + 1] = gl1;
+    }
+}
+
 static int rc_check(const char* who, const void* x, const void* y, int64_t N, int M, float max_abs) {
     if (!x || !y) return fail(GOLF_EINVAL, "%s: null pointer", who);
     if (N < 1 || M < 1 || M > RC_MAX_ORDER) return fail(GOLF_EINVAL, "%s: bad size (N=%lld, order %d, max %d)", who, (long long)N, M, RC_MAX_ORDER);
@@ -236,6 +348,30 @@ extern "C" int golf_rc2lpc_bwd_f32(const float* logits, const float* g_a, float*
     else
         hipLaunchKernelGGL(rc2lpc_bwd_kernel, grid, block, sizeof(float) * (size_t)(3 * M + 2) * RC_THREADS, st, logits,
                            g_a, g_logits, N, M, max_abs, apply_tanh);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_sos2lpc_fwd_f32(const float* logits, float* a, int64_t N, int K, float max_abs_pole, int rep,
+                                    void* stream) {
+    if (!logits || !a) return fail(GOLF_EINVAL, "sos2lpc_fwd: null pointer");
+    if (N < 1 || K < 1 || 2 * K > RC_MAX_ORDER || rep < 0 || rep > 2 || !(max_abs_pole > 0.f))
+        return fail(GOLF_EINVAL, "sos2lpc_fwd: bad size / parameterisation (N=%lld K=%d rep=%d)", (long long)N, K, rep);
+    hipLaunchKernelGGL(sos2lpc_fwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS),
+                       sizeof(float) * (size_t)(2 * K + 1) * RC_THREADS, (hipStream_t)stream, logits, a, N, K,
+                       max_abs_pole, rep);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_sos2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits, int64_t N, int K,
+                                    float max_abs_pole, int rep, void* stream) {
+    if (!logits || !g_a || !g_logits) return fail(GOLF_EINVAL, "sos2lpc_bwd: null pointer");
+    if (N < 1 || K < 1 || 2 * K > RC_MAX_ORDER || rep < 0 || rep > 2 || !(max_abs_pole > 0.f))
+        return fail(GOLF_EINVAL, "sos2lpc_bwd: bad size / parameterisation (N=%lld K=%d rep=%d)", (long long)N, K, rep);
+    hipLaunchKernelGGL(sos2lpc_bwd_kernel, dim3((unsigned)ceil_div(N, RC_THREADS)), dim3(RC_THREADS),
+                       sizeof(float) * (size_t)(4 * K + 4) * RC_THREADS, (hipStream_t)stream, logits, g_a, g_logits, N, K,
+                       max_abs_pole, rep);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -55,6 +55,8 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
             to_biquads = get_logits2biquads(lpc_parameterisation, max_abs_value)
 
             def logits2lpc(logits: Tensor) -> Tensor:
+                if logits.is_cuda and logits.shape[-1] <= 64 and logits.shape[-1] % 2 == 0:   # one fused kernel
+                    return GF.biquad_logits2lpc(logits, lpc_parameterisation, max_abs_value)
                 return biquads2lpc(to_biquads(logits.view(logits.shape[0], logits.shape[1], -1, 2)))
 
             num_logits = lpc_order

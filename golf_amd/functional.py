@@ -303,6 +303,44 @@ def rc2lpc(rc: torch.Tensor) -> torch.Tensor:
     return _RC2LPC.apply(rc, 1.0, False)
 
 
+_SOS_REP = {"coef": 0, "conj": 1, "real": 2}
+
+
+class _SOS2LPC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, max_abs_pole, rep):
+        _lib.require_device(logits)
+        lib = _lib.load()
+        x = logits.float().contiguous()
+        M = x.shape[-1]
+        assert M % 2 == 0, "two logits per second-order section"
+        N = x.numel() // M
+        a = torch.empty_like(x)
+        _lib.check(lib.golf_sos2lpc_fwd_f32(x.data_ptr(), a.data_ptr(), N, M // 2, float(max_abs_pole), int(rep),
+                                            _lib.stream_ptr()), "golf_sos2lpc_fwd_f32")
+        ctx.cfg = (float(max_abs_pole), int(rep))
+        ctx.save_for_backward(x)
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        (x,) = ctx.saved_tensors
+        rho, rep = ctx.cfg
+        lib = _lib.load()
+        M = x.shape[-1]
+        g = g_a.float().contiguous()
+        out = torch.empty_like(x)
+        _lib.check(lib.golf_sos2lpc_bwd_f32(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel() // M, M // 2, rho, rep,
+                                            _lib.stream_ptr()), "golf_sos2lpc_bwd_f32")
+        return out, None, None
+
+
+def biquad_logits2lpc(logits: torch.Tensor, rep_type: str, max_abs_pole: float = 0.99) -> torch.Tensor:
+    """``biquads2lpc(get_logits2biquads(rep_type, max_abs_pole)(logits.view(..., K, 2)))`` (..., 2K) -> (..., 2K) as
+    ONE kernel, forward and backward."""
+    return _SOS2LPC.apply(logits, float(max_abs_pole), _SOS_REP[rep_type])
+
+
 # ------------------------------------------------------------------------------------------------
 def osc_lengths(Tp: int, phase_hop: int, os: int):
     """(N oversampled length, Tout)."""

@@ -166,6 +166,13 @@ int golf_rc2lpc_fwd_f32(const float* logits, float* a, int64_t N, int M, float m
 int golf_rc2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits, int64_t N, int M, float max_abs,
                         int apply_tanh, void* stream);
 
+/* The biquad parameterisations of the ISMIR'23 configs, logits (N, 2K) -> K second-order sections -> their product in
+ * direct form a (N, 2K).  Replaces get_logits2biquads(rep)(logits) + biquads2lpc, models/utils.py:487-525 and :444-484
+ * (models/filters.py:71-81), 112 kernels in PyTorch ops.  rep: 0 "coef", 1 "conj", 2 "real"; 2K <= 64. */
+int golf_sos2lpc_fwd_f32(const float* logits, float* a, int64_t N, int K, float max_abs_pole, int rep, void* stream);
+int golf_sos2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits, int64_t N, int K, float max_abs_pole,
+                         int rep, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a-8/a-9: indexed glottal-flow wavetable oscillator.
  * Replaces IndexedGlottalFlowTable.forward, models/synth.py:213-263 (table blend, phase/oversampling,

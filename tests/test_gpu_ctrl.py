@@ -80,3 +80,42 @@ def test_errors():
         GF.rc2lpc_logits(torch.zeros(2, 3, 65, device="cuda"))   # order above the kernel's limit
     with pytest.raises(_lib.GolfError):
         GF.rc2lpc_logits(torch.zeros(2, 3, 4))                     # CPU tensor: there is no CPU path in the library
+
+
+@pytest.mark.parametrize("rep", ["coef", "conj", "real"])
+@pytest.mark.parametrize("B,F,K", [(32, 200, 11), (2, 9, 1), (3, 17, 13), (1, 40, 32)])
+def test_biquad_parameterisations_vs_torch(rep, B, F, K):
+    """golf_sos2lpc_{fwd,bwd}_f32 (logits -> K biquads -> direct form, the ISMIR'23 parameterisations) against the
+    PyTorch restatement pinned by golden g2, in float64, values and gradients."""
+    from golf_amd import functional as GF
+    from golf_amd.utils import biquads2lpc, get_logits2biquads
+
+    gen = torch.Generator().manual_seed(K * 10 + len(rep))
+    logits = torch.randn(B, F, 2 * K, generator=gen) * 0.8
+    gy = torch.randn(B, F, 2 * K, generator=gen)
+    ref_in = logits.double().requires_grad_(True)
+    ref = biquads2lpc(get_logits2biquads(rep, 0.97)(ref_in.view(B, F, K, 2)))
+    (ref * gy.double()).sum().backward()
+    x = logits.cuda().requires_grad_(True)
+    a = GF.biquad_logits2lpc(x, rep, 0.97)
+    assert a.shape == (B, F, 2 * K)
+    (a * gy.cuda()).sum().backward()
+    emax, el2 = rel_err(a.detach().cpu().numpy(), ref.detach().numpy())
+    gmax, gl2 = rel_err(x.grad.cpu().numpy(), ref_in.grad.numpy())
+    print(f"sos2lpc {rep} B{B} F{F} K{K}: fwd {emax:.2e} {el2:.2e}  grad {gmax:.2e} {gl2:.2e}")
+    tol = 5e-5 if K > 16 else 5e-6          # a degree-64 product in fp32
+    assert emax < tol and el2 < tol and gmax < 10 * tol and gl2 < 10 * tol
+
+
+def test_golden_g2_biquads(golden):
+    """The reference's own logits -> biquads -> direct form (g2, default pole radius 0.99) through the fused kernel."""
+    from golf_amd import functional as GF
+
+    g = golden("g2_biquads")
+    lg = torch.as_tensor(np.asarray(g["logits"]), dtype=torch.float32)
+    flat = lg.reshape(*lg.shape[:-2], -1).cuda()
+    for rep in ("coef", "conj", "real"):
+        a = GF.biquad_logits2lpc(flat, rep, 0.99).cpu().numpy()
+        emax, el2 = rel_err(a, np.asarray(g[f"lpc_{rep}"]))
+        print("g2", rep, emax, el2)
+        assert emax < 5e-6 and el2 < 5e-6
