@@ -112,6 +112,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
+    for f in os.listdir(LIB_DIR):   # clang-offload-bundler leaves its temporaries next to the output
+        if f.startswith("libgolf_hip.so.") and ("hipv4-" in f or "host-" in f):
+            os.remove(os.path.join(LIB_DIR, f))
     return LIB_PATH
 
 
