@@ -70,6 +70,17 @@ def parse():
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
                     help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N>1: stage this many steps' audio per slot and exchange them in ONE all-gather (fewer, larger "
+                         "collectives: xGMI is per-link bound and a 6 MB gather per ~80 us step sits at the link rate)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (EXACTLY --steps steps, barrier + synchronize on both sides) is run this many "
+                         "times; ms_per_step / value are the MEDIAN region, every region is listed under 'timing'")
+    ap.add_argument("--prereplay", type=int, default=16,
+                    help="setup: replays of every captured hipGraph before the warm-up steps (graph upload, code objects, "
+                         "clocks: instantiation is setup, not a step)")
+    ap.add_argument("--shared-inputs", action="store_true",
+                    help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
 
 
@@ -307,6 +318,47 @@ def cpu_baseline(B, hop, M, budget_s=15.0):
                       f"models/synth.py:213-263 arranges them + C/OpenMP sample_wise_lpc port), drop min/max, mean"}
 
 
+# Algorithmic bytes per output sample (fp32, module-boundary traffic): SURVEY.md §8d for the oscillator (8.0) and the
+# LPC filter (8.38 = ex 4 + y 4 + (22 + 1) * 4 / 240 frame parameters); derived the same way for the
+# zero-phase FIR noise filter (noise 4 + log_mag 256 * 4 / 240 in, 4 out = 12.27) and the room filter (4 in, 4 out).
+STAGE_BYTES = {"osc": 8.0, "lpc": 8.38, "noise_fir": 12.27, "room": 8.0}
+PATH_BYTES = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0,
+              "golf-ss-train": 16.4 + 16.8, "golf-ss-decoder": 16.4 + 12.27 + 8.0,
+              "golf-ss-decoder-logits": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
+              "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
+              # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
+              "ddsp-decoder": 10.6 + 12.27 + 8.0}
+
+
+def stage_bytes_per_sample(kernel_name):
+    if "osc" in kernel_name or "harm" in kernel_name:
+        return STAGE_BYTES["osc"]
+    if "fir_frames" in kernel_name or "zp_gemm" in kernel_name:
+        return STAGE_BYTES["noise_fir"]
+    if "lti_fir" in kernel_name:
+        return STAGE_BYTES["room"]
+    return STAGE_BYTES["lpc"]
+
+
+def stream_set_time(streams, issue):
+    """Run ``issue()`` (which launches work on ``streams``) between HIP events: a start event on the current stream
+    (the device is idle: the caller synchronised) and one end event per stream; returns (wall_s, event_s) with
+    event_s = the latest end event.  torch.cuda.Event only sees the stream it is recorded on, hence one per stream."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(torch.cuda.current_stream())
+    for st in streams:
+        st.wait_event(e0)   # orders every slot stream after the start mark (no work precedes it)
+    issue()
+    for st, e in zip(streams, ends):
+        e.record(st)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, max(e0.elapsed_time(e) for e in ends) * 1e-3
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -337,25 +389,38 @@ def main():
     if args.workload == "golf-ss-train-step":  # the optimiser couples consecutive steps: no batches in flight
         args.streams, args.no_graphs, args.no_cpu_baseline = 1, True, True
         args.no_gather = True   # N > 1: the exchange of this workload is DDP's gradient all-reduce, not an audio gather
-    inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload)
-    if args.workload == "golf-ss-decoder-logits":
-        assert world == 1, "golf-ss-decoder-logits is a single-GPU side benchmark"
-    if args.workload == "ddsp-decoder":
-        assert world == 1, "ddsp-decoder is a single-GPU side benchmark"
-    inp = {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
-           for k, v in shard_inputs(inp_all, rank, world).items()}
+    if args.workload in ("golf-ss-decoder-logits", "ddsp-decoder"):
+        assert world == 1, f"{args.workload} is a single-GPU side benchmark"
+    S = max(1, args.streams)
     osc, ss, ff = build_modules(device)
-    step, samples, t_out = make_step(args.workload, inp, osc, ss, ff, fast=not args.fp64_transitions,
-                                     overlap=args.overlap_transitions)
+
+    # ---- every in-flight slot owns its inputs (seed 2434 + slot; slot 0 = the SURVEY §8d tensors) and its output
+    def slot_inputs(slot):
+        inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload,
+                              seed=2434 + slot)
+        return {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
+                for k, v in shard_inputs(inp_all, rank, world).items()}
+
+    steps_fn, samples, t_out = [], None, None
+    for i in range(S):
+        if i > 0 and args.shared_inputs:
+            steps_fn.append(steps_fn[0])
+            continue
+        fn, samples, t_out = make_step(args.workload, slot_inputs(i), osc, ss, ff, fast=not args.fp64_transitions,
+                                       overlap=args.overlap_transitions)
+        steps_fn.append(fn)
+    step = steps_fn[0]
+
     do_gather = world > 1 and not args.no_gather
-    gather_bufs = [torch.empty(world * B, t_out, device=device) for _ in range(max(1, args.streams))] if do_gather else None
+    GE = max(1, args.gather_every) if do_gather else 1
     pipelined = args.gather_mode == "pipelined"
-    pending = []  # keeps gather sources alive
+    if do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank
+        stage = [torch.empty(GE * B, t_out, device=device) for _ in range(S)] if GE > 1 else None
+        gather_bufs = [torch.empty(world * GE * B, t_out, device=device) for _ in range(S)]
     # ---- execution mode: S independent batches in flight.  The serial phases of the filter occupy a few dozen
     # waves for tens of microseconds (the boundary scan: B waves), so one batch leaves most of the chip idle;
     # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
     # (8 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
-    S = max(1, args.streams)
     use_graphs = not args.no_graphs  # training steps (forward + custom backward) are captured whole, like inference
     graphs, outs = [], []
     if use_graphs:
@@ -364,50 +429,69 @@ def main():
             warm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(warm):
                 for _ in range(2):
-                    step()
+                    steps_fn[i]()
             torch.cuda.current_stream().wait_stream(warm)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                yg = step()
+                yg = steps_fn[i]()
             graphs.append(g)
             outs.append(yg)
         torch.cuda.synchronize()
-        ref = step()
-        graphs[0].replay()
-        torch.cuda.synchronize()
-        assert torch.equal(outs[0], ref), "hipGraph replay differs from eager execution"
+        for i in range(S):   # every slot's replay equals an eager call on that slot's inputs, bit for bit
+            ref = steps_fn[i]()
+            graphs[i].replay()
+            torch.cuda.synchronize()
+            assert torch.equal(outs[i], ref), f"hipGraph replay of slot {i} differs from eager execution"
+        if S > 1 and not args.shared_inputs:
+            assert not torch.equal(outs[0], outs[1]), "slots were expected to hold different batches"
     # replay streams are created after capture: ROCm maps streams round-robin onto a few hardware queues, and
     # streams that alias one queue serialise (measured: 131 vs 105 us/step at S=4 depending on creation order)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
+    if use_graphs:   # setup, not steps: upload every executable graph and bring the device out of its idle state
+        for _ in range(max(0, args.prereplay)):
+            for i in range(S):
+                with torch.cuda.stream(streams[i]):
+                    graphs[i].replay()
+        torch.cuda.synchronize()
 
     step_no = [0]
-    slot_pending = [None] * S  # gather still reading slot i's output
+    slot_pending = [None] * S  # gather still reading slot i's staging/output buffer
+    slot_fill = [0] * S
 
     def full_step():
         i = step_no[0] % S
         step_no[0] += 1
         with torch.cuda.stream(streams[i]):
-            if do_gather and slot_pending[i] is not None:  # output buffer of this slot is about to be overwritten
-                slot_pending[i].wait()
+            if do_gather and slot_pending[i] is not None and slot_fill[i] == 0:
+                slot_pending[i].wait()   # the buffer the coming steps overwrite is still being sent
                 slot_pending[i] = None
             if use_graphs:
                 graphs[i].replay()
                 y = outs[i]
             else:
-                y = step()
+                y = steps_fn[i]()
             if do_gather:
-                buf = gather_bufs[i]
-                if pipelined:
-                    yd = y.detach()
-                    slot_pending[i] = gather_audio_async(yd, buf)
-                    pending.append((None, yd))
-                    del pending[:-2 * S]
-                else:
-                    gather_audio(y.detach(), buf)
+                src = y.detach()
+                if GE > 1:
+                    stage[i][slot_fill[i] * B:(slot_fill[i] + 1) * B].copy_(src, non_blocking=True)
+                    src = stage[i]
+                slot_fill[i] += 1
+                if slot_fill[i] == GE:
+                    slot_fill[i] = 0
+                    if pipelined:
+                        slot_pending[i] = gather_audio_async(src, gather_bufs[i])
+                    else:
+                        gather_audio(src, gather_bufs[i])
         return y
 
-    def drain(keep=0):
+    def drain():
         for i in range(S):
+            if do_gather and slot_fill[i]:   # partial group at the end of a region: exchange what is staged
+                with torch.cuda.stream(streams[i]):
+                    if slot_pending[i] is not None:
+                        slot_pending[i].wait()
+                    slot_pending[i] = gather_audio_async(stage[i], gather_bufs[i])
+                slot_fill[i] = 0
             if slot_pending[i] is not None:
                 with torch.cuda.stream(streams[i]):
                     slot_pending[i].wait()
@@ -419,24 +503,31 @@ def main():
 
             dist.barrier()
 
+    def issue_region():
+        for _ in range(args.steps):
+            full_step()
+        drain()  # every gather issued inside the timed region completes inside it
+
     for _ in range(args.warmup):
         full_step()
     drain()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full_step()
-    drain()  # every gather issued inside the timed region completes inside it
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    regions = []
+    for _ in range(max(1, args.repeats)):   # each region: EXACTLY --steps steps between barrier + synchronize
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, ev_s = stream_set_time(streams, issue_region)
+        barrier()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            t = torch.tensor([wall, ev_s], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, ev_s = float(t[0].item()), float(t[1].item())
+        regions.append((wall, ev_s))
+    walls = sorted(w for w, _ in regions)
+    elapsed = walls[len(walls) // 2]   # median region (max over ranks inside each region)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * samples / (elapsed / args.steps)
 
@@ -450,49 +541,67 @@ def main():
         ktimes = device_kernel_times(step)
         ours = {k: v for k, v in ktimes.items() if "golf::" in k}
         dom, dom_us = max(ours.items(), key=lambda kv: kv[1]) if ours else ("n/a", float("nan"))
-        # algorithmic bytes of the stage the dominant kernel belongs to (SURVEY.md §8d / BASELINE.md §2)
-        bytes_per_sample = 8.0 if "osc" in dom else (12.27 if ("fir_frames" in dom or "zp_gemm" in dom) else 8.38)
+        bytes_per_sample = stage_bytes_per_sample(dom)
         alg_bytes = bytes_per_sample * samples
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
-        # decoder: + noise filter (noise 4 + log_mag 256*4/240 in, 4 out = 12.27) + room filter (4 in, 4 out)
-        path_bytes = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0, "golf-ss-train": 16.4 + 16.8,
-                      "golf-ss-decoder": 16.4 + 12.27 + 8.0, "golf-ss-decoder-logits": 16.4 + 12.27 + 8.0,
-                      "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
-                      "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
-                      # phase 4 + amplitudes 155*4/240 in, 4 out; + noise filter 12.27 + room 8
-                      "ddsp-decoder": 10.6 + 12.27 + 8.0}
-        step_us = event_time_us(step)
+        step_us = event_time_us(step)                       # one batch alone, eager, one stream
+        graph_us = event_time_us(graphs[0].replay) if use_graphs else None   # the same as one hipGraph launch
         traffic = None
         try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            for kname, v in tr.get("kernels", {}).items():
-                if kname in dom and tr.get("batch") == B:
-                    traffic = v["hbm_bytes_per_launch"]
+            for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                fn = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(fn):
+                    continue
+                tr = json.load(open(fn))
+                for kname, v in tr.get("kernels", {}).items():
+                    if kname in dom and tr.get("batch") == B:
+                        traffic = v["hbm_bytes_per_launch"]
+                if traffic is not None:
+                    break
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "path_frac": round(path_bytes[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "B=32 is bound by the serial T=47761 recursion (dependency/issue latency), not by HBM; "
-                            "see DESIGN.md §roofline"}
+                    "path_frac": round(PATH_BYTES[args.workload] * samples / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                    "path_frac_single_stream": round(PATH_BYTES[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": f"B={B}: bound by the serial T=47761 recursion (dependency/issue latency), not by HBM; "
+                            "frac = the dominant kernel's stage bytes / its duration, path_frac = the whole step's "
+                            "algorithmic bytes / the step time (pipelined and single stream); DESIGN.md §5"}
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
+        single_us = graph_us if graph_us is not None else step_us
         result = {
-            "metric": "audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s" if args.workload == "golf-ss-synth"
-                      else f"audio samples/sec (24 kHz) {args.workload}, batch={B}x2 s",
+            "metric": ("audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s" if args.workload == "golf-ss-synth" and B == 32
+                       else f"audio samples/sec (24 kHz) {args.workload}, batch={B}x2 s")
+                      + (f", {S} batches in flight" if S > 1 else ""),
             "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": B, "seconds": 2.0, "sample_rate": SR,
                        "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
-                       "samples_out_per_utterance": t_out, "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode})" if do_gather else ""),
-                       "batches_in_flight": S, "hipgraph_replay": bool(use_graphs)},
+                       "samples_out_per_utterance": t_out,
+                       "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode}, every {GE} step(s))" if do_gather else ""),
+                       "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
+                       "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),
+            "timing": {"regions": len(regions), "statistic": "median region wall time (max over ranks per region)",
+                       "ms_per_step_regions_wall": [round(w / args.steps * 1e3, 5) for w, _ in regions],
+                       "ms_per_step_regions_hip_events": [round(e / args.steps * 1e3, 5) for _, e in regions],
+                       "prereplay_per_graph": args.prereplay if use_graphs else 0},
+            # one batch at a time on ONE stream (no batches in flight): the latency view of the same step
+            "single_stream": {"value": samples / (single_us * 1e-6), "unit": "audio samples/s",
+                              "us_per_step_graph": None if graph_us is None else round(graph_us, 2),
+                              "us_per_step_eager": round(step_us, 2)},
             "single_batch_latency_us": round(step_us, 2),  # one batch alone, eager, HIP events on the launch stream
             "roofline": roofline,
             "stages_us": stages,
         }
+        if world > 1:
+            result["exchange"] = {"backend": args.dist_backend, "world_size": world,
+                                  "bytes_in_per_rank_per_step": int((world - 1) * B * t_out * 4) if do_gather else 0,
+                                  "bytes_per_collective_per_rank": int(GE * B * t_out * 4) if do_gather else 0,
+                                  "collectives_per_step": (1.0 / GE) if do_gather else 0.0}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(B, 240, 22)

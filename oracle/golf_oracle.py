@@ -60,6 +60,9 @@ __all__ = [
     "biquad_frames_ola_forward",
     "harmonic_oscillator_forward",
     "harmonic_oscillator_backward_amp",
+    "wavetable_generate_backward",
+    "decimate_fir_adjoint",
+    "indexed_glottal_backward",
 ]
 
 
@@ -565,6 +568,97 @@ def indexed_glottal_forward(phase, phase_hop: int, weight, weight_hop: int, tabl
     if oversampling > 1:
         out = decimate_fir(y, decim_taps, oversampling) if decim_taps is not None else None
     return {"instant_phase": inst, "pre": y, "out": out}
+
+
+def wavetable_generate_backward(g_y, wrapped_phase, tables, hop_t: int):
+    """Adjoint of wavetable_generate (what autograd computes through F.grid_sample, models/synth.py:167-176):
+    returns (g_phase (B,N) = d/d wrapped_phase, g_tables (B,K,L)).  The bilinear lookup is linear in the table and
+    piecewise linear in the phase: d v/d phase = L * [(1-rf)(T[r0,c0+1]-T[r0,c0]) + rf(T[r0+1,c0+1]-T[r0+1,c0])];
+    replicated rows (synth.py:141-146) credit the last real row, the wrap column credits column 0."""
+    g = np.asarray(g_y, dtype=np.float64)
+    ph = np.asarray(wrapped_phase, dtype=np.float64)
+    tb0 = np.asarray(tables, dtype=np.float64)
+    B, N = ph.shape
+    K, L = tb0.shape[1], tb0.shape[2]
+    blocks = (N + hop_t - 1) // hop_t
+    rows = np.minimum(np.arange(blocks + 1), K - 1)            # padded-image row -> real row (replicate / truncate)
+    tb = np.concatenate([tb0[:, rows], tb0[:, rows][:, :, :1]], axis=2)
+    c = ph * L
+    c0 = np.clip(np.floor(c).astype(np.int64), 0, L - 1)
+    cf = c - c0
+    r = np.arange(N) / hop_t
+    r0 = np.minimum(np.floor(r).astype(np.int64), blocks - 1)
+    rf = (r - r0)[None, :]
+    bi = np.arange(B)[:, None]
+    r0b = np.broadcast_to(r0[None, :], (B, N))
+    dtop = tb[bi, r0b, c0 + 1] - tb[bi, r0b, c0]
+    dbot = tb[bi, r0b + 1, c0 + 1] - tb[bi, r0b + 1, c0]
+    g_phase = g * L * (dtop * (1 - rf) + dbot * rf)
+    g_tb = np.zeros((B, K, L), dtype=np.float64)
+    bb = np.broadcast_to(bi, (B, N))
+    c1 = (c0 + 1) % L
+    for rr, wr in ((r0b, 1 - rf), (r0b + 1, rf)):
+        real = rows[rr]
+        np.add.at(g_tb, (bb, real, c0), g * wr * (1 - cf))
+        np.add.at(g_tb, (bb, real, c1), g * wr * cf)
+    return g_phase, g_tb
+
+
+def decimate_fir_adjoint(g_out, taps, q: int, N: int) -> np.ndarray:
+    """Adjoint of decimate_fir: g_x[m*q + k - half] += taps[k] * g_out[m]."""
+    g_out = np.asarray(g_out, dtype=np.float64)
+    taps = np.asarray(taps, dtype=np.float64)
+    K = taps.shape[0]
+    half = (K - 1) // 2
+    B, n_out = g_out.shape
+    gp = np.zeros((B, half + N + half + q))
+    for k in range(K):
+        gp[:, k : k + (n_out - 1) * q + 1 : q] += taps[k] * g_out
+    return gp[:, half : half + N]
+
+
+def indexed_glottal_backward(g_out, phase, phase_hop: int, weight, weight_hop: int, table, oversampling: int = 1,
+                             equal_energy: bool = False, phase_offset=None, decim_taps=None):
+    """Closed-form gradients of indexed_glottal_forward w.r.t. everything the reference differentiates
+    (models/synth.py:213-263 under autograd): table_select_weight, phase, phase_offset, table.
+    Returns dict(g_weight (B,Fw), g_phase (B,Tp), g_phase_offset (B,N) or None, g_table (n_tab,L))."""
+    phase = np.asarray(phase, dtype=np.float64)
+    weight = np.asarray(weight, dtype=np.float64)
+    table = np.asarray(table, dtype=np.float64)
+    n_tab, L = table.shape
+    Fw = weight.shape[1]
+    idx_raw = weight * (n_tab - 1)
+    i0 = np.clip(np.trunc(idx_raw).astype(np.int64), 0, n_tab - 2)
+    p = (idx_raw - i0)[..., None]
+    interp_tables = table[i0] * (1 - p) + table[i0 + 1] * p
+    hop_t, ph, ph_hop = weight_hop, phase, phase_hop
+    if oversampling > 1:
+        hop_t, ph, ph_hop = weight_hop * oversampling, phase / oversampling, phase_hop * oversampling
+    up = linear_upsample(ph, ph_hop, axis=1)
+    inst = np.cumsum(up, axis=1)
+    if phase_offset is not None:
+        inst = inst + np.asarray(phase_offset, dtype=np.float64)
+    wrapped = inst % 1.0
+    N = up.shape[1]
+    g_y = np.asarray(g_out, dtype=np.float64)
+    if oversampling > 1:
+        g_y = decimate_fir_adjoint(g_y, decim_taps, oversampling, N)
+    g_up = np.zeros_like(up)
+    if equal_energy:
+        v = wavetable_generate(wrapped, interp_tables, hop_t)
+        g_up += g_y * v * (-0.5) * up ** -1.5
+        g_v = g_y / np.sqrt(up)
+    else:
+        g_v = g_y
+    g_inst, g_T = wavetable_generate_backward(g_v, wrapped, interp_tables, hop_t)
+    g_up += np.cumsum(g_inst[:, ::-1], axis=1)[:, ::-1]           # adjoint of the cumulative sum
+    g_phase = _upsample_adjoint(g_up, ph_hop, phase.shape[1]) / (oversampling if oversampling > 1 else 1)
+    g_p = np.einsum("bkl,bkl->bk", g_T, table[i0 + 1] - table[i0])
+    g_table = np.zeros_like(table)
+    np.add.at(g_table, i0, g_T * (1 - p))
+    np.add.at(g_table, i0 + 1, g_T * p)
+    return {"g_weight": g_p * (n_tab - 1), "g_phase": g_phase,
+            "g_phase_offset": g_inst if phase_offset is not None else None, "g_table": g_table}
 
 
 def default_decimation_taps(q: int, zeros: int = 16, rolloff: float = 0.945) -> np.ndarray:

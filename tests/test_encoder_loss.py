@@ -42,7 +42,11 @@ def close(y, ref, what, tol=2e-5):
     assert emax <= tol and el2 <= tol, (what, emax, el2)
 
 
-def test_encoder_matches_reference_g20(golden):
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_encoder_matches_reference_g20(golden, device):
     from golf_amd.audiotensor import AudioTensor
 
     g = golden("g20_encoder_and_loss")
@@ -53,24 +57,25 @@ def test_encoder_matches_reference_g20(golden):
     state0 = {k[len("state0/"):]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("state0/")}
     assert set(state0) == set(iface.state_dict())          # the reference's checkpoint keys, exactly
     iface.load_state_dict(state0)
-    x = [torch.from_numpy(g[f"x{i}"]) for i in range(3)]
-    f0 = [torch.from_numpy(g[f"f0_{i}"]) for i in range(3)]
+    iface.to(device)                                        # "cuda": MIOpen / rocBLAS / rocFFT run the same modules
+    x = [torch.from_numpy(g[f"x{i}"]).to(device) for i in range(3)]
+    f0 = [torch.from_numpy(g[f"f0_{i}"]).to(device) for i in range(3)]
     iface.train()
     for i in range(2):
         h = iface.backbone(AudioTensor(x[i]), f0=AudioTensor(f0[i]))
         assert h.hop_length == 16
-        close(h.as_tensor().detach(), g[f"h_train{i}"], f"h_train{i}")
+        close(h.as_tensor().detach().cpu(), g[f"h_train{i}"], f"h_train{i}")
     iface.eval()
-    close(iface.backbone(AudioTensor(x[2]), f0=AudioTensor(f0[2])).as_tensor().detach(), g["h_eval"], "h_eval")
+    close(iface.backbone(AudioTensor(x[2]), f0=AudioTensor(f0[2])).as_tensor().detach().cpu(), g["h_eval"], "h_eval")
     sd = iface.state_dict()
     for k in g.files:                                       # running extrema and BatchNorm statistics evolved alike
         if k.startswith("state1/"):
-            np.testing.assert_allclose(sd[k[len("state1/"):]].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(sd[k[len("state1/"):]].cpu().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
     params = iface(AudioTensor(x[2]), f0=AudioTensor(f0[2]))
     seen = 0
     for key, val in params.items():
         for j, t in enumerate(val if isinstance(val, tuple) else (val,)):
-            close(t.as_tensor().detach(), g[f"param/{key}/{j}"], f"param {key}[{j}]")
+            close(t.as_tensor().detach().cpu(), g[f"param/{key}/{j}"], f"param {key}[{j}]")
             assert t.hop_length == int(g[f"param_hop/{key}/{j}"])
             seen += 1
     assert seen == sum(1 for k in g.files if k.startswith("param/"))
@@ -83,20 +88,22 @@ def test_out_linear_starts_at_zero():
     assert float(iface.backbone.out_linear.bias.detach().abs().max()) == 0.0
 
 
-def test_mss_loss_matches_reference_g20(golden):
+@pytest.mark.parametrize("device", DEVICES)
+def test_mss_loss_matches_reference_g20(golden, device):
     from golf_amd.audiotensor import AudioTensor
     from golf_amd.loss import MSSLoss
 
     g = golden("g20_encoder_and_loss")
-    crit = MSSLoss([61, 127, 251], alpha=1.0, window="hanning", center=True)
+    crit = MSSLoss([61, 127, 251], alpha=1.0, window="hanning", center=True).to(device)
     assert [l.spec.hop_length for l in crit.losses] == list(g["loss_hops"])
-    pred = torch.from_numpy(g["loss_pred"]).requires_grad_(True)
-    val = crit(pred, torch.from_numpy(g["loss_true"]))
+    pred = torch.from_numpy(g["loss_pred"]).to(device).requires_grad_(True)
+    true = torch.from_numpy(g["loss_true"]).to(device)
+    val = crit(pred, true)
     val.backward()
-    np.testing.assert_allclose(float(val), float(g["loss_value"]), rtol=2e-6)
-    close(pred.grad, g["loss_g_pred"], "d loss / d pred", 1e-4)
+    np.testing.assert_allclose(float(val), float(g["loss_value"]), rtol=2e-6 if device == "cpu" else 2e-5)
+    close(pred.grad.cpu(), g["loss_g_pred"], "d loss / d pred", 1e-4)
     # AudioTensor in -> AudioTensor out (the reference's step calls .as_tensor() on it, ltng/ae.py:116-118)
-    val2 = crit(AudioTensor(pred.detach()), AudioTensor(torch.from_numpy(g["loss_true"])))
+    val2 = crit(AudioTensor(pred.detach()), AudioTensor(true))
     assert float(val2.as_tensor()) == pytest.approx(float(val), rel=1e-6)
 
 
@@ -275,3 +282,93 @@ def test_data_parallel_training_step_gloo_world2():
         assert p.exitcode == 0
     assert same, "ranks diverged: gradients were not averaged"
     assert moved and all(np.isfinite(losses))
+
+
+@pytest.mark.gpu
+def test_config5_training_step_full_size_vs_oracle():
+    """BASELINE configs[4]: one optimisation step of the golf-precise autoencoder at B = 64 x 2 s (cfg/ae/vctk.yaml:
+    U-Net/LSTM encoder -> control transforms -> golf-precise decoder -> MSSLoss(509, 1021, 2053) -> backward -> clip 0.5
+    -> Adam 1e-4; reference ltng/ae.py:86-143).  The decoder is what this package replaces, so it is what is pinned:
+    on the control tensors the encoder produced, the decoder output equals the float64 oracle composition
+    (oracle.golf_ss_decoder) and the gradients arriving at the encoder head (d loss / d table_select_weight, log_mag,
+    gain, a) and at the room filter's taps equal the float64 closed-form backward of the same composition driven by the
+    same d loss / d x_hat.  Then the real train_step runs (finite, clipped, parameters move)."""
+    from golf_amd.ae import train_step
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synthetic import make_decoder, make_inputs
+    from oracle import golf_oracle as O
+
+    torch.manual_seed(2434)
+    B, T, hop = 64, 48000, 240
+    inp = make_inputs(B=B, device="cuda")
+    noise = inp["noise"]
+    dec = make_decoder(injected_noise=noise)
+    model = _autoencoder(dec, hop=hop, n_fft=1024, n_ffts=[509, 1021, 2053], channels=[32, 64, 128, 256],
+                         strides=[4, 4, 4, 4], lstm_hidden_size=256, num_layers=3, dropout=0.1).cuda()
+    with torch.no_grad():   # the reference starts the head at exactly 0 (constant parameters); make them vary
+        model.encoder.backbone.out_linear.weight.normal_(0, 0.02)
+        model.decoder.room_filter.kernel.copy_(make_inputs(B=1, with_noise_filter=True)["room_kernel"])
+    model.train()
+    phase = inp["phase"]
+    f0 = phase * 24000
+    f0[:, :4800] = 0                                           # an unvoiced stretch, driven at uv Hz
+    uv = torch.empty(B, 1, device="cuda").uniform_(50, 500)
+    ph64 = torch.cumsum(phase.double(), 1)
+    x = (sum(torch.sin(2 * np.pi * h * ph64) / h for h in range(1, 9)).float() * 0.05 + 0.005 * noise)
+
+    # ---- the step, opened up at the encoder/decoder interface
+    params = model.encoder(AudioTensor(x), f0=AudioTensor(f0))
+    assert set(params) >= {"harm_oscillator_params", "noise_filter_params", "end_filter_params"}
+    leaves = {}
+    for key, val in params.items():
+        new = []
+        for j, t in enumerate(val):
+            leaf = t.as_tensor().detach().clone().requires_grad_(True)
+            leaves[(key, j)] = leaf
+            new.append(AudioTensor(leaf, t.hop_length))
+        params[key] = tuple(new)
+    drive = torch.where(f0 == 0, uv, f0) / 24000
+    x_hat = model.decoder(phase=AudioTensor(drive), **params).as_tensor()
+    x_hat.retain_grad()
+    n = min(x.shape[1], x_hat.shape[1])
+    loss = model.criterion(x_hat[:, :n], x[:, :n])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert x_hat.shape == (B, 47760) and torch.isfinite(loss)
+    g_xhat = x_hat.grad.double().cpu().numpy()
+
+    wsel, log_mag = leaves[("harm_oscillator_params", 0)], leaves[("noise_filter_params", 0)]
+    gain, a = leaves[("end_filter_params", 0)], leaves[("end_filter_params", 1)]
+    assert wsel.shape == (B, 21) and log_mag.shape == (B, 200, 256) and gain.shape == (B, 200) and a.shape == (B, 200, 22)
+    osc = model.decoder.harm_oscillator
+    table, taps = osc.table.cpu().numpy(), osc.decimater.taps.cpu().numpy()
+    room = model.decoder.room_filter.kernel.detach().cpu().numpy()
+    win = torch.hann_window(510, dtype=torch.float64).numpy()
+    npf = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    # ---- float64 forward of the same composition
+    src, y_lpc = O.golf_ss_decoder(npf(drive), 1, npf(wsel), 2400, table, npf(noise), npf(log_mag), win, npf(gain),
+                                   npf(a), hop, room_kernel=None, oversampling=4, equal_energy=True, decim_taps=taps)
+    y_ref = O.lti_acoustic_filter_forward(y_lpc, room)
+    close(x_hat.detach().cpu().numpy(), y_ref, "config-5 decoder output B=64", 1e-4)
+    # ---- float64 backward, stage by stage, driven by the loss gradient of the GPU run
+    g_y, g_room = O.lti_acoustic_filter_backward(g_xhat, y_lpc, room)
+    g_src, g_gain, g_a = O.ltv_allpole_ss_backward(g_y, src, npf(gain), npf(a), hop)
+    nz = npf(noise)[:, :48000]
+    g_nz_in, g_log_mag = O.ltv_fir_frames_backward(g_src, nz, npf(log_mag), win, hop)
+    g_osc = np.zeros((B, 48000))
+    g_osc[:, : g_src.shape[1]] = g_src
+    g_w = O.indexed_glottal_backward(g_osc, npf(drive), 1, npf(wsel), 2400, table, 4, True, None, taps)["g_weight"]
+    for name, got, ref, tol in (("gain", gain.grad, g_gain, 2e-4), ("a", a.grad, g_a, 2e-4),
+                                ("log_mag", log_mag.grad, g_log_mag, 2e-4), ("table_select_weight", wsel.grad, g_w, 2e-4),
+                                ("room kernel", model.decoder.room_filter.kernel.grad, g_room, 2e-4)):
+        close(got.cpu().numpy(), ref, f"config-5 d loss / d {name} (B=64)", tol)
+
+    # ---- and the step itself, as bench.py --workload golf-ss-train-step times it
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    w0 = model.encoder.backbone.out_linear.weight.detach().clone()
+    l1, _ = train_step(model, opt, (x, f0), clip=0.5, unvoiced_f0=uv, return_output=True)
+    assert torch.isfinite(l1) and abs(float(l1) - float(loss)) <= 0.25 * abs(float(loss))   # dropout differs per call
+    g = [p.grad for p in model.parameters() if p.grad is not None]
+    total = torch.sqrt(sum((v.float() ** 2).sum() for v in g))
+    assert float(total) <= 0.5 * 1.001
+    assert not torch.equal(model.encoder.backbone.out_linear.weight, w0)

@@ -86,10 +86,51 @@ def test_osc_full_size_module():
     y, pre = m(AudioTensor(inp["phase"].cuda()), AudioTensor(inp["wsel"].cuda(), inp["w_hop"]), return_pre=True)
     torch.cuda.synchronize()
     assert y.shape == (32, 48000) and pre.shape == (32, 191997) and y.hop_length == 1
-    ref = O.indexed_glottal_forward(inp["phase"].numpy()[:4], 1, inp["wsel"].numpy()[:4], inp["w_hop"],
+    ref = O.indexed_glottal_forward(inp["phase"].numpy(), 1, inp["wsel"].numpy(), inp["w_hop"],
                                     m.table.cpu().numpy(), 4, True, decim_taps=m.decimater.taps.cpu().numpy())
-    check(pre.cpu().numpy()[:4], ref["pre"], "full-size pre (first 4)")
-    check(y.as_tensor().cpu().numpy()[:4], ref["out"], "full-size out (first 4)")
+    if pre is not None:
+        check(pre.cpu().numpy(), ref["pre"], "full-size pre (all 32)")
+    yh = y.as_tensor().cpu().numpy()
+    check(yh, ref["out"], "full-size out (all 32)")
+    for b in range(32):
+        emax, el2 = rel_err(yh[b], ref["out"][b])
+        assert emax <= TOL and el2 <= TOL, (b, emax, el2)
+
+
+def test_osc_full_length_closer_to_f64_than_reference_fp32_order():
+    """north_star: "within 1e-4 of the reference output".  The reference accumulates the oversampled phase with an
+    fp32 cumsum over 192 k samples (models/synth.py:250-251); on a 2 s clip that alone moves ITS output ~1e-3 (max-norm)
+    away from exact arithmetic: the LF derivative table has a near-discontinuity at glottal closure, so a phase error
+    of 1e-5 cycles flips isolated samples.  The HIP oscillator accumulates phase exactly (Q0.64 fixed point).  This test
+    makes that a measured fact: on the BASELINE shape the HIP output is within 1e-4 of the float64 oracle, the
+    reference's own fp32 op sequence (oracle/cpu_baseline.py::oscillator_reference_ops, same taps) is NOT, and the HIP
+    output is the closer of the two in both norms -- i.e. the deviation from the reference's fp32 path is the
+    reference's rounding, not ours."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+    from oracle.cpu_baseline import oscillator_reference_ops
+
+    inp = make_inputs(B=32)
+    m = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True,
+                                           lf_v2=True, points=2048)
+    ref64 = O.indexed_glottal_forward(inp["phase"].numpy(), 1, inp["wsel"].numpy(), inp["w_hop"], m.table.numpy(), 4,
+                                      True, decim_taps=m.decimater.taps.numpy())["out"]
+    ref32 = oscillator_reference_ops(inp["phase"], inp["wsel"], inp["w_hop"], m.table, m.decimater.kernel, 4,
+                                     True).numpy()
+    hip = GF.glottal_osc(inp["phase"].cuda(), inp["wsel"].cuda(), m.table.cuda(), m.decimater.taps.cuda(), 1,
+                         inp["w_hop"], 4, True).cpu().numpy()
+    assert hip.shape == ref64.shape == ref32.shape == (32, 48000)
+    e_hip, e_ref = rel_err(hip, ref64), rel_err(ref32, ref64)
+    e_hip_ref = rel_err(hip, ref32)
+    print(f"HIP vs f64 {e_hip[0]:.2e}/{e_hip[1]:.2e}   reference-fp32-order vs f64 {e_ref[0]:.2e}/{e_ref[1]:.2e}   "
+          f"HIP vs reference-fp32-order {e_hip_ref[0]:.2e}/{e_hip_ref[1]:.2e}")
+    assert e_hip[0] <= TOL and e_hip[1] <= TOL
+    assert e_hip[0] < e_ref[0] and e_hip[1] < e_ref[1]
+    assert e_ref[0] > TOL            # the reference's fp32 cumsum is what breaks 1e-4 (max-norm), documented in DESIGN.md
+    # and HIP-vs-reference is explained by the reference's own error (triangle inequality, 10 % slack)
+    assert e_hip_ref[0] <= 1.1 * (e_ref[0] + e_hip[0])
 
 
 @pytest.mark.parametrize("os_,eq", [(1, False), (4, True)])
