@@ -20,6 +20,7 @@
 #include "common.h"
 #include "device_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace golf {
 
@@ -559,6 +560,227 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
     g_wsel[idx] = acc * (float)(n_tab - 1);
 }
 
+// ---- O2+O3 fused (the GOLF configuration: phase at hop 1, 4x oversampling, power-of-two table) --------------------
+// The three-kernel path above moves 105 MB for 12 MB of algorithmic traffic at B=32: a 64-bit phase prefix per coarse
+// sample is written and read back (12 MB each way) and the 4x oversampled signal makes a round trip through HBM
+// (24 MB written by the render kernel, read again by the decimator).  Here one workgroup owns OSCF_TO output samples
+// of one utterance and keeps everything in between on chip:
+//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of OSCF_TO coarse samples -> Ttot[b][tile]
+//   1. base phase of the tile = sum of the earlier tiles' totals (exact: Q0.64 integers, order cannot matter)
+//   2. the tile's coarse phase samples (+ the decimator's halo) are scanned in the block: C_j relative to the tile
+//   3. every fine sample is rendered (same integer walk and bilinear LDS lookup as osc_render_kernel) straight into
+//      the decimator's polyphase LDS tile; the table rows of the <= OSCF_MAXROWS control frames the tile touches are
+//      staged once per block
+//   4. the polyphase FIR of osc_decimate_kernel runs on that tile, + the fused addend, one store per output.
+// HBM traffic: phase in (twice: totals + tile), addend in, audio out, tables from L2.  Results are bit-identical to the
+// three-kernel path (same arithmetic on the same exact phases; tests/test_gpu_osc.py asserts equality).
+#define OSCF_TO 2048
+#define OSCF_THREADS 512
+#define OSCF_CPT 5          // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + halo
+#define OSCF_MAXROWS 4
+
+__global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
+                                                              u64* __restrict__ Ttot, int Tp, int P, int os, int ntile) {
+    __shared__ u64 wsum[4];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
+    const double scale_a = 18446744073709551616.0 / (double)os;
+    const double scale_d = scale_a / (double)P;
+    const u64 tri = (u64)P * (u64)(P - 1) / 2;
+    constexpr int PER = OSCF_TO / 256;
+    const int j0 = tile * OSCF_TO + tid * PER;
+    float pv[PER + 1];
+#pragma unroll
+    for (int r = 0; r <= PER; ++r) pv[r] = prow.ld(min(j0 + r, Tp - 1));
+    u64 tsum = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+        if (j0 + r < Tp - 1) tsum += (u64)P * osc_fix_a(pv[r], scale_a) + osc_fix_d(pv[r], pv[r + 1], scale_d) * tri;
+    const u64 incl = wave_incl_scan(tsum, tid & 63);
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) Ttot[(size_t)b * ntile + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <int EE>
+__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
+    int hop_t, int N, const float* __restrict__ taps, int K, float* __restrict__ out, int64_t out_stride, int Tout,
+    int RS4, int dmin, int ngrp, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
+    constexpr int OS = 4, P = 4;
+    constexpr int NTH = OSCF_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ u64 wtot[NTH / 64];
+    __shared__ u64 base_sh;
+    // layout: X polyphase tile | H taps | rows (nrows x (L+1)) | ps coarse phase samples
+    float* X = smem;
+    const int hoff = (OS * 4 * RS4 + 3) & ~3;
+    float* H = smem + hoff;
+    const int HS = ngrp * 4 + 8;
+    float* rows = H + OS * HS;
+    const int LR = L + 1;
+    float* ps = rows + (((size_t)nrows * LR + 3) & ~(size_t)3);
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int o0 = tile * OSCF_TO;
+    const int span = OSCF_TO + ngrp * 4 + 4;     // coarse samples staged (polyphase index i <-> coarse sample j_lo + i)
+    const int j_lo = o0 + dmin;                  // may be negative for the first tile
+    // ---- 1. base phase: the tiles before this one (wave 0), and the taps / table rows / phase samples into LDS
+    if (wv == 0) {
+        u64 acc = 0;
+        for (int i = lane; i < tile; i += 64) acc += Ttot[(size_t)b * ntile + i];
+        acc = wave_incl_scan(acc, lane);
+        if (lane == 63) base_sh = acc;
+    }
+    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
+    for (int u = tid; u <= span; u += NTH) {
+        const int j = j_lo + u;
+        ps[u] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
+    }
+    for (int e = tid; e < OS * HS; e += NTH) {   // H[ph][3 + q] = tap of (ph, d = dmin + q), zero elsewhere
+        const int half = (K - 1) / 2;
+        const int ph = e / HS, q = e - ph * HS - 3;
+        const int k = half + OS * (dmin + q) + ph;
+        H[e] = (q >= 0 && k >= 0 && k < K) ? taps[k] : 0.f;
+    }
+    const int m_first = max(j_lo, 0) * P;        // first fine sample that exists in this tile
+    const int r_first = m_first / hop_t;         // control frame of that sample; rows r_first .. r_first + nrows - 1
+    for (int rr = 0; rr < nrows; ++rr) {
+        int k = r_first + rr;
+        if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
+        const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+        int i0 = (int)idx;
+        i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+        const float pw = idx - (float)i0;
+        const float* t0 = table + (size_t)i0 * L;
+        float* dst = rows + (size_t)rr * LR;
+        constexpr int SU = 4;
+        for (int cb0 = 0; cb0 < L + 1; cb0 += SU * NTH) {   // all loads of a batch before the first blend
+            float va[SU], vb[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                int c = cb0 + u * NTH + tid;
+                c = c > L ? L : c;
+                c = c == L ? 0 : c;                          // column L = wrap-around copy of column 0
+                va[u] = t0[c];
+                vb[u] = t0[L + c];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int c = cb0 + u * NTH + tid;
+                if (c <= L) dst[c] = va[u] * (1.0f - pw) + vb[u] * pw;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
+    const double scale_a = 18446744073709551616.0 / (double)OS;
+    const double scale_d = scale_a / (double)P;
+    const int u0 = tid * OSCF_CPT;
+    u64 av[OSCF_CPT], dv[OSCF_CPT];
+    u64 tsum = 0;
+#pragma unroll
+    for (int r = 0; r < OSCF_CPT; ++r) {
+        const int u = min(u0 + r, span - 1);
+        const int j = j_lo + u;
+        const float p0 = ps[u], p1 = ps[u + 1];
+        av[r] = osc_fix_a(p0, scale_a);
+        dv[r] = osc_fix_d(p0, p1, scale_d);
+        const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
+        tsum += seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
+    }
+    const u64 incl = wave_incl_scan(tsum, lane);
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    u64 run = base_sh + incl - tsum;
+    for (int w = 0; w < wv; ++w) run += wtot[w];
+    // base_sh counts from coarse sample o0 = tile start; the halo in front of it (j_lo .. o0-1, -dmin samples) belongs
+    // to the previous tile's total: subtract the halo's own advance, i.e. the local prefix at u = -dmin
+    {
+        __shared__ u64 halo_sh;
+        // the thread that owns u = -dmin publishes its exclusive prefix there
+        const int uh = -dmin;
+        u64 r2 = run;
+#pragma unroll
+        for (int r = 0; r < OSCF_CPT; ++r) {
+            if (u0 + r == uh) halo_sh = r2 - base_sh;
+            const int j = j_lo + u0 + r;
+            const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;
+            r2 += seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
+        }
+        __syncthreads();
+        run -= halo_sh;
+    }
+    // ---- 3. render the fine samples of the owned coarse samples into the polyphase tile
+    const float inv_hop_t = 1.0f / (float)hop_t;
+    // nrows - 1 control intervals are staged (rows r_first .. r_first + nrows - 1): interval index 0 .. nrows - 2
+    const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < OSCF_CPT; ++r) {
+        const int u = u0 + r;
+        if (u < span) {
+            const int j = j_lo + u;
+            const float p0 = ps[u], p1 = ps[u + 1];
+            const float d = (p1 - p0) * 0.25f;
+            u64 ph = run, inc = av[r];
+            const u64 dinc = dv[r];
+            const bool segv = j >= 0 && j < Tp - 1;
+            run += segv ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
+            float* xp = X + (u & 3) * RS4 + (u >> 2);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                ph += inc;
+                inc += dinc;
+                const int m = j * P + k;
+                const unsigned hi = (unsigned)(ph >> 32);
+                const int c0 = (int)(hi >> (32 - lshift));
+                const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+                const int rr = (m >= bnd1) + (m >= bnd2);
+                const float rf = (float)(m - (r_first + rr) * hop_t) * inv_hop_t;
+                const float* ra = rows + (size_t)rr * LR;
+                const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
+                const float top = fmaf(cf, a01 - a00, a00);
+                const float bot = fmaf(cf, a11 - a10, a10);
+                float v = fmaf(rf, bot - top, top);
+                if (EE) v *= rsqrtf(fmaf((float)k, d, p0) * 0.25f);
+                xp[k * 4 * RS4] = (m >= 0 && m < N && j >= 0) ? v : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4. polyphase FIR (osc_decimate_kernel's inner loop), 4 outputs per thread
+    const int u = tid;
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+    const float ad0 = arow.ld(o0 + 4 * u), ad1 = arow.ld(o0 + 4 * u + 1), ad2 = arow.ld(o0 + 4 * u + 2),
+                ad3 = arow.ld(o0 + 4 * u + 3);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < OS; ++ph) {
+        const float* Xp = X + (size_t)ph * 4 * RS4 + u;
+        const float4* Hp = reinterpret_cast<const float4*>(H + (size_t)ph * HS);
+        float4 hprev = Hp[0];
+        for (int g = 0; g <= ngrp; ++g) {
+            const float4 hcur = Hp[g + 1];
+            const float x0 = Xp[0 * RS4 + g], x1 = Xp[1 * RS4 + g], x2 = Xp[2 * RS4 + g], x3 = Xp[3 * RS4 + g];
+            acc0 = fmaf(hprev.w, x0, acc0); acc1 = fmaf(hprev.z, x0, acc1);
+            acc2 = fmaf(hprev.y, x0, acc2); acc3 = fmaf(hprev.x, x0, acc3);
+            acc0 = fmaf(hcur.x, x1, acc0); acc1 = fmaf(hprev.w, x1, acc1);
+            acc2 = fmaf(hprev.z, x1, acc2); acc3 = fmaf(hprev.y, x1, acc3);
+            acc0 = fmaf(hcur.y, x2, acc0); acc1 = fmaf(hcur.x, x2, acc1);
+            acc2 = fmaf(hprev.w, x2, acc2); acc3 = fmaf(hprev.z, x2, acc3);
+            acc0 = fmaf(hcur.z, x3, acc0); acc1 = fmaf(hcur.y, x3, acc1);
+            acc2 = fmaf(hcur.x, x3, acc2); acc3 = fmaf(hprev.w, x3, acc3);
+            hprev = hcur;
+        }
+    }
+    const BufRow orow(out + (size_t)b * out_stride, Tout);
+    const int o = o0 + 4 * u;
+    orow.st(o, acc0 + ad0);
+    orow.st(o + 1, acc1 + ad1);
+    orow.st(o + 2, acc2 + ad2);
+    orow.st(o + 3, acc3 + ad3);
+}
+
 static int osc_check(int B, int Tp, int phase_hop, int Fw, int w_hop, int n_tab, int L, int os, int K,
                      const float* taps) {
     if (B < 1 || Tp < 1 || phase_hop < 1 || Fw < 1 || w_hop < 1 || n_tab < 2 || L < 2 || os < 1)
@@ -844,6 +1066,50 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     hipStream_t st = (hipStream_t)stream;
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
+    // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
+    static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
+    if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !pre && !unfused_env) {
+        const int half = (K - 1) / 2;
+        const int dmin = -((half + os - 1) / os);
+        const int dmax = half / os;
+        const int nq = dmax - dmin + 1;
+        const int ngrp = (nq + 2) / 4;
+        int RS4 = OSCF_TO / 4 + ngrp + 2;
+        while (RS4 % 32 != 2) ++RS4;
+        const int span = OSCF_TO + ngrp * 4 + 4;
+        const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
+        const int nrows = nint_touched + 1;
+        const int hoff = (os * 4 * RS4 + 3) & ~3;
+        const size_t ldsf = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) +
+                                             (((size_t)nrows * (L + 1) + 3) & ~(size_t)3) + (size_t)span + 4);
+        if (nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin <= span && ldsf <= 96 * 1024) {
+            const int ntile2 = (int)ceil_div(Tout, OSCF_TO);       // <= g.ntile: fits the Ttot region of the workspace
+            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,
+                               g.P, os, ntile2);
+            GOLF_LAUNCH_CHECK();
+            const int lshift = 31 - __builtin_clz((unsigned)L);
+            static const hipError_t lds_attr = [] {   // > 64 KB of dynamic LDS per workgroup needs the opt-in
+                hipError_t e = hipFuncSetAttribute((const void*)osc_fused_kernel<1>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void*)osc_fused_kernel<0>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                return e;
+            }();
+            if (lds_attr != hipSuccess)
+                return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",
+                            hipGetErrorString(lds_attr));
+#define GOLF_FUSED(EE)                                                                                                \
+    hipLaunchKernelGGL((osc_fused_kernel<EE>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsf, st, phase, phase_stride,   \
+                       (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t, g.N, taps, K, out,  \
+                       out_stride, Tout, RS4, dmin, ngrp, nrows, addend, addend_stride, Tadd)
+            if (equal_energy) GOLF_FUSED(1);
+            else GOLF_FUSED(0);
+#undef GOLF_FUSED
+            GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
+        }
+    }
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, os, g.ntile, B, st)) return rc;
     float* fine = os > 1 ? (pre ? pre : (float*)((char*)ws + g.off_pre)) : out;
     // the internal oversampled buffer uses a row stride that is a multiple of 4 floats (16-byte stores / loads); a
@@ -906,7 +1172,12 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         return fail(GOLF_EWORKSPACE, "glottal_osc_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
-    const u64* Cw = (const u64*)((char*)ws + g.off_cw);  // still valid from the forward
+    // recomputed: the fused forward leaves no per-sample prefix behind, and the backward must not depend on which
+    // forward variant ran or on the caller keeping the workspace untouched in between
+    u64* Cw = (u64*)((char*)ws + g.off_cw);
+    if (int rc = launch_phase_tiles(phase, phase_stride, Cw, (u64*)((char*)ws + g.off_ttot), Tp, g.P, os, g.ntile, B,
+                                    (hipStream_t)stream))
+        return rc;
     float* g_pre = (float*)((char*)ws + g.off_pre);
     float* part = (float*)((char*)ws + g.off_part);
     if (os == 4) {

@@ -290,3 +290,32 @@ def test_long_input_beyond_256_tiles():
         wm[0, k] -= 1e-4
         fd = (f(wp) - f(wm)) / 2e-4
         assert abs(got[0, k] - fd) <= 5e-3 * max(1.0, abs(fd)), (k, got[0, k], fd)
+
+
+@pytest.mark.parametrize("Tp,w_hop,eq", [(48000, 2400, True), (48000, 2400, False), (1, 2400, True), (5, 2400, True),
+                                         (2047, 2400, True), (2048, 1200, True), (2049, 2400, True),
+                                         (5000, 1200, False), (6000, 800, True), (9999, 4000, True)])
+def test_fused_render_decimate_is_bit_identical(Tp, w_hop, eq):
+    """The fused oscillator kernel (in-block phase scan -> render into LDS -> polyphase decimation, no HBM round trip
+    of the oversampled signal) against the three-kernel path (taken when `pre` is requested): the same arithmetic on the
+    same exact Q0.64 phases, so every output bit must agree -- with and without the fused addend, ragged tile counts,
+    control hops that need 3 and 4 staged table rows (and one, w_hop 800, that falls back to the unfused path)."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    rng = np.random.default_rng(Tp + w_hop)
+    B = 3
+    f0 = rng.uniform(80, 400, (B, 1)) * (1 + 0.03 * np.sin(2 * np.pi * 5.5 * np.arange(Tp) / 24000 + rng.uniform(0, 6, (B, 1))))
+    phase = dev((f0 / 24000).astype(np.float32))
+    Fw = (Tp - 1) // w_hop + 2
+    w = dev(rng.uniform(0, 1, (B, Fw)).astype(np.float32))
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=eq)
+    table, taps = m.table.cuda(), m.decimater.taps.cuda()
+    add = dev(rng.normal(0, 1, (B, Tp)).astype(np.float32))
+    for a in (None, add):
+        fused = GF.glottal_osc(phase, w, table, taps, 1, w_hop, 4, eq, add=a)
+        unfused, pre = GF.glottal_osc(phase, w, table, taps, 1, w_hop, 4, eq, return_pre=True, add=a)
+        torch.cuda.synchronize()
+        assert fused.shape == unfused.shape == (B, Tp)
+        assert torch.isfinite(fused).all()
+        assert torch.equal(fused, unfused), (Tp, w_hop, eq, a is not None, float((fused - unfused).abs().max()))
