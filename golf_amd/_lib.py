@@ -32,11 +32,12 @@ SIGNATURES = {
     "golf_last_error": (ctypes.c_char_p, []),
     "golf_target_arch": (ctypes.c_char_p, []),
     "golf_ltv_allpole_workspace_bytes": (_sz, [_int] * 5),
+    "golf_ltv_allpole_workspace_bytes_ex": (_sz, [_int] * 6),
     "golf_ltv_allpole_transitions_f32": (_int, [_c_f32p] + [_int] * 5 + [_vp, _sz, _int, _vp]),
     "golf_ltv_allpole_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 5
                                  + [_vp, _sz, _int, _vp, _vp]),
     "golf_ltv_allpole_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64,
-                                        _c_f32p, _c_f32p] + [_int] * 5 + [_vp, _sz, _vp]),
+                                        _c_f32p, _c_f32p] + [_int] * 5 + [_vp, _sz, _int, _vp]),
     "golf_ltv_inverse_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _i64] + [_int] * 5 + [_vp]),
     "golf_ltv_inverse_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _i64, _c_f32p] + [_int] * 5
                                  + [_vp]),
@@ -79,6 +80,7 @@ SIGNATURES = {
                                           _vp]),
 }
 
+ABI_VERSION = 2
 _lock = threading.Lock()
 _lib = None
 
@@ -134,8 +136,8 @@ def load():
             fn.restype = res
             fn.argtypes = args
         ver = lib.golf_abi_version()
-        if ver != 1:
-            raise RuntimeError(f"golf_amd: ABI version {ver} != 1")
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"golf_amd: ABI version {ver} != {ABI_VERSION}")
         _lib = lib
         return lib
 

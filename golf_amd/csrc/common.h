@@ -35,9 +35,11 @@ struct SsPlan {
     int NP;     // chunks that own a transition matrix = NC-1
     int seg;    // gradient segment length = min(L, hop)
     int NSEG;   // ceil(T/seg)
+    bool serial;  // batch-parallel serial kernels (large batches): no transition matrices / boundary states in ws
     // workspace offsets (bytes)
     size_t off_phi, off_phiT, off_z, off_E, off_z2, off_S, off_zadj, off_lam, off_g, off_pa, off_pg, total;
 };
-bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p);
+bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode = 0);
+int ss_serial_min_batch();
 
 }  // namespace golf

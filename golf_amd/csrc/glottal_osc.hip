@@ -574,8 +574,8 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 //   4. the polyphase FIR of osc_decimate_kernel runs on that tile, + the fused addend, one store per output.
 // HBM traffic: phase in (twice: totals + tile), addend in, audio out, tables from L2.  Results are bit-identical to the
 // three-kernel path (same arithmetic on the same exact phases; tests/test_gpu_osc.py asserts equality).
-#define OSCF_TO 2048
-#define OSCF_THREADS 512
+#define OSCF_TO 1024
+#define OSCF_THREADS 256
 #define OSCF_CPT 5          // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + halo
 #define OSCF_MAXROWS 4
 
@@ -624,6 +624,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int o0 = tile * OSCF_TO;
     const int span = OSCF_TO + ngrp * 4 + 4;     // coarse samples staged (polyphase index i <-> coarse sample j_lo + i)
+    u64* Cs = reinterpret_cast<u64*>(ps + ((span + 1 + 3) & ~3));   // start phase of every staged coarse sample
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
     // ---- 1. base phase: the tiles before this one (wave 0), and the taps / table rows / phase samples into LDS
     if (wv == 0) {
@@ -673,78 +674,71 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
         }
     }
     __syncthreads();
-    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
+    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1 for the scan and
+    // publishes their start phases C_u (Q0.64) in LDS; the render loop below walks the samples strided over the block
     const double scale_a = 18446744073709551616.0 / (double)OS;
     const double scale_d = scale_a / (double)P;
-    const int u0 = tid * OSCF_CPT;
-    u64 av[OSCF_CPT], dv[OSCF_CPT];
-    u64 tsum = 0;
-#pragma unroll
-    for (int r = 0; r < OSCF_CPT; ++r) {
-        const int u = min(u0 + r, span - 1);
-        const int j = j_lo + u;
-        const float p0 = ps[u], p1 = ps[u + 1];
-        av[r] = osc_fix_a(p0, scale_a);
-        dv[r] = osc_fix_d(p0, p1, scale_d);
-        const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-        tsum += seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
-    }
-    const u64 incl = wave_incl_scan(tsum, lane);
-    if (lane == 63) wtot[wv] = incl;
-    __syncthreads();
-    u64 run = base_sh + incl - tsum;
-    for (int w = 0; w < wv; ++w) run += wtot[w];
-    // base_sh counts from coarse sample o0 = tile start; the halo in front of it (j_lo .. o0-1, -dmin samples) belongs
-    // to the previous tile's total: subtract the halo's own advance, i.e. the local prefix at u = -dmin
     {
-        __shared__ u64 halo_sh;
-        // the thread that owns u = -dmin publishes its exclusive prefix there
-        const int uh = -dmin;
-        u64 r2 = run;
+        const int u0 = tid * OSCF_CPT;
+        u64 tv[OSCF_CPT];
+        u64 tsum = 0;
 #pragma unroll
         for (int r = 0; r < OSCF_CPT; ++r) {
-            if (u0 + r == uh) halo_sh = r2 - base_sh;
-            const int j = j_lo + u0 + r;
-            const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;
-            r2 += seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
+            const int u = min(u0 + r, span - 1);
+            const int j = j_lo + u;
+            const float p0 = ps[u], p1 = ps[u + 1];
+            const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
+            tv[r] = seg ? (u64)P * osc_fix_a(p0, scale_a) + osc_fix_d(p0, p1, scale_d) * (u64)6 : 0;
+            tsum += tv[r];
         }
+        const u64 incl = wave_incl_scan(tsum, lane);
+        if (lane == 63) wtot[wv] = incl;
         __syncthreads();
-        run -= halo_sh;
+        u64 run = incl - tsum;                 // exclusive prefix relative to coarse sample j_lo
+        for (int w = 0; w < wv; ++w) run += wtot[w];
+#pragma unroll
+        for (int r = 0; r < OSCF_CPT; ++r) {
+            if (u0 + r < span) Cs[u0 + r] = run;
+            run += tv[r];
+        }
     }
-    // ---- 3. render the fine samples of the owned coarse samples into the polyphase tile
+    __syncthreads();
+    // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
+    // (j_lo .. o0-1) belongs to the previous tile's total, so the phase at local index u is base - Cs[-dmin] + Cs[u]
+    const u64 base = base_sh - Cs[-dmin];
+    // ---- 3. render: thread takes coarse samples u = tid, tid + NTH, ...; its 4 fine samples lie in ONE control
+    // interval (hop_t is a multiple of 4), so the interval / row pointers are found once per coarse sample
     const float inv_hop_t = 1.0f / (float)hop_t;
     // nrows - 1 control intervals are staged (rows r_first .. r_first + nrows - 1): interval index 0 .. nrows - 2
     const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
+    for (int u = tid; u < span; u += NTH) {
+        const int j = j_lo + u;
+        const float p0 = ps[u], p1 = ps[u + 1];
+        const float d = (p1 - p0) * 0.25f;
+        u64 ph = base + Cs[u];
+        u64 inc = osc_fix_a(p0, scale_a);
+        const u64 dinc = osc_fix_d(p0, p1, scale_d);
+        const int m0 = j * P;
+        const int rr = (m0 >= bnd1) + (m0 >= bnd2);
+        const float* ra = rows + (size_t)rr * LR;
+        float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
+        const bool v0 = j >= 0 && j <= Tp - 1;         // fine sample k = 0 exists
+        const bool vk = j >= 0 && j < Tp - 1;          // fine samples k = 1..3 exist (the last coarse sample has only k = 0)
+        float* xp = X + (u & 3) * RS4 + (u >> 2);
 #pragma unroll
-    for (int r = 0; r < OSCF_CPT; ++r) {
-        const int u = u0 + r;
-        if (u < span) {
-            const int j = j_lo + u;
-            const float p0 = ps[u], p1 = ps[u + 1];
-            const float d = (p1 - p0) * 0.25f;
-            u64 ph = run, inc = av[r];
-            const u64 dinc = dv[r];
-            const bool segv = j >= 0 && j < Tp - 1;
-            run += segv ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
-            float* xp = X + (u & 3) * RS4 + (u >> 2);
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                ph += inc;
-                inc += dinc;
-                const int m = j * P + k;
-                const unsigned hi = (unsigned)(ph >> 32);
-                const int c0 = (int)(hi >> (32 - lshift));
-                const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
-                const int rr = (m >= bnd1) + (m >= bnd2);
-                const float rf = (float)(m - (r_first + rr) * hop_t) * inv_hop_t;
-                const float* ra = rows + (size_t)rr * LR;
-                const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
-                const float top = fmaf(cf, a01 - a00, a00);
-                const float bot = fmaf(cf, a11 - a10, a10);
-                float v = fmaf(rf, bot - top, top);
-                if (EE) v *= rsqrtf(fmaf((float)k, d, p0) * 0.25f);
-                xp[k * 4 * RS4] = (m >= 0 && m < N && j >= 0) ? v : 0.f;
-            }
+        for (int k = 0; k < P; ++k) {
+            ph += inc;
+            inc += dinc;
+            const unsigned hi = (unsigned)(ph >> 32);
+            const int c0 = (int)(hi >> (32 - lshift));
+            const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+            const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
+            const float top = fmaf(cf, a01 - a00, a00);
+            const float bot = fmaf(cf, a11 - a10, a10);
+            float v = fmaf(rf, bot - top, top);
+            if (EE) v *= rsqrtf(fmaf((float)k, d, p0) * 0.25f);
+            xp[k * 4 * RS4] = (k == 0 ? v0 : vk) ? v : 0.f;
+            rf = (float)(m0 + k + 1 - (r_first + rr) * hop_t) * inv_hop_t;
         }
     }
     __syncthreads();
@@ -1081,7 +1075,8 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int nrows = nint_touched + 1;
         const int hoff = (os * 4 * RS4 + 3) & ~3;
         const size_t ldsf = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) +
-                                             (((size_t)nrows * (L + 1) + 3) & ~(size_t)3) + (size_t)span + 4);
+                                             (((size_t)nrows * (L + 1) + 3) & ~(size_t)3) + (size_t)((span + 1 + 3) & ~3) +
+                                             2 * (size_t)span + 4);
         if (nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin <= span && ldsf <= 96 * 1024) {
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);       // <= g.ntile: fits the Ttot region of the workspace
             hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,

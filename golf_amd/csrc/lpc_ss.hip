@@ -43,9 +43,20 @@ static const WNT kTable[] = {{8, 2},   {8, 4},   {8, 6},   {16, 8},  {16, 12}, {
                              {24, 16}, {24, 20}, {24, 22}, {32, 16}, {32, 22}, {32, 26}, {32, 30}, {40, 22},
                              {40, 26}, {40, 32}, {40, 38}};
 
-bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
+// Batch size from which the batch-parallel serial kernels replace the chunked scan (dev knob: GOLF_SS_SERIAL_MIN_BATCH).
+// Chunking buys parallelism in time at the price of (M+2)-fold arithmetic; once the batch alone fills the chip's wave
+// slots that price stops paying.  Measured crossover on MI355X (M=22, T=47761): DESIGN.md §4.1.
+int ss_serial_min_batch() {
+    static const int v = [] { const char* e = getenv("GOLF_SS_SERIAL_MIN_BATCH"); return e ? atoi(e) : 1024; }();
+    return v;
+}
+
+bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->W = 0;
     p->NT = 0;
+    // mode: 0 = by batch size, GOLF_SS_SERIAL / GOLF_SS_CHUNKED force one; rows of 16 utterances must fit a 2 GB
+    // buffer descriptor
+    p->serial = mode == GOLF_SS_SERIAL || (mode != GOLF_SS_CHUNKED && B >= ss_serial_min_batch());
     if (F >= 2) {
         for (const WNT& e : kTable) {
             if (e.NT < M || hop % e.W != 0) continue;
@@ -69,6 +80,14 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p) {
     p->seg = L < hop ? L : hop;
     p->NSEG = (int)ceil_div(T, p->seg);
     size_t o = 0;
+    if (p->serial) {   // batch-parallel serial path: no transition matrices, no boundary states
+        p->off_phi = p->off_phiT = p->off_z = p->off_E = p->off_z2 = p->off_S = p->off_zadj = p->off_lam = 0;
+        p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
+        p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
+        p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
+        p->total = o;
+        return true;
+    }
     p->off_phi = o;  o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_phiT = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->off_z = o;    o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1) * W, 256);
@@ -228,6 +247,230 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
     fwdq_body<W, NT, MODE>(ex, ex_stride, gain, a, S, out, y_stride, T, F, M, hop, L, NCQ, NCS, zin, xt, yt,
                            blockIdx.y, blockIdx.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch-parallel SERIAL variant (large batches; the north_star's "serial sample recursion in-lane, batch x channel
+// across wavefronts"): a quad of 4 lanes runs ONE WHOLE utterance from t = 0 to T, 16 utterances per wave, B/16 waves.
+// Same tap-parallel systolic inner loop as fwdq_body; what differs is the data movement: the wave's 16 rows belong to
+// 16 utterances (row stride = the tensor's row stride, one buffer descriptor over the 16 rows, out-of-range elements
+// get offset -1 = out of bounds -> the hardware returns 0 / drops the store), and the frame parameters of frame f+2 are
+// loaded while frame f is being processed (a lone wave would otherwise stall ~1 us on dependent loads at each of the
+// 200 frame boundaries).  No transition matrices, no scan, no redundant arithmetic: 1x the reference's FMA count.
+// ------------------------------------------------------------------------------------------
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_serial_fwd_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                            const float* __restrict__ gain,
+                                                            const float* __restrict__ a, float* __restrict__ y,
+                                                            int64_t y_stride, int B, int T, int F, int M, int hop) {
+    constexpr int TPL = quad_tpl(W, NT);
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
+    const int lane = threadIdx.x;
+    const int lq = lane / W, lr = lane % W;
+    const int row = lane >> 2, r = lane & 3;
+    const int b0 = blockIdx.x * 16;
+    const int nrow = B - b0 < 16 ? B - b0 : 16;
+    const int b = b0 + (row < nrow ? row : nrow - 1);  // idle quads shadow the last utterance; their stores are masked
+    const int xs = (int)ex_stride, ys = (int)y_stride;
+    const BufRow xblk(ex + (size_t)b0 * ex_stride, nrow * xs);
+    const BufRow yblk(y + (size_t)b0 * y_stride, nrow * ys);
+    auto fetch = [&](float (&v)[TL::ITS], int t0) {
+#pragma unroll
+        for (int it = 0; it < TL::ITS; ++it) {
+            int rw, col;
+            TL::rowcol(it, lq, lr, rw, col);
+            const int t = t0 + col;
+            v[it] = xblk.ld((t < T && rw < nrow) ? rw * xs + t : -1);
+        }
+    };
+    auto load_row = [&](float (&dst)[TPL], int f) {
+        const float* pa = a + ((size_t)b * F + f) * M;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            const int i = r * TPL + k;
+            dst[k] = pa[i < M ? i : 0];
+            if (i >= M) dst[k] = 0.f;
+        }
+    };
+    const float inv_hop = 1.0f / (float)hop;
+    float w[TPL], a0[TPL], a1[TPL], an[TPL], dd[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) w[k] = 0.f;
+    int f = 0, n0 = 0;
+    load_row(a0, 0);
+    load_row(a1, 1);
+    load_row(an, F > 2 ? 2 : F - 1);
+    const float* gb = gain + (size_t)b * F;
+    float g0 = gb[0], g1 = gb[1], gn = gb[F > 2 ? 2 : F - 1];
+    float dg = (g1 - g0) * inv_hop;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) dd[k] = (a1[k] - a0[k]) * inv_hop;
+    float nx[TL::ITS];
+    fetch(nx, 0);
+    for (int t0 = 0; t0 < T; t0 += W) {
+        TL::scatter(xt, nx, lq, lr);
+        wave_lds_fence();
+        float xin[W];
+        TL::rows_load(xin, xt, row);
+        fetch(nx, t0 + W);
+        if (n0 == hop && f < F - 2) {   // frame boundary (wave-uniform): rotate the parameter rows, prefetch frame f+2
+            ++f;
+            n0 = 0;
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) { a0[k] = a1[k]; a1[k] = an[k]; dd[k] = (a1[k] - a0[k]) * inv_hop; }
+            g0 = g1; g1 = gn; dg = (g1 - g0) * inv_hop;
+            const int fn = f + 2 < F ? f + 2 : F - 1;
+            load_row(an, fn);
+            gn = gb[fn];
+        }
+        float keep[W / 4];
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
+        const float nb = (float)n0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const float n = nb + (float)s;
+            const float x = xin[s] * fmaf(n, dg, g0);
+            float cf[TPL];
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) cf[k] = fmaf(n, dd[k], a0[k]);
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int k = TPL - 1; k >= 1; --k) {
+                const int slot = (s - 1 - k + 4 * TPL) % TPL;
+                if (k & 1) pa = fmaf(cf[k], w[slot], pa);
+                else       pb = fmaf(cf[k], w[slot], pb);
+            }
+            float part = fmaf(cf[0], w[(s - 1 + TPL) % TPL], pa + pb);
+            part += dppf<DPP_XOR1>(part);
+            part += dppf<DPP_XOR2>(part);
+            const float yv = x - part;
+            const float oldest = w[s % TPL];
+            const float inc = dppf<DPP_SHR1>(oldest);
+            w[s % TPL] = r == 0 ? yv : inc;
+            keep[s >> 2] = ((s & 3) == r) ? yv : keep[s >> 2];
+        }
+        n0 += W;
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
+        wave_lds_fence();
+        float o[TL::ITS];
+        TL::gather(o, yt, lq, lr);
+#pragma unroll
+        for (int it = 0; it < TL::ITS; ++it) {
+            int rw, col;
+            TL::rowcol(it, lq, lr, rw, col);
+            const int t = t0 + col;
+            yblk.st((t < T && rw < nrow) ? rw * ys + t : -1, o[it]);
+        }
+        wave_lds_fence();
+    }
+}
+
+// Serial adjoint (backward of the above): the transposed-form recursion of lpc_adjq_kernel run over the whole utterance
+// in reverse time, lam(T) = 0, writes g[b][t] = dL/dy_total; the parallel gradient kernels (lpc_grad_corr / _reduce)
+// follow unchanged.  Parameter rows are prefetched one frame ahead in the direction of travel (frame f-1).
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_serial_adj_kernel(const float* __restrict__ gy, int64_t gy_stride,
+                                                            const float* __restrict__ a, float* __restrict__ g,
+                                                            int64_t g_stride, int B, int T, int F, int M, int hop) {
+    constexpr int TPL = quad_tpl(W, NT);
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
+    const int lane = threadIdx.x;
+    const int lq = lane / W, lr = lane % W;
+    const int row = lane >> 2, r = lane & 3;
+    const int b0 = blockIdx.x * 16;
+    const int nrow = B - b0 < 16 ? B - b0 : 16;
+    const int b = b0 + (row < nrow ? row : nrow - 1);
+    const int xs = (int)gy_stride, ys = (int)g_stride;
+    const BufRow xblk(gy + (size_t)b0 * gy_stride, nrow * xs);
+    const BufRow yblk(g + (size_t)b0 * g_stride, nrow * ys);
+    auto fetch = [&](float (&v)[TL::ITS], int t0) {
+#pragma unroll
+        for (int it = 0; it < TL::ITS; ++it) {
+            int rw, col;
+            TL::rowcol(it, lq, lr, rw, col);
+            const int t = t0 + col;
+            v[it] = xblk.ld((t0 >= 0 && t < T && rw < nrow) ? rw * xs + t : -1);
+        }
+    };
+    auto load_row = [&](float (&dst)[TPL], int f) {
+        const float* pa = a + ((size_t)b * F + f) * M;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            const int i = r * TPL + k;
+            dst[k] = pa[i < M ? i : 0];
+            if (i >= M) dst[k] = 0.f;
+        }
+    };
+    const float inv_hop = 1.0f / (float)hop;
+    float p[TPL], a0[TPL], a1[TPL], an[TPL], dd[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) p[k] = 0.f;
+    int t0 = ((T - 1) / W) * W;
+    int f = t0 / hop;
+    if (f > F - 2) f = F - 2;
+    int n0 = t0 - f * hop;
+    load_row(a0, f);
+    load_row(a1, f + 1);
+    load_row(an, f > 0 ? f - 1 : 0);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) dd[k] = (a1[k] - a0[k]) * inv_hop;
+    float nx[TL::ITS];
+    fetch(nx, t0);
+    for (; t0 >= 0; t0 -= W) {
+        TL::scatter(xt, nx, lq, lr);
+        wave_lds_fence();
+        float gin[W];
+        TL::rows_load(gin, xt, row);
+        fetch(nx, t0 - W);
+        if (n0 < 0) {   // crossed into frame f-1 (wave-uniform)
+            --f;
+            n0 += hop;
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) { a1[k] = a0[k]; a0[k] = an[k]; dd[k] = (a1[k] - a0[k]) * inv_hop; }
+            load_row(an, f > 0 ? f - 1 : 0);
+        }
+        float keep[W / 4];
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
+        const float nb = (float)n0;
+#pragma unroll
+        for (int s = W - 1; s >= 0; --s) {
+            const int st = W - 1 - s;
+            const float n = nb + (float)s;
+            const float head = p[st % TPL];
+            const float gv = dppf<DPP_BC0>(gin[s] + head);
+            float inc = dppf<DPP_SHL1>(head);
+            inc = r == 3 ? 0.f : inc;
+#pragma unroll
+            for (int k = 0; k < TPL - 1; ++k) {
+                const float cf = fmaf(n, dd[k], a0[k]);
+                p[(k + st + 1) % TPL] = fmaf(-cf, gv, p[(k + st + 1) % TPL]);
+            }
+            const float cfl = fmaf(n, dd[TPL - 1], a0[TPL - 1]);
+            p[st % TPL] = fmaf(-cfl, gv, inc);
+            keep[s >> 2] = ((s & 3) == r) ? gv : keep[s >> 2];
+        }
+        n0 -= W;
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
+        wave_lds_fence();
+        float o[TL::ITS];
+        TL::gather(o, yt, lq, lr);
+#pragma unroll
+        for (int it = 0; it < TL::ITS; ++it) {
+            int rw, col;
+            TL::rowcol(it, lq, lr, rw, col);
+            const int t = t0 + col;
+            yblk.st((t < T && rw < nrow) ? rw * ys + t : -1, o[it]);
+        }
+        wave_lds_fence();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1214,6 +1457,37 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     return GOLF_OK;
 }
 
+template <int W, int NT>
+static int launch_serial_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a,
+                             float* y, int64_t y_stride, int B, int T, int F, int M, int hop, hipStream_t st) {
+    hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT>), dim3((unsigned)ceil_div(B, 16)), dim3(64), 0, st, ex, ex_stride,
+                       gain, a, y, y_stride, B, T, F, M, hop);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+template <int W, int NT>
+static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
+                             const float* ex, int64_t ex_stride, const float* gain, const float* a, float* g_ex,
+                             int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T, int F, int M, int hop,
+                             char* ws, hipStream_t st) {
+    float* gbuf = (float*)(ws + p.off_g);
+    float* pa = (float*)(ws + p.off_pa);
+    float* pg = (float*)(ws + p.off_pg);
+    hipLaunchKernelGGL((lpc_serial_adj_kernel<W, NT>), dim3((unsigned)ceil_div(B, 16)), dim3(64), 0, st, gy, gy_stride,
+                       a, gbuf, (int64_t)T, B, T, F, M, hop);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st,
+                       (const float*)gbuf, (int64_t)T, y, y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T,
+                       F, NT, W, hop, p.seg, p.NSEG);
+    GOLF_LAUNCH_CHECK();
+    const int64_t n4 = (int64_t)B * F * (M + 1);
+    hipLaunchKernelGGL(lpc_grad_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)pa,
+                       (const float*)pg, g_a, g_gain, B, F, M, W, hop, p.seg, p.NSEG);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
 // (W, NT) instantiation table — must list exactly kTable.
 #define GOLF_SS_CASE(FN, w, nt, ...) case (w) * 100 + (nt): return FN<w, nt>(__VA_ARGS__);
 #define GOLF_SS_DISPATCH(FN, ...)               \
@@ -1240,8 +1514,14 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
         default: break;                         \
     }
 
-static bool plan_fast(int B, int T, int F, int M, int hop, SsPlan* p) {
-    return make_ss_plan(B, T, F, M, hop, p);
+static int ss_mode(int flags) {
+    return (flags & GOLF_SS_SERIAL) ? GOLF_SS_SERIAL : ((flags & GOLF_SS_CHUNKED) ? GOLF_SS_CHUNKED : 0);
+}
+// rows of 16 utterances are addressed through one 32-bit buffer descriptor: the serial path needs 16 * stride * 4 B < 2 GB
+static bool serial_strides_ok(int64_t s0, int64_t s1) { return s0 < (1 << 24) && s1 < (1 << 24); }
+
+static bool plan_fast(int B, int T, int F, int M, int hop, SsPlan* p, int flags = 0) {
+    return make_ss_plan(B, T, F, M, hop, p, ss_mode(flags));
 }
 
 }  // namespace golf
@@ -1256,11 +1536,17 @@ static int check_ss_args(int B, int T, int F, int M, int hop) {
     return GOLF_OK;
 }
 
-extern "C" size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop) {
+extern "C" size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, int flags) {
     SsPlan p;
     if (B < 1 || T < 1 || F < 1 || M < 1 || hop < 1) return 0;
-    if (!plan_fast(B, T, F, M, hop, &p)) return 256;
+    if (!plan_fast(B, T, F, M, hop, &p, flags)) return 256;
     return p.total;
+}
+
+// Default path selection.  Below the serial threshold the chunked layout is returned, which also covers a forced
+// GOLF_SS_SERIAL call (its buffers are a subset); at or above it only the (much smaller) serial layout.
+extern "C" size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop) {
+    return golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, 0);
 }
 
 extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop, void* ws,
@@ -1268,7 +1554,8 @@ extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, in
     if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
     if (!a) return fail(GOLF_EINVAL, "ltv_allpole_transitions: null pointer");
     SsPlan p;
-    if (!plan_fast(B, T, F, M, hop, &p)) return GOLF_OK;  // generic path has no transition matrices
+    if (!plan_fast(B, T, F, M, hop, &p, flags)) return GOLF_OK;  // generic path has no transition matrices
+    if (p.serial) return GOLF_OK;                                 // nor has the batch-parallel serial path
     if (!ws || ws_bytes < p.total || ((uintptr_t)ws & 255))
         return fail(GOLF_EWORKSPACE, "ltv_allpole_transitions: workspace needs %zu bytes, 256-aligned (got %zu)",
                     p.total, ws_bytes);
@@ -1286,15 +1573,23 @@ extern "C" int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, cons
     if (ex_stride < T || y_stride < T) return fail(GOLF_EINVAL, "ltv_allpole_fwd: row stride < T");
     hipStream_t st = (hipStream_t)stream;
     SsPlan p;
-    if (!plan_fast(B, T, F, M, hop, &p)) {
+    if (!plan_fast(B, T, F, M, hop, &p, flags)) {
         hipLaunchKernelGGL(lpc_ss_generic_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, st, ex, ex_stride, gain,
                            a, y, y_stride, B, T, F, M, hop);
         GOLF_LAUNCH_CHECK();
         return GOLF_OK;
     }
+    if (p.serial && !serial_strides_ok(ex_stride, y_stride)) {
+        if (flags & GOLF_SS_SERIAL) return fail(GOLF_EUNSUPPORTED, "ltv_allpole_fwd: serial path needs row strides < 2^24");
+        plan_fast(B, T, F, M, hop, &p, GOLF_SS_CHUNKED);
+    }
     if (!ws || ws_bytes < p.total || ((uintptr_t)ws & 255))
         return fail(GOLF_EWORKSPACE, "ltv_allpole_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", p.total,
                     ws_bytes);
+    if (p.serial) {
+        GOLF_SS_DISPATCH(launch_serial_fwd, p, ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop, st)
+        return fail(GOLF_EUNSUPPORTED, "ltv_allpole_fwd: no kernel for W=%d NT=%d", p.W, p.NT);
+    }
     hipStream_t side = (hipStream_t)side_stream;
     if (side == st) side = nullptr;
     GOLF_SS_DISPATCH(launch_fwd, p, ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop, (char*)ws, flags, side, st)
@@ -1304,14 +1599,14 @@ extern "C" int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, cons
 extern "C" int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                                         const float* ex, int64_t ex_stride, const float* gain, const float* a,
                                         float* g_ex, int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T,
-                                        int F, int M, int hop, void* ws, size_t ws_bytes, void* stream) {
+                                        int F, int M, int hop, void* ws, size_t ws_bytes, int flags, void* stream) {
     if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
     if (!gy || !y || !ex || !gain || !a || !g_ex || !g_gain || !g_a)
         return fail(GOLF_EINVAL, "ltv_allpole_bwd: null pointer");
     if (gy_stride < T || y_stride < T || ex_stride < T || g_ex_stride < T)
         return fail(GOLF_EINVAL, "ltv_allpole_bwd: row stride < T");
     SsPlan p;
-    if (!plan_fast(B, T, F, M, hop, &p))
+    if (!plan_fast(B, T, F, M, hop, &p, flags))
         return fail(GOLF_EUNSUPPORTED,
                     "ltv_allpole_bwd: needs a ring width W in {8,16,24,32,40} with W >= M+1 and hop %% W == 0 "
                     "(M=%d hop=%d)", M, hop);
@@ -1319,6 +1614,13 @@ extern "C" int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, cons
         return fail(GOLF_EWORKSPACE, "ltv_allpole_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", p.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (p.serial && !serial_strides_ok(gy_stride, gy_stride))
+        return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: serial path needs row strides < 2^24");
+    if (p.serial) {
+        GOLF_SS_DISPATCH(launch_serial_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride,
+                         g_gain, g_a, B, T, F, M, hop, (char*)ws, st)
+        return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
+    }
     GOLF_SS_DISPATCH(launch_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride, g_gain, g_a,
                      B, T, F, M, hop, (char*)ws, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);

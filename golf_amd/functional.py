@@ -91,7 +91,7 @@ def ss_output_length(Tx: int, F: int, hop: int) -> int:
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ex, gain, a, hop, prepared, fast_inference):
+    def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
         ex = _rows(ex)
@@ -110,9 +110,10 @@ class _LTVAllPoleSS(torch.autograd.Function):
             if prepared.fast:
                 flags |= FAST_TRANSITIONS
         else:
-            ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), ex.device)
+            ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
+            flags = mode
             if not needs_grad and fast_inference:
-                flags = FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
+                flags |= FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
             if SPLIT_P1:
                 flags |= 4                # GOLF_SS_SPLIT_P1 (diagnostic): two launches instead of the fused one
             if FORK_TRANSITIONS:
@@ -124,7 +125,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
                                           side.cuda_stream if side is not None else 0, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_fwd_f32")
-        ctx.hop = hop
+        ctx.hop, ctx.mode = hop, mode
         ctx.save_for_backward(ex, gain, a, y, ws)
         return y
 
@@ -145,19 +146,25 @@ class _LTVAllPoleSS(torch.autograd.Function):
         rc = lib.golf_ltv_allpole_bwd_f32(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), ex.data_ptr(),
                                           ex.stride(0), gain.data_ptr(), a.data_ptr(), g_ex.data_ptr(),
                                           g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
-                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                          ws.data_ptr(), ws.numel(), ctx.mode, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
-        return g_ex, g_gain, g_a, None, None, None
+        return g_ex, g_gain, g_a, None, None, None, None
+
+
+SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16}   # GOLF_SS_SERIAL / GOLF_SS_CHUNKED
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
-                   prepared: "PreparedTransitions" = None, fast_inference: bool = True) -> torch.Tensor:
+                   prepared: "PreparedTransitions" = None, fast_inference: bool = True,
+                   mode: str = None) -> torch.Tensor:
     """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
     Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward).
     ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match).
     ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
-    fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel)."""
-    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference))
+    fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
+    ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 1024 utterances, batch-parallel
+    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one."""
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode])
 
 
 class _LTVInverse(torch.autograd.Function):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GOLF_ABI_VERSION 1
+#define GOLF_ABI_VERSION 2
 
 enum {
     GOLF_OK = 0,
@@ -57,6 +57,8 @@ const char* golf_target_arch(void);
  *        matrices the backward pass reuses — keep it alive (unmodified) until the backward ran.
  * ------------------------------------------------------------------------------------------- */
 size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
+/* The same for a forced algorithm (GOLF_SS_SERIAL / GOLF_SS_CHUNKED in `flags`; 0 = default selection). */
+size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, int flags);
 
 /* The per-chunk transition matrices depend only on the coefficients `a`, not on the excitation, and are the
  * most expensive phase.  golf_ltv_allpole_transitions_f32 computes them into `ws` on its own, so a caller that
@@ -77,6 +79,13 @@ size_t golf_ltv_allpole_workspace_bytes(int B, int T, int F, int M, int hop);
 /*          GOLF_SS_SPLIT_P1  (diagnostic) launch the fp32 transition kernel and the zero-state pass separately instead
  *                of as one horizontally fused kernel (the default with FAST and without HAVE / side_stream). */
 #define GOLF_SS_SPLIT_P1 4
+/*          GOLF_SS_SERIAL / GOLF_SS_CHUNKED  force one of the two algorithms (default: by batch size).
+ *                CHUNKED: time is cut into chunks whose transition matrices are scanned (B*T/L*(M+2) lanes of work,
+ *                (M+2)-fold arithmetic: what makes B = 32 fast).  SERIAL: one quad of lanes per utterance runs the
+ *                recursion from t = 0 to T, B/16 waves, no redundant arithmetic and no transition matrices: the
+ *                large-batch kernel (default from B >= 1024).  The backward must be given the flag the forward ran with. */
+#define GOLF_SS_SERIAL 8
+#define GOLF_SS_CHUNKED 16
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);
@@ -90,13 +99,14 @@ int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* ga
  *     g[t]      = gy[t] - sum_i A[t+1+i,i]*g[t+1+i]      (reverse-time recursion)
  *     g_ex[t]   = g[t]*G[t]
  *     g_gain[f] = up^T(g*ex)[f]         g_a[f,i] = up^T(-g[t]*y[t-1-i])[f,i]
- *   gy,y (B,T) with strides; ws = the forward's workspace (same B,T,F,M,hop);
+ *   gy,y (B,T) with strides; ws = the forward's workspace (same B,T,F,M,hop); flags = the forward's
+ *   GOLF_SS_SERIAL / GOLF_SS_CHUNKED bits (ABI 2);
  *   g_ex (B,T) stride g_ex_stride, g_gain (B,F), g_a (B,F,M) are fully overwritten. */
 int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                              const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* g_ex, int64_t g_ex_stride, float* g_gain, float* g_a,
                              int B, int T, int F, int M, int hop,
-                             void* ws, size_t ws_bytes, void* stream);
+                             void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* a-5: inverse (analysis) filter e[t] = y[t] + sum_i A[t,i]*y[t-1-i].
  * Replaces LTVMinimumPhaseFilter.reverse -> fir_filt, models/filters.py:186-195, utils.py:433-441. */

@@ -287,3 +287,86 @@ def test_random_shape_sweep():
                 emax, el2 = rel_err(g[:, : want.shape[1]] if name == "g_ex" else g, want)
                 assert emax <= 2e-4 and el2 <= 2e-4, (case, name, B, F, M, hop, Tx, emax, el2)
     print("random sweep worst forward rel-max", worst)
+
+
+# ---------------------------------------------------------------------------------------------
+# batch-parallel serial kernels (GOLF_SS_SERIAL: the large-batch path, default from B >= 1024)
+# ---------------------------------------------------------------------------------------------
+def run_mode(ex, gain, a, hop, mode, gy=None):
+    from golf_amd import functional as GF
+
+    t = [dev(v).requires_grad_(gy is not None) for v in (ex, gain, a)]
+    y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, mode=mode)
+    if gy is None:
+        torch.cuda.synchronize()
+        return y.detach().cpu().numpy()
+    (y * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    return (y.detach().cpu().numpy(),) + tuple(v.grad.cpu().numpy() for v in t)
+
+
+@pytest.mark.parametrize("B,F,M,hop,Tx", [(1, 2, 22, 240, None), (5, 12, 22, 240, None), (17, 9, 4, 8, 60),
+                                          (33, 7, 6, 16, 100), (3, 30, 12, 24, None), (16, 12, 26, 240, 2500),
+                                          (2, 5, 30, 256, None), (40, 6, 22, 120, 601)])
+def test_serial_path_vs_oracle(B, F, M, hop, Tx):
+    """One quad per utterance, 16 utterances per wave, t = 0..T in one go: forward and all three gradients against the
+    float64 oracle, with batches that are not multiples of 16, ragged excitation lengths and every ring width."""
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=B + F)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    gy = np.random.default_rng(B).normal(0, 1, ref.shape).astype(np.float32)
+    y, g_ex, g_gain, g_a = run_mode(ex, gain, a, hop, "serial", gy)
+    assert y.shape == ref.shape
+    check(y, ref, f"serial fwd B{B} F{F} M{M} hop{hop}")
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+    check(g_ex[:, : r_ex.shape[1]], r_ex, "serial g_ex", 2e-4)
+    check(g_gain, r_gain, "serial g_gain", 2e-4)
+    check(g_a, r_a, "serial g_a", 2e-4)
+    assert np.all(g_ex[:, ref.shape[1]:] == 0)
+    # and the two algorithms agree with each other far inside the tolerance
+    yc = run_mode(ex, gain, a, hop, "chunked")
+    check(y, yc, "serial vs chunked", 5e-5)
+
+
+def test_serial_path_full_length():
+    """2 s utterances (T = 47761, 200 frames) through the serial kernels, B = 48 (three waves), fwd + bwd."""
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=48)
+    ex, gain, a = inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy()
+    gy = np.random.default_rng(3).normal(0, 1, (48, 47761)).astype(np.float32)
+    y, g_ex, g_gain, g_a = run_mode(ex, gain, a, 240, "serial", gy)
+    check(y, O.ltv_allpole_ss_forward(ex, gain, a, 240), "serial full-length fwd")
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, 240)
+    check(g_ex[:, :47761], r_ex, "serial full-length g_ex")
+    check(g_gain, r_gain, "serial full-length g_gain")
+    check(g_a, r_a, "serial full-length g_a")
+
+
+def test_large_batch_defaults_to_serial_and_matches_chunked():
+    """B = 1024 (the default switch-over): the automatic selection runs the serial kernels (its workspace has no room
+    for transition matrices) and equals the chunked algorithm on the same inputs; rows are tiled copies of a B = 32
+    batch so the oracle check stays cheap."""
+    from golf_amd import functional as GF
+    from golf_amd._lib import load
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=32, T=9600)
+    rep = 32
+    ex, gain, a = (inp[k].repeat(rep, *([1] * (inp[k].ndim - 1))).cuda() for k in ("noise", "gain", "a"))
+    lib = load()
+    assert lib.golf_ltv_allpole_workspace_bytes(1024, 9361, 40, 22, 240) == \
+        lib.golf_ltv_allpole_workspace_bytes_ex(1024, 9361, 40, 22, 240, 8)
+    assert lib.golf_ltv_allpole_workspace_bytes_ex(1024, 9361, 40, 22, 240, 16) > \
+        lib.golf_ltv_allpole_workspace_bytes(1024, 9361, 40, 22, 240)
+    y = GF.ltv_allpole_ss(ex, gain, a, 240)
+    yc = GF.ltv_allpole_ss(ex, gain, a, 240, mode="chunked")
+    torch.cuda.synchronize()
+    ref = O.ltv_allpole_ss_forward(inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy(), 240)
+    check(y.cpu().numpy()[:32], ref, "auto (serial) B=1024 rows 0..31")
+    check(y.cpu().numpy()[-32:], ref, "auto (serial) B=1024 rows 992..1023")
+    check(y.cpu().numpy(), yc.cpu().numpy(), "serial vs chunked B=1024", 5e-5)
+    assert torch.equal(y[:32], y[-32:])          # identical rows -> identical results whatever wave they ran in
