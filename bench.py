@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--prereplay", type=int, default=16,
                     help="setup: replays of every captured hipGraph before the warm-up steps (graph upload, code objects, "
                          "clocks: instantiation is setup, not a step)")
+    ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked"],
+                    help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
@@ -98,7 +100,7 @@ def build_modules(device):
     return osc, ss, ff
 
 
-def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
+def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
     """Returns (step_fn, samples_per_step, stage_fns) working on plain tensors (module internals)."""
     from golf_amd import functional as GF
 
@@ -114,13 +116,13 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
 
     if workload == "golf-ss-synth":
         def step():
-            return GF.ltv_allpole_ss(source(), gain, a, hop, fast_inference=fast)
+            return GF.ltv_allpole_ss(source(), gain, a, hop, fast_inference=fast, mode=mode)
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)
     elif workload == "lpc-ss-fast":   # the inference filter alone (diagnostic: its share of the pipelined step)
         def step():
-            return GF.ltv_allpole_ss(noise, gain, a, hop, fast_inference=True)
+            return GF.ltv_allpole_ss(noise, gain, a, hop, fast_inference=True, mode=mode)
     elif workload == "osc-only":      # the source alone (diagnostic)
         def step():
             return source()
@@ -244,7 +246,7 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False):
 
         def step():
             y = GF.ltv_allpole_ss(GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True, add=noise), gain_g, a_g,
-                                  hop)
+                                  hop, mode=mode)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y
@@ -407,7 +409,7 @@ def main():
             steps_fn.append(steps_fn[0])
             continue
         fn, samples, t_out = make_step(args.workload, slot_inputs(i), osc, ss, ff, fast=not args.fp64_transitions,
-                                       overlap=args.overlap_transitions)
+                                       overlap=args.overlap_transitions, mode=args.lpc_mode)
         steps_fn.append(fn)
     step = steps_fn[0]
 
@@ -582,7 +584,7 @@ def main():
                        "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
                        "samples_out_per_utterance": t_out,
                        "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode}, every {GE} step(s))" if do_gather else ""),
-                       "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
+                       "lpc_mode": args.lpc_mode, "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
                        "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),
             "timing": {"regions": len(regions), "statistic": "median region wall time (max over ranks per region)",
