@@ -563,22 +563,21 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 // ---- O2+O3 fused (the GOLF configuration: phase at hop 1, 4x oversampling, power-of-two table) --------------------
 // The three-kernel path above moves 105 MB for 12 MB of algorithmic traffic at B=32: a 64-bit phase prefix per coarse
 // sample is written and read back (12 MB each way) and the 4x oversampled signal makes a round trip through HBM
-// (24 MB written by the render kernel, read again by the decimator).  Here one workgroup owns OSCF_TO output samples
+// (24 MB written by the render kernel, read again by the decimator).  Here one workgroup owns TO output samples
 // of one utterance and keeps everything in between on chip:
-//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of OSCF_TO coarse samples -> Ttot[b][tile]
+//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of TO coarse samples -> Ttot[b][tile]
 //   1. base phase of the tile = sum of the earlier tiles' totals (exact: Q0.64 integers, order cannot matter)
 //   2. the tile's coarse phase samples (+ the decimator's halo) are scanned in the block: C_j relative to the tile
 //   3. every fine sample is rendered (same integer walk and bilinear LDS lookup as osc_render_kernel) straight into
-//      the decimator's polyphase LDS tile; the table rows of the <= OSCF_MAXROWS control frames the tile touches are
+//      the decimator's polyphase LDS tile; the table rows of the <= 4 control frames the tile touches are
 //      staged once per block
 //   4. the polyphase FIR of osc_decimate_kernel runs on that tile, + the fused addend, one store per output.
 // HBM traffic: phase in (twice: totals + tile), addend in, audio out, tables from L2.  Results are bit-identical to the
 // three-kernel path (same arithmetic on the same exact phases; tests/test_gpu_osc.py asserts equality).
-#define OSCF_TO 1024
-#define OSCF_THREADS 256
-#define OSCF_CPT 5          // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + halo
 #define OSCF_MAXROWS 4
+constexpr int oscf_cpt(int TO, int NTH) { return (TO + 64 + NTH - 1) / NTH; }   // coarse samples per thread (scan)
 
+template <int TO>
 __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile) {
     __shared__ u64 wsum[4];
@@ -587,8 +586,8 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
     const double scale_a = 18446744073709551616.0 / (double)os;
     const double scale_d = scale_a / (double)P;
     const u64 tri = (u64)P * (u64)(P - 1) / 2;
-    constexpr int PER = OSCF_TO / 256;
-    const int j0 = tile * OSCF_TO + tid * PER;
+    constexpr int PER = TO / 256;
+    const int j0 = tile * TO + tid * PER;
     float pv[PER + 1];
 #pragma unroll
     for (int r = 0; r <= PER; ++r) pv[r] = prow.ld(min(j0 + r, Tp - 1));
@@ -602,18 +601,58 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
     if (tid == 0) Ttot[(size_t)b * ntile + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// The 4 fine samples of one coarse phase sample (they lie in ONE control interval: hop_t is a multiple of 4): integer
+// phase walk, bilinear lookup in the staged rows, equal-energy scaling, written to the polyphase tile.
 template <int EE>
-__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
+__device__ __forceinline__ void oscf_render_coarse(int u, int j, u64 ph, float p0, float p1, const float* __restrict__ rows,
+                                                   int LR, int lshift, int r_first, int hop_t, float inv_hop_t, int bnd1,
+                                                   int bnd2, int Tp, float* __restrict__ X, int RS4, double scale_a,
+                                                   double scale_d) {
+    const float d = (p1 - p0) * 0.25f;
+    u64 inc = osc_fix_a(p0, scale_a);
+    const u64 dinc = osc_fix_d(p0, p1, scale_d);
+    const int m0 = j * 4;
+    const int rr = (m0 >= bnd1) + (m0 >= bnd2);
+    const float* ra = rows + (size_t)rr * LR;
+    const int mrel = m0 - (r_first + rr) * hop_t;
+    const bool v0 = j >= 0 && j <= Tp - 1;         // fine sample k = 0 exists
+    const bool vk = j >= 0 && j < Tp - 1;          // k = 1..3 exist (the last coarse sample has only k = 0)
+    float* xp = X + (u & 3) * RS4 + (u >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ph += inc;
+        inc += dinc;
+        const unsigned hi = (unsigned)(ph >> 32);
+        const int c0 = (int)(hi >> (32 - lshift));
+        const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+        const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
+        const float top = fmaf(cf, a01 - a00, a00);
+        const float bot = fmaf(cf, a11 - a10, a10);
+        const float rf = (float)(mrel + k) * inv_hop_t;
+        float v = fmaf(rf, bot - top, top);
+        // raw v_rsq_f32: the argument is a normal number (p/4 with p in (0, 0.5]), where rsqrtf() returns exactly this
+        // after spending 5 more instructions on denormal scaling
+        if (EE) v *= __builtin_amdgcn_rsqf(fmaf((float)k, d, p0) * 0.25f);
+        xp[k * 4 * RS4] = (k == 0 ? v0 : vk) ? v : 0.f;
+    }
+}
+
+// Geometry: TO outputs per workgroup of NTH threads (TO / NTH = 4 outputs per thread in the FIR).  STRIDED: the render
+// loop walks the coarse samples strided over the block (balanced, start phases published in LDS); otherwise every
+// thread renders the CPT consecutive coarse samples it scanned (no phase array in LDS: room for a larger tile).
+template <int EE, int TO, int NTH, bool STRIDED>
+__global__ __launch_bounds__(NTH) void osc_fused_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
     int hop_t, int N, const float* __restrict__ taps, int K, float* __restrict__ out, int64_t out_stride, int Tout,
     int RS4, int dmin, int ngrp, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
+    static_assert(TO == 4 * NTH, "4 outputs per thread");
     constexpr int OS = 4, P = 4;
-    constexpr int NTH = OSCF_THREADS;
+    constexpr int CPT = oscf_cpt(TO, NTH);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u64 wtot[NTH / 64];
-    __shared__ u64 base_sh;
-    // layout: X polyphase tile | H taps | rows (nrows x (L+1)) | ps coarse phase samples
+    __shared__ u64 base_sh, halo_sh;
+    // layout: X polyphase tile | H taps | rows (nrows x (L+1)) | ps coarse phase samples | (STRIDED) Cs start phases
     float* X = smem;
     const int hoff = (OS * 4 * RS4 + 3) & ~3;
     float* H = smem + hoff;
@@ -622,9 +661,9 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const int LR = L + 1;
     float* ps = rows + (((size_t)nrows * LR + 3) & ~(size_t)3);
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int o0 = tile * OSCF_TO;
-    const int span = OSCF_TO + ngrp * 4 + 4;     // coarse samples staged (polyphase index i <-> coarse sample j_lo + i)
-    u64* Cs = reinterpret_cast<u64*>(ps + ((span + 1 + 3) & ~3));   // start phase of every staged coarse sample
+    const int o0 = tile * TO;
+    const int span = TO + ngrp * 4 + 4;          // coarse samples staged (polyphase index i <-> coarse sample j_lo + i)
+    u64* Cs = reinterpret_cast<u64*>(ps + ((span + 1 + 3) & ~3));
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
     // ---- 1. base phase: the tiles before this one (wave 0), and the taps / table rows / phase samples into LDS
     if (wv == 0) {
@@ -674,71 +713,56 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
         }
     }
     __syncthreads();
-    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1 for the scan and
-    // publishes their start phases C_u (Q0.64) in LDS; the render loop below walks the samples strided over the block
+    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
     const double scale_a = 18446744073709551616.0 / (double)OS;
     const double scale_d = scale_a / (double)P;
+    const int u0 = tid * CPT;
+    u64 tv[CPT];
+    u64 tsum = 0;
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int u = min(u0 + r, span - 1);
+        const int j = j_lo + u;
+        const float p0 = ps[u], p1 = ps[u + 1];
+        const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
+        tv[r] = seg ? (u64)P * osc_fix_a(p0, scale_a) + osc_fix_d(p0, p1, scale_d) * (u64)6 : 0;
+        tsum += tv[r];
+    }
+    const u64 incl = wave_incl_scan(tsum, lane);
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    u64 run = incl - tsum;                       // exclusive prefix relative to coarse sample j_lo
+    for (int w = 0; w < wv; ++w) run += wtot[w];
+    // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
+    // (j_lo .. o0-1) belongs to the previous tile's total: phase at local index u = base_sh - prefix(-dmin) + prefix(u)
     {
-        const int u0 = tid * OSCF_CPT;
-        u64 tv[OSCF_CPT];
-        u64 tsum = 0;
+        u64 r2 = run;
 #pragma unroll
-        for (int r = 0; r < OSCF_CPT; ++r) {
-            const int u = min(u0 + r, span - 1);
-            const int j = j_lo + u;
-            const float p0 = ps[u], p1 = ps[u + 1];
-            const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-            tv[r] = seg ? (u64)P * osc_fix_a(p0, scale_a) + osc_fix_d(p0, p1, scale_d) * (u64)6 : 0;
-            tsum += tv[r];
-        }
-        const u64 incl = wave_incl_scan(tsum, lane);
-        if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
-        u64 run = incl - tsum;                 // exclusive prefix relative to coarse sample j_lo
-        for (int w = 0; w < wv; ++w) run += wtot[w];
-#pragma unroll
-        for (int r = 0; r < OSCF_CPT; ++r) {
-            if (u0 + r < span) Cs[u0 + r] = run;
-            run += tv[r];
+        for (int r = 0; r < CPT; ++r) {
+            if (u0 + r == -dmin) halo_sh = r2;
+            if (STRIDED && u0 + r < span) Cs[u0 + r] = r2;
+            r2 += tv[r];
         }
     }
     __syncthreads();
-    // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
-    // (j_lo .. o0-1) belongs to the previous tile's total, so the phase at local index u is base - Cs[-dmin] + Cs[u]
-    const u64 base = base_sh - Cs[-dmin];
-    // ---- 3. render: thread takes coarse samples u = tid, tid + NTH, ...; its 4 fine samples lie in ONE control
-    // interval (hop_t is a multiple of 4), so the interval / row pointers are found once per coarse sample
+    const u64 base = base_sh - halo_sh;
+    // ---- 3. render into the polyphase tile
     const float inv_hop_t = 1.0f / (float)hop_t;
     // nrows - 1 control intervals are staged (rows r_first .. r_first + nrows - 1): interval index 0 .. nrows - 2
     const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
-    for (int u = tid; u < span; u += NTH) {
-        const int j = j_lo + u;
-        const float p0 = ps[u], p1 = ps[u + 1];
-        const float d = (p1 - p0) * 0.25f;
-        u64 ph = base + Cs[u];
-        u64 inc = osc_fix_a(p0, scale_a);
-        const u64 dinc = osc_fix_d(p0, p1, scale_d);
-        const int m0 = j * P;
-        const int rr = (m0 >= bnd1) + (m0 >= bnd2);
-        const float* ra = rows + (size_t)rr * LR;
-        float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
-        const bool v0 = j >= 0 && j <= Tp - 1;         // fine sample k = 0 exists
-        const bool vk = j >= 0 && j < Tp - 1;          // fine samples k = 1..3 exist (the last coarse sample has only k = 0)
-        float* xp = X + (u & 3) * RS4 + (u >> 2);
+    if (STRIDED) {
+        for (int u = tid; u < span; u += NTH)
+            oscf_render_coarse<EE>(u, j_lo + u, base + Cs[u], ps[u], ps[u + 1], rows, LR, lshift, r_first, hop_t,
+                                   inv_hop_t, bnd1, bnd2, Tp, X, RS4, scale_a, scale_d);
+    } else {
+        u64 ph = base + run;
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            ph += inc;
-            inc += dinc;
-            const unsigned hi = (unsigned)(ph >> 32);
-            const int c0 = (int)(hi >> (32 - lshift));
-            const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
-            const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
-            const float top = fmaf(cf, a01 - a00, a00);
-            const float bot = fmaf(cf, a11 - a10, a10);
-            float v = fmaf(rf, bot - top, top);
-            if (EE) v *= rsqrtf(fmaf((float)k, d, p0) * 0.25f);
-            xp[k * 4 * RS4] = (k == 0 ? v0 : vk) ? v : 0.f;
-            rf = (float)(m0 + k + 1 - (r_first + rr) * hop_t) * inv_hop_t;
+        for (int r = 0; r < CPT; ++r) {
+            const int u = u0 + r;
+            if (u < span)
+                oscf_render_coarse<EE>(u, j_lo + u, ph, ps[u], ps[u + 1], rows, LR, lshift, r_first, hop_t, inv_hop_t,
+                                       bnd1, bnd2, Tp, X, RS4, scale_a, scale_d);
+            ph += tv[r];
         }
     }
     __syncthreads();
@@ -773,6 +797,32 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     orow.st(o + 1, acc1 + ad1);
     orow.st(o + 2, acc2 + ad2);
     orow.st(o + 3, acc3 + ad3);
+}
+
+struct OscfGeom { int TO, NTH, strided; };
+static const OscfGeom kOscfGeoms[] = {{2048, 512, 0}, {1024, 256, 1}, {2048, 512, 1}, {1024, 256, 0}};
+static int oscf_geom_index() {   // dev knob GOLF_OSCF_GEOM: which (tile, threads, render order) instance runs
+    static const int v = [] { const char* e = getenv("GOLF_OSCF_GEOM"); int i = e ? atoi(e) : 0; return (i < 0 || i > 3) ? 0 : i; }();
+    return v;
+}
+
+template <int EE, int TO, int NTH, bool STRIDED>
+static int oscf_launch(size_t ldsf, int ntile2, int B, hipStream_t st, const float* phase, int64_t phase_stride, u64* Ttot,
+                       const float* wsel, int Fw, const float* table, int n_tab, int L, int lshift, int Tp, int P, int os,
+                       int hop_t, int N, const float* taps, int K, float* out, int64_t out_stride, int Tout, int RS4,
+                       int dmin, int ngrp, int nrows, const float* addend, int64_t addend_stride, int Tadd) {
+    static const hipError_t lds_attr = hipFuncSetAttribute((const void*)osc_fused_kernel<EE, TO, NTH, STRIDED>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (lds_attr != hipSuccess)   // > 64 KB of dynamic LDS per workgroup needs the opt-in
+        return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(lds_attr));
+    hipLaunchKernelGGL(osc_tile_totals_kernel<TO>, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp, P, os,
+                       ntile2);
+    GOLF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((osc_fused_kernel<EE, TO, NTH, STRIDED>), dim3(ntile2, B), dim3(NTH), ldsf, st, phase, phase_stride,
+                       (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, N, taps, K, out, out_stride,
+                       Tout, RS4, dmin, ngrp, nrows, addend, addend_stride, Tadd);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
 }
 
 static int osc_check(int B, int Tp, int phase_hop, int Fw, int w_hop, int n_tab, int L, int os, int K,
@@ -1063,46 +1113,40 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
     static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
     if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !pre && !unfused_env) {
+        const OscfGeom geo = kOscfGeoms[oscf_geom_index()];
         const int half = (K - 1) / 2;
         const int dmin = -((half + os - 1) / os);
         const int dmax = half / os;
         const int nq = dmax - dmin + 1;
         const int ngrp = (nq + 2) / 4;
-        int RS4 = OSCF_TO / 4 + ngrp + 2;
+        int RS4 = geo.TO / 4 + ngrp + 2;
         while (RS4 % 32 != 2) ++RS4;
-        const int span = OSCF_TO + ngrp * 4 + 4;
+        const int span = geo.TO + ngrp * 4 + 4;
         const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
         const int nrows = nint_touched + 1;
         const int hoff = (os * 4 * RS4 + 3) & ~3;
         const size_t ldsf = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) +
                                              (((size_t)nrows * (L + 1) + 3) & ~(size_t)3) + (size_t)((span + 1 + 3) & ~3) +
-                                             2 * (size_t)span + 4);
-        if (nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin <= span && ldsf <= 96 * 1024) {
-            const int ntile2 = (int)ceil_div(Tout, OSCF_TO);       // <= g.ntile: fits the Ttot region of the workspace
-            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2);
-            GOLF_LAUNCH_CHECK();
+                                             (geo.strided ? 2 * (size_t)span : 0) + 4);
+        if (nrows <= OSCF_MAXROWS && span <= geo.TO + 64 && -dmin < span && ldsf <= 128 * 1024) {
+            const int ntile2 = (int)ceil_div(Tout, geo.TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
-            static const hipError_t lds_attr = [] {   // > 64 KB of dynamic LDS per workgroup needs the opt-in
-                hipError_t e = hipFuncSetAttribute((const void*)osc_fused_kernel<1>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                if (e == hipSuccess)
-                    e = hipFuncSetAttribute((const void*)osc_fused_kernel<0>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                return e;
-            }();
-            if (lds_attr != hipSuccess)
-                return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",
-                            hipGetErrorString(lds_attr));
-#define GOLF_FUSED(EE)                                                                                                \
-    hipLaunchKernelGGL((osc_fused_kernel<EE>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsf, st, phase, phase_stride,   \
-                       (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t, g.N, taps, K, out,  \
-                       out_stride, Tout, RS4, dmin, ngrp, nrows, addend, addend_stride, Tadd)
-            if (equal_energy) GOLF_FUSED(1);
-            else GOLF_FUSED(0);
+#define GOLF_FUSED(EE, TO, NTH, STR)                                                                                  \
+    return oscf_launch<EE, TO, NTH, STR>(ldsf, ntile2, B, st, phase, phase_stride, Ttot, wsel, Fw, table, n_tab, L,  \
+                                         lshift, Tp, g.P, os, g.hop_t, g.N, taps, K, out, out_stride, Tout, RS4,     \
+                                         dmin, ngrp, nrows, addend, addend_stride, Tadd)
+            const int key = oscf_geom_index() * 2 + (equal_energy ? 1 : 0);
+            switch (key) {
+                case 0: GOLF_FUSED(0, 2048, 512, false);
+                case 1: GOLF_FUSED(1, 2048, 512, false);
+                case 2: GOLF_FUSED(0, 1024, 256, true);
+                case 3: GOLF_FUSED(1, 1024, 256, true);
+                case 4: GOLF_FUSED(0, 2048, 512, true);
+                case 5: GOLF_FUSED(1, 2048, 512, true);
+                case 6: GOLF_FUSED(0, 1024, 256, false);
+                default: GOLF_FUSED(1, 1024, 256, false);
+            }
 #undef GOLF_FUSED
-            GOLF_LAUNCH_CHECK();
-            return GOLF_OK;
         }
     }
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, os, g.ntile, B, st)) return rc;

@@ -47,7 +47,7 @@ static const WNT kTable[] = {{8, 2},   {8, 4},   {8, 6},   {16, 8},  {16, 12}, {
 // Chunking buys parallelism in time at the price of (M+2)-fold arithmetic; once the batch alone fills the chip's wave
 // slots that price stops paying.  Measured crossover on MI355X (M=22, T=47761): DESIGN.md §4.1.
 int ss_serial_min_batch() {
-    static const int v = [] { const char* e = getenv("GOLF_SS_SERIAL_MIN_BATCH"); return e ? atoi(e) : 1024; }();
+    static const int v = [] { const char* e = getenv("GOLF_SS_SERIAL_MIN_BATCH"); return e ? atoi(e) : 2048; }();
     return v;
 }
 

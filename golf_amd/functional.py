@@ -162,7 +162,7 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match).
     ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
     fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
-    ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 1024 utterances, batch-parallel
+    ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
     serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one."""
     return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode])
 

@@ -83,7 +83,7 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                CHUNKED: time is cut into chunks whose transition matrices are scanned (B*T/L*(M+2) lanes of work,
  *                (M+2)-fold arithmetic: what makes B = 32 fast).  SERIAL: one quad of lanes per utterance runs the
  *                recursion from t = 0 to T, B/16 waves, no redundant arithmetic and no transition matrices: the
- *                large-batch kernel (default from B >= 1024).  The backward must be given the flag the forward ran with. */
+ *                large-batch kernel (default from B >= 2048, where the two meet on MI355X).  The backward must be given the flag the forward ran with. */
 #define GOLF_SS_SERIAL 8
 #define GOLF_SS_CHUNKED 16
 
