@@ -60,6 +60,11 @@ SIGNATURES = {
     "golf_glottal_osc_bwd_wsel_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p,
                                              _int, _int, _int, _int, _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz,
                                              _vp]),
+    "golf_wavetable_lookup_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
+    "golf_wavetable_lookup_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64,
+                                             _c_f32p, _int, _int, _vp]),
+    "golf_decimate_fir_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
+    "golf_decimate_fir_adj_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _vp]),
     "golf_harmonic_osc_workspace_bytes": (_sz, [_int] * 5),
     "golf_harmonic_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _c_f32p,
                                          _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),

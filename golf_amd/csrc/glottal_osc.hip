@@ -825,6 +825,153 @@ static int oscf_launch(size_t ldsf, int ntile2, int B, hipStream_t st, const flo
     return GOLF_OK;
 }
 
+// ---- decimator launches (shared by the oscillator entry points and golf_decimate_fir_*) -----------------------------
+static int launch_decimate(const float* fine, int N, int64_t fine_stride, const float* taps, int K, int os, float* out,
+                           int64_t out_stride, int Tout, int B, const float* addend, int64_t addend_stride, int Tadd,
+                           hipStream_t st) {
+    const int half = (K - 1) / 2;
+    const int dmin = -((half + os - 1) / os);  // floor(-half/os)
+    const int dmax = half / os;
+    const int nq = dmax - dmin + 1;             // taps per polyphase branch (upper bound)
+    const int ngrp = (nq + 2) / 4;
+    int RS4 = OSC_TILE / 4 + ngrp + 2;
+    while (RS4 % 32 != 2) ++RS4;                // (ph,i&3) sub-arrays land 2 banks apart: conflict-free fill at os=4
+    const int hoff = (os * 4 * RS4 + 3) & ~3;
+    const size_t lds3 = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8));
+    if (lds3 > 64 * 1024) return fail(GOLF_EUNSUPPORTED, "decimate: %d taps x os %d exceed LDS", K, os);
+    const int vec4 = (fine_stride % 4 == 0 && ((uintptr_t)fine & 15) == 0) ? 1 : 0;
+    if (os == 4)
+        hipLaunchKernelGGL(osc_decimate_kernel<4>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st, fine,
+                           N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin, ngrp, vec4, addend,
+                           addend_stride, Tadd);
+    else
+        hipLaunchKernelGGL(osc_decimate_kernel<0>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st, fine,
+                           N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin, ngrp, vec4, addend,
+                           addend_stride, Tadd);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+// g_pre (B, N) dense <- transposed decimator of g_out (B, Tout); os == 1: plain copy
+static int launch_decimate_T(const float* g_out, int64_t g_out_stride, int Tout, const float* taps, int K, int os,
+                             float* g_pre, int N, int B, hipStream_t st) {
+    if (os == 4) {
+        const int half = (K - 1) / 2;
+        const int dmin = -((half + os - 1) / os);
+        const int dmax = half / os;
+        const int nq = dmax - dmin + 1;
+        const int ngrp = (nq + 2) / 4;
+        int RS4 = OSC_TILE / 4 + ngrp + 2;
+        while (RS4 % 32 != 8) ++RS4;
+        const int hoff = (4 * RS4 + 3) & ~3;
+        const size_t ldsT = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) + (size_t)OSC_TILE * os);
+        if (ldsT > 64 * 1024) return fail(GOLF_EUNSUPPORTED, "decimate (transposed): %d taps exceed LDS", K);
+        hipLaunchKernelGGL(osc_decimate_T4_kernel, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), ldsT, st,
+                           g_out, g_out_stride, Tout, taps, K, g_pre, N, RS4, dmax, ngrp);
+        GOLF_LAUNCH_CHECK();
+    } else if (os > 1) {
+        const int64_t n = (int64_t)B * N;
+        hipLaunchKernelGGL(osc_decimate_T_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, g_out,
+                           g_out_stride, Tout, taps, K, os, g_pre, N, B);
+        GOLF_LAUNCH_CHECK();
+    } else {
+        hipError_t e = hipMemcpy2DAsync(g_pre, sizeof(float) * N, g_out, sizeof(float) * g_out_stride,
+                                        sizeof(float) * N, B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail((int)e, "decimate (transposed): copy failed: %s", hipGetErrorString(e));
+    }
+    return GOLF_OK;
+}
+
+// =============================================================================================
+// Generic wavetable lookup: GlottalFlowTable.generate (models/synth.py:124-177, F.grid_sample bilinear over
+// (control frame, phase)) for ARBITRARY per-frame tables (B,K,L) and a given wrapped phase (B,N) in [0,1).
+// This is what every table oscillator of the reference reduces to once its tables are formed --
+// WeightedGlottalFlowTable (:266-294, tables = softmax weights @ table), WrappedPhaseDownsampledIndexed... (:343-375),
+// and IndexedGlottalFlowTable itself when the phase, a phase offset or a trainable table must receive gradients (the
+// fused fast path above differentiates w.r.t. table_select_weight only).
+//   out[b,n] = (1-rf) lerp_c(T[ra]) + rf lerp_c(T[rb]),   r0 = n / hop_t, rf = (n - r0 hop_t)/hop_t,
+//   ra = min(r0, K-1), rb = min(r0+1, K-1)  (replicate-padded frames, synth.py:141-146),
+//   c = phi L, c0 = floor(c), cf = c - c0, columns c0 and (c0+1) mod L  (wrap column, synth.py:148-150)
+// Backward: d/d phi = g L [(1-rf)(T[ra][c1]-T[ra][c0]) + rf (T[rb][c1]-T[rb][c0])]; d/d T scattered with the four
+// bilinear weights -- one workgroup per (utterance, control interval) accumulates its two rows in LDS (ds_add_f32),
+// then adds them to g_tables (each row receives from at most two intervals: the result does not depend on their order).
+// =============================================================================================
+__global__ __launch_bounds__(256) void wt_lookup_fwd_kernel(const float* __restrict__ wrapped, int64_t w_stride,
+                                                            const float* __restrict__ tables, int K, int L, int hop_t,
+                                                            int N, float* __restrict__ out, int64_t out_stride, int B) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * N) return;
+    const int b = (int)(idx / N), n = (int)(idx - (int64_t)b * N);
+    const int r0 = n / hop_t;
+    const float rf = (float)(n - r0 * hop_t) / (float)hop_t;
+    const int ra = r0 < K - 1 ? r0 : K - 1, rb = r0 + 1 < K - 1 ? r0 + 1 : K - 1;
+    const float c = wrapped[(size_t)b * w_stride + n] * (float)L;
+    int c0 = (int)floorf(c);
+    c0 = c0 < 0 ? 0 : (c0 > L - 1 ? L - 1 : c0);
+    const float cf = c - (float)c0;
+    const int c1 = c0 + 1 == L ? 0 : c0 + 1;
+    const float* Ta = tables + ((size_t)b * K + ra) * L;
+    const float* Tb = tables + ((size_t)b * K + rb) * L;
+    const float a00 = Ta[c0], a01 = Ta[c1], a10 = Tb[c0], a11 = Tb[c1];
+    const float top = fmaf(cf, a01 - a00, a00), bot = fmaf(cf, a11 - a10, a10);
+    out[(size_t)b * out_stride + n] = fmaf(rf, bot - top, top);
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void wt_lookup_bwd_kernel(const float* __restrict__ g_out, int64_t g_stride,
+                                                            const float* __restrict__ wrapped, int64_t w_stride,
+                                                            const float* __restrict__ tables, int K, int L, int hop_t,
+                                                            int N, float* __restrict__ g_wrapped, int64_t gw_stride,
+                                                            float* __restrict__ g_tables) {
+    extern __shared__ float acc[];   // [2][L] when USE_LDS
+    const int r0 = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ra = r0 < K - 1 ? r0 : K - 1, rb = r0 + 1 < K - 1 ? r0 + 1 : K - 1;
+    if (USE_LDS && g_tables) {
+        for (int e = tid; e < 2 * L; e += 256) acc[e] = 0.f;
+        __syncthreads();
+    }
+    const float* Ta = tables + ((size_t)b * K + ra) * L;
+    const float* Tb = tables + ((size_t)b * K + rb) * L;
+    float* Ga = g_tables ? g_tables + ((size_t)b * K + ra) * L : nullptr;
+    float* Gb = g_tables ? g_tables + ((size_t)b * K + rb) * L : nullptr;
+    const int n_lo = r0 * hop_t, n_hi = n_lo + hop_t < N ? n_lo + hop_t : N;
+    const float inv = 1.0f / (float)hop_t;
+    for (int n = n_lo + tid; n < n_hi; n += 256) {
+        const float g = g_out[(size_t)b * g_stride + n];
+        const float rf = (float)(n - n_lo) * inv;
+        const float c = wrapped[(size_t)b * w_stride + n] * (float)L;
+        int c0 = (int)floorf(c);
+        c0 = c0 < 0 ? 0 : (c0 > L - 1 ? L - 1 : c0);
+        const float cf = c - (float)c0;
+        const int c1 = c0 + 1 == L ? 0 : c0 + 1;
+        if (g_wrapped) {
+            const float dt = Ta[c1] - Ta[c0], db = Tb[c1] - Tb[c0];
+            g_wrapped[(size_t)b * gw_stride + n] = g * (float)L * fmaf(rf, db - dt, dt);
+        }
+        if (g_tables) {
+            const float wa = g * (1.0f - rf), wb = g * rf;
+            if (USE_LDS) {
+                atomicAdd(&acc[c0], wa * (1.0f - cf));
+                atomicAdd(&acc[c1], wa * cf);
+                atomicAdd(&acc[L + c0], wb * (1.0f - cf));
+                atomicAdd(&acc[L + c1], wb * cf);
+            } else {
+                atomicAdd(&Ga[c0], wa * (1.0f - cf));
+                atomicAdd(&Ga[c1], wa * cf);
+                atomicAdd(&Gb[c0], wb * (1.0f - cf));
+                atomicAdd(&Gb[c1], wb * cf);
+            }
+        }
+    }
+    if (USE_LDS && g_tables) {
+        __syncthreads();
+        for (int e = tid; e < L; e += 256) {
+            atomicAdd(&Ga[e], acc[e]);
+            atomicAdd(&Gb[e], acc[L + e]);
+        }
+    }
+}
+
 static int osc_check(int B, int Tp, int phase_hop, int Fw, int w_hop, int n_tab, int L, int os, int K,
                      const float* taps) {
     if (B < 1 || Tp < 1 || phase_hop < 1 || Fw < 1 || w_hop < 1 || n_tab < 2 || L < 2 || os < 1)
@@ -1172,26 +1319,9 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
                            os, g.hop_t, g.N, equal_energy, fine, fine_stride, (const float*)nullptr, (float*)nullptr);
     GOLF_LAUNCH_CHECK();
     if (os > 1) {
-        const int half = (K - 1) / 2;
-        const int dmin = -((half + os - 1) / os);  // floor(-half/os)
-        const int dmax = half / os;
-        const int nq = dmax - dmin + 1;             // taps per polyphase branch (upper bound)
-        const int ngrp = (nq + 2) / 4;
-        int RS4 = OSC_TILE / 4 + ngrp + 2;
-        while (RS4 % 32 != 2) ++RS4;                // (ph,i&3) sub-arrays land 2 banks apart: conflict-free fill at os=4
-        const int hoff = (os * 4 * RS4 + 3) & ~3;
-        const size_t lds3 = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8));
-        if (lds3 > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_fwd: %d taps x os %d exceed LDS", K, os);
-        const int vec4 = (fine_stride % 4 == 0 && ((uintptr_t)fine & 15) == 0) ? 1 : 0;
-        if (os == 4)
-            hipLaunchKernelGGL(osc_decimate_kernel<4>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
-                               (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp, vec4, addend, addend_stride, Tadd);
-        else
-            hipLaunchKernelGGL(osc_decimate_kernel<0>, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), lds3, st,
-                               (const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, RS4, dmin,
-                               ngrp, vec4, addend, addend_stride, Tadd);
-        GOLF_LAUNCH_CHECK();
+        if (int rc = launch_decimate((const float*)fine, g.N, fine_stride, taps, K, os, out, out_stride, Tout, B, addend,
+                                     addend_stride, Tadd, st))
+            return rc;
     }
     return GOLF_OK;
 }
@@ -1219,30 +1349,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         return rc;
     float* g_pre = (float*)((char*)ws + g.off_pre);
     float* part = (float*)((char*)ws + g.off_part);
-    if (os == 4) {
-        const int half = (K - 1) / 2;
-        const int dmin = -((half + os - 1) / os);
-        const int dmax = half / os;
-        const int nq = dmax - dmin + 1;
-        const int ngrp = (nq + 2) / 4;
-        int RS4 = OSC_TILE / 4 + ngrp + 2;
-        while (RS4 % 32 != 8) ++RS4;
-        const int hoff = (4 * RS4 + 3) & ~3;
-        const size_t ldsT = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) + (size_t)OSC_TILE * os);
-        if (ldsT > 160 * 1024) return fail(GOLF_EUNSUPPORTED, "glottal_osc_bwd: %d taps exceed LDS", K);
-        hipLaunchKernelGGL(osc_decimate_T4_kernel, dim3((unsigned)ceil_div(Tout, OSC_TILE), B), dim3(256), ldsT, st,
-                           g_out, g_out_stride, Tout, taps, K, g_pre, g.N, RS4, dmax, ngrp);
-        GOLF_LAUNCH_CHECK();
-    } else if (os > 1) {
-        const int64_t n = (int64_t)B * g.N;
-        hipLaunchKernelGGL(osc_decimate_T_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, g_out,
-                           g_out_stride, Tout, taps, K, os, g_pre, g.N, B);
-        GOLF_LAUNCH_CHECK();
-    } else {
-        hipError_t e = hipMemcpy2DAsync(g_pre, sizeof(float) * g.N, g_out, sizeof(float) * g_out_stride,
-                                        sizeof(float) * g.N, B, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return fail((int)e, "glottal_osc_bwd: copy failed: %s", hipGetErrorString(e));
-    }
+    if (int rc = launch_decimate_T(g_out, g_out_stride, Tout, taps, K, os, g_pre, g.N, B, st)) return rc;
     size_t lds = sizeof(float) * 2 * (size_t)(L + 1);
     if (lds < sizeof(float) * 2 * OSC_RENDER_THREADS) lds = sizeof(float) * 2 * OSC_RENDER_THREADS;
     const u64* Ttot = (const u64*)((char*)ws + g.off_ttot);
@@ -1254,6 +1361,62 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
                        (const float*)part, g_wsel, B, Fw, g.nint, n_tab);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
+}
+
+extern "C" int golf_wavetable_lookup_fwd_f32(const float* wrapped, int64_t wrapped_stride, const float* tables, int K,
+                                             int L, int hop_t, float* out, int64_t out_stride, int B, int N,
+                                             void* stream) {
+    if (!wrapped || !tables || !out || B < 1 || N < 1 || K < 1 || L < 2 || hop_t < 1)
+        return fail(GOLF_EINVAL, "wavetable_lookup_fwd: bad argument");
+    if (wrapped_stride < N || out_stride < N) return fail(GOLF_EINVAL, "wavetable_lookup_fwd: row stride < N");
+    const int64_t n = (int64_t)B * N;
+    hipLaunchKernelGGL(wt_lookup_fwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, wrapped,
+                       wrapped_stride, tables, K, L, hop_t, N, out, out_stride, B);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_wavetable_lookup_bwd_f32(const float* g_out, int64_t g_out_stride, const float* wrapped,
+                                             int64_t wrapped_stride, const float* tables, int K, int L, int hop_t,
+                                             float* g_wrapped, int64_t g_wrapped_stride, float* g_tables, int B, int N,
+                                             void* stream) {
+    if (!g_out || !wrapped || !tables || B < 1 || N < 1 || K < 1 || L < 2 || hop_t < 1)
+        return fail(GOLF_EINVAL, "wavetable_lookup_bwd: bad argument");
+    if (g_out_stride < N || wrapped_stride < N || (g_wrapped && g_wrapped_stride < N))
+        return fail(GOLF_EINVAL, "wavetable_lookup_bwd: row stride < N");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_tables) {
+        hipError_t e = hipMemsetAsync(g_tables, 0, sizeof(float) * (size_t)B * K * L, st);
+        if (e != hipSuccess) return fail((int)e, "wavetable_lookup_bwd: memset failed: %s", hipGetErrorString(e));
+    }
+    const int nint = (int)ceil_div(N, hop_t);
+    const size_t lds = sizeof(float) * 2 * (size_t)L;
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(wt_lookup_bwd_kernel<true>, dim3(nint, B), dim3(256), g_tables ? lds : 0, st, g_out,
+                           g_out_stride, wrapped, wrapped_stride, tables, K, L, hop_t, N, g_wrapped, g_wrapped_stride,
+                           g_tables);
+    else
+        hipLaunchKernelGGL(wt_lookup_bwd_kernel<false>, dim3(nint, B), dim3(256), 0, st, g_out, g_out_stride, wrapped,
+                           wrapped_stride, tables, K, L, hop_t, N, g_wrapped, g_wrapped_stride, g_tables);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" int golf_decimate_fir_f32(const float* x, int64_t x_stride, int N, const float* taps, int K, int os,
+                                     float* out, int64_t out_stride, int B, int Tout, void* stream) {
+    if (!x || !taps || !out || B < 1 || N < 1 || os < 2 || os > 64 || K < 1 || (K & 1) == 0)
+        return fail(GOLF_EINVAL, "decimate_fir: bad argument (needs os in [2,64] and an odd number of taps)");
+    if (Tout != (N - 1) / os + 1) return fail(GOLF_EINVAL, "decimate_fir: Tout=%d, expected %d", Tout, (N - 1) / os + 1);
+    if (x_stride < N || out_stride < Tout) return fail(GOLF_EINVAL, "decimate_fir: row stride too small");
+    return launch_decimate(x, N, x_stride, taps, K, os, out, out_stride, Tout, B, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int golf_decimate_fir_adj_f32(const float* g_out, int64_t g_out_stride, int Tout, const float* taps, int K,
+                                       int os, float* g_x, int N, int B, void* stream) {
+    if (!g_out || !taps || !g_x || B < 1 || N < 1 || os < 2 || os > 64 || K < 1 || (K & 1) == 0)
+        return fail(GOLF_EINVAL, "decimate_fir_T: bad argument");
+    if (Tout != (N - 1) / os + 1 || g_out_stride < Tout) return fail(GOLF_EINVAL, "decimate_fir_T: bad Tout / stride");
+    return launch_decimate_T(g_out, g_out_stride, Tout, taps, K, os, g_x, N, B, (hipStream_t)stream);
 }
 
 extern "C" size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fa, int H) {

@@ -366,8 +366,9 @@ class _GlottalOsc(torch.autograd.Function):
             _lib.require_device(add)
             add = _rows(add.float())
         if phase.requires_grad or table.requires_grad:
-            raise NotImplementedError("golf_amd: the glottal oscillator backward covers table_select_weight only "
-                                      "(phase / trainable tables are not differentiable in this round)")
+            raise NotImplementedError("golf_amd: the FUSED glottal oscillator differentiates w.r.t. table_select_weight "
+                                      "only; use functional.wavetable_osc (IndexedGlottalFlowTable does so on its own) "
+                                      "for gradients w.r.t. phase / the table")
         lib = _lib.load()
         phase = _rows(phase)
         wsel = wsel.contiguous()
@@ -432,6 +433,138 @@ def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampli
     out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
                                  bool(equal_energy), bool(return_pre), add)
     return (out, pre) if return_pre else out
+
+
+# ------------------------------------------------------------------------------------------------
+# generic (fully differentiable) table oscillator: wrapped phase -> bilinear table lookup (-> decimation)
+# ------------------------------------------------------------------------------------------------
+class _WavetableLookup(torch.autograd.Function):
+    """GlottalFlowTable.generate (reference models/synth.py:124-177) on golf_wavetable_lookup_{fwd,bwd}_f32:
+    out[b,n] = bilerp(tables[b], row n/hop_t, column wrapped[b,n]*L); differentiable w.r.t. both inputs."""
+
+    @staticmethod
+    def forward(ctx, wrapped, tables, hop_t):
+        _lib.require_device(wrapped, tables)
+        lib = _lib.load()
+        wrapped = _rows(wrapped)
+        tables = tables.contiguous()
+        B, N = wrapped.shape
+        assert tables.ndim == 3 and tables.shape[0] == B
+        K, L = tables.shape[1], tables.shape[2]
+        out = torch.empty(B, N, dtype=torch.float32, device=wrapped.device)
+        rc = lib.golf_wavetable_lookup_fwd_f32(wrapped.data_ptr(), wrapped.stride(0), tables.data_ptr(), K, L, hop_t,
+                                               out.data_ptr(), out.stride(0), B, N, _lib.stream_ptr())
+        _lib.check(rc, "golf_wavetable_lookup_fwd_f32")
+        ctx.hop_t = hop_t
+        ctx.save_for_backward(wrapped, tables)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        wrapped, tables = ctx.saved_tensors
+        lib = _lib.load()
+        B, N = wrapped.shape
+        K, L = tables.shape[1], tables.shape[2]
+        g_out = _rows(g_out.float())
+        g_w = torch.empty_like(wrapped) if ctx.needs_input_grad[0] else None
+        g_t = torch.empty_like(tables) if ctx.needs_input_grad[1] else None
+        rc = lib.golf_wavetable_lookup_bwd_f32(g_out.data_ptr(), g_out.stride(0), wrapped.data_ptr(), wrapped.stride(0),
+                                               tables.data_ptr(), K, L, ctx.hop_t, _lib.ptr(g_w),
+                                               0 if g_w is None else g_w.stride(0), _lib.ptr(g_t), B, N,
+                                               _lib.stream_ptr())
+        _lib.check(rc, "golf_wavetable_lookup_bwd_f32")
+        return g_w, g_t, None
+
+
+def wavetable_lookup(wrapped: torch.Tensor, tables: torch.Tensor, hop_t: int) -> torch.Tensor:
+    """wrapped (B,N) in [0,1], tables (B,K,L) at hop ``hop_t`` (frames beyond K-1 replicate the last) -> (B,N)."""
+    return _WavetableLookup.apply(wrapped, tables, int(hop_t))
+
+
+class _DecimateFIR(torch.autograd.Function):
+    """The oscillator's decimator on its own (golf_decimate_fir_f32 / its adjoint)."""
+
+    @staticmethod
+    def forward(ctx, x, taps, os):
+        _lib.require_device(x, taps)
+        lib = _lib.load()
+        x = _rows(x)
+        taps = taps.contiguous()
+        B, N = x.shape
+        Tout = (N - 1) // os + 1
+        out = torch.empty(B, Tout, dtype=torch.float32, device=x.device)
+        rc = lib.golf_decimate_fir_f32(x.data_ptr(), x.stride(0), N, taps.data_ptr(), taps.numel(), os, out.data_ptr(),
+                                       out.stride(0), B, Tout, _lib.stream_ptr())
+        _lib.check(rc, "golf_decimate_fir_f32")
+        ctx.cfg = (N, os)
+        ctx.save_for_backward(taps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (taps,) = ctx.saved_tensors
+        N, os = ctx.cfg
+        lib = _lib.load()
+        g_out = _rows(g_out.float())
+        B, Tout = g_out.shape
+        g_x = torch.empty(B, N, dtype=torch.float32, device=g_out.device)
+        rc = lib.golf_decimate_fir_adj_f32(g_out.data_ptr(), g_out.stride(0), Tout, taps.data_ptr(), taps.numel(), os,
+                                           g_x.data_ptr(), N, B, _lib.stream_ptr())
+        _lib.check(rc, "golf_decimate_fir_adj_f32")
+        return g_x, None, None
+
+
+def decimate_fir(x: torch.Tensor, taps: torch.Tensor, os: int) -> torch.Tensor:
+    return _DecimateFIR.apply(x, taps, int(os))
+
+
+def linear_upsample(z: torch.Tensor, hop: int) -> torch.Tensor:
+    """AudioTensor.reduce_hop_length on a plain (B,F) tensor (models/utils.py:171-191, 538-544)."""
+    if hop == 1 or z.shape[1] == 1:
+        return z
+    n = (z.shape[1] - 1) * hop + 1
+    return torch.nn.functional.interpolate(z[:, None], n, mode="linear", align_corners=True)[:, 0]
+
+
+def instantaneous_phase(phase: torch.Tensor, phase_hop: int, oversampling: int = 1, phase_offset: torch.Tensor = None):
+    """(wrapped phase (B,N) float32 in [0,1], per-sample increment (B,N)): phase/os upsampled to the (oversampled) sample
+    rate, accumulated in float64 (the reference: float32 cumsum, models/synth.py:250-251; 2^-44 cycles of resolution
+    here) plus the optional offset, wrapped.  Plain tensor ops, so autograd carries d/d phase and d/d phase_offset
+    (reverse cumulative sum, the transposed upsampling) exactly as in the reference."""
+    ph = phase / oversampling if oversampling > 1 else phase
+    up = linear_upsample(ph, phase_hop * oversampling)
+    inst = torch.cumsum(up.double(), 1)
+    if phase_offset is not None:   # AudioTensor addition truncates to the shorter operand (utils.py:230-232)
+        n = min(inst.shape[1], phase_offset.shape[1])
+        inst, up = inst[:, :n] + phase_offset[:, :n].double(), up[:, :n]
+    return torch.remainder(inst, 1.0).float(), up
+
+
+def wavetable_osc(phase: torch.Tensor, phase_hop: int, tables: torch.Tensor, table_hop: int, oversampling: int = 1,
+                  equal_energy: bool = False, phase_offset: torch.Tensor = None, taps: torch.Tensor = None,
+                  decimate: bool = True) -> torch.Tensor:
+    """The table oscillators of the reference in their general, fully differentiable form (models/synth.py:213-294):
+    per-frame tables (B,K,L) at ``table_hop`` looked up at the running phase.  Differentiable w.r.t. ``phase``,
+    ``tables`` and ``phase_offset``.  IndexedGlottalFlowTable routes here when anything but table_select_weight needs a
+    gradient; the forward-only / weight-gradient case stays on the fused kernel (glottal_osc).
+    ``decimate=False`` returns the oversampled signal."""
+    wrapped, up = instantaneous_phase(phase, phase_hop, oversampling, phase_offset)
+    v = wavetable_lookup(wrapped, tables, table_hop * oversampling)
+    if equal_energy:
+        v = v * torch.rsqrt(up)
+    if oversampling > 1 and decimate:
+        assert taps is not None, "decimation taps required when oversampling > 1"
+        v = decimate_fir(v, taps, oversampling)
+    return v
+
+
+def blend_tables(table: torch.Tensor, wsel: torch.Tensor) -> torch.Tensor:
+    """Two-row table blend of IndexedGlottalFlowTable (models/synth.py:223-237): (n_tab,L), (B,Fw) -> (B,Fw,L)."""
+    n_tab = table.shape[0]
+    idx = wsel * (n_tab - 1)
+    i0 = idx.detach().long().clip_(0, n_tab - 2)
+    p = (idx - i0).unsqueeze(-1)
+    return table[i0] * (1 - p) + table[i0 + 1] * p
 
 
 # ------------------------------------------------------------------------------------------------

@@ -4,7 +4,11 @@
 arguments, buffers (``table``, ``R_d_values`` persistent; ``decimater.kernel`` non-persistent),
 ``model.{1,3}`` parameter names and ``.ctrl`` transforms, so reference checkpoints load unchanged.
 ``forward`` is one fused HIP path (golf_glottal_osc_fwd_f32): table blend, phase accumulation,
-bilinear lookup, equal-energy scaling and decimation.
+bilinear lookup, equal-energy scaling and decimation -- forward and the gradient w.r.t. table_select_weight, which is
+all GOLF training needs (f0 is data).  When the phase, a phase offset or a trainable table must receive gradients
+(reference models/synth.py:59-70,213-218) the same module routes through the general differentiable form
+(functional.wavetable_osc: HIP table lookup + HIP decimator with their own backward kernels, phase accumulation as
+tensor ops); the other table oscillators of the reference (Weighted / WrappedPhase / PulseTrain) build on the same pieces.
 """
 from __future__ import annotations
 
@@ -18,8 +22,10 @@ from .audiotensor import AudioTensor
 from .ctrl import Controllable, wrap_ctrl_fn
 from .utils import get_transformed_lf, get_transformed_lf_v2
 
-__all__ = ["OscillatorInterface", "GlottalFlowTable", "IndexedGlottalFlowTable",
-           "DownsampledIndexedGlottalFlowTable", "Decimate", "get_downsampler", "HarmonicOscillator",
+__all__ = ["OscillatorInterface", "GlottalFlowTable", "IndexedGlottalFlowTable", "WeightedGlottalFlowTable",
+           "DownsampledIndexedGlottalFlowTable", "DownsampledWeightedGlottalFlowTable",
+           "WrappedPhaseDownsampledIndexedGlottalFlowTable", "PulseTrain", "Decimate", "get_downsampler",
+           "HarmonicOscillator",
            "AdditiveSynthesizer", "V1AdditiveSynthesizer", "SawToothOscillator", "AdditivePulseTrain"]
 
 
@@ -112,14 +118,30 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
                 return_pre: bool = False, add: AudioTensor = None) -> AudioTensor:
         assert phase.ndim == 2, phase.shape
         assert table_select_weight.dim() == 2
-        if phase_offset is not None:
-            raise NotImplementedError("golf_amd: phase_offset is not supported by the fused oscillator")
         if self.check_ranges:
             assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
             assert torch.all(table_select_weight >= 0) and torch.all(table_select_weight <= 1)
         taps = self.decimater.taps if self.oversampling > 1 else None
-        res = GF.glottal_osc(phase.as_tensor(), table_select_weight.as_tensor(), self.table, taps,
-                             phase_hop=phase.hop_length, w_hop=table_select_weight.hop_length,
+        ph, w = phase.as_tensor(), table_select_weight.as_tensor()
+        grads = torch.is_grad_enabled() and (ph.requires_grad or self.table.requires_grad)
+        if grads or phase_offset is not None:
+            # general path (reference semantics under autograd, models/synth.py:213-263): a differentiable phase,
+            # a phase offset or a trainable table.  Tables are blended with tensor ops (gradients to the weight and the
+            # table), the lookup and the decimation are HIP kernels with their own backward.
+            off = None if phase_offset is None else (phase_offset.as_tensor() if isinstance(phase_offset, AudioTensor)
+                                                      else phase_offset)
+            res = GF.wavetable_osc(ph, int(phase.hop_length), GF.blend_tables(self.table, w),
+                                   int(table_select_weight.hop_length), self.oversampling, self.equal_energy, off, taps,
+                                   decimate=not return_pre)
+            if return_pre:
+                pre = res
+                res = GF.decimate_fir(pre, taps, self.oversampling) if self.oversampling > 1 else pre
+                return AudioTensor(res), pre
+            if add is not None:
+                n = min(res.shape[1], add.shape[1])
+                return AudioTensor(res[:, :n] + add.as_tensor()[:, :n])
+            return AudioTensor(res)
+        res = GF.glottal_osc(ph, w, self.table, taps, phase_hop=phase.hop_length, w_hop=table_select_weight.hop_length,
                              oversampling=self.oversampling, equal_energy=self.equal_energy, return_pre=return_pre,
                              add=None if add is None else add.as_tensor())
         if add is not None:   # what AudioTensor addition of two hop-1 signals does: truncate to the shorter
@@ -128,6 +150,26 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
         if return_pre:
             return AudioTensor(res[0]), res[1]
         return AudioTensor(res)
+
+
+class WeightedGlottalFlowTable(GlottalFlowTable):
+    """Soft table selection (reference models/synth.py:266-294): per-frame tables = softmax weights @ table, looked up at
+    the running phase (no oversampling, no equal-energy scaling).  Differentiable w.r.t. everything."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.ctrl = wrap_ctrl_fn(split_size=(self.table.shape[0],), trsfm_fn=lambda x: (torch.softmax(x, 2),))
+
+    def forward(self, phase: AudioTensor, table_select_weight: AudioTensor, phase_offset: AudioTensor = None) -> AudioTensor:
+        assert table_select_weight.dim() == 3 and table_select_weight.shape[2] == self.table.shape[0]
+        if self.check_ranges:
+            assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
+            assert torch.all(table_select_weight >= 0) and torch.all(table_select_weight <= 1)
+        tables = table_select_weight.as_tensor() @ self.table
+        off = None if phase_offset is None else (phase_offset.as_tensor() if isinstance(phase_offset, AudioTensor)
+                                                  else phase_offset)
+        return AudioTensor(GF.wavetable_osc(phase.as_tensor(), int(phase.hop_length), tables,
+                                            int(table_select_weight.hop_length), 1, False, off))
 
 
 def get_downsampler(hop_rate: int, in_channels: int, output_channels: int) -> nn.Sequential:
@@ -157,6 +199,59 @@ class DownsampledIndexedGlottalFlowTable(IndexedGlottalFlowTable):
                 ),
             ),
         )
+
+
+class WrappedPhaseDownsampledIndexedGlottalFlowTable(DownsampledIndexedGlottalFlowTable):
+    """Indexed table lookup at a GIVEN wrapped phase (reference models/synth.py:343-375): no accumulation, no
+    oversampling, no range hook on the first argument."""
+
+    def forward(self, wrapped_phase: AudioTensor, table_select_weight: AudioTensor) -> AudioTensor:
+        assert wrapped_phase.hop_length == 1
+        assert table_select_weight.dim() == 2
+        if self.check_ranges:
+            assert torch.all(table_select_weight >= 0) and torch.all(table_select_weight <= 1)
+        tables = GF.blend_tables(self.table, table_select_weight.as_tensor())
+        return AudioTensor(GF.wavetable_lookup(wrapped_phase.as_tensor().float(), tables,
+                                               int(table_select_weight.hop_length)))
+
+
+class DownsampledWeightedGlottalFlowTable(WeightedGlottalFlowTable):
+    """Soft table weights predicted at hop_rate x the encoder hop (reference models/synth.py:378-400)."""
+
+    def __init__(self, hop_rate: int, in_channels: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.hop_rate = hop_rate
+        self.model = get_downsampler(hop_rate, in_channels, self.table.shape[0])
+        self.ctrl = wrap_ctrl_fn(
+            split_size=(in_channels,),
+            trsfm_fn=lambda h: (
+                AudioTensor(
+                    self.model(torch.transpose(h.as_tensor(), 1, 2)).softmax(dim=1).transpose(1, 2),
+                    hop_length=h.hop_length * self.hop_rate,
+                ),
+            ),
+        )
+
+
+class PulseTrain(OscillatorInterface):
+    """One impulse of height rsqrt(phase increment) at every sample where the running phase wraps (reference
+    models/synth.py:507-523).  The wrap instants are a comparison of neighbouring wrapped phases -- elementwise work on
+    the accumulated phase (float64 here, float32 in the reference); gradients reach the impulse heights only, as there."""
+
+    def forward(self, phase: AudioTensor, phase_offset: AudioTensor = None) -> AudioTensor:
+        if self.check_ranges:
+            assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
+        up = GF.linear_upsample(phase.as_tensor(), int(phase.hop_length))
+        inst = torch.cumsum(up.double(), 1)
+        if phase_offset is not None:
+            off = phase_offset.as_tensor() if isinstance(phase_offset, AudioTensor) else phase_offset
+            n = min(inst.shape[1], off.shape[1])
+            inst, up = inst[:, :n] + off[:, :n].double(), up[:, :n]
+        wrapped = torch.remainder(inst, 1.0)
+        hit = (wrapped[:, 1:] - wrapped[:, :-1]) < 0
+        out = torch.zeros_like(up)
+        out[:, 1:] = torch.where(hit, torch.rsqrt(up[:, 1:]), torch.zeros_like(up[:, 1:]))
+        return AudioTensor(out)
 
 
 # ---------------------------------------------------------------------------------------------

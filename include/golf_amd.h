@@ -218,6 +218,26 @@ int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_stride,
                                   float* g_wsel, int B, int Tout,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* Generic wavetable lookup = GlottalFlowTable.generate, models/synth.py:124-177 (F.grid_sample bilinear over
+ * (control frame, phase)), for arbitrary per-frame tables (B,K,L) at hop hop_t and a given wrapped phase (B,N) in [0,1):
+ * what WeightedGlottalFlowTable (:266-294), WrappedPhaseDownsampledIndexedGlottalFlowTable (:343-375) and
+ * IndexedGlottalFlowTable with a differentiable phase / phase_offset / trainable table (:59-70,:213-218) reduce to.
+ *   out[b,n] = bilerp(T[b], row n/hop_t (frames beyond K-1 replicate the last), column wrapped*L (wraps to column 0))
+ * Backward: g_wrapped (B,N) and/or g_tables (B,K,L) (either may be NULL; both are fully overwritten). */
+int golf_wavetable_lookup_fwd_f32(const float* wrapped, int64_t wrapped_stride, const float* tables, int K, int L,
+                                  int hop_t, float* out, int64_t out_stride, int B, int N, void* stream);
+int golf_wavetable_lookup_bwd_f32(const float* g_out, int64_t g_out_stride, const float* wrapped, int64_t wrapped_stride,
+                                  const float* tables, int K, int L, int hop_t, float* g_wrapped,
+                                  int64_t g_wrapped_stride, float* g_tables, int B, int N, void* stream);
+
+/* The oscillator's decimator on its own (kazane.Decimate(os) stand-in, models/synth.py:208,262; taps are an input):
+ *   out[b,o] = sum_k taps[k] * x[b, o*os + k - (K-1)/2], zero padded, Tout = (N-1)/os + 1, K odd, os in [2,64];
+ * golf_decimate_fir_adj_f32 is its transpose (g_x (B,N) dense, fully overwritten). */
+int golf_decimate_fir_f32(const float* x, int64_t x_stride, int N, const float* taps, int K, int os, float* out,
+                          int64_t out_stride, int B, int Tout, void* stream);
+int golf_decimate_fir_adj_f32(const float* g_out, int64_t g_out_stride, int Tout, const float* taps, int K, int os,
+                            float* g_x, int N, int B, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * f-1: zero-phase FIR noise filter of every GOLF decoder.
  * Replaces LTVZeroPhaseFIRFilter.forward, models/filters.py:340-384:

@@ -63,6 +63,9 @@ __all__ = [
     "wavetable_generate_backward",
     "decimate_fir_adjoint",
     "indexed_glottal_backward",
+    "weighted_glottal_forward",
+    "weighted_glottal_backward",
+    "pulse_train",
 ]
 
 
@@ -618,7 +621,7 @@ def decimate_fir_adjoint(g_out, taps, q: int, N: int) -> np.ndarray:
 
 
 def indexed_glottal_backward(g_out, phase, phase_hop: int, weight, weight_hop: int, table, oversampling: int = 1,
-                             equal_energy: bool = False, phase_offset=None, decim_taps=None):
+                             equal_energy: bool = False, phase_offset=None, decim_taps=None, g_is_pre: bool = False):
     """Closed-form gradients of indexed_glottal_forward w.r.t. everything the reference differentiates
     (models/synth.py:213-263 under autograd): table_select_weight, phase, phase_offset, table.
     Returns dict(g_weight (B,Fw), g_phase (B,Tp), g_phase_offset (B,N) or None, g_table (n_tab,L))."""
@@ -641,7 +644,7 @@ def indexed_glottal_backward(g_out, phase, phase_hop: int, weight, weight_hop: i
     wrapped = inst % 1.0
     N = up.shape[1]
     g_y = np.asarray(g_out, dtype=np.float64)
-    if oversampling > 1:
+    if oversampling > 1 and not g_is_pre:      # g_is_pre: the gradient is given on the oversampled signal `pre`
         g_y = decimate_fir_adjoint(g_y, decim_taps, oversampling, N)
     g_up = np.zeros_like(up)
     if equal_energy:
@@ -659,6 +662,45 @@ def indexed_glottal_backward(g_out, phase, phase_hop: int, weight, weight_hop: i
     np.add.at(g_table, i0 + 1, g_T * p)
     return {"g_weight": g_p * (n_tab - 1), "g_phase": g_phase,
             "g_phase_offset": g_inst if phase_offset is not None else None, "g_table": g_table}
+
+
+def weighted_glottal_forward(phase, phase_hop: int, weights, weight_hop: int, table, phase_offset=None):
+    """WeightedGlottalFlowTable.forward, models/synth.py:275-294: tables = weights (B,Fw,n_tab) @ table (n_tab,L),
+    looked up at the wrapped running phase (no oversampling, no equal-energy scaling)."""
+    tables = np.asarray(weights, dtype=np.float64) @ np.asarray(table, dtype=np.float64)
+    up = linear_upsample(np.asarray(phase, dtype=np.float64), phase_hop, axis=1)
+    inst = np.cumsum(up, axis=1)
+    if phase_offset is not None:
+        inst = inst + np.asarray(phase_offset, dtype=np.float64)
+    return wavetable_generate(inst % 1.0, tables, weight_hop)
+
+
+def weighted_glottal_backward(g_out, phase, phase_hop: int, weights, weight_hop: int, table):
+    """Gradients of weighted_glottal_forward: dict(g_phase, g_weights, g_table)."""
+    weights = np.asarray(weights, dtype=np.float64)
+    table = np.asarray(table, dtype=np.float64)
+    phase = np.asarray(phase, dtype=np.float64)
+    up = linear_upsample(phase, phase_hop, axis=1)
+    wrapped = np.cumsum(up, axis=1) % 1.0
+    g_inst, g_T = wavetable_generate_backward(g_out, wrapped, weights @ table, weight_hop)
+    g_up = np.cumsum(g_inst[:, ::-1], axis=1)[:, ::-1]
+    return {"g_phase": _upsample_adjoint(g_up, phase_hop, phase.shape[1]), "g_weights": g_T @ table.T,
+            "g_table": np.einsum("bkn,bkl->nl", weights, g_T)}
+
+
+def pulse_train(phase, phase_hop: int, phase_offset=None) -> np.ndarray:
+    """PulseTrain.forward, models/synth.py:507-523: rsqrt(increment) where the wrapped running phase steps down."""
+    up = linear_upsample(np.asarray(phase, dtype=np.float64), phase_hop, axis=1)
+    inst = np.cumsum(up, axis=1)
+    if phase_offset is not None:
+        off = np.asarray(phase_offset, dtype=np.float64)
+        n = min(inst.shape[1], off.shape[1])
+        inst, up = inst[:, :n] + off[:, :n], up[:, :n]
+    wrapped = inst % 1.0
+    out = np.zeros_like(up)
+    hit = (wrapped[:, 1:] - wrapped[:, :-1]) < 0
+    out[:, 1:][hit] = 1.0 / np.sqrt(up[:, 1:][hit])
+    return out
 
 
 def default_decimation_taps(q: int, zeros: int = 16, rolloff: float = 0.945) -> np.ndarray:

@@ -144,6 +144,7 @@ class Decimate(nn.Module):
 
     def forward(self, x):
         Decimate.last_input = x.detach().clone()
+        Decimate.last_input_live = x          # still attached to the autograd graph (g23: gradients of the oversampled signal)
         return x[..., :: self.q]
 
 
@@ -670,4 +671,65 @@ gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
 (y * gy).sum().backward()
 save("g22_world_sp_filter", ex=ex, logmel=logmel, y=y, gy=gy, g_ex=ex.grad, g_logmel=logmel.grad, inv_fb=flt.fb,
      split=np.array(split[0]))
+# ----------------------------------------------------------------------------- g23 oscillator surface (a-8 gradients, a-11)
+# What the reference differentiates through its oscillators and the table oscillators no GOLF config uses:
+# IndexedGlottalFlowTable with a trainable table / differentiable phase / phase_offset (models/synth.py:59-70,213-263),
+# WeightedGlottalFlowTable (:266-294), WrappedPhaseDownsampledIndexedGlottalFlowTable (:343-375), PulseTrain (:507-523).
+# The reference runs these in float32 (synth.py:251 forces .float()); phases are dyadic so that its fp32 cumsum is exact.
+d = {}
+for name, os_, eq, with_off in (("ix1", 1, True, True), ("ix4", 4, True, False)):
+    osc = rs.IndexedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                     align_peak=True, lf_v2=True, points=16, oversampling=os_, equal_energy=eq,
+                                     trainable=True)
+    phase = dyadic((2, 64), 10, 0.01, 0.12).requires_grad_(True)
+    w = torch.from_numpy(rng.uniform(0.02, 0.98, (2, 5)).astype(np.float32)).requires_grad_(True)
+    n_fine = (64 - 1) * os_ + 1
+    off = dyadic((2, n_fine), 10, 0.0, 1.0).requires_grad_(True) if with_off else None
+    Decimate.last_input = None
+    y = osc(AT(phase, 1), AT(w, 16), AT(off, 1) if with_off else None).as_tensor()
+    sig = Decimate.last_input_live if os_ > 1 else y     # gradients are taken on the pre-decimation signal (kazane absent)
+    gy = torch.from_numpy(rng.normal(0, 1, tuple(sig.shape)).astype(np.float32))
+    (sig * gy).sum().backward()
+    d.update({f"{name}_table": osc.table.detach().clone(), f"{name}_phase": phase.detach(), f"{name}_w": w.detach(),
+              f"{name}_sig": sig.detach(), f"{name}_gy": gy, f"{name}_g_phase": phase.grad, f"{name}_g_w": w.grad,
+              f"{name}_g_table": osc.table.grad})
+    if with_off:
+        d.update({f"{name}_off": off.detach(), f"{name}_g_off": off.grad})
+# weighted table mix
+osc = rs.WeightedGlottalFlowTable(table_size=7, table_type="derivative", normalize_method="constant_power",
+                                  align_peak=True, lf_v2=True, points=16, trainable=True)
+phase = dyadic((2, 64), 10, 0.01, 0.12).requires_grad_(True)
+wl = torch.from_numpy(rng.normal(0, 1, (2, 5, 7)).astype(np.float32)).requires_grad_(True)
+(split, trs) = osc.ctrl(lambda s_, t_: (s_, t_))((), ())
+(wsm,) = trs[0](AT(wl, 16))
+y = osc(AT(phase, 1), wsm).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
+(y * gy).sum().backward()
+d.update(wt_table=osc.table.detach().clone(), wt_phase=phase.detach(), wt_logits=wl.detach(), wt_w=wsm.as_tensor().detach(),
+         wt_out=y.detach(), wt_gy=gy, wt_g_phase=phase.grad, wt_g_logits=wl.grad, wt_g_table=osc.table.grad,
+         wt_split=np.array(split[0]))
+# phase at a coarser hop (test_rtf style) through the weighted oscillator, forward only
+phase8 = dyadic((2, 9), 10, 0.01, 0.12)
+w8 = torch.softmax(torch.from_numpy(rng.normal(0, 1, (2, 3, 7)).astype(np.float32)), 2)
+d.update(wt_phase8=phase8, wt_w8=w8, wt_out8=osc(AT(phase8, 8), AT(w8, 32)).as_tensor().detach())
+# wrapped-phase input
+osc = rs.WrappedPhaseDownsampledIndexedGlottalFlowTable(hop_rate=2, in_channels=3, table_size=7, table_type="derivative",
+                                                        normalize_method="constant_power", align_peak=True, lf_v2=True,
+                                                        points=16)
+wp = torch.from_numpy(rng.uniform(0, 1, (2, 64)).astype(np.float32)).requires_grad_(True)
+w = torch.from_numpy(rng.uniform(0.02, 0.98, (2, 5)).astype(np.float32)).requires_grad_(True)
+y = osc(AT(wp, 1), AT(w, 16)).as_tensor()
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
+(y * gy).sum().backward()
+d.update(wp_table=osc.table.clone(), wp_phase=wp.detach(), wp_w=w.detach(), wp_out=y.detach(), wp_gy=gy,
+         wp_g_phase=wp.grad, wp_g_w=w.grad, wp_state_keys=np.array(sorted(osc.state_dict().keys())))
+# pulse train
+pt = rs.PulseTrain()
+phase = dyadic((2, 200), 10, 0.01, 0.12)
+d.update(pt_phase=phase, pt_out=pt(AT(phase, 1)).as_tensor())
+phase8 = dyadic((2, 30), 10, 0.01, 0.12)
+off8 = dyadic((2, 233), 10, 0.0, 1.0)
+# (offset as a plain tensor: the stand-in AudioTensor type has no Tensor methods on indexed results, models/utils.py:41-56)
+d.update(pt_phase8=phase8, pt_off8=off8, pt_out8=pt(AT(phase8, 8), off8).as_tensor())
+save("g23_oscillator_surface", **d)
 print("done")

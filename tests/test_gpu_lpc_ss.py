@@ -340,7 +340,7 @@ def test_serial_path_full_length():
     y, g_ex, g_gain, g_a = run_mode(ex, gain, a, 240, "serial", gy)
     check(y, O.ltv_allpole_ss_forward(ex, gain, a, 240), "serial full-length fwd")
     r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, 240)
-    check(g_ex[:, :47761], r_ex, "serial full-length g_ex")
+    check(g_ex, r_ex, "serial full-length g_ex")
     check(g_gain, r_gain, "serial full-length g_gain")
     check(g_a, r_a, "serial full-length g_a")
 

@@ -189,3 +189,31 @@ def test_decimator_design():
     d = Decimate(4)
     assert d.kernel.shape == (1, 1, 129)
     np.testing.assert_allclose(d.taps.numpy(), O.default_decimation_taps(4), atol=1e-7)
+
+
+def test_remaining_oscillator_surface_cpu():
+    """Constructor / control-protocol / checkpoint-key surface of the table oscillators outside the GOLF configs
+    (reference models/synth.py:266-294, 343-400, 507-523) -- no kernels involved."""
+    import torch
+    from golf_amd.synth import (DownsampledWeightedGlottalFlowTable, PulseTrain, WeightedGlottalFlowTable,
+                                WrappedPhaseDownsampledIndexedGlottalFlowTable)
+
+    w = WeightedGlottalFlowTable(table_size=9, lf_v2=True, points=32)
+    split, trs, _ = w.ctrl(lambda s_, t_: (s_, t_, None))((), ())
+    assert split == ((9,),)
+    d = DownsampledWeightedGlottalFlowTable(hop_rate=10, in_channels=6, table_size=9, lf_v2=True, points=32)
+    split, trs, _ = d.ctrl(lambda s_, t_: (s_, t_, None))((), ())
+    assert split == ((6,),)
+    assert sorted(d.state_dict()) == ["R_d_values", "model.1.bias", "model.1.weight", "model.3.bias", "model.3.weight",
+                                      "table"]
+    assert d.model[3].out_channels == 9
+    from golf_amd.audiotensor import AudioTensor
+    (ws,) = trs[0](AudioTensor(torch.randn(2, 40, 6), 240))
+    assert ws.shape == (2, 5, 9) and ws.hop_length == 2400
+    assert torch.allclose(ws.as_tensor().sum(-1), torch.ones(2, 5), atol=1e-6)
+    t = WeightedGlottalFlowTable(table_size=4, lf_v2=True, points=32, trainable=True)
+    assert isinstance(t.table, torch.nn.Parameter)
+    assert sorted(WrappedPhaseDownsampledIndexedGlottalFlowTable(hop_rate=2, in_channels=3, table_size=5, lf_v2=True,
+                                                                 points=32).state_dict()) == \
+        ["R_d_values", "model.1.bias", "model.1.weight", "model.3.bias", "model.3.weight", "table"]
+    assert PulseTrain().state_dict() == {}
