@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgolf_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip", "ctrl.hip")
+SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip", "ctrl.hip", "noise_band.hip")
 
 _c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -65,6 +65,10 @@ SIGNATURES = {
                                              _c_f32p, _int, _int, _vp]),
     "golf_decimate_fir_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
     "golf_decimate_fir_adj_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _vp]),
+    "golf_noise_band_workspace_bytes": (_sz, [_int] * 3),
+    "golf_noise_band_fwd_f32": (_int, [_c_f32p, _int, _vp, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _int, _vp]),
+    "golf_noise_band_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _vp, _c_f32p, _int, _int, _c_f32p, _int, _int, _int,
+                                       _vp, _sz, _vp]),
     "golf_harmonic_osc_workspace_bytes": (_sz, [_int] * 5),
     "golf_harmonic_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _c_f32p,
                                          _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),

@@ -295,6 +295,21 @@ int golf_lti_fir_taps_grad_f32(const float* gy, int64_t gy_stride, const float* 
                                int ntaps, int lead, int B, int T, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a-12: filtered-noise-band generator.  Replaces NoiseBand.forward, models/noise.py:114-124:
+ *     out[b,t] = sum_k noise_bands[k][(t + offsets[b,k]) mod Lb] * up(exp(log_gain))[b,t,k]
+ *   noise_bands (K, Lb) one loopable period per band (Lb a power of two; built at init by the host module as
+ *   models/noise.py:141-213 does), offsets (B,K) int32 in [0,Lb) (the random start per utterance and band),
+ *   log_gain (B,F,K) at hop `hop`, out (B,T), T <= (F-1)*hop+1.  The (B,K,T) gather and the (B,T,K) upsampled gains of
+ *   the reference are never formed.  Backward w.r.t. log_gain (g_log_gain (B,F,K) fully overwritten).
+ * ------------------------------------------------------------------------------------------- */
+size_t golf_noise_band_workspace_bytes(int B, int F, int K);
+int golf_noise_band_fwd_f32(const float* noise_bands, int Lb, const int* offsets, const float* log_gain, int F, int hop,
+                            float* out, int64_t out_stride, int B, int T, int K, void* stream);
+int golf_noise_band_bwd_f32(const float* g_out, int64_t g_out_stride, const float* noise_bands, int Lb,
+                            const int* offsets, const float* log_gain, int F, int hop, float* g_log_gain, int B, int T,
+                            int K, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a-11: harmonic oscillator bank — the source of the DDSP / NHV / WORLD / MLSA / SawSing / PULF baselines.
  * Replaces HarmonicOscillator.forward, models/synth.py:403-446, and what AdditiveSynthesizer (:449-468),
  * SawToothOscillator (:486-504) and AdditivePulseTrain (:526-547) feed it:

@@ -732,4 +732,49 @@ off8 = dyadic((2, 233), 10, 0.0, 1.0)
 # (offset as a plain tensor: the stand-in AudioTensor type has no Tensor methods on indexed results, models/utils.py:41-56)
 d.update(pt_phase8=phase8, pt_off8=off8, pt_out8=pt(AT(phase8, 8), off8).as_tensor())
 save("g23_oscillator_surface", **d)
+# ----------------------------------------------------------------------------- g24 NoiseBand (a-12), checkpoint key remaps and the
+# biquads.py dump (f-4 on-disk formats)
+import io
+import contextlib
+
+torch.manual_seed(7)                      # NoiseBand draws its band phases from torch's global generator (noise.py:199)
+with contextlib.redirect_stdout(io.StringIO()):
+    nb = rn.NoiseBand(n_filters=12, fs=24000, attenuation=50, normalize_noise_bands=True)
+(split, trs) = nb.ctrl(lambda s_, t_: (s_, t_))((), ())
+log_gain = torch.from_numpy(rng.normal(-2, 0.5, (2, 6, 12)).astype(np.float32)).requires_grad_(True)
+ref_sig = AT(torch.zeros(2, 330), 1)
+torch.manual_seed(11)
+offs = torch.randint(0, nb.noise_bands.shape[1], (2, nb.noise_bands.shape[0]))     # the draw forward() makes first
+torch.manual_seed(11)
+y = nb(ref_sig, AT(log_gain, 64))
+y = y.as_tensor() if hasattr(y, "as_tensor") else y
+gy = torch.from_numpy(rng.normal(0, 1, tuple(y.shape)).astype(np.float32))
+(y * gy).sum().backward()
+d = dict(nb_band_centers=nb.band_centers, nb_noise_bands=nb.noise_bands, nb_split=np.array(split[0]),
+         nb_log_gain=log_gain.detach(), nb_offsets=offs, nb_out=y.detach(), nb_gy=gy, nb_g_log_gain=log_gain.grad,
+         nb_state_keys=np.array(sorted(nb.state_dict().keys())))
+# ISMIR'23 -> Interspeech'24 head permutation (models/utils.py:12-38) on a random state dict
+sd = {"encoder.backbone.out_linear.weight": torch.from_numpy(rng.normal(0, 1, (2 + 2 * 23 + 8, 5)).astype(np.float32)),
+      "encoder.backbone.out_linear.bias": torch.from_numpy(rng.normal(0, 1, (2 + 2 * 23 + 8,)).astype(np.float32)),
+      "encoder.backbone.norm.weight": torch.from_numpy(rng.normal(0, 1, (5,)).astype(np.float32))}
+sd2 = ru.ismir2interspeech_ckpt(sd, lpc_order=22, h_size=8)
+d.update({"ck_in/" + k: v for k, v in sd.items()})
+d.update({"ck_out/" + k: v for k, v in sd2.items()})
+# biquads.py get_biquads on a stand-in model (its imports need torchaudio / harm_and_noise, absent: inert placeholders)
+_mod("harm_and_noise", loader=lambda *a, **k: None)
+if "torchaudio" in sys.modules and not hasattr(sys.modules["torchaudio"], "load"):
+    sys.modules["torchaudio"].load = lambda *a, **k: None
+import biquads as rbq  # noqa: E402
+
+bq_logits = torch.from_numpy(rng.normal(0, 1, (2, 7, 2 + 8 + 23 + 23)).astype(np.float32))
+enc = types.SimpleNamespace(
+    backbone=lambda h: bq_logits, split_sizes=((1,), (1,), (8,), (), (1, 22), (1, 22), ()),
+    args_keys=("f0", "voicing_logits", "harm_oscillator_params", "noise_generator_params", "harm_filter_params",
+               "noise_filter_params", "end_filter_params"),
+    trsfms=(None, None, lambda h: (torch.sigmoid(h.mean(-1)),), None, None, None, None))
+fake = types.SimpleNamespace(feature_trsfm=lambda x: x, encoder=enc)
+res = rbq.get_biquads(fake, torch.zeros(1, 10))
+d.update(bq_logits=bq_logits, bq_voicing=res[0], bq_harm_log_gain=res[1], bq_harm_biquads=res[2], bq_noise_log_gain=res[3],
+         bq_noise_biquads=res[4], bq_table_select_weight=res[5])
+save("g24_noiseband_ckpt_biquads", **d)
 print("done")
