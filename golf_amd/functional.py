@@ -568,6 +568,48 @@ def blend_tables(table: torch.Tensor, wsel: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# filtered-noise-band generator (reference models/noise.py:114-124)
+# ------------------------------------------------------------------------------------------------
+class _NoiseBand(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_gain, bands, offsets, hop, T):
+        _lib.require_device(log_gain, bands)
+        lib = _lib.load()
+        log_gain, bands = log_gain.contiguous(), bands.contiguous()
+        offsets = offsets.to(torch.int32).contiguous()
+        B, F, K = log_gain.shape
+        assert bands.shape[0] == K and offsets.shape == (B, K) and offsets.is_cuda
+        Tout = min(T, (F - 1) * hop + 1) if F > 1 else T
+        out = torch.empty(B, Tout, dtype=torch.float32, device=log_gain.device)
+        rc = lib.golf_noise_band_fwd_f32(bands.data_ptr(), bands.shape[1], offsets.data_ptr(), log_gain.data_ptr(), F,
+                                         hop, out.data_ptr(), out.stride(0), B, Tout, K, _lib.stream_ptr())
+        _lib.check(rc, "golf_noise_band_fwd_f32")
+        ctx.hop = hop
+        ctx.save_for_backward(log_gain, bands, offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        log_gain, bands, offsets = ctx.saved_tensors
+        lib = _lib.load()
+        B, F, K = log_gain.shape
+        g_out = _rows(g_out.float())
+        g_lg = torch.empty_like(log_gain)
+        ws = _workspace(lib.golf_noise_band_workspace_bytes(B, F, K), log_gain.device)
+        rc = lib.golf_noise_band_bwd_f32(g_out.data_ptr(), g_out.stride(0), bands.data_ptr(), bands.shape[1],
+                                         offsets.data_ptr(), log_gain.data_ptr(), F, ctx.hop, g_lg.data_ptr(), B,
+                                         g_out.shape[1], K, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_noise_band_bwd_f32")
+        return g_lg, None, None, None, None
+
+
+def noise_band(bands: torch.Tensor, offsets: torch.Tensor, log_gain: torch.Tensor, hop: int, T: int) -> torch.Tensor:
+    """bands (K, L) loopable noise periods, offsets (B,K) start indices, log_gain (B,F,K) at ``hop`` ->
+    (B, min(T, (F-1)*hop+1)); differentiable w.r.t. log_gain (include/golf_amd.h golf_noise_band_*)."""
+    return _NoiseBand.apply(log_gain, bands, offsets, int(hop), int(T))
+
+
+# ------------------------------------------------------------------------------------------------
 # zero-phase FIR noise filter (reference models/filters.py:286-384)
 # ------------------------------------------------------------------------------------------------
 _basis_cache = {}

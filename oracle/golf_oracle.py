@@ -66,6 +66,8 @@ __all__ = [
     "weighted_glottal_forward",
     "weighted_glottal_backward",
     "pulse_train",
+    "noise_band_forward",
+    "noise_band_backward",
 ]
 
 
@@ -701,6 +703,33 @@ def pulse_train(phase, phase_hop: int, phase_offset=None) -> np.ndarray:
     hit = (wrapped[:, 1:] - wrapped[:, :-1]) < 0
     out[:, 1:][hit] = 1.0 / np.sqrt(up[:, 1:][hit])
     return out
+
+
+def noise_band_forward(noise_bands, offsets, log_gain, hop: int, T: int) -> np.ndarray:
+    """NoiseBand.forward, models/noise.py:114-124, with the random start offsets given:
+    out[b,t] = sum_k noise_bands[k, (t + offsets[b,k]) % L] * up(exp(log_gain))[b,t,k], length min(T, (F-1)*hop+1)."""
+    nb = np.asarray(noise_bands, dtype=np.float64)
+    off = np.asarray(offsets, dtype=np.int64)
+    G = linear_upsample(np.exp(np.asarray(log_gain, dtype=np.float64)), hop, axis=1)      # (B, T', K)
+    n = min(T, G.shape[1])
+    K, L = nb.shape
+    idx = (np.arange(n)[None, None, :] + off[:, :, None]) % L                             # (B, K, n)
+    noise = nb[np.arange(K)[None, :, None], idx]                                          # (B, K, n)
+    return np.einsum("bkt,btk->bt", noise, G[:, :n])
+
+
+def noise_band_backward(g_out, noise_bands, offsets, log_gain, hop: int) -> np.ndarray:
+    """d/d log_gain of noise_band_forward: up^T(g * noise) * exp(log_gain)."""
+    nb = np.asarray(noise_bands, dtype=np.float64)
+    off = np.asarray(offsets, dtype=np.int64)
+    lg = np.asarray(log_gain, dtype=np.float64)
+    g = np.asarray(g_out, dtype=np.float64)
+    n = g.shape[1]
+    K, L = nb.shape
+    idx = (np.arange(n)[None, None, :] + off[:, :, None]) % L
+    noise = nb[np.arange(K)[None, :, None], idx]
+    gG = g[:, :, None] * np.transpose(noise, (0, 2, 1))                                  # (B, n, K)
+    return _upsample_adjoint(gG, hop, lg.shape[1]) * np.exp(lg)
 
 
 def default_decimation_taps(q: int, zeros: int = 16, rolloff: float = 0.945) -> np.ndarray:
