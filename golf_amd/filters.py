@@ -15,7 +15,7 @@ from torch import Tensor
 from . import functional as GF
 from .audiotensor import AudioTensor
 from .ctrl import Controllable, wrap_ctrl_fn
-from .utils import biquads2lpc, get_logits2biquads, get_window_fn, rc2lpc
+from .utils import biquads2lpc, get_logits2biquads, get_window_fn, lsp2lpc, rc2lpc
 
 __all__ = ["LTVCepFilter", "DiffWorldSPFilter", "melscale_fbanks", "FilterInterface", "LTVFilterInterface", "LTVMinimumPhaseFilterPrecise", "LTVMinimumPhaseFilter",
            "LTVZeroPhaseFIRFilter", "LTVZeroPhaseFIRFilterPrecise", "LTVAPZeroPhaseFIRFilter", "LTIAcousticFilter",
@@ -68,7 +68,12 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
 
             num_logits = lpc_order
         elif lpc_parameterisation == "lsp2lpc":
-            raise NotImplementedError("lsp2lpc needs diffsptk (not used by any shipped GOLF config)")
+            # softmax -> cumulative sum: M+1 increasing values ending at 1; rolled so that the 1 (-> pi) sits in the gain
+            # slot and the other M are interlaced line spectral frequencies on (0, pi) (models/filters.py:82-86)
+            def logits2lpc(logits: Tensor) -> Tensor:
+                return lsp2lpc(logits.softmax(-1).cumsum(-1).roll(1, -1) * torch.pi)[..., 1:]
+
+            num_logits = lpc_order + 1
         else:
             raise ValueError(f"Unknown lpc_parameterisation: {lpc_parameterisation}")
         self.logits2lpc = logits2lpc

@@ -13,7 +13,7 @@ from typing import Callable
 import torch
 from torch import Tensor
 
-__all__ = [
+__all__ = ["lsp2lpc", 
     "rc2lpc", "get_logits2biquads", "biquads2lpc", "coeff_product", "get_window_fn",
     "get_transformed_lf", "get_transformed_lf_v2", "linear_upsample", "TimeContext",
 ]
@@ -169,3 +169,37 @@ def get_transformed_lf_v2(Rd: Tensor, points: int = 1024) -> Tensor:
     opening = E0 * torch.exp(alpha * t) * torch.sin(w * t)
     ret = (shift - torch.exp(-eps * (t - Te))) / delta
     return torch.where(t < Te, opening, ret).squeeze()
+
+
+def lsp2lpc(w: Tensor) -> Tensor:
+    """Line spectral pairs -> LPC, standing in for ``diffsptk.functional.lsp2lpc`` (third party, absent: parity with
+    diffsptk itself is unpinned; reference call site models/filters.py:82-86).
+
+    ``w`` (..., M+1) = [K, w_1 < ... < w_M] with the line spectral frequencies in radians on (0, pi); returns
+    (..., M+1) = [K, a_1 .. a_M] of A(z) = 1 + sum_k a_k z^-k = (P(z) + Q(z)) / 2, the textbook construction (Itakura):
+    the odd-indexed frequencies w_1, w_3, ... are the roots of the symmetric polynomial P, the even-indexed ones of the
+    antisymmetric Q; for even M, P carries the extra factor (1 + z^-1) and Q (1 - z^-1); for odd M, Q carries (1 - z^-2).
+    Interlaced frequencies give a minimum-phase A(z).  Plain tensor ops (differentiable)."""
+    K, freq = w[..., :1], w[..., 1:]
+    M = freq.shape[-1]
+    c = -2.0 * torch.cos(freq)
+    one = torch.ones_like(K)
+
+    def product(first: Tensor, cos_terms: Tensor) -> Tensor:
+        poly = first                                         # (..., n) coefficients, lowest power of z^-1 first
+        for i in range(cos_terms.shape[-1]):
+            sec = torch.stack([one[..., 0], cos_terms[..., i], one[..., 0]], dim=-1)      # 1 + c z^-1 + z^-2
+            out = poly.new_zeros(poly.shape[:-1] + (poly.shape[-1] + 2,))
+            for k in range(3):
+                out[..., k:k + poly.shape[-1]] = out[..., k:k + poly.shape[-1]] + sec[..., k:k + 1] * poly
+            poly = out
+        return poly
+
+    if M % 2 == 0:
+        P = product(torch.cat([one, one], -1), c[..., 0::2])          # (1 + z^-1) * prod over w_1, w_3, ...
+        Q = product(torch.cat([one, -one], -1), c[..., 1::2])         # (1 - z^-1) * prod over w_2, w_4, ...
+    else:
+        P = product(one, c[..., 0::2])
+        Q = product(torch.cat([one, torch.zeros_like(one), -one], -1), c[..., 1::2])   # (1 - z^-2) * prod
+    A = 0.5 * (P + Q)                                                  # degree M+1, whose top coefficient cancels
+    return torch.cat([K, A[..., 1:M + 1]], dim=-1)

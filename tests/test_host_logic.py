@@ -290,3 +290,44 @@ def test_biquads_dump_g24(golden, tmp_path):
                                                   "noise_biquads", "table_select_weight")} | \
         {f"utt_1.{n}" for n in ("voicing", "harm_log_gain", "harm_biquads", "noise_log_gain", "noise_biquads")}
     assert back["utt_0.harm_biquads"].shape == (2, 7, 11, 3)
+
+
+def test_lsp2lpc_construction():
+    """LSP -> LPC (stand-in for diffsptk.functional.lsp2lpc; models/filters.py:82-86): the closed form for M = 2, the
+    defining property for M = 22 and M = 5 -- the roots of P = A + z^-(M+1) A(1/z) and Q = A - z^-(M+1) A(1/z) lie on the
+    unit circle at exactly the given frequencies, interlaced -- minimum phase, and the module's control transform."""
+    import torch
+    from golf_amd.utils import lsp2lpc
+
+    w = torch.tensor([[0.7, 0.4, 1.9]], dtype=torch.float64)
+    a = lsp2lpc(w)
+    c1, c2 = np.cos(0.4), np.cos(1.9)
+    np.testing.assert_allclose(a.numpy(), [[0.7, -(c1 + c2), 1 - c1 + c2]], rtol=1e-12)
+    rng = np.random.default_rng(5)
+    for M in (22, 5):
+        freq = np.sort(rng.uniform(0.05, np.pi - 0.05, (3, M)), axis=-1)
+        out = lsp2lpc(torch.from_numpy(np.concatenate([np.ones((3, 1)), freq], -1))).numpy()
+        assert out.shape == (3, M + 1)
+        for row, fr in zip(out, freq):
+            A = np.concatenate([[1.0], row[1:]])
+            P = np.concatenate([A, [0.0]]) + np.concatenate([[0.0], A[::-1]])
+            Q = np.concatenate([A, [0.0]]) - np.concatenate([[0.0], A[::-1]])
+            ang = lambda poly: np.sort(np.angle(np.roots(poly)))
+            pa, qa = ang(P), ang(Q)
+            assert np.allclose(np.abs(np.roots(P)), 1, atol=1e-6) and np.allclose(np.abs(np.roots(Q)), 1, atol=1e-6)
+            pos = lambda v: np.sort(v[(v > 1e-6) & (v < np.pi - 1e-6)])
+            np.testing.assert_allclose(pos(pa), fr[0::2], atol=1e-7)
+            np.testing.assert_allclose(pos(qa), fr[1::2], atol=1e-7)
+            assert np.all(np.abs(np.roots(A)) < 1)                    # interlaced LSPs => minimum phase
+    from golf_amd.filters import LTVMinimumPhaseFilterPrecise
+    from golf_amd.audiotensor import AudioTensor
+    m = LTVMinimumPhaseFilterPrecise(lpc_order=10, lpc_parameterisation="lsp2lpc")
+    split, trs, _ = m.ctrl(lambda s_, t_: (s_, t_, None))((), ())
+    assert split == ((1, 11),)
+    logits = torch.randn(2, 5, 11, requires_grad=True)
+    gain, a = trs[0](AudioTensor(torch.zeros(2, 5), 240), AudioTensor(logits, 240))
+    assert a.shape == (2, 5, 10) and a.hop_length == 240
+    a.as_tensor().sum().backward()
+    assert torch.isfinite(logits.grad).all()
+    for row in a.as_tensor().detach().reshape(-1, 10).numpy():
+        assert np.all(np.abs(np.roots(np.concatenate([[1.0], row]))) < 1)
