@@ -1321,14 +1321,32 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     return GOLF_OK;
 }
 
+// CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
+static int device_cu_count() {
+    constexpr int kMaxDev = 16;
+    static int cache[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
 // Fork/join helper: `side` runs P1h (needs only `a`) while `st` runs P1z (needs the excitation).
 // Events come from a small per-thread ring that is never destroyed (destroying an event another stream still
 // waits on proved racy); an event is reused only 64 fork/joins later, long after its wait has been consumed.
 struct ForkJoin {
     static hipEvent_t next_event() {
-        static thread_local hipEvent_t ring[64] = {};
-        static thread_local unsigned head = 0;
-        hipEvent_t& e = ring[head++ & 63];
+        // events belong to the device that was current when they were created: one ring per (thread, device)
+        constexpr int kMaxDev = 16;
+        static thread_local hipEvent_t ring[kMaxDev][64] = {};
+        static thread_local unsigned head[kMaxDev] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+        hipEvent_t& e = ring[dev][head[dev]++ & 63];
         if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
         return e;
     }
@@ -1362,13 +1380,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             if (!side && !(flags & GOLF_SS_SPLIT_P1)) {   // transitions + zero-state pass in one launch
                 const int nq = B * p.NP, ncg = (int)ceil_div(p.NP, 16);
                 const int64_t nunit = (int64_t)ncg * B;
-                static const int n_cu = [] {
-                    int dev = 0, n = 0;
-                    if (hipGetDevice(&dev) != hipSuccess ||
-                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-                        n = 256;
-                    return n;
-                }();
+                const int n_cu = device_cu_count();
                 if (fast) {
                     const int nblk_f = (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
                     int upw = 1;

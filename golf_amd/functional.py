@@ -88,6 +88,17 @@ def ss_output_length(Tx: int, F: int, hop: int) -> int:
     return min(Tx, (F - 1) * hop + 1)
 
 
+# (ring width, largest order it serves) of the sample-wise filter's kernels (csrc/lpc_ss.hip kTable): the fast path --
+# and with it the custom backward -- needs one ring width that divides the hop and exceeds the order.
+SS_RINGS = ((8, 6), (16, 14), (24, 22), (32, 30), (40, 38))
+
+
+def ss_is_trainable(M: int, hop: int, F: int = 2) -> bool:
+    """True when (lpc order, hop) has a fast-path kernel, i.e. gradients are available.  Other shapes still run the
+    forward (serial generic kernel) but cannot be trained through."""
+    return F >= 2 and any(M <= order and hop % ring == 0 for ring, order in SS_RINGS)
+
+
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
@@ -104,6 +115,12 @@ class _LTVAllPoleSS(torch.autograd.Function):
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
         side, flags = None, 0
         needs_grad = any(ctx.needs_input_grad[:3])
+        if needs_grad and not ss_is_trainable(M, hop, F):
+            # fail before the forward, not at the first backward: name the supported grid
+            raise _lib.GolfError(
+                f"golf_amd: the sample-wise LPC filter has no backward for lpc_order={M}, hop={hop}, frames={F}: training "
+                f"needs >= 2 frames and a ring width W in {[r for r, _ in SS_RINGS]} with hop % W == 0 and lpc_order <= W - 2 "
+                f"(e.g. hop 240 -> orders up to 38, hop 256 -> up to 30, hop 100 -> none)")
         if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version)
                 and not (prepared.fast and needs_grad)):
             ws, flags, side = prepared.ws, HAVE_TRANSITIONS, prepared.stream

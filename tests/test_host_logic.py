@@ -331,3 +331,11 @@ def test_lsp2lpc_construction():
     assert torch.isfinite(logits.grad).all()
     for row in a.as_tensor().detach().reshape(-1, 10).numpy():
         assert np.all(np.abs(np.roots(np.concatenate([[1.0], row]))) < 1)
+
+
+def test_trainable_shape_grid():
+    from golf_amd.functional import ss_is_trainable
+
+    assert ss_is_trainable(22, 240) and ss_is_trainable(26, 240) and ss_is_trainable(38, 240) and ss_is_trainable(30, 256)
+    assert not ss_is_trainable(39, 240) and not ss_is_trainable(22, 100) and not ss_is_trainable(31, 256)
+    assert not ss_is_trainable(22, 240, F=1)
