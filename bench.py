@@ -416,9 +416,10 @@ def main():
     do_gather = world > 1 and not args.no_gather
     GE = max(1, args.gather_every) if do_gather else 1
     pipelined = args.gather_mode == "pipelined"
-    if do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank
-        stage = [torch.empty(GE * B, t_out, device=device) for _ in range(S)] if GE > 1 else None
-        gather_bufs = [torch.empty(world * GE * B, t_out, device=device) for _ in range(S)]
+    if do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank (golf_amd.dist.StagedGather)
+        from golf_amd.dist import StagedGather
+
+        stagers = [StagedGather(B, t_out, GE, device, world=world) for _ in range(S)]
     # ---- execution mode: S independent batches in flight.  The serial phases of the filter occupy a few dozen
     # waves for tens of microseconds (the boundary scan: B waves), so one batch leaves most of the chip idle;
     # a serving loop keeps several batches in flight on separate HIP streams, each step replayed as ONE hipGraph
@@ -457,47 +458,27 @@ def main():
         torch.cuda.synchronize()
 
     step_no = [0]
-    slot_pending = [None] * S  # gather still reading slot i's staging/output buffer
-    slot_fill = [0] * S
 
     def full_step():
         i = step_no[0] % S
         step_no[0] += 1
         with torch.cuda.stream(streams[i]):
-            if do_gather and slot_pending[i] is not None and slot_fill[i] == 0:
-                slot_pending[i].wait()   # the buffer the coming steps overwrite is still being sent
-                slot_pending[i] = None
             if use_graphs:
                 graphs[i].replay()
                 y = outs[i]
             else:
                 y = steps_fn[i]()
-            if do_gather:
-                src = y.detach()
-                if GE > 1:
-                    stage[i][slot_fill[i] * B:(slot_fill[i] + 1) * B].copy_(src, non_blocking=True)
-                    src = stage[i]
-                slot_fill[i] += 1
-                if slot_fill[i] == GE:
-                    slot_fill[i] = 0
-                    if pipelined:
-                        slot_pending[i] = gather_audio_async(src, gather_bufs[i])
-                    else:
-                        gather_audio(src, gather_bufs[i])
+            if do_gather:   # copy into the slot's staging buffer; every GE-th step starts one all-gather (async)
+                handle = stagers[i].push(y.detach())
+                if handle is not None and not pipelined:
+                    handle.wait()
         return y
 
     def drain():
-        for i in range(S):
-            if do_gather and slot_fill[i]:   # partial group at the end of a region: exchange what is staged
+        if do_gather:
+            for i in range(S):
                 with torch.cuda.stream(streams[i]):
-                    if slot_pending[i] is not None:
-                        slot_pending[i].wait()
-                    slot_pending[i] = gather_audio_async(stage[i], gather_bufs[i])
-                slot_fill[i] = 0
-            if slot_pending[i] is not None:
-                with torch.cuda.stream(streams[i]):
-                    slot_pending[i].wait()
-                slot_pending[i] = None
+                    stagers[i].flush()   # a partial group at the end of a region is exchanged too, then all are waited for
 
     def barrier():
         if world > 1:

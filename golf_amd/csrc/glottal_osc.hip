@@ -561,23 +561,31 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 }
 
 // ---- O2+O3 fused (the GOLF configuration: phase at hop 1, 4x oversampling, power-of-two table) --------------------
-// The three-kernel path above moves 105 MB for 12 MB of algorithmic traffic at B=32: a 64-bit phase prefix per coarse
-// sample is written and read back (12 MB each way) and the 4x oversampled signal makes a round trip through HBM
-// (24 MB written by the render kernel, read again by the decimator).  Here one workgroup owns TO output samples
-// of one utterance and keeps everything in between on chip:
-//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of TO coarse samples -> Ttot[b][tile]
+// The three-kernel path above moves 105 MB for 12 MB of algorithmic traffic at B=32 (a 64-bit phase prefix per coarse
+// sample written and read back, the 4x oversampled signal on a round trip through HBM) and -- what the counters showed
+// to matter more -- spends 433 VALU lane-instructions per output sample at 75 % VALU-busy: it is instruction-issue
+// bound.  Here one workgroup of 8 waves owns OSCF_TO = 2048 output samples of one utterance:
+//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of OSCF_TO coarse samples -> Ttot[b][tile]
 //   1. base phase of the tile = sum of the earlier tiles' totals (exact: Q0.64 integers, order cannot matter)
-//   2. the tile's coarse phase samples (+ the decimator's halo) are scanned in the block: C_j relative to the tile
-//   3. every fine sample is rendered (same integer walk and bilinear LDS lookup as osc_render_kernel) straight into
-//      the decimator's polyphase LDS tile; the table rows of the <= 4 control frames the tile touches are
-//      staged once per block
-//   4. the polyphase FIR of osc_decimate_kernel runs on that tile, + the fused addend, one store per output.
-// HBM traffic: phase in (twice: totals + tile), addend in, audio out, tables from L2.  Results are bit-identical to the
-// three-kernel path (same arithmetic on the same exact phases; tests/test_gpu_osc.py asserts equality).
+//   2. the tile's coarse phase samples (+ the decimator's halo) are scanned in the block; a thread keeps the converted
+//      increments of its 5 consecutive coarse samples in registers for step 3
+//   3. render into LDS.  Table rows are staged as PAIRS (row_k[c], row_{k+1}[c] - row_k[c]): one ds_read2_b64 brings
+//      what a bilinear lookup needs, and interpolating along the control frame first makes it 2 + 2 instructions;
+//      the equal-energy factor rsqrt(p) is linear over the 4 fine samples of a coarse sample to 1e-6 whenever p moves by
+//      less than 0.2 % per sample (speech f0; otherwise the exact v_rsq_f32 runs)
+//   4. the 129-tap polyphase FIR runs on the MATRIX pipe, which is idle otherwise: per polyphase branch the outputs of
+//      a 256-sample stretch are the product of 16 overlapping signal windows (A: 16 x 48) with a banded Toeplitz matrix
+//      of the branch's 33 taps (B: 48 x 16), accumulated over the 4 branches in exact fp32 (v_mfma_f32_16x16x4_f32,
+//      48 of them per wave).  The signal tile is laid out with 4 pad words per 16 so that the window fragments are read
+//      without bank conflicts.  132 VALU multiply-adds per output become 12 LDS reads.
+// About 125 VALU lane-instructions per output instead of 433.  Same exact phases as the three-kernel path; the values
+// agree to 1e-6 (tests/test_gpu_osc.py).
+#define OSCF_TO 2048
+#define OSCF_THREADS 512
+#define OSCF_CPT 5            // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + 4 * KS
 #define OSCF_MAXROWS 4
-constexpr int oscf_cpt(int TO, int NTH) { return (TO + 64 + NTH - 1) / NTH; }   // coarse samples per thread (scan)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int TO>
 __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile) {
     __shared__ u64 wsum[4];
@@ -586,8 +594,8 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
     const double scale_a = 18446744073709551616.0 / (double)os;
     const double scale_d = scale_a / (double)P;
     const u64 tri = (u64)P * (u64)(P - 1) / 2;
-    constexpr int PER = TO / 256;
-    const int j0 = tile * TO + tid * PER;
+    constexpr int PER = OSCF_TO / 256;
+    const int j0 = tile * OSCF_TO + tid * PER;
     float pv[PER + 1];
 #pragma unroll
     for (int r = 0; r <= PER; ++r) pv[r] = prow.ld(min(j0 + r, Tp - 1));
@@ -601,71 +609,46 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
     if (tid == 0) Ttot[(size_t)b * ntile + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// The 4 fine samples of one coarse phase sample (they lie in ONE control interval: hop_t is a multiple of 4): integer
-// phase walk, bilinear lookup in the staged rows, equal-energy scaling, written to the polyphase tile.
-template <int EE>
-__device__ __forceinline__ void oscf_render_coarse(int u, int j, u64 ph, float p0, float p1, const float* __restrict__ rows,
-                                                   int LR, int lshift, int r_first, int hop_t, float inv_hop_t, int bnd1,
-                                                   int bnd2, int Tp, float* __restrict__ X, int RS4, double scale_a,
-                                                   double scale_d) {
-    const float d = (p1 - p0) * 0.25f;
-    u64 inc = osc_fix_a(p0, scale_a);
-    const u64 dinc = osc_fix_d(p0, p1, scale_d);
-    const int m0 = j * 4;
-    const int rr = (m0 >= bnd1) + (m0 >= bnd2);
-    const float* ra = rows + (size_t)rr * LR;
-    const int mrel = m0 - (r_first + rr) * hop_t;
-    const bool v0 = j >= 0 && j <= Tp - 1;         // fine sample k = 0 exists
-    const bool vk = j >= 0 && j < Tp - 1;          // k = 1..3 exist (the last coarse sample has only k = 0)
-    float* xp = X + (u & 3) * RS4 + (u >> 2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ph += inc;
-        inc += dinc;
-        const unsigned hi = (unsigned)(ph >> 32);
-        const int c0 = (int)(hi >> (32 - lshift));
-        const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
-        const float a00 = ra[c0], a01 = ra[c0 + 1], a10 = ra[LR + c0], a11 = ra[LR + c0 + 1];
-        const float top = fmaf(cf, a01 - a00, a00);
-        const float bot = fmaf(cf, a11 - a10, a10);
-        const float rf = (float)(mrel + k) * inv_hop_t;
-        float v = fmaf(rf, bot - top, top);
-        // raw v_rsq_f32: the argument is a normal number (p/4 with p in (0, 0.5]), where rsqrtf() returns exactly this
-        // after spending 5 more instructions on denormal scaling
-        if (EE) v *= __builtin_amdgcn_rsqf(fmaf((float)k, d, p0) * 0.25f);
-        xp[k * 4 * RS4] = (k == 0 ? v0 : vk) ? v : 0.f;
-    }
-}
+// signal tile: polyphase branch ph, coarse index i  ->  X[ph * XS + i + 4 * (i >> 4)]
+__device__ __forceinline__ int oscf_xaddr(int i) { return i + 4 * (i >> 4); }
 
-// Geometry: TO outputs per workgroup of NTH threads (TO / NTH = 4 outputs per thread in the FIR).  STRIDED: the render
-// loop walks the coarse samples strided over the block (balanced, start phases published in LDS); otherwise every
-// thread renders the CPT consecutive coarse samples it scanned (no phase array in LDS: room for a larger tile).
-template <int EE, int TO, int NTH, bool STRIDED>
-__global__ __launch_bounds__(NTH) void osc_fused_kernel(
+// KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
+template <int EE, int KS>
+__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, int N, const float* __restrict__ taps, int K, float* __restrict__ out, int64_t out_stride, int Tout,
-    int RS4, int dmin, int ngrp, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
-    static_assert(TO == 4 * NTH, "4 outputs per thread");
-    constexpr int OS = 4, P = 4;
-    constexpr int CPT = oscf_cpt(TO, NTH);
+    int hop_t, const float* __restrict__ taps, int K, float* __restrict__ out, int64_t out_stride, int Tout, int XS,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
+    constexpr int OS = 4, P = 4, NTH = OSCF_THREADS, CPT = OSCF_CPT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u64 wtot[NTH / 64];
     __shared__ u64 base_sh, halo_sh;
-    // layout: X polyphase tile | H taps | rows (nrows x (L+1)) | ps coarse phase samples | (STRIDED) Cs start phases
+    // layout: X polyphase signal tile [4][XS] | row pairs [(nrows-1)][L+1] float2
     float* X = smem;
-    const int hoff = (OS * 4 * RS4 + 3) & ~3;
-    float* H = smem + hoff;
-    const int HS = ngrp * 4 + 8;
-    float* rows = H + OS * HS;
+    float2* pairs = reinterpret_cast<float2*>(smem + OS * XS);
     const int LR = L + 1;
-    float* ps = rows + (((size_t)nrows * LR + 3) & ~(size_t)3);
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int o0 = tile * TO;
-    const int span = TO + ngrp * 4 + 4;          // coarse samples staged (polyphase index i <-> coarse sample j_lo + i)
-    u64* Cs = reinterpret_cast<u64*>(ps + ((span + 1 + 3) & ~3));
+    const int li = lane & 15, lk = lane >> 4;
+    const int o0 = tile * OSCF_TO;
+    constexpr int span = OSCF_TO + 4 * KS;       // coarse samples rendered (index u <-> coarse sample j_lo + u)
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
-    // ---- 1. base phase: the tiles before this one (wave 0), and the taps / table rows / phase samples into LDS
+    // ---- 0. Toeplitz fragments of the taps, straight into registers (consumed in step 4; the loads fly meanwhile):
+    //         B[k'][n] = tap of branch ph at d = dmin + (k' - n), k' = 4*kk + lk, n = li
+    float bfrag[OS][KS];
+    {
+        const int half = (K - 1) / 2;
+#pragma unroll
+        for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int q = 4 * kk + lk - li;
+                const int k = half + OS * (dmin + q) + ph;
+                const bool ok = q >= 0 && k >= 0 && k < K;
+                const float t = taps[ok ? k : 0];
+                bfrag[ph][kk] = ok ? t : 0.f;
+            }
+    }
+    // ---- 1. base phase: the tiles before this one (wave 0); the thread's own coarse phase samples; the row pairs
     if (wv == 0) {
         u64 acc = 0;
         for (int i = lane; i < tile; i += 64) acc += Ttot[(size_t)b * ntile + i];
@@ -673,156 +656,158 @@ __global__ __launch_bounds__(NTH) void osc_fused_kernel(
         if (lane == 63) base_sh = acc;
     }
     const BufRow prow(phase + (size_t)b * phase_stride, Tp);
-    for (int u = tid; u <= span; u += NTH) {
-        const int j = j_lo + u;
-        ps[u] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
-    }
-    for (int e = tid; e < OS * HS; e += NTH) {   // H[ph][3 + q] = tap of (ph, d = dmin + q), zero elsewhere
-        const int half = (K - 1) / 2;
-        const int ph = e / HS, q = e - ph * HS - 3;
-        const int k = half + OS * (dmin + q) + ph;
-        H[e] = (q >= 0 && k >= 0 && k < K) ? taps[k] : 0.f;
+    const int u0 = tid * CPT;
+    float pv[CPT + 1];
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) {
+        const int j = j_lo + u0 + r;
+        pv[r] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
     }
     const int m_first = max(j_lo, 0) * P;        // first fine sample that exists in this tile
     const int r_first = m_first / hop_t;         // control frame of that sample; rows r_first .. r_first + nrows - 1
-    for (int rr = 0; rr < nrows; ++rr) {
-        int k = r_first + rr;
-        if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
-        const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
-        int i0 = (int)idx;
-        i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
-        const float pw = idx - (float)i0;
-        const float* t0 = table + (size_t)i0 * L;
-        float* dst = rows + (size_t)rr * LR;
-        constexpr int SU = 4;
-        for (int cb0 = 0; cb0 < L + 1; cb0 += SU * NTH) {   // all loads of a batch before the first blend
-            float va[SU], vb[SU];
+    for (int rr = 0; rr + 1 < nrows; ++rr) {     // pair rr = (row r_first+rr, row r_first+rr+1 - row r_first+rr)
+        const float* t0[2];
+        float pw[2];
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                int c = cb0 + u * NTH + tid;
-                c = c > L ? L : c;
-                c = c == L ? 0 : c;                          // column L = wrap-around copy of column 0
-                va[u] = t0[c];
-                vb[u] = t0[L + c];
-            }
+        for (int e = 0; e < 2; ++e) {
+            int k = r_first + rr + e;
+            if (k > Fw - 1) k = Fw - 1;          // replicate-padded frames (models/synth.py:141-146)
+            const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+            int i0 = (int)idx;
+            i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+            pw[e] = idx - (float)i0;
+            t0[e] = table + (size_t)i0 * L;
+        }
+        float2* dst = pairs + (size_t)rr * LR;
+        constexpr int SU = 2;
+        for (int cb0 = 0; cb0 < L + 1; cb0 += SU * NTH) {   // all loads of a batch before the first blend
+            float va[2][SU], vb[2][SU];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    int c = cb0 + u * NTH + tid;
+                    c = c > L ? L : c;
+                    c = c == L ? 0 : c;                      // column L = wrap-around copy of column 0
+                    va[e][u] = t0[e][c];
+                    vb[e][u] = t0[e][L + c];
+                }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const int c = cb0 + u * NTH + tid;
-                if (c <= L) dst[c] = va[u] * (1.0f - pw) + vb[u] * pw;
+                const float ra = va[0][u] * (1.0f - pw[0]) + vb[0][u] * pw[0];
+                const float rb = va[1][u] * (1.0f - pw[1]) + vb[1][u] * pw[1];
+                if (c <= L) dst[c] = make_float2(ra, rb - ra);
             }
         }
     }
-    __syncthreads();
     // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
     const double scale_a = 18446744073709551616.0 / (double)OS;
     const double scale_d = scale_a / (double)P;
-    const int u0 = tid * CPT;
-    u64 tv[CPT];
+    u64 av[CPT], dv[CPT], tv[CPT];
     u64 tsum = 0;
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
-        const int u = min(u0 + r, span - 1);
-        const int j = j_lo + u;
-        const float p0 = ps[u], p1 = ps[u + 1];
+        const int j = j_lo + u0 + r;
+        av[r] = osc_fix_a(pv[r], scale_a);
+        dv[r] = osc_fix_d(pv[r], pv[r + 1], scale_d);
         const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-        tv[r] = seg ? (u64)P * osc_fix_a(p0, scale_a) + osc_fix_d(p0, p1, scale_d) * (u64)6 : 0;
+        tv[r] = seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
         tsum += tv[r];
     }
     const u64 incl = wave_incl_scan(tsum, lane);
     if (lane == 63) wtot[wv] = incl;
-    __syncthreads();
+    __syncthreads();                             // also: row pairs and base_sh are in place
     u64 run = incl - tsum;                       // exclusive prefix relative to coarse sample j_lo
     for (int w = 0; w < wv; ++w) run += wtot[w];
-    // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
-    // (j_lo .. o0-1) belongs to the previous tile's total: phase at local index u = base_sh - prefix(-dmin) + prefix(u)
-    {
+    {   // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
+        // (j_lo .. o0-1) belongs to the previous tile's total: phase at local u = base_sh - prefix(-dmin) + prefix(u)
         u64 r2 = run;
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
             if (u0 + r == -dmin) halo_sh = r2;
-            if (STRIDED && u0 + r < span) Cs[u0 + r] = r2;
             r2 += tv[r];
         }
     }
     __syncthreads();
-    const u64 base = base_sh - halo_sh;
-    // ---- 3. render into the polyphase tile
+    // ---- 3. render the 4 fine samples of every owned coarse sample (they lie in ONE control interval: hop_t is a
+    //         multiple of 4) into the polyphase tile
     const float inv_hop_t = 1.0f / (float)hop_t;
-    // nrows - 1 control intervals are staged (rows r_first .. r_first + nrows - 1): interval index 0 .. nrows - 2
+    // nrows - 1 control intervals are staged (pairs 0 .. nrows - 2)
     const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
-    if (STRIDED) {
-        for (int u = tid; u < span; u += NTH)
-            oscf_render_coarse<EE>(u, j_lo + u, base + Cs[u], ps[u], ps[u + 1], rows, LR, lshift, r_first, hop_t,
-                                   inv_hop_t, bnd1, bnd2, Tp, X, RS4, scale_a, scale_d);
-    } else {
-        u64 ph = base + run;
+    u64 ph = base_sh - halo_sh + run;
 #pragma unroll
-        for (int r = 0; r < CPT; ++r) {
-            const int u = u0 + r;
-            if (u < span)
-                oscf_render_coarse<EE>(u, j_lo + u, ph, ps[u], ps[u + 1], rows, LR, lshift, r_first, hop_t, inv_hop_t,
-                                       bnd1, bnd2, Tp, X, RS4, scale_a, scale_d);
-            ph += tv[r];
+    for (int r = 0; r < CPT; ++r) {
+        const int u = u0 + r;
+        if (u < span) {
+            const int j = j_lo + u;
+            const float p0 = pv[r], p1 = pv[r + 1];
+            u64 phk = ph, inc = av[r];
+            const u64 dinc = dv[r];
+            const int m0 = j * P;
+            const int rr = (m0 >= bnd1) + (m0 >= bnd2);
+            const float2* ra = pairs + (size_t)rr * LR;
+            float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
+            const bool v0 = j >= 0 && j <= Tp - 1;     // fine sample k = 0 exists
+            const bool vk = j >= 0 && j < Tp - 1;      // k = 1..3 exist (the last coarse sample has only k = 0)
+            float s0 = 1.0f, ds = 0.f;
+            bool lin = true;
+            const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;   // fine increment q0 + k*dq (cycles per fine sample)
+            if (EE) {
+                s0 = __builtin_amdgcn_rsqf(q0);        // raw v_rsq_f32: q0 is a normal number, rsqrtf() returns the same
+                ds = -0.5f * s0 * s0 * s0 * dq;        // d/dk rsqrt(q0 + k dq) at k = 0
+                lin = fabsf(p1 - p0) <= 0.002f * p0;   // second-order term below 1e-6 (3 steps): speech f0 always is
+            }
+            float* xp = X + oscf_xaddr(u);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                phk += inc;
+                inc += dinc;
+                const unsigned hi = (unsigned)(phk >> 32);
+                const int c0 = (int)(hi >> (32 - lshift));
+                const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+                const float2 e0 = ra[c0], e1 = ra[c0 + 1];
+                const float t0 = fmaf(rf, e0.y, e0.x), t1 = fmaf(rf, e1.y, e1.x);
+                float v = fmaf(cf, t1 - t0, t0);
+                if (EE) {
+                    float sc = fmaf((float)k, ds, s0);
+                    if (!lin) sc = __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));   // f0 jumps (voicing boundaries): exact
+                    v *= sc;
+                }
+                xp[k * XS] = (k == 0 ? v0 : vk) ? v : 0.f;
+                rf += inv_hop_t;
+            }
         }
+        ph += tv[r];
     }
     __syncthreads();
-    // ---- 4. polyphase FIR (osc_decimate_kernel's inner loop), 4 outputs per thread
-    const int u = tid;
-    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
-    const float ad0 = arow.ld(o0 + 4 * u), ad1 = arow.ld(o0 + 4 * u + 1), ad2 = arow.ld(o0 + 4 * u + 2),
-                ad3 = arow.ld(o0 + 4 * u + 3);
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
+    //         D[m][n] (output 256*wv + 16*m + n) = sum_ph sum_k' X_ph[256*wv + 16*m + k'] * B_ph[k'][n]
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        // A[m = li][k' = 4*kk + lk]: element 256*wv + 16*li + 4*kk + lk  ->  address + 4 * (16*wv + li + (kk >> 2))
+        const float* ap = X + 320 * wv + 20 * li + lk;
 #pragma unroll
-    for (int ph = 0; ph < OS; ++ph) {
-        const float* Xp = X + (size_t)ph * 4 * RS4 + u;
-        const float4* Hp = reinterpret_cast<const float4*>(H + (size_t)ph * HS);
-        float4 hprev = Hp[0];
-        for (int g = 0; g <= ngrp; ++g) {
-            const float4 hcur = Hp[g + 1];
-            const float x0 = Xp[0 * RS4 + g], x1 = Xp[1 * RS4 + g], x2 = Xp[2 * RS4 + g], x3 = Xp[3 * RS4 + g];
-            acc0 = fmaf(hprev.w, x0, acc0); acc1 = fmaf(hprev.z, x0, acc1);
-            acc2 = fmaf(hprev.y, x0, acc2); acc3 = fmaf(hprev.x, x0, acc3);
-            acc0 = fmaf(hcur.x, x1, acc0); acc1 = fmaf(hprev.w, x1, acc1);
-            acc2 = fmaf(hprev.z, x1, acc2); acc3 = fmaf(hprev.y, x1, acc3);
-            acc0 = fmaf(hcur.y, x2, acc0); acc1 = fmaf(hcur.x, x2, acc1);
-            acc2 = fmaf(hprev.w, x2, acc2); acc3 = fmaf(hprev.z, x2, acc3);
-            acc0 = fmaf(hcur.z, x3, acc0); acc1 = fmaf(hcur.y, x3, acc1);
-            acc2 = fmaf(hcur.x, x3, acc2); acc3 = fmaf(hprev.w, x3, acc3);
-            hprev = hcur;
+        for (int phs = 0; phs < OS; ++phs) {
+            float a[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + 4 * (kk >> 2)];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], bfrag[phs][kk + 1], acc1, 0, 0, 0);
+            }
         }
     }
+    // D rows 4*lk + r, column li  ->  output o0 + 256*wv + 16*(4*lk + r) + li
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
     const BufRow orow(out + (size_t)b * out_stride, Tout);
-    const int o = o0 + 4 * u;
-    orow.st(o, acc0 + ad0);
-    orow.st(o + 1, acc1 + ad1);
-    orow.st(o + 2, acc2 + ad2);
-    orow.st(o + 3, acc3 + ad3);
-}
-
-struct OscfGeom { int TO, NTH, strided; };
-static const OscfGeom kOscfGeoms[] = {{2048, 512, 0}, {1024, 256, 1}, {2048, 512, 1}, {1024, 256, 0}};
-static int oscf_geom_index() {   // dev knob GOLF_OSCF_GEOM: which (tile, threads, render order) instance runs
-    static const int v = [] { const char* e = getenv("GOLF_OSCF_GEOM"); int i = e ? atoi(e) : 0; return (i < 0 || i > 3) ? 0 : i; }();
-    return v;
-}
-
-template <int EE, int TO, int NTH, bool STRIDED>
-static int oscf_launch(size_t ldsf, int ntile2, int B, hipStream_t st, const float* phase, int64_t phase_stride, u64* Ttot,
-                       const float* wsel, int Fw, const float* table, int n_tab, int L, int lshift, int Tp, int P, int os,
-                       int hop_t, int N, const float* taps, int K, float* out, int64_t out_stride, int Tout, int RS4,
-                       int dmin, int ngrp, int nrows, const float* addend, int64_t addend_stride, int Tadd) {
-    static const hipError_t lds_attr = hipFuncSetAttribute((const void*)osc_fused_kernel<EE, TO, NTH, STRIDED>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (lds_attr != hipSuccess)   // > 64 KB of dynamic LDS per workgroup needs the opt-in
-        return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(lds_attr));
-    hipLaunchKernelGGL(osc_tile_totals_kernel<TO>, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp, P, os,
-                       ntile2);
-    GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((osc_fused_kernel<EE, TO, NTH, STRIDED>), dim3(ntile2, B), dim3(NTH), ldsf, st, phase, phase_stride,
-                       (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, N, taps, K, out, out_stride,
-                       Tout, RS4, dmin, ngrp, nrows, addend, addend_stride, Tadd);
-    GOLF_LAUNCH_CHECK();
-    return GOLF_OK;
+    const int ob = o0 + 256 * wv + 64 * lk + li;
+    float ad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
 }
 
 // ---- decimator launches (shared by the oscillator entry points and golf_decimate_fir_*) -----------------------------
@@ -1023,6 +1008,9 @@ __device__ __forceinline__ void harm_sincos(u64 x, float& s, float& c) {
 }
 
 // Forward: one block per 256 consecutive output samples.
+// DERIV: d out / d Phi(t) = 2 pi * sum_h [..] amp(t,h) * h * cos(2 pi h Phi(t)) instead of the signal itself (the
+// Nyquist mask is piecewise constant in the phase); feeds the gradient w.r.t. the phase input.
+template <bool DERIV>
 __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
     int ntile, int Tp, int P, const float* __restrict__ amp, int Fa, int amp_hop, const float* __restrict__ tscale,
@@ -1091,14 +1079,15 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
             if (h <= H) {  // uniform
                 const float a0 = r0[h - 1];
                 const float a = fmaf(wa, r1[h - 1] - a0, a0);
-                acc = h <= hl ? fmaf(a, s, acc) : acc;
+                if (DERIV) acc = h <= hl ? fmaf(a * (float)h, c, acc) : acc;
+                else       acc = h <= hl ? fmaf(a, s, acc) : acc;
                 const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
                 s = sn;
                 c = cn;
             }
         }
     }
-    out[(size_t)b * out_stride + t] = acc * ts;
+    out[(size_t)b * out_stride + t] = DERIV ? acc * ts * 6.283185307179586f : acc * ts;
 }
 
 // Gradient w.r.t. the amplitude rows.  One wave per (utterance, amplitude segment sg): every sample of the segment is
@@ -1260,40 +1249,39 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
     static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
     if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !pre && !unfused_env) {
-        const OscfGeom geo = kOscfGeoms[oscf_geom_index()];
         const int half = (K - 1) / 2;
         const int dmin = -((half + os - 1) / os);
         const int dmax = half / os;
-        const int nq = dmax - dmin + 1;
-        const int ngrp = (nq + 2) / 4;
-        int RS4 = geo.TO / 4 + ngrp + 2;
-        while (RS4 % 32 != 2) ++RS4;
-        const int span = geo.TO + ngrp * 4 + 4;
+        const int nq = dmax - dmin + 1;                             // taps per polyphase branch
+        const int KS = nq + 15 <= 48 ? 12 : 16;                     // K-steps of the 16-window Toeplitz product
+        const int span = OSCF_TO + 4 * KS;
         const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
         const int nrows = nint_touched + 1;
-        const int hoff = (os * 4 * RS4 + 3) & ~3;
-        const size_t ldsf = sizeof(float) * ((size_t)hoff + (size_t)os * (ngrp * 4 + 8) +
-                                             (((size_t)nrows * (L + 1) + 3) & ~(size_t)3) + (size_t)((span + 1 + 3) & ~3) +
-                                             (geo.strided ? 2 * (size_t)span : 0) + 4);
-        if (nrows <= OSCF_MAXROWS && span <= geo.TO + 64 && -dmin < span && ldsf <= 128 * 1024) {
-            const int ntile2 = (int)ceil_div(Tout, geo.TO);        // <= g.ntile: fits the Ttot region of the workspace
+        const int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;       // padded polyphase row: i + 4 * (i >> 4)
+        const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1));
+        if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin < span &&
+            ldsf <= 80 * 1024) {
+            const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
-#define GOLF_FUSED(EE, TO, NTH, STR)                                                                                  \
-    return oscf_launch<EE, TO, NTH, STR>(ldsf, ntile2, B, st, phase, phase_stride, Ttot, wsel, Fw, table, n_tab, L,  \
-                                         lshift, Tp, g.P, os, g.hop_t, g.N, taps, K, out, out_stride, Tout, RS4,     \
-                                         dmin, ngrp, nrows, addend, addend_stride, Tadd)
-            const int key = oscf_geom_index() * 2 + (equal_energy ? 1 : 0);
-            switch (key) {
-                case 0: GOLF_FUSED(0, 2048, 512, false);
-                case 1: GOLF_FUSED(1, 2048, 512, false);
-                case 2: GOLF_FUSED(0, 1024, 256, true);
-                case 3: GOLF_FUSED(1, 1024, 256, true);
-                case 4: GOLF_FUSED(0, 2048, 512, true);
-                case 5: GOLF_FUSED(1, 2048, 512, true);
-                case 6: GOLF_FUSED(0, 1024, 256, false);
-                default: GOLF_FUSED(1, 1024, 256, false);
-            }
+            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,
+                               g.P, os, ntile2);
+            GOLF_LAUNCH_CHECK();
+#define GOLF_FUSED(EE, KSV)                                                                                           \
+    do {                                                                                                              \
+        static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
+            (const void*)osc_fused_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);           \
+        if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
+            return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
+                        hipGetErrorString(lds_attr));                                                                 \
+        hipLaunchKernelGGL((osc_fused_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsf, st, phase,         \
+                           phase_stride, (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t,    \
+                           taps, K, out, out_stride, Tout, XS, dmin, nrows, addend, addend_stride, Tadd);             \
+    } while (0)
+            if (KS == 12) { if (equal_energy) GOLF_FUSED(1, 12); else GOLF_FUSED(0, 12); }
+            else          { if (equal_energy) GOLF_FUSED(1, 16); else GOLF_FUSED(0, 16); }
 #undef GOLF_FUSED
+            GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
         }
     }
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, os, g.ntile, B, st)) return rc;
@@ -1426,25 +1414,47 @@ extern "C" size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop
     return g.total;
 }
 
+template <bool DERIV>
+static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                            const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
+                            const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout, void* ws,
+                            size_t ws_bytes, void* stream);
+
 extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                          const float* amp, int Fa, int amp_hop, const float* tscale, int Fs,
                                          int ts_hop, const float* hscale, int H, float* out, int64_t out_stride, int B,
                                          int Tout, void* ws, size_t ws_bytes, void* stream) {
+    return harmonic_osc_run<false>("harmonic_osc_fwd", phase, phase_stride, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs,
+                                   ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream);
+}
+
+extern "C" int golf_harmonic_osc_dphase_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                                            const float* amp, int Fa, int amp_hop, const float* tscale, int Fs,
+                                            int ts_hop, const float* hscale, int H, float* out, int64_t out_stride,
+                                            int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
+    return harmonic_osc_run<true>("harmonic_osc_dphase", phase, phase_stride, Tp, phase_hop, amp, Fa, amp_hop, tscale,
+                                  Fs, ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream);
+}
+
+template <bool DERIV>
+static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                            const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
+                            const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout, void* ws,
+                            size_t ws_bytes, void* stream) {
     HarmGeom g;
     harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp ? amp_hop : HARM_THREADS, &g,
               amp ? Fa : 0, H > 0 ? H : 1);
-    if (int rc = harm_check("harmonic_osc_fwd", phase, B, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs, ts_hop, H, Tout, g))
+    if (int rc = harm_check(who, phase, B, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs, ts_hop, H, Tout, g))
         return rc;
-    if (!out || out_stride < Tout || phase_stride < Tp) return fail(GOLF_EINVAL, "harmonic_osc_fwd: bad output / stride");
+    if (!out || out_stride < Tout || phase_stride < Tp) return fail(GOLF_EINVAL, "%s: bad output / stride", who);
     if (!ws || ws_bytes < g.total || ((uintptr_t)ws & 255))
-        return fail(GOLF_EWORKSPACE, "harmonic_osc_fwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
-                    ws_bytes);
+        return fail(GOLF_EWORKSPACE, "%s: workspace needs %zu bytes, 256-aligned (got %zu)", who, g.total, ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, 1, g.ntile, B, st)) return rc;
     const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H);
-    hipLaunchKernelGGL(harm_kernel, dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
+    hipLaunchKernelGGL(harm_kernel<DERIV>, dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
                        phase, phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, amp, amp ? Fa : 1,
                        amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, Tout, g.nrows);
     GOLF_LAUNCH_CHECK();

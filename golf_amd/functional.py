@@ -883,22 +883,34 @@ class _HarmonicOsc(torch.autograd.Function):
                                            _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(),
                                            out.stride(0), B, Tout, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_harmonic_osc_fwd_f32")
-        ctx.save_for_backward(phase, tscale, hscale)
+        ctx.save_for_backward(phase, tscale, hscale, amp)
         ctx.geom = (H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, amp is not None)
         return out
 
     @staticmethod
+    def _run(lib, name, phase, amp, tscale, hscale, geom):
+        H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = geom
+        B, Tp = phase.shape
+        out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
+        ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa if has_amp else 0, H), phase.device)
+        rc = getattr(lib, name)(phase.data_ptr(), phase.stride(0), Tp, phase_hop, _lib.ptr(amp), Fa, amp_hop,
+                                _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(), out.stride(0), B, Tout,
+                                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, name)
+        return out
+
+    @staticmethod
     def backward(ctx, g_out):
-        phase, tscale, hscale = ctx.saved_tensors
+        phase, tscale, hscale, amp = ctx.saved_tensors
         H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = ctx.geom
-        if any(ctx.needs_input_grad[i] for i in (0, 2, 3)):
-            raise NotImplementedError("golf_amd: the harmonic oscillator is differentiable w.r.t. the amplitudes only "
-                                      "(phase and the per-sample / per-harmonic scales are data)")
-        g_amp = None
+        if ctx.needs_input_grad[3]:
+            raise NotImplementedError("golf_amd: the per-harmonic scale of the harmonic oscillator is a constant "
+                                      "(SawToothOscillator's 1/h buffer)")
+        lib = _lib.load()
+        g_out = _rows(g_out.float())
+        B, Tp = phase.shape
+        g_phase = g_amp = g_ts = None
         if has_amp and ctx.needs_input_grad[1]:
-            lib = _lib.load()
-            g_out = _rows(g_out)
-            B, Tp = phase.shape
             g_amp = torch.empty(B, Fa, H, dtype=torch.float32, device=phase.device)
             ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa, H), phase.device)
             rc = lib.golf_harmonic_osc_bwd_amp_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(),
@@ -906,13 +918,41 @@ class _HarmonicOsc(torch.autograd.Function):
                                                    ts_hop, _lib.ptr(hscale), H, g_amp.data_ptr(), B, Tout,
                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "golf_harmonic_osc_bwd_amp_f32")
-        return None, g_amp, None, None, None, None, None, None
+        if ctx.needs_input_grad[0]:
+            # out depends on the phase input through Phi = cumsum(up(phase)) (the Nyquist mask is piecewise constant):
+            # g_phase = up^T( reverse-cumsum( g_out * d out / d Phi ) ), the derivative bank from the same kernel
+            d = _HarmonicOsc._run(lib, "golf_harmonic_osc_dphase_f32", phase, amp if has_amp else None, tscale, hscale,
+                                  ctx.geom)
+            g_inst = (g_out[:, :Tout] * d).double()
+            g_up = torch.flip(torch.cumsum(torch.flip(g_inst, [1]), 1), [1]).float()
+            g_phase = upsample_adjoint(g_up, phase_hop, Tp)
+        if tscale is not None and ctx.needs_input_grad[2]:
+            # out = up(tscale) * S: S is the same kernel without the per-sample scale
+            geom = (H, phase_hop, amp_hop, ts_hop, Fa, 1, Tout, has_amp)
+            S = _HarmonicOsc._run(lib, "golf_harmonic_osc_fwd_f32", phase, amp if has_amp else None, None, hscale, geom)
+            g_ts = upsample_adjoint(g_out[:, :Tout] * S, ts_hop, Fs)
+        return g_phase, g_amp, g_ts, None, None, None, None, None
+
+
+def upsample_adjoint(v: torch.Tensor, hop: int, F: int) -> torch.Tensor:
+    """Adjoint of linear_upsample along dim 1: v (B,T) with T <= (F-1)*hop+1 -> (B,F)."""
+    B, T = v.shape
+    out = v.new_zeros(B, F)
+    if hop == 1 or F == 1:
+        out[:, :T] = v
+        return out
+    n = torch.arange(T, device=v.device)
+    f = torch.clamp(torch.div(n, hop, rounding_mode="floor"), max=F - 2)
+    w = (n - f * hop).to(v.dtype) / hop
+    out.index_add_(1, f, v * (1 - w))
+    out.index_add_(1, f + 1, v * w)
+    return out
 
 
 def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, tscale=None, ts_hop: int = 1,
                  hscale=None) -> torch.Tensor:
     """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h] * sin(2 pi h cumsum(p)[t]),
-    p = up(phase); differentiable w.r.t. ``amp``."""
+    p = up(phase); differentiable w.r.t. ``amp``, ``phase`` and ``tscale``."""
     return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop)
 
 

@@ -319,11 +319,17 @@ int golf_noise_band_bwd_f32(const float* g_out, int64_t g_out_stride, const floa
  *     each may be NULL (= 1).  Tout = min of the upsampled lengths ((n-1)*hop+1) of phase and the given factors.
  *   The (B,T,H) tensors of the reference are never formed; the phase is exact (64-bit fixed point, as in the
  *   wavetable oscillator), sin(h theta) by a rotation recurrence re-anchored from the exact phase every 32 harmonics.
- * Backward w.r.t. A only (the phase is data in every shipped config): g_amp (B,Fa,H) fully overwritten.
+ * Backward w.r.t. A (g_amp (B,Fa,H) fully overwritten); golf_harmonic_osc_dphase_f32 serves the gradient w.r.t. the phase.
  * ------------------------------------------------------------------------------------------- */
 /* Fa = amplitude frames (0 if amp is NULL); sized for the forward and the backward */
 size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fa, int H);
 int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                              const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
+                              const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
+                              void* ws, size_t ws_bytes, void* stream);
+/* d out / d Phi(t) (Phi = the running phase in cycles): 2 pi sum_h [h p < 0.5] amp(t,h) h cos(2 pi h Phi(t)); the
+ * gradient w.r.t. the phase input is the transposed upsampling of the reverse cumulative sum of g_out * this (host). */
+int golf_harmonic_osc_dphase_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                               const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                               const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
                               void* ws, size_t ws_bytes, void* stream);

@@ -295,17 +295,20 @@ def test_long_input_beyond_256_tiles():
 @pytest.mark.parametrize("Tp,w_hop,eq", [(48000, 2400, True), (48000, 2400, False), (1, 2400, True), (5, 2400, True),
                                          (2047, 2400, True), (2048, 1200, True), (2049, 2400, True),
                                          (5000, 1200, False), (6000, 800, True), (9999, 4000, True)])
-def test_fused_render_decimate_is_bit_identical(Tp, w_hop, eq):
-    """The fused oscillator kernel (in-block phase scan -> render into LDS -> polyphase decimation, no HBM round trip
-    of the oversampled signal) against the three-kernel path (taken when `pre` is requested): the same arithmetic on the
-    same exact Q0.64 phases, so every output bit must agree -- with and without the fused addend, ragged tile counts,
-    control hops that need 3 and 4 staged table rows (and one, w_hop 800, that falls back to the unfused path)."""
+def test_fused_kernel_matches_three_kernel_path(Tp, w_hop, eq):
+    """The fused oscillator kernel (in-block phase scan -> render into LDS -> polyphase decimation on the matrix pipe, no
+    HBM round trip of the oversampled signal) against the three-kernel path (taken when `pre` is requested).  Both walk
+    the same exact Q0.64 phases; the fused one linearises rsqrt over 4 fine samples, interpolates along the control frame
+    first and sums the taps in MFMA order, so the values agree to a few 1e-7 -- with and without the fused addend, ragged
+    tile counts, control hops that need 3 and 4 staged table rows (and one, w_hop 800, that falls back)."""
     from golf_amd import functional as GF
     from golf_amd.synth import IndexedGlottalFlowTable
 
     rng = np.random.default_rng(Tp + w_hop)
     B = 3
     f0 = rng.uniform(80, 400, (B, 1)) * (1 + 0.03 * np.sin(2 * np.pi * 5.5 * np.arange(Tp) / 24000 + rng.uniform(0, 6, (B, 1))))
+    if Tp > 4000:
+        f0[0, 1000:1003] = [50.0, 180.0, 420.0]       # f0 jumps (voicing boundaries): the exact-rsqrt branch
     phase = dev((f0 / 24000).astype(np.float32))
     Fw = (Tp - 1) // w_hop + 2
     w = dev(rng.uniform(0, 1, (B, Fw)).astype(np.float32))
@@ -318,4 +321,27 @@ def test_fused_render_decimate_is_bit_identical(Tp, w_hop, eq):
         torch.cuda.synchronize()
         assert fused.shape == unfused.shape == (B, Tp)
         assert torch.isfinite(fused).all()
-        assert torch.equal(fused, unfused), (Tp, w_hop, eq, a is not None, float((fused - unfused).abs().max()))
+        scale = float((unfused - (0 if a is None else a)).abs().max()) + 1e-30
+        err = float((fused - unfused).abs().max()) / scale
+        print(f"Tp={Tp} w_hop={w_hop} eq={eq} add={a is not None}: fused vs three-kernel rel-max {err:.2e}")
+        assert err <= 5e-6, (Tp, w_hop, eq, a is not None, err)
+
+
+def test_fused_kernel_other_tap_counts():
+    """193 taps (zeros = 24, kazane's default design length at q = 4): the 16-step Toeplitz instance; 257 taps exceed it
+    and take the three-kernel path -- either way equal to the float64 oracle."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import Decimate, IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(11)
+    B, Tp, w_hop = 2, 5000, 2400
+    f0 = rng.uniform(80, 400, (B, 1)) * np.ones((1, Tp))
+    phase = (f0 / 24000).astype(np.float32)
+    w = rng.uniform(0, 1, (B, 4)).astype(np.float32)
+    m = IndexedGlottalFlowTable(table_size=50, lf_v2=True, points=1024, oversampling=4, equal_energy=True)
+    for zeros in (24, 32, 4):
+        taps = Decimate(4, zeros=zeros).taps
+        out = GF.glottal_osc(dev(phase), dev(w), m.table.cuda(), taps.cuda(), 1, w_hop, 4, True).cpu().numpy()
+        ref = O.indexed_glottal_forward(phase, 1, w, w_hop, m.table.numpy(), 4, True, decim_taps=taps.numpy())["out"]
+        check(out, ref, f"fused osc, {taps.numel()} taps")

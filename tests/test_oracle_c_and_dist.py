@@ -138,3 +138,61 @@ def test_shard_helpers():
     assert torch.equal(s1["x"][2], d["x"][4])  # padded with the last utterance
     y = torch.ones(3, 4)
     assert gather_audio(y, total=2).shape == (2, 4)  # no process group: identity + trim
+
+
+def _staged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from golf_amd.dist import StagedGather
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, T, every, steps = 3, 17, 2, 5
+    sg = StagedGather(rows, T, every, device="cpu")
+    seen = []
+    for k in range(steps):
+        y = torch.full((rows, T), float(100 * rank + k))
+        h = sg.push(y)
+        if h is not None:                                     # a full group went out: steps k-1, k
+            h.wait()
+            seen.append(sg.result(1 - sg.cur).clone())        # the pair just sent
+    sg.flush()                                                # the half-filled third group (step 4)
+    seen.append(sg.result(1 - sg.cur).clone())
+    if rank == 0:
+        q.put((torch.stack(seen).numpy(), sg.groups_sent, sg.bytes_per_collective))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_staged_gather_gloo_world2():
+    """K steps' audio per collective (the N > 1 mitigation for the per-link xGMI bound): every rank sees every rank's
+    output of every step, grouped, double buffered, with a ragged last group."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen, groups, nbytes = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert groups == 3 and nbytes == 2 * 3 * 17 * 4
+    assert seen.shape == (3, 2, 2, 3, 17)                     # (group, rank, step in group, rows, T)
+    for grp in range(3):
+        for r in range(2):
+            for j in range(2):
+                k = 2 * grp + j
+                if k < 5:
+                    assert np.all(seen[grp, r, j] == 100 * r + k), (grp, r, j)
+
+
+def test_staged_gather_single_process():
+    from golf_amd.dist import StagedGather
+
+    sg = StagedGather(2, 5, 3, device="cpu", world=1)
+    for k in range(3):
+        sg.push(torch.full((2, 5), float(k)))
+    sg.flush()
+    assert torch.equal(sg.result(0)[0, :, 0, 0], torch.tensor([0.0, 1.0, 2.0]))
