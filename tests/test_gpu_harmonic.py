@@ -122,3 +122,64 @@ def test_random_shape_sweep():
         gmax, gl2 = rel_err(a.grad.cpu().numpy(), gref)
         assert gmax <= 3e-4 and gl2 <= 3e-4, (trial, "g_amp", B, Tp, ph, ah, H, gmax, gl2)
     print("random harmonic sweep worst forward rel-max", worst)
+
+
+@pytest.mark.parametrize("phase_hop,amp_hop", [(1, 8), (4, 8)])
+def test_phase_gradient_vs_finite_differences(phase_hop, amp_hop):
+    """d out / d phase (HarmonicPlusNoiseSynth with non-detached voicing and AdditiveSynthesizer with a
+    differentiable f0 used to raise): the derivative bank + reverse cumulative sum + transposed upsampling against central
+    differences of the float64 oracle.  Harmonics are kept clear of Nyquist, where the mask makes the output
+    discontinuous in the phase (a measure-zero set the reference's autograd ignores as well)."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(phase_hop)
+    B, Tp, H = 2, 24, 6
+    phase = rng.uniform(0.01, 0.03, (B, Tp))
+    N = (Tp - 1) * phase_hop + 1
+    Fa = (N - 1) // amp_hop + 2
+    amp = rng.uniform(0.1, 1.0, (B, Fa, H))
+    pt, at = dev(phase, True), dev(amp, True)
+    y = GF.harmonic_osc(pt, H, phase_hop=phase_hop, amp=at, amp_hop=amp_hop)
+    gy = rng.normal(0, 1, tuple(y.shape))
+    (y * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    f = lambda p: (O.harmonic_oscillator_forward(p, phase_hop, amp, amp_hop) * gy).sum()
+    ref = np.zeros_like(phase)
+    eps = 1e-7
+    for i in np.ndindex(*phase.shape):
+        pp, pm = phase.copy(), phase.copy()
+        pp[i] += eps
+        pm[i] -= eps
+        ref[i] = (f(pp) - f(pm)) / (2 * eps)
+    check(pt.grad.cpu().numpy(), ref, f"harmonic d/d phase (hop {phase_hop})", 2e-3)
+    check(at.grad.cpu().numpy(), O.harmonic_oscillator_backward_amp(gy, phase, phase_hop, amp.shape, amp_hop),
+          "harmonic d/d amp", 1e-4)
+
+
+def test_additive_synth_trains_through_f0():
+    """AdditiveSynthesizer derives its per-sample scale from the phase: with a differentiable phase both the phase and the
+    scale paths carry gradient (the reference: autograd through rsqrt(0.5 / phase) and the cumsum)."""
+    from golf_amd.audiotensor import AudioTensor as AT
+    from golf_amd import synth as S
+
+    torch.manual_seed(0)
+    B, T, H = 2, 960, 12
+    phase = (torch.rand(B, T, device="cuda") * 0.01 + 0.005).requires_grad_(True)
+    amp = torch.rand(B, 5, H, device="cuda").requires_grad_(True)
+    y = S.AdditiveSynthesizer(num_harmonics=H).cuda()(AT(phase), AT(amp, 240)).as_tensor()
+    y.square().mean().backward()
+    assert torch.isfinite(phase.grad).all() and float(phase.grad.abs().max()) > 0
+    assert torch.isfinite(amp.grad).all()
+    # the scale path alone: compare with autograd through the explicit product out = S * rsqrt(0.5 / phase)
+    p2 = phase.detach().clone().requires_grad_(True)
+    from golf_amd import functional as GF
+    S_ = GF.harmonic_osc(phase.detach(), H, 1, amp.detach(), 240)
+    n = S_.shape[1]
+    (S_ * torch.rsqrt(0.5 / p2[:, :n])).square().mean().backward()
+    ts = torch.rsqrt(0.5 / phase.detach()).requires_grad_(True)
+    y3 = GF.harmonic_osc(phase.detach(), H, 1, amp.detach(), 240, ts, 1)
+    y3.square().mean().backward()
+    ref = ts.grad[:, :n] * (0.5 * (0.5 / phase.detach()[:, :n]) ** -1.5 * 0.5 / phase.detach()[:, :n] ** 2)
+    emax, el2 = rel_err(ref.cpu().numpy(), p2.grad[:, :n].cpu().numpy())
+    assert emax < 1e-4 and el2 < 1e-4, (emax, el2)
