@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bf, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -47,6 +47,7 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->pre_stride = (g->N + 3) & ~3;
     g->off_pre = o;  o = align_up(o + sizeof(float) * (size_t)B * g->pre_stride, 256);
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
+    g->off_bf = o;   o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused kernel
     g->total = o;
 }
 
@@ -586,10 +587,23 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 #define OSCF_MAXROWS 4
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
+//  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
 __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
-                                                              u64* __restrict__ Ttot, int Tp, int P, int os, int ntile) {
+                                                              u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
+                                                              const float* __restrict__ taps, int K, int dmin, int KS,
+                                                              float* __restrict__ Bf) {
     __shared__ u64 wsum[4];
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tile == 0 && b == 0) {
+        const int half = (K - 1) / 2;
+        for (int e = tid; e < 4 * KS * 64; e += 256) {
+            const int lane = e & 63, kk = (e >> 6) % KS, ph = (e >> 6) / KS;
+            const int q = 4 * kk + (lane >> 4) - (lane & 15);
+            const int k = half + 4 * (dmin + q) + ph;
+            Bf[e] = (q >= 0 && k >= 0 && k < K) ? taps[k] : 0.f;
+        }
+    }
     const BufRow prow(phase + (size_t)b * phase_stride, Tp);
     const double scale_a = 18446744073709551616.0 / (double)os;
     const double scale_d = scale_a / (double)P;
@@ -617,7 +631,7 @@ template <int EE, int KS>
 __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, const float* __restrict__ taps, int K, float* __restrict__ out, int64_t out_stride, int Tout, int XS,
+    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout, int XS,
     int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
     constexpr int OS = 4, P = 4, NTH = OSCF_THREADS, CPT = OSCF_CPT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -632,22 +646,13 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const int o0 = tile * OSCF_TO;
     constexpr int span = OSCF_TO + 4 * KS;       // coarse samples rendered (index u <-> coarse sample j_lo + u)
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
-    // ---- 0. Toeplitz fragments of the taps, straight into registers (consumed in step 4; the loads fly meanwhile):
-    //         B[k'][n] = tap of branch ph at d = dmin + (k' - n), k' = 4*kk + lk, n = li
+    // ---- 0. Toeplitz fragments of the taps (laid out by osc_tile_totals_kernel), straight into registers: coalesced
+    //         loads issued now, consumed in step 4
     float bfrag[OS][KS];
-    {
-        const int half = (K - 1) / 2;
 #pragma unroll
-        for (int ph = 0; ph < OS; ++ph)
+    for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int q = 4 * kk + lk - li;
-                const int k = half + OS * (dmin + q) + ph;
-                const bool ok = q >= 0 && k >= 0 && k < K;
-                const float t = taps[ok ? k : 0];
-                bfrag[ph][kk] = ok ? t : 0.f;
-            }
-    }
+        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
     // ---- 1. base phase: the tiles before this one (wave 0); the thread's own coarse phase samples; the row pairs
     if (wv == 0) {
         u64 acc = 0;
@@ -758,6 +763,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
                 ds = -0.5f * s0 * s0 * s0 * dq;        // d/dk rsqrt(q0 + k dq) at k = 0
                 lin = fabsf(p1 - p0) <= 0.002f * p0;   // second-order term below 1e-6 (3 steps): speech f0 always is
             }
+            const bool any_jump = EE && __builtin_amdgcn_ballot_w64(!lin) != 0;
             float* xp = X + oscf_xaddr(u);
 #pragma unroll
             for (int k = 0; k < P; ++k) {
@@ -771,7 +777,9 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
                 float v = fmaf(cf, t1 - t0, t0);
                 if (EE) {
                     float sc = fmaf((float)k, ds, s0);
-                    if (!lin) sc = __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));   // f0 jumps (voicing boundaries): exact
+                    // f0 jumps (voicing boundaries): exact.  Wave-uniform test, so that the transcendental is not
+                    // issued at all in the common case (a per-lane select made hipcc evaluate both forms always)
+                    if (any_jump) sc = lin ? sc : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
                     v *= sc;
                 }
                 xp[k * XS] = (k == 0 ? v0 : vk) ? v : 0.f;
@@ -1263,8 +1271,9 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
             ldsf <= 80 * 1024) {
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
+            float* Bf = (float*)((char*)ws + g.off_bf);
             hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2);
+                               g.P, os, ntile2, taps, K, dmin, KS, Bf);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
     do {                                                                                                              \
@@ -1275,7 +1284,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
                         hipGetErrorString(lds_attr));                                                                 \
         hipLaunchKernelGGL((osc_fused_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsf, st, phase,         \
                            phase_stride, (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t,    \
-                           taps, K, out, out_stride, Tout, XS, dmin, nrows, addend, addend_stride, Tadd);             \
+                           (const float*)Bf, out, out_stride, Tout, XS, dmin, nrows, addend, addend_stride, Tadd);    \
     } while (0)
             if (KS == 12) { if (equal_energy) GOLF_FUSED(1, 12); else GOLF_FUSED(0, 12); }
             else          { if (equal_energy) GOLF_FUSED(1, 16); else GOLF_FUSED(0, 16); }
