@@ -259,18 +259,24 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
 // 200 frame boundaries).  No transition matrices, no scan, no redundant arithmetic: 1x the reference's FMA count.
 // ------------------------------------------------------------------------------------------
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_serial_fwd_kernel(const float* __restrict__ ex, int64_t ex_stride,
+__global__ __launch_bounds__(256) void lpc_serial_fwd_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                             const float* __restrict__ gain,
                                                             const float* __restrict__ a, float* __restrict__ y,
                                                             int64_t y_stride, int B, int T, int F, int M, int hop) {
     constexpr int TPL = quad_tpl(W, NT);
     using TL = Tile<W, 16>;
-    __shared__ float xt[TL::SIZE];
-    __shared__ float yt[TL::SIZE];
-    const int lane = threadIdx.x;
+    // workgroups of 4 INDEPENDENT waves (one per SIMD of a CU; they never synchronise): single-wave workgroups are
+    // placed unevenly by the dispatcher once there are about as many waves as SIMDs (measured on the transition kernel)
+    __shared__ float xt_all[4][TL::SIZE];
+    __shared__ float yt_all[4][TL::SIZE];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xt = xt_all[wv];
+    float* yt = yt_all[wv];
+    const int lane = threadIdx.x & 63;
     const int lq = lane / W, lr = lane % W;
     const int row = lane >> 2, r = lane & 3;
-    const int b0 = blockIdx.x * 16;
+    const int b0 = (blockIdx.x * 4 + wv) * 16;
+    if (b0 >= B) return;   // wave-uniform
     const int nrow = B - b0 < 16 ? B - b0 : 16;
     const int b = b0 + (row < nrow ? row : nrow - 1);  // idle quads shadow the last utterance; their stores are masked
     const int xs = (int)ex_stride, ys = (int)y_stride;
@@ -373,17 +379,23 @@ __global__ __launch_bounds__(64) void lpc_serial_fwd_kernel(const float* __restr
 // in reverse time, lam(T) = 0, writes g[b][t] = dL/dy_total; the parallel gradient kernels (lpc_grad_corr / _reduce)
 // follow unchanged.  Parameter rows are prefetched one frame ahead in the direction of travel (frame f-1).
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_serial_adj_kernel(const float* __restrict__ gy, int64_t gy_stride,
+__global__ __launch_bounds__(256) void lpc_serial_adj_kernel(const float* __restrict__ gy, int64_t gy_stride,
                                                             const float* __restrict__ a, float* __restrict__ g,
                                                             int64_t g_stride, int B, int T, int F, int M, int hop) {
     constexpr int TPL = quad_tpl(W, NT);
     using TL = Tile<W, 16>;
-    __shared__ float xt[TL::SIZE];
-    __shared__ float yt[TL::SIZE];
-    const int lane = threadIdx.x;
+    // workgroups of 4 INDEPENDENT waves (one per SIMD of a CU; they never synchronise): single-wave workgroups are
+    // placed unevenly by the dispatcher once there are about as many waves as SIMDs (measured on the transition kernel)
+    __shared__ float xt_all[4][TL::SIZE];
+    __shared__ float yt_all[4][TL::SIZE];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xt = xt_all[wv];
+    float* yt = yt_all[wv];
+    const int lane = threadIdx.x & 63;
     const int lq = lane / W, lr = lane % W;
     const int row = lane >> 2, r = lane & 3;
-    const int b0 = blockIdx.x * 16;
+    const int b0 = (blockIdx.x * 4 + wv) * 16;
+    if (b0 >= B) return;   // wave-uniform
     const int nrow = B - b0 < 16 ? B - b0 : 16;
     const int b = b0 + (row < nrow ? row : nrow - 1);
     const int xs = (int)gy_stride, ys = (int)g_stride;
@@ -1472,7 +1484,7 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
 template <int W, int NT>
 static int launch_serial_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop, hipStream_t st) {
-    hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT>), dim3((unsigned)ceil_div(B, 16)), dim3(64), 0, st, ex, ex_stride,
+    hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, ex, ex_stride,
                        gain, a, y, y_stride, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
@@ -1486,7 +1498,7 @@ static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride
     float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
-    hipLaunchKernelGGL((lpc_serial_adj_kernel<W, NT>), dim3((unsigned)ceil_div(B, 16)), dim3(64), 0, st, gy, gy_stride,
+    hipLaunchKernelGGL((lpc_serial_adj_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, gy, gy_stride,
                        a, gbuf, (int64_t)T, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st,

@@ -1,18 +1,20 @@
-"""Build profiles/r01_* from gpurun_out/r01 (written by tools/refresh_profiles.sh on the GPU box)."""
+"""Build profiles/<round>_* from gpurun_out/<round> (written by tools/refresh_profiles.sh on the GPU box).
+usage: python tools/collect_profiles.py [r02]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r01")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import rocpd_summary
 
 for f in glob.glob(os.path.join(SRC, "bench_*.json")):
-    shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
+    shutil.copy(f, os.path.join(DST, RND + "_" + os.path.basename(f)))
 if os.path.exists(os.path.join(SRC, "train_step_profile.json")):
-    shutil.copy(os.path.join(SRC, "train_step_profile.json"), os.path.join(DST, "r01_train_step_profile.json"))
+    shutil.copy(os.path.join(SRC, "train_step_profile.json"), os.path.join(DST, RND + "_train_step_profile.json"))
 for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh
-    shutil.copy(f, os.path.join(DST, "r01_" + os.path.basename(f)))
+    shutil.copy(f, os.path.join(DST, RND + "_" + os.path.basename(f)))
 
 def counters(tag):
     out = collections.defaultdict(dict)
@@ -30,13 +32,14 @@ def counters(tag):
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
     return dict(out)
 
-kern = counters("decoder")
+kern = counters("synth")
+kern.update({k: v for k, v in counters("decoder").items() if k not in kern})
 kern.update({k: v for k, v in counters("train").items() if k not in kern})
-json.dump({"batch": 32, "workload": "golf-ss-decoder (inference) + golf-ss-decoder-train kernels",
+json.dump({"batch": 32, "workload": "golf-ss-synth (headline), golf-ss-decoder (inference) + golf-ss-decoder-train kernels",
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_pmc.sh), "
                      "per-launch averages; hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH doubled per "
                      "MI355X_MICROARCH.md gfx950 note: exact for wide coalesced reads, an upper bound for narrow ones)",
-           "kernels": kern}, open(os.path.join(DST, "r01_hbm_traffic.json"), "w"), indent=1)
+           "kernels": kern}, open(os.path.join(DST, RND + "_hbm_traffic.json"), "w"), indent=1)
 
 # ---- SQ counters -> per-kernel utilisation figures
 sq = collections.defaultdict(dict)
@@ -62,5 +65,5 @@ if sq:
                "eager single-stream golf-ss-decoder and golf-ss-decoder-train steps; per-launch averages. valu_busy_frac = "
                "4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); wave_wait_frac = SQ_WAIT_INST_ANY / "
                "SQ_WAVE_CYCLES; lds_busy_frac = SQ_LDS_IDX_ACTIVE / (cycles * 256 CUs)",
-               "kernels": dict(sq)}, open(os.path.join(DST, "r01_sq_counters.json"), "w"), indent=1)
+               "kernels": dict(sq)}, open(os.path.join(DST, RND + "_sq_counters.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))

@@ -2,13 +2,21 @@
 # Runs ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): every bench line, rocprofv3 kernel traces and the
 # separate HBM-counter passes that profiles/ is built from (tools/collect_profiles.py turns the output into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r01
+RND=${ROUND_TAG:-r02}
+O=$R/gpurun_out/$RND
 rm -rf $O; mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 b() { python bench.py "$@" 2>/dev/null | tail -1; }
 b > $O/bench_golf_ss_synth.json
+b --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_golf_ss_synth_driver_cmd.json     # the driver's command line
 b --streams 1 --no-graphs --no-cpu-baseline > $O/bench_single_stream.json
+b --batch 2048 --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b2048.json
+b --batch 8192 --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b8192.json
+b --batch 16384 --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b16384.json
+b --batch 8192 --workload lpc-ss-fast --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b8192_lpc_only.json
+b --batch 16384 --workload lpc-ss-fast --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b16384_lpc_only.json
+b --batch 2048 --workload golf-ss-train --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b2048_train.json
 b --workload golf-ss-train --no-cpu-baseline --steps 100 > $O/bench_train.json
 b --workload golf-ff-synth --no-cpu-baseline > $O/bench_ff.json
 b --workload golf-ff-train --no-cpu-baseline --steps 100 > $O/bench_ff_train.json
@@ -28,6 +36,7 @@ prof trace_decoder --workload golf-ss-decoder --streams 1 --no-graphs
 prof trace_decoder_train --workload golf-ss-decoder-train
 prof trace_ff_train --workload golf-ff-train
 for c in FETCH_SIZE WRITE_SIZE; do
+  bash tools/prof_pmc.sh $O/pmc_${c}_synth $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-synth --streams 1 --no-graphs > $O/pmc_${c}_synth.log 2>&1
   bash tools/prof_pmc.sh $O/pmc_${c}_decoder $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/pmc_${c}_decoder.log 2>&1
   bash tools/prof_pmc.sh $O/pmc_${c}_train $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train > $O/pmc_${c}_train.log 2>&1
 done
