@@ -82,6 +82,8 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     size_t o = 0;
     if (p->serial) {   // batch-parallel serial path: no transition matrices, no boundary states
         p->off_phi = p->off_phiT = p->off_z = p->off_E = p->off_z2 = p->off_S = p->off_zadj = p->off_lam = 0;
+        p->NG = p->GS = 0;
+        p->off_mt = p->off_madj = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -99,6 +101,18 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
+    // two-level boundary scan (lpc_group_composite_kernel + lpc_hscan_kernel): worth it from ~48 chunk maps on, and the
+    // composite kernel's 32 x 32 MFMA tile holds up to 24 state components
+    p->NG = 0;
+    p->GS = 0;
+    p->off_mt = p->off_madj = o;
+    if (p->NP >= 48 && p->NT <= 24) {
+        p->NG = 16;
+        p->GS = (int)ceil_div(p->NP, p->NG);
+        p->NG = (int)ceil_div(p->NP, p->GS);
+        p->off_mt = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
+        p->off_madj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
+    }
     p->total = o;
     return true;
 }
@@ -135,7 +149,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     const BufRow xrow(ex + (size_t)b * ex_stride, T);
     const BufRow yrow(MODE == 1 ? out + (size_t)b * y_stride : nullptr, MODE == 1 ? T : 0);
     float w[TPL];
-    if (MODE >= 1 && mine) {
+    if (MODE >= 1 && mine) {   // MODE 1, 2, 3 start from the scanned state
         const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
@@ -230,6 +244,9 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 // zero-state response (one Parareal iteration; the boundary error becomes second order in the
                 // transition-matrix error).
                 if (MODE == 2) v += zin[((size_t)b * NCQ + c) * W + i] - S[((size_t)b * NCS + c + 1) * 64 + i];
+                // MODE 3: the defect alone (two-level scan: the second scan propagates only the correction, so that
+                // the rounding of the group composites acts on a quantity that is already second order)
+                if (MODE == 3) v -= S[((size_t)b * NCS + c + 1) * 64 + i];
                 zp[i] = v;
             }
         }
@@ -813,6 +830,188 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
     const int qblk = unit / NG, grp = unit - qblk * NG;
     if (qblk >= nqb) return;
     p1_hom_body<W, NT, KT, R>(qblk, grp, a, Phi, PhiT, F, M, hop, L, NP, nq);
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-level boundary scan (round 2).  The flat scan below is 199 dependent 22 x 22 matvecs on ONE wave per utterance:
+// 31 us, twice per inference step (38 % of the single-stream step).  Here the NP chunk maps of an utterance are cut
+// into NG = 16 groups of GS = 13:
+//   lpc_group_composite_kernel  M_g = Phi_{c1-1} ... Phi_{c0} for every group, ONCE per step (both scans share it):
+//       a chain of GS exact-fp32 32x32 MFMA products per wave.  The running product stays in the accumulator registers:
+//       for v_mfma_f32_32x32x2_f32 the D layout (register v, lane l -> row 8(v/4) + 4(l/32) + v%4, column l%32) IS the
+//       B layout of K-step v if the contraction index is enumerated as k = 8(v/4) + 4(l/32) + v%4, so D feeds back as
+//       B with no data movement; the A fragments for that enumeration are three float4 loads of the lane's row of
+//       Phi_c (columns 8q + 4(l/32) .. +3).
+//   lpc_hscan_kernel (one launch, 16 waves per utterance)
+//       phase 1  every wave scans its group from a zero state -> v_g            (GS steps)
+//       phase 2  wave 0 scans the groups: t <- M_g t + v_g                      (NG steps)
+//       phase 3  every wave re-scans its group from its now-known start state   (GS steps)
+//   2*GS + NG = 42 dependent steps instead of 199.
+// In the inference path the SECOND scan propagates only the defect observed by the refinement sweep (S += delta), so
+// the composites' rounding (a 13-factor fp32 product) multiplies a quantity that is already ~1e-4 of the state.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int W, int NT>
+__global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __restrict__ PhiT,
+                                                                 float* __restrict__ MT, float* __restrict__ Madj,
+                                                                 int NP, int GS, int NG) {
+    static_assert(NT <= 24, "the 12 K-steps of the product cover state components 0..23");
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int n = lane & 31, kh = lane >> 5;
+    const int c0 = g * GS, c1 = c0 + GS < NP ? c0 + GS : NP;
+    f32x16 P;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int row = 8 * (v / 4) + 4 * kh + (v % 4);
+        P[v] = (row == n && row < NT) ? 1.f : 0.f;
+    }
+    const bool rowok = n < NT;
+    const float* base = PhiT + ((size_t)b * NP * NT + (rowok ? n : 0)) * W;
+    float4 a4[3], nx[3];
+    auto load = [&](float4 (&dst)[3], int c) {
+        const float* rp = base + (size_t)c * NT * W;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int col = 8 * q + 4 * kh;
+            dst[q] = (rowok && col < NT) ? *reinterpret_cast<const float4*>(rp + (col < W ? col : 0))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load(nx, c0);
+    for (int c = c0; c < c1; ++c) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a4[q] = nx[q];
+        if (c + 1 < c1) load(nx, c + 1);
+        f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk)
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[kk / 4], kk % 4), P[kk], D, 0, 0, 0);
+        P = D;
+    }
+    float* mt = MT + ((size_t)b * NG + g) * NT * W;
+    float* ma = Madj + ((size_t)b * NG + g) * NT * W;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v / 4) + 4 * kh + (v % 4);   // row of the composite, column n
+        if (i < NT && n < W) mt[(size_t)i * W + n] = P[v];
+        if (n < NT && i < W) ma[(size_t)n * W + i] = P[v];
+    }
+}
+
+// MODE 0: S[c] = state at the start of chunk c from the inputs x = z;  MODE 1: S[c] += delta_c, x = the defects
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(1024) void lpc_hscan_kernel(const float* __restrict__ PhiT, const float* __restrict__ x,
+                                                          const float* __restrict__ MT, float* __restrict__ S, int NC,
+                                                          int NP, int GS, int NG) {
+    __shared__ float vg[16][32];
+    __shared__ float sg[16][32];
+    const int b = blockIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
+    const bool act = i < NT;
+    const int ii = act ? i : 0;
+    const int c0 = g * GS, c1 = c0 + GS < NP ? c0 + GS : NP;
+    const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+    const size_t cstride4 = (size_t)NT * W / 4;
+    const float* xb = x + (size_t)b * NP * W + ii;
+    constexpr int D = 3;
+    float4 buf[D][W / 4];
+    float xc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c < NP ? c : NP - 1;
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
+        xc[u] = xb[(size_t)cl * W];
+    };
+    auto step = [&](float s, int u) {
+        float acc0 = xc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float pj = f4get(buf[u][j / 4], j % 4);
+            const float sj = lane_bcast(s, j);
+            if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
+            else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
+            else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
+            else acc3 = fmaf(pj, sj, acc3);
+        }
+        return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+    };
+    // ---- phase 1: zero-state response of the group
+    float s = 0.f;
+    if (g < NG) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
+        for (int cb = c0; cb < c1; cb += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (cb + u < c1) {           // wave-uniform
+                    s = step(s, u);
+                    fetch(u, cb + u + D < c1 ? cb + u + D : c1 - 1);
+                }
+            }
+        }
+        if (i < 32) vg[g][i] = s;
+    }
+    __syncthreads();
+    // ---- phase 2: wave 0 scans the groups with the composites (two row buffers, loop unrolled by 2: no selects)
+    if (g == 0) {
+        const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
+        float4 mA[W / 4], mB[W / 4];
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) mA[k] = mrows[k];
+        float t = 0.f;
+        auto gstep = [&](const float4 (&m)[W / 4], float t0, float v) {
+            float acc0 = v, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float pj = f4get(m[j / 4], j % 4);
+                const float tj = lane_bcast(t0, j);
+                if ((j & 3) == 0) acc0 = fmaf(pj, tj, acc0);
+                else if ((j & 3) == 1) acc1 = fmaf(pj, tj, acc1);
+                else if ((j & 3) == 2) acc2 = fmaf(pj, tj, acc2);
+                else acc3 = fmaf(pj, tj, acc3);
+            }
+            return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+        };
+        for (int gg = 0; gg < NG; gg += 2) {
+            if (i < 32) sg[gg][i] = t;
+            const int g1 = gg + 1 < NG ? gg + 1 : NG - 1;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mB[k] = mrows[(size_t)g1 * cstride4 + k];
+            t = gstep(mA, t, vg[gg][ii]);
+            if (gg + 1 < NG) {
+                if (i < 32) sg[gg + 1][i] = t;
+                const int g2 = gg + 2 < NG ? gg + 2 : NG - 1;
+#pragma unroll
+                for (int k = 0; k < W / 4; ++k) mA[k] = mrows[(size_t)g2 * cstride4 + k];
+                t = gstep(mB, t, vg[gg + 1][ii]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: re-scan the group from its start state, writing the chunk start states
+    if (g < NG) {
+        float* Sb = S + (size_t)b * NC * 64 + i;   // rows padded to 64 floats: every lane stores
+        s = i < 32 ? sg[g][i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
+        for (int cb = c0; cb < c1; cb += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (cb + u < c1) {
+                    const int c = cb + u;
+                    if (MODE == 0) Sb[(size_t)c * 64] = s;
+                    else Sb[(size_t)c * 64] += s;
+                    s = step(s, u);
+                    fetch(u, c + D < c1 ? c + D : c1 - 1);
+                }
+            }
+        }
+        if (c1 == NP) {   // the last group also owns the start state of the final chunk
+            if (MODE == 0) Sb[(size_t)NP * 64] = s;
+            else Sb[(size_t)NP * 64] += s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1429,6 +1628,32 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             GOLF_LAUNCH_CHECK();
         }
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
+    }
+    static const int flat_env = [] { const char* e = getenv("GOLF_SS_FLAT_SCAN"); return e ? atoi(e) : 0; }();  // A/B knob
+    if constexpr (NT <= 24) {
+        if (fast && p.NG > 0 && !flat_env) {   // two-level scan, composites shared by both scans (see above)
+            float* MT = (float*)(ws + p.off_mt);
+            float* Madj = (float*)(ws + p.off_madj);
+            hipLaunchKernelGGL((lpc_group_composite_kernel<W, NT>), dim3(p.NG, B), dim3(64), 0, st, (const float*)PhiT, MT,
+                               Madj, p.NP, p.GS, p.NG);
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT, 0>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
+                               (const float*)z, (const float*)MT, S, p.NC, p.NP, p.GS, p.NG);
+            GOLF_LAUNCH_CHECK();
+            float* dfc = (float*)(ws + p.off_z2);   // defects E_c - S_{c+1} of the refinement sweep
+            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
+                               ex_stride, gain, a, (const float*)S, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
+                               (const float*)nullptr);
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT, 1>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
+                               (const float*)dfc, (const float*)MT, S, p.NC, p.NP, p.GS, p.NG);
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
+                               ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC,
+                               (const float*)nullptr);
+            GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
+        }
     }
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
                        S, p.NC, p.NP);
