@@ -129,6 +129,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
 //   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
 //   MODE 1 (P3) : initial state S[(b*NCS+c)*64 + i], writes y[b][t]
 //   MODE 2      : initial state S[(b*NCS+c)*64 + i], chunks c < NCQ=NP, final state -> out (refinement sweep)
+//   MODE 3      : as MODE 2 but the defect alone;  MODE 4: as MODE 1 from S + zin (the corrected states)
 // The body is a device function of ONE wave (its LDS tiles are passed in, its only synchronisation is the wave-level
 // LDS fence) so that it can also run as one of the four independent waves of lpc_p1fz_kernel's workgroups.
 template <int W, int NT, int MODE>
@@ -139,6 +140,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                                           const float* __restrict__ zin, float* __restrict__ xt,
                                           float* __restrict__ yt, int b, int cg, int lane) {
     constexpr int TPL = quad_tpl(W, NT);
+    constexpr bool WY = MODE == 1 || MODE == 4;   // the passes that write y
     constexpr int R = 16;
     using TL = Tile<W, R>;
     const int lq = lane / W, lr = lane % W;
@@ -147,12 +149,17 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     const int c = c0 + row;
     const bool mine = c < NCQ;
     const BufRow xrow(ex + (size_t)b * ex_stride, T);
-    const BufRow yrow(MODE == 1 ? out + (size_t)b * y_stride : nullptr, MODE == 1 ? T : 0);
+    const BufRow yrow(WY ? out + (size_t)b * y_stride : nullptr, WY ? T : 0);
     float w[TPL];
-    if (MODE >= 1 && mine) {   // MODE 1, 2, 3 start from the scanned state
+    if (MODE >= 1 && mine) {   // MODE 1, 2, 3, 4 start from the scanned state (MODE 4: plus its correction zin)
         const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
+        if (MODE == 4) {
+            const float* dp = zin + ((size_t)b * NCS + c) * 64 + r * TPL;
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] += dp[k];
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < TPL; ++k) w[k] = 0.f;
@@ -219,10 +226,10 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 const float oldest = w[s % TPL];
                 const float inc = dppf<DPP_SHR1>(oldest);
                 w[s % TPL] = r == 0 ? y : inc;
-                if (MODE == 1) keep[s >> 2] = ((s & 3) == r) ? y : keep[s >> 2];
+                if (WY) keep[s >> 2] = ((s & 3) == r) ? y : keep[s >> 2];
             }
         }
-        if (MODE == 1) {
+        if (WY) {
 #pragma unroll
             for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
             wave_lds_fence();
@@ -232,7 +239,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
         }
         wave_lds_fence();
     }
-    if (MODE != 1 && mine) {
+    if (!WY && mine) {
         float* zp = out + ((size_t)b * NCQ + c) * W;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
                                                       int NCS, const float* __restrict__ zin) {
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
-    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    __shared__ float yt[(MODE == 1 || MODE == 4) ? TL::SIZE : 1];
     fwdq_body<W, NT, MODE>(ex, ex_stride, gain, a, S, out, y_stride, T, F, M, hop, L, NCQ, NCS, zin, xt, yt,
                            blockIdx.y, blockIdx.x, threadIdx.x);
 }
@@ -868,9 +875,11 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
     }
     const bool rowok = n < NT;
     const float* base = PhiT + ((size_t)b * NP * NT + (rowok ? n : 0)) * W;
-    float4 a4[3], nx[3];
+    // row fragments prefetched PF chunks ahead: one product is 12 x 64 cycles = 0.3 us, a load from L2 takes ~1 us
+    constexpr int PF = 4;
+    float4 nx[PF][3];
     auto load = [&](float4 (&dst)[3], int c) {
-        const float* rp = base + (size_t)c * NT * W;
+        const float* rp = base + (size_t)(c < c1 ? c : c1 - 1) * NT * W;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int col = 8 * q + 4 * kh;
@@ -878,16 +887,23 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    load(nx, c0);
-    for (int c = c0; c < c1; ++c) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a4[q] = nx[q];
-        if (c + 1 < c1) load(nx, c + 1);
-        f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < PF; ++u) load(nx[u], c0 + u);
+    for (int cb = c0; cb < c1; cb += PF) {
 #pragma unroll
-        for (int kk = 0; kk < 12; ++kk)
-            D = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[kk / 4], kk % 4), P[kk], D, 0, 0, 0);
-        P = D;
+        for (int u = 0; u < PF; ++u) {
+            if (cb + u < c1) {   // wave-uniform
+                float4 a4[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a4[q] = nx[u][q];
+                load(nx[u], cb + u + PF);
+                f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 12; ++kk)
+                    D = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[kk / 4], kk % 4), P[kk], D, 0, 0, 0);
+                P = D;
+            }
+        }
     }
     float* mt = MT + ((size_t)b * NG + g) * NT * W;
     float* ma = Madj + ((size_t)b * NG + g) * NT * W;
@@ -899,13 +915,15 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
     }
 }
 
-// MODE 0: S[c] = state at the start of chunk c from the inputs x = z;  MODE 1: S[c] += delta_c, x = the defects
-template <int W, int NT, int MODE>
+// Scans x through the chunk maps: out[c] = state at the start of chunk c (c = 0 .. NP), zero at c = 0.
+// (First scan: x = z, out = S.  Second scan: x = the defects, out = dS; the final pass adds S + dS.)
+template <int W, int NT>
 __global__ __launch_bounds__(1024) void lpc_hscan_kernel(const float* __restrict__ PhiT, const float* __restrict__ x,
-                                                          const float* __restrict__ MT, float* __restrict__ S, int NC,
+                                                          const float* __restrict__ MT, float* __restrict__ out, int NC,
                                                           int NP, int GS, int NG) {
     __shared__ float vg[16][32];
     __shared__ float sg[16][32];
+    __shared__ __attribute__((aligned(16))) float msh[16][NT * W];   // the utterance's group composites (34 KB at 22 x 24)
     const int b = blockIdx.x;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
     const bool act = i < NT;
@@ -914,6 +932,17 @@ __global__ __launch_bounds__(1024) void lpc_hscan_kernel(const float* __restrict
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* xb = x + (size_t)b * NP * W + ii;
+    // this wave's composite -> registers now (the loads fly during phase 1), -> LDS before the first barrier
+    constexpr int MQ = (NT * W / 4 + 63) / 64;   // float4 per lane
+    float4 mreg[MQ];
+    if (g < NG) {
+        const float4* mg = reinterpret_cast<const float4*>(MT + ((size_t)b * NG + g) * NT * W);
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const int e = q * 64 + i;
+            mreg[q] = mg[e < NT * W / 4 ? e : 0];
+        }
+    }
     constexpr int D = 3;
     float4 buf[D][W / 4];
     float xc[D];
@@ -947,70 +976,66 @@ __global__ __launch_bounds__(1024) void lpc_hscan_kernel(const float* __restrict
                 if (cb + u < c1) {           // wave-uniform
                     s = step(s, u);
                     fetch(u, cb + u + D < c1 ? cb + u + D : c1 - 1);
+                    if (u == 0 && cb == c0) {   // the composite's loads were issued before this step's: they are in
+                        float4* md = reinterpret_cast<float4*>(msh[g]);
+#pragma unroll
+                        for (int q = 0; q < MQ; ++q) {
+                            const int e = q * 64 + i;
+                            if (e < NT * W / 4) md[e] = mreg[q];
+                        }
+                    }
                 }
             }
         }
         if (i < 32) vg[g][i] = s;
+        // phase 3 re-reads the same rows: start its first fetches now, they land while wave 0 scans the groups
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
     }
     __syncthreads();
-    // ---- phase 2: wave 0 scans the groups with the composites (two row buffers, loop unrolled by 2: no selects)
+    // ---- phase 2: wave 0 scans the groups with the composites (rows from LDS)
     if (g == 0) {
-        const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
-        float4 mA[W / 4], mB[W / 4];
-#pragma unroll
-        for (int k = 0; k < W / 4; ++k) mA[k] = mrows[k];
         float t = 0.f;
-        auto gstep = [&](const float4 (&m)[W / 4], float t0, float v) {
-            float acc0 = v, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float pj = f4get(m[j / 4], j % 4);
-                const float tj = lane_bcast(t0, j);
-                if ((j & 3) == 0) acc0 = fmaf(pj, tj, acc0);
-                else if ((j & 3) == 1) acc1 = fmaf(pj, tj, acc1);
-                else if ((j & 3) == 2) acc2 = fmaf(pj, tj, acc2);
-                else acc3 = fmaf(pj, tj, acc3);
-            }
-            return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-        };
-        for (int gg = 0; gg < NG; gg += 2) {
+        for (int gg = 0; gg < NG; ++gg) {
             if (i < 32) sg[gg][i] = t;
-            const int g1 = gg + 1 < NG ? gg + 1 : NG - 1;
+            const float4* mrow = reinterpret_cast<const float4*>(msh[gg] + (size_t)ii * W);
+            float acc0 = vg[gg][ii], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < W / 4; ++k) mB[k] = mrows[(size_t)g1 * cstride4 + k];
-            t = gstep(mA, t, vg[gg][ii]);
-            if (gg + 1 < NG) {
-                if (i < 32) sg[gg + 1][i] = t;
-                const int g2 = gg + 2 < NG ? gg + 2 : NG - 1;
+            for (int k = 0; k < W / 4; ++k) {
+                const float4 m4 = mrow[k];
 #pragma unroll
-                for (int k = 0; k < W / 4; ++k) mA[k] = mrows[(size_t)g2 * cstride4 + k];
-                t = gstep(mB, t, vg[gg + 1][ii]);
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * k + e;
+                    if (j < NT) {
+                        const float tj = lane_bcast(t, j);
+                        const float pj = f4get(m4, e);
+                        if (e == 0) acc0 = fmaf(pj, tj, acc0);
+                        else if (e == 1) acc1 = fmaf(pj, tj, acc1);
+                        else if (e == 2) acc2 = fmaf(pj, tj, acc2);
+                        else acc3 = fmaf(pj, tj, acc3);
+                    }
+                }
             }
+            t = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
         }
     }
     __syncthreads();
     // ---- phase 3: re-scan the group from its start state, writing the chunk start states
     if (g < NG) {
-        float* Sb = S + (size_t)b * NC * 64 + i;   // rows padded to 64 floats: every lane stores
+        float* ob = out + (size_t)b * NC * 64 + i;   // rows padded to 64 floats: every lane stores
         s = i < 32 ? sg[g][i] : 0.f;
-#pragma unroll
-        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
         for (int cb = c0; cb < c1; cb += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 if (cb + u < c1) {
                     const int c = cb + u;
-                    if (MODE == 0) Sb[(size_t)c * 64] = s;
-                    else Sb[(size_t)c * 64] += s;
+                    ob[(size_t)c * 64] = s;
                     s = step(s, u);
                     fetch(u, c + D < c1 ? c + D : c1 - 1);
                 }
             }
         }
-        if (c1 == NP) {   // the last group also owns the start state of the final chunk
-            if (MODE == 0) Sb[(size_t)NP * 64] = s;
-            else Sb[(size_t)NP * 64] += s;
-        }
+        if (c1 == NP) ob[(size_t)NP * 64] = s;   // the last group also owns the start state of the final chunk
     }
 }
 
@@ -1637,7 +1662,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             hipLaunchKernelGGL((lpc_group_composite_kernel<W, NT>), dim3(p.NG, B), dim3(64), 0, st, (const float*)PhiT, MT,
                                Madj, p.NP, p.GS, p.NG);
             GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT, 0>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
+            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
                                (const float*)z, (const float*)MT, S, p.NC, p.NP, p.GS, p.NG);
             GOLF_LAUNCH_CHECK();
             float* dfc = (float*)(ws + p.off_z2);   // defects E_c - S_{c+1} of the refinement sweep
@@ -1645,12 +1670,13 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                                ex_stride, gain, a, (const float*)S, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
                                (const float*)nullptr);
             GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT, 1>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
-                               (const float*)dfc, (const float*)MT, S, p.NC, p.NP, p.GS, p.NG);
+            float* dS = (float*)(ws + p.off_lam);    // correction of the chunk start states ([b][c][64], as S)
+            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
+                               (const float*)dfc, (const float*)MT, dS, p.NC, p.NP, p.GS, p.NG);
             GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
+            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 4>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
                                ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC,
-                               (const float*)nullptr);
+                               (const float*)dS);
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }
