@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--prereplay", type=int, default=16,
                     help="setup: replays of every captured hipGraph before the warm-up steps (graph upload, code objects, "
                          "clocks: instantiation is setup, not a step)")
-    ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked"],
+    ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "two-level"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")

@@ -854,6 +854,15 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 //       phase 2  wave 0 scans the groups: t <- M_g t + v_g                      (NG steps)
 //       phase 3  every wave re-scans its group from its now-known start state   (GS steps)
 //   2*GS + NG = 42 dependent steps instead of 199.
+// MEASURED (MI355X, B = 32, NP = 199): correct (tests/test_gpu_lpc_ss.py::test_two_level_scan_shapes) and NOT faster:
+// 31.5 us per scan against 31.3 for the flat one, plus 10.5 us for the composites.  Phase by phase (phases skipped in
+// turn): phases 1 and 3 take 7.5 and 8.3 us for 13 steps each, phase 2 with launch and set-up 16 us.  A step costs
+// ~360 cycles of SIMD time whether the wave is alone on its SIMD (flat scan: 377) or shares it with three others (here:
+// 16 waves of one utterance on ONE CU): the 22 v_readlane_b32 of a matvec occupy the issue port ~12 cycles each, so
+// waves on a SIMD do not overlap and the 16 groups of an utterance run four deep.  The variant that would pay spreads
+// the groups over CUs (one single-wave workgroup per group) and hands phase 2 to the last group to finish; it needs a
+// device-scope counter per utterance.  Kept as an opt-in (GOLF_SS_TWO_LEVEL_SCAN) for that next step; the default is
+// the flat scan.
 // In the inference path the SECOND scan propagates only the defect observed by the refinement sweep (S += delta), so
 // the composites' rounding (a 13-factor fp32 product) multiplies a quantity that is already ~1e-4 of the state.
 // ------------------------------------------------------------------------------------------
@@ -1654,9 +1663,8 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         }
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
-    static const int flat_env = [] { const char* e = getenv("GOLF_SS_FLAT_SCAN"); return e ? atoi(e) : 0; }();  // A/B knob
     if constexpr (NT <= 24) {
-        if (fast && p.NG > 0 && !flat_env) {   // two-level scan, composites shared by both scans (see above)
+        if (fast && p.NG > 0 && (flags & GOLF_SS_TWO_LEVEL_SCAN)) {   // opt-in: measured no faster than the flat scan (see above)
             float* MT = (float*)(ws + p.off_mt);
             float* Madj = (float*)(ws + p.off_madj);
             hipLaunchKernelGGL((lpc_group_composite_kernel<W, NT>), dim3(p.NG, B), dim3(64), 0, st, (const float*)PhiT, MT,

@@ -168,7 +168,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
         return g_ex, g_gain, g_a, None, None, None, None
 
 
-SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16}   # GOLF_SS_SERIAL / GOLF_SS_CHUNKED
+SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "two-level": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _TWO_LEVEL_SCAN
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,

@@ -375,9 +375,9 @@ def test_large_batch_defaults_to_serial_and_matches_chunked():
 @pytest.mark.parametrize("B,F,M,hop", [(3, 520, 12, 24), (2, 1500, 4, 8), (2, 800, 14, 16), (5, 60, 22, 240),
                                        (2, 210, 20, 240)])
 def test_two_level_scan_shapes(B, F, M, hop):
-    """Long utterances at other ring widths / orders: the inference path then runs the two-level boundary scan (group
-    composites as MFMA product chains + three-phase scan); 60 frames of hop 240 exercise a partial last group, 1500 frames
-    of hop 8 the 8-wide ring.  Both forward paths against the float64 oracle."""
+    """Long utterances at other ring widths / orders through both forward paths and through the opt-in two-level boundary
+    scan (group composites as MFMA product chains + three-phase scan; measured no faster than the flat scan, hence not
+    the default): 60 frames of hop 240 exercise a partial last group, 1500 frames of hop 8 the 8-wide ring."""
     from oracle import golf_oracle as O
 
     ex, gain, a = smooth_case(B, F, M, hop, seed=F + M, walk=0.02 * (240 / max(hop, 24)) ** 0.5 * 0.3)
@@ -385,4 +385,6 @@ def test_two_level_scan_shapes(B, F, M, hop):
     for fast in (True, False):
         y = run_fwd(ex, gain, a, hop, fast=fast)
         assert y.shape == ref.shape
-        check(y, ref, f"two-level scan B{B} F{F} M{M} hop{hop} fast={fast}")
+        check(y, ref, f"flat scan B{B} F{F} M{M} hop{hop} fast={fast}")
+    y2 = run_mode(ex, gain, a, hop, "two-level")      # opt-in variant (GOLF_SS_TWO_LEVEL_SCAN)
+    check(y2, ref, f"two-level scan B{B} F{F} M{M} hop{hop}")
