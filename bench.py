@@ -70,9 +70,10 @@ def parse():
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
     ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
                     help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
-    ap.add_argument("--gather-every", type=int, default=1,
+    ap.add_argument("--gather-every", type=int, default=0,
                     help="N>1: stage this many steps' audio per slot and exchange them in ONE all-gather (fewer, larger "
-                         "collectives: xGMI is per-link bound and a 6 MB gather per ~80 us step sits at the link rate)")
+                         "collectives: xGMI is per-link bound and a 6 MB gather per ~70 us step sits at the link rate); "
+                         "0 (default) = min(8, steps per slot in one timed region)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (EXACTLY --steps steps, barrier + synchronize on both sides) is run this many "
                          "times; ms_per_step / value are the MEDIAN region, every region is listed under 'timing'")
@@ -414,7 +415,7 @@ def main():
     step = steps_fn[0]
 
     do_gather = world > 1 and not args.no_gather
-    GE = max(1, args.gather_every) if do_gather else 1
+    GE = (args.gather_every if args.gather_every > 0 else max(1, min(8, args.steps // S))) if do_gather else 1
     pipelined = args.gather_mode == "pipelined"
     if do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank (golf_amd.dist.StagedGather)
         from golf_amd.dist import StagedGather

@@ -111,7 +111,7 @@ class StagedGather:
         self.stage = [torch.empty(self.every * rows, T, device=device, dtype=dtype) for _ in range(2)]
         self.recv = [torch.empty(self.world * self.every * rows, T, device=device, dtype=dtype) for _ in range(2)]
         self.pending = [None, None]
-        self.cur, self.fill, self.groups_sent = 0, 0, 0
+        self.cur, self.fill, self.groups_sent, self.last_fill = 0, 0, 0, 0
 
     @property
     def bytes_per_collective(self) -> int:
@@ -130,9 +130,16 @@ class StagedGather:
 
     def _send(self):
         i = self.cur
-        handle = gather_audio_async(self.stage[i], self.recv[i]) if self.world > 1 else None
+        n = self.fill * self.rows                      # a partial group (flush) sends only what was staged
+        src = self.stage[i][:n]
+        if self.fill == self.every:
+            dst = self.recv[i]
+        else:                                          # rank r's rows land at [r*n, (r+1)*n): a compact prefix of recv
+            dst = self.recv[i][: self.world * n]
+        self.last_fill = self.fill
+        handle = gather_audio_async(src, dst) if self.world > 1 else None
         if self.world == 1:
-            self.recv[i].copy_(self.stage[i])
+            dst.copy_(src)
         self.pending[i] = handle
         self.cur, self.fill = 1 - i, 0
         self.groups_sent += 1
@@ -147,5 +154,8 @@ class StagedGather:
                 self.pending[i].wait()
                 self.pending[i] = None
 
-    def result(self, i: int) -> torch.Tensor:
-        return self.recv[i].view(self.world, self.every, self.rows, self.T)
+    def result(self, i: int, steps: Optional[int] = None) -> torch.Tensor:
+        """(world, steps, rows, T) view of receive buffer ``i``; ``steps`` = how many steps the group held (``every`` for
+        a full group, fewer for the partial group a flush sent)."""
+        k = self.every if steps is None else steps
+        return self.recv[i][: self.world * k * self.rows].view(self.world, k, self.rows, self.T)

@@ -155,8 +155,10 @@ def _staged_worker(rank, world, port, q):
         if h is not None:                                     # a full group went out: steps k-1, k
             h.wait()
             seen.append(sg.result(1 - sg.cur).clone())        # the pair just sent
-    sg.flush()                                                # the half-filled third group (step 4)
-    seen.append(sg.result(1 - sg.cur).clone())
+    sg.flush()                                                # the half-filled third group (step 4): 1 step is sent
+    assert sg.last_fill == 1
+    part = sg.result(1 - sg.cur, steps=1)                     # (world, 1, rows, T)
+    seen.append(torch.cat([part, torch.full_like(part, -1.0)], 1).clone())
     if rank == 0:
         q.put((torch.stack(seen).numpy(), sg.groups_sent, sg.bytes_per_collective))
     dist.barrier()
