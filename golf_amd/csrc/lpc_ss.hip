@@ -107,11 +107,10 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->GS = 0;
     p->off_mt = p->off_madj = o;
     if (p->NP >= 48 && p->NT <= 24) {
-        p->NG = 16;
-        p->GS = (int)ceil_div(p->NP, p->NG);
+        p->GS = 16;                                  // = the 16 chunks a wave of the chunk kernels owns
         p->NG = (int)ceil_div(p->NP, p->GS);
         p->off_mt = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
-        p->off_madj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
+        p->off_madj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * 32 * 2, 256);   // group responses (z, defects)
     }
     p->total = o;
     return true;
@@ -132,13 +131,16 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
 //   MODE 3      : as MODE 2 but the defect alone;  MODE 4: as MODE 1 from S + zin (the corrected states)
 // The body is a device function of ONE wave (its LDS tiles are passed in, its only synchronisation is the wave-level
 // LDS fence) so that it can also run as one of the four independent waves of lpc_p1fz_kernel's workgroups.
-template <int W, int NT, int MODE>
+template <int W, int NT, int MODE, bool LS = false>
 __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t ex_stride,
                                           const float* __restrict__ gain, const float* __restrict__ a,
                                           const float* __restrict__ S, float* __restrict__ out, int64_t y_stride, int T,
                                           int F, int M, int hop, int L, int NCQ, int NCS,
                                           const float* __restrict__ zin, float* __restrict__ xt,
-                                          float* __restrict__ yt, int b, int cg, int lane) {
+                                          float* __restrict__ yt, int b, int cg, int lane,
+                                          const float* lst = nullptr, float* ldl = nullptr) {
+    // lst (two-level scan): the chunk start states of this wave's 16 chunks (+ the next one) in LDS, row stride 32,
+    // instead of the scanned states S in HBM; ldl: the defects of MODE 3 are also left in LDS ([16][32])
     constexpr int TPL = quad_tpl(W, NT);
     constexpr bool WY = MODE == 1 || MODE == 4;   // the passes that write y
     constexpr int R = 16;
@@ -152,9 +154,14 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     const BufRow yrow(WY ? out + (size_t)b * y_stride : nullptr, WY ? T : 0);
     float w[TPL];
     if (MODE >= 1 && mine) {   // MODE 1, 2, 3, 4 start from the scanned state (MODE 4: plus its correction zin)
-        const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
+        if constexpr (LS) {   // (LDS and HBM pointers are kept in separate code paths: no pointer selects)
 #pragma unroll
-        for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
+            for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = lst[row * 32 + r * TPL + k];
+        } else {
+            const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
+        }
         if (MODE == 4) {
             const float* dp = zin + ((size_t)b * NCS + c) * 64 + r * TPL;
 #pragma unroll
@@ -253,7 +260,12 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 if (MODE == 2) v += zin[((size_t)b * NCQ + c) * W + i] - S[((size_t)b * NCS + c + 1) * 64 + i];
                 // MODE 3: the defect alone (two-level scan: the second scan propagates only the correction, so that
                 // the rounding of the group composites acts on a quantity that is already second order)
-                if (MODE == 3) v -= S[((size_t)b * NCS + c + 1) * 64 + i];
+                if constexpr (MODE == 3 && LS) {
+                    v -= lst[(row + 1) * 32 + i];
+                    ldl[row * 32 + i] = v;
+                } else if constexpr (MODE == 3) {
+                    v -= S[((size_t)b * NCS + c + 1) * 64 + i];
+                }
                 zp[i] = v;
             }
         }
@@ -840,42 +852,51 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Two-level boundary scan (round 2).  The flat scan below is 199 dependent 22 x 22 matvecs on ONE wave per utterance:
-// 31 us, twice per inference step (38 % of the single-stream step).  Here the NP chunk maps of an utterance are cut
-// into NG = 16 groups of GS = 13:
-//   lpc_group_composite_kernel  M_g = Phi_{c1-1} ... Phi_{c0} for every group, ONCE per step (both scans share it):
-//       a chain of GS exact-fp32 32x32 MFMA products per wave.  The running product stays in the accumulator registers:
-//       for v_mfma_f32_32x32x2_f32 the D layout (register v, lane l -> row 8(v/4) + 4(l/32) + v%4, column l%32) IS the
-//       B layout of K-step v if the contraction index is enumerated as k = 8(v/4) + 4(l/32) + v%4, so D feeds back as
-//       B with no data movement; the A fragments for that enumeration are three float4 loads of the lane's row of
-//       Phi_c (columns 8q + 4(l/32) .. +3).
-//   lpc_hscan_kernel (one launch, 16 waves per utterance)
-//       phase 1  every wave scans its group from a zero state -> v_g            (GS steps)
-//       phase 2  wave 0 scans the groups: t <- M_g t + v_g                      (NG steps)
-//       phase 3  every wave re-scans its group from its now-known start state   (GS steps)
-//   2*GS + NG = 42 dependent steps instead of 199.
-// MEASURED (MI355X, B = 32, NP = 199): correct (tests/test_gpu_lpc_ss.py::test_two_level_scan_shapes) and NOT faster:
-// 31.5 us per scan against 31.3 for the flat one, plus 10.5 us for the composites.  Phase by phase (phases skipped in
-// turn): phases 1 and 3 take 7.5 and 8.3 us for 13 steps each, phase 2 with launch and set-up 16 us.  A step costs
-// ~360 cycles of SIMD time whether the wave is alone on its SIMD (flat scan: 377) or shares it with three others (here:
-// 16 waves of one utterance on ONE CU): the 22 v_readlane_b32 of a matvec occupy the issue port ~12 cycles each, so
-// waves on a SIMD do not overlap and the 16 groups of an utterance run four deep.  The variant that would pay spreads
-// the groups over CUs (one single-wave workgroup per group) and hands phase 2 to the last group to finish; it needs a
-// device-scope counter per utterance.  Kept as an opt-in (GOLF_SS_TWO_LEVEL_SCAN) for that next step; the default is
-// the flat scan.
-// In the inference path the SECOND scan propagates only the defect observed by the refinement sweep (S += delta), so
-// the composites' rounding (a 13-factor fp32 product) multiplies a quantity that is already ~1e-4 of the state.
+// Two-level boundary scan (round 2; opt-in GOLF_SS_TWO_LEVEL_SCAN).  The flat scan below is 199 dependent 22 x 22
+// matvecs on ONE wave per utterance: 31 us, twice per inference step (38 % of the single-stream step).  The chunk maps
+// of an utterance are cut into groups of 16 -- the 16 chunks one wave of the chunk kernels (lpc_fwdq*) owns:
+//   lpc_group_composite_kernel  M_g = Phi_{c0+15} ... Phi_{c0} for every group, once per step: a chain of 16 exact-fp32
+//       32x32 MFMA products per wave whose running product stays in the accumulator registers: for
+//       v_mfma_f32_32x32x2_f32 the D layout (register v, lane l -> row 8(v/4) + 4(l/32) + v%4, column l%32) IS the B
+//       layout of K-step v if the contraction index is enumerated as k = 8(v/4) + 4(l/32) + v%4, so D feeds back as B
+//       with no data movement; the A fragments for that enumeration are three float4 loads of the lane's row of Phi_c.
+//   lpc_group_zscan_kernel      v_g = the group's zero-state response to its inputs z (16 steps), one wave per group,
+//       spread over the chip (a first version ran the 16 groups of an utterance as 16 waves of ONE workgroup: a scan
+//       step occupies its SIMD's issue port for ~360 cycles -- the 22 v_readlane_b32 -- so four waves on a SIMD simply
+//       queue; 31.5 us per scan, no gain).
+//   lpc_fwdq2_kernel            the chunk kernels with a prologue: the wave folds the (M_g, v_g) of the groups before
+//       its own (<= 12 steps) and then scans its own 16 chunk maps (16 steps), leaving its 17 chunk start states in LDS
+//       -- no boundary-state array in HBM, no device-wide dependency besides kernel order.  The refinement pass ends
+//       with an epilogue that scans the group's 16 defects (-> v'_g), so the second scan needs no launch of its own:
+//       the final pass folds (M_g, v_g + v'_g) and scans with inputs z + defect.
+//   16 + <= 12 + 16 dependent steps on the critical path of each pass instead of 199 per scan.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the chunk kernels
+
+// s' = rows . s + add with the state broadcast by v_readlane (lane i = component i, `rw` = row i of the matrix)
+template <int W, int NT>
+__device__ __forceinline__ float matvec_step(const float4* rw, float s, float add, bool act) {
+    float acc0 = add, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float pj = f4get(rw[j / 4], j % 4);
+        const float sj = lane_bcast(s, j);
+        if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
+        else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
+        else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
+        else acc3 = fmaf(pj, sj, acc3);
+    }
+    return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+}
 
 template <int W, int NT>
 __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __restrict__ PhiT,
-                                                                 float* __restrict__ MT, float* __restrict__ Madj,
-                                                                 int NP, int GS, int NG) {
+                                                                 float* __restrict__ MT, int NP, int NG) {
     static_assert(NT <= 24, "the 12 K-steps of the product cover state components 0..23");
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int n = lane & 31, kh = lane >> 5;
-    const int c0 = g * GS, c1 = c0 + GS < NP ? c0 + GS : NP;
+    const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     f32x16 P;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -884,7 +905,7 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
     }
     const bool rowok = n < NT;
     const float* base = PhiT + ((size_t)b * NP * NT + (rowok ? n : 0)) * W;
-    // row fragments prefetched PF chunks ahead: one product is 12 x 64 cycles = 0.3 us, a load from L2 takes ~1 us
+    // row fragments prefetched PF chunks ahead (a load from L2 takes ~1 us, a product a fraction of that)
     constexpr int PF = 4;
     float4 nx[PF][3];
     auto load = [&](float4 (&dst)[3], int c) {
@@ -898,6 +919,7 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) load(nx[u], c0 + u);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int cb = c0; cb < c1; cb += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -906,145 +928,186 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a4[q] = nx[u][q];
                 load(nx[u], cb + u + PF);
-                f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                // four independent accumulators (3 K-steps each): the 12 MFMAs of a product would otherwise form one
+                // dependent chain of 12 x 64 cycles
+                f32x16 D0 = zero16, D1 = zero16, D2 = zero16, D3 = zero16;
+#define GOLF_MM(ACC, KK) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[(KK) / 4], (KK) % 4), P[KK], ACC, 0, 0, 0)
+                GOLF_MM(D0, 0); GOLF_MM(D1, 1); GOLF_MM(D2, 2);  GOLF_MM(D3, 3);
+                GOLF_MM(D0, 4); GOLF_MM(D1, 5); GOLF_MM(D2, 6);  GOLF_MM(D3, 7);
+                GOLF_MM(D0, 8); GOLF_MM(D1, 9); GOLF_MM(D2, 10); GOLF_MM(D3, 11);
+#undef GOLF_MM
 #pragma unroll
-                for (int kk = 0; kk < 12; ++kk)
-                    D = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[kk / 4], kk % 4), P[kk], D, 0, 0, 0);
-                P = D;
+                for (int v = 0; v < 16; ++v) P[v] = (D0[v] + D1[v]) + (D2[v] + D3[v]);
             }
         }
     }
     float* mt = MT + ((size_t)b * NG + g) * NT * W;
-    float* ma = Madj + ((size_t)b * NG + g) * NT * W;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int i = 8 * (v / 4) + 4 * kh + (v % 4);   // row of the composite, column n
         if (i < NT && n < W) mt[(size_t)i * W + n] = P[v];
-        if (n < NT && i < W) ma[(size_t)n * W + i] = P[v];
     }
 }
 
-// Scans x through the chunk maps: out[c] = state at the start of chunk c (c = 0 .. NP), zero at c = 0.
-// (First scan: x = z, out = S.  Second scan: x = the defects, out = dS; the final pass adds S + dS.)
+// Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
+// One wave per (utterance, group); four independent waves per workgroup.
 template <int W, int NT>
-__global__ __launch_bounds__(1024) void lpc_hscan_kernel(const float* __restrict__ PhiT, const float* __restrict__ x,
-                                                          const float* __restrict__ MT, float* __restrict__ out, int NC,
-                                                          int NP, int GS, int NG) {
-    __shared__ float vg[16][32];
-    __shared__ float sg[16][32];
-    __shared__ __attribute__((aligned(16))) float msh[16][NT * W];   // the utterance's group composites (34 KB at 22 x 24)
-    const int b = blockIdx.x;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void lpc_group_zscan_kernel(const float* __restrict__ PhiT, const float* __restrict__ x,
+                                                              float* __restrict__ V, int NP, int NG, int B) {
+    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (unit >= NG * B) return;   // wave-uniform
+    const int b = unit / NG, g = unit - b * NG, i = threadIdx.x & 63;
     const bool act = i < NT;
     const int ii = act ? i : 0;
-    const int c0 = g * GS, c1 = c0 + GS < NP ? c0 + GS : NP;
+    const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* xb = x + (size_t)b * NP * W + ii;
-    // this wave's composite -> registers now (the loads fly during phase 1), -> LDS before the first barrier
-    constexpr int MQ = (NT * W / 4 + 63) / 64;   // float4 per lane
-    float4 mreg[MQ];
-    if (g < NG) {
-        const float4* mg = reinterpret_cast<const float4*>(MT + ((size_t)b * NG + g) * NT * W);
-#pragma unroll
-        for (int q = 0; q < MQ; ++q) {
-            const int e = q * 64 + i;
-            mreg[q] = mg[e < NT * W / 4 ? e : 0];
-        }
-    }
-    constexpr int D = 3;
+    constexpr int D = 8;
     float4 buf[D][W / 4];
     float xc[D];
-    auto fetch = [&](int u, int c) {
-        const int cl = c < NP ? c : NP - 1;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
         xc[u] = xb[(size_t)cl * W];
-    };
-    auto step = [&](float s, int u) {
-        float acc0 = xc[u], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const float pj = f4get(buf[u][j / 4], j % 4);
-            const float sj = lane_bcast(s, j);
-            if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
-            else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
-            else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
-            else acc3 = fmaf(pj, sj, acc3);
-        }
-        return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-    };
-    // ---- phase 1: zero-state response of the group
+    }
     float s = 0.f;
-    if (g < NG) {
+    for (int cb = c0; cb < c1; cb += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (cb + u < c1) {   // wave-uniform
+                s = matvec_step<W, NT>(buf[u], s, xc[u], act);
+                const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
+#pragma unroll
+                for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
+                xc[u] = xb[(size_t)cn * W];
+            }
+        }
+    }
+    if (i < 32) V[((size_t)b * NG + g) * 32 + i] = s;
+}
+
+// Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
+//   t = fold of (M_g', v_g' (+ v2_g')) over the groups before g, then the wave's own chunk maps with inputs x (+ x2).
+template <int W, int NT>
+__device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, const float* __restrict__ MT,
+                                               const float* __restrict__ V, const float* __restrict__ V2,
+                                               const float* __restrict__ x, const float* __restrict__ x2,
+                                               float* __restrict__ st, int b, int g, int NP, int NG, int lane) {
+    const bool act = lane < NT;
+    const int ii = act ? lane : 0;
+    const size_t cstride4 = (size_t)NT * W / 4;
+    constexpr int D = 4;
+    float t = 0.f;
+    {   // (a) the groups before this one
+        const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
+        const float* vb = V + (size_t)b * NG * 32 + ii;
+        const float* v2b = V2 ? V2 + (size_t)b * NG * 32 + ii : nullptr;
+        float4 mb[D][W / 4];
+        float vv[D];
+        auto fetch = [&](int u, int gg) {
+            const int gl = gg < NG ? gg : NG - 1;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[u][k] = mrows[(size_t)gl * cstride4 + k];
+            vv[u] = vb[(size_t)gl * 32] + (v2b ? v2b[(size_t)gl * 32] : 0.f);
+        };
+        const int ng = g < NG ? g : NG;
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, u);
+        for (int gb = 0; gb < ng; gb += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (gb + u < ng) {   // wave-uniform
+                    t = matvec_step<W, NT>(mb[u], t, vv[u], act);
+                    fetch(u, gb + u + D);
+                }
+            }
+        }
+    }
+    {   // (b) the wave's own chunk maps
+        const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+        const float* xb = x + (size_t)b * NP * W + ii;
+        const float* x2b = x2 ? x2 + (size_t)b * NP * W + ii : nullptr;
+        const int c0 = g * kGroup;
+        float4 pb[D][W / 4];
+        float xx[D];
+        auto fetch = [&](int u, int c) {
+            const int cl = c < NP ? c : NP - 1;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+            xx[u] = xb[(size_t)cl * W] + (x2b ? x2b[(size_t)cl * W] : 0.f);
+        };
 #pragma unroll
         for (int u = 0; u < D; ++u) fetch(u, c0 + u);
+        for (int k0 = 0; k0 < kGroup; k0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = c0 + k0 + u;
+                if (lane < 32) st[(k0 + u) * 32 + lane] = t;
+                if (c < NP) t = matvec_step<W, NT>(pb[u], t, xx[u], act);   // wave-uniform
+                fetch(u, c + D);
+            }
+        }
+        if (lane < 32) st[kGroup * 32 + lane] = t;
+    }
+    wave_lds_fence();
+}
+
+// The chunk kernels of the two-level path.  MODE 3: refinement pass (re-run every chunk from its start state, write
+// the defects E_c - S_{c+1}; epilogue: scan the group's defects -> V2[b][g]).  MODE 1: final pass (writes y).
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                       const float* __restrict__ gain, const float* __restrict__ a,
+                                                       float* __restrict__ out, int64_t y_stride, int T, int F, int M,
+                                                       int hop, int L, int NCQ, const float* __restrict__ PhiT,
+                                                       const float* __restrict__ MT, const float* __restrict__ V,
+                                                       const float* __restrict__ V2in, float* __restrict__ V2out,
+                                                       const float* __restrict__ x, const float* __restrict__ x2, int NP,
+                                                       int NG) {
+    static_assert(MODE == 1 || MODE == 3, "final pass or refinement pass");
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    __shared__ float st[(kGroup + 1) * 32];
+    __shared__ float dl[MODE == 3 ? kGroup * 32 : 1];
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    group_prologue<W, NT>(PhiT, MT, V, V2in, x, x2, st, b, g, NP, NG, lane);
+    if (MODE == 3) {
+        for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
+        wave_lds_fence();
+    }
+    fwdq_body<W, NT, MODE, true>(ex, ex_stride, gain, a, nullptr, out, y_stride, T, F, M, hop, L, NCQ, 0, nullptr, xt, yt,
+                                 b, g, lane, st, dl);
+    if (MODE == 3) {   // epilogue: the group's response to its own defects, for the final pass's fold
+        wave_lds_fence();
+        const bool act = lane < NT;
+        const int ii = act ? lane : 0;
+        const size_t cstride4 = (size_t)NT * W / 4;
+        const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+        const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+        constexpr int D = 4;
+        float4 pb[D][W / 4];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+        }
+        float s = 0.f;
         for (int cb = c0; cb < c1; cb += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                if (cb + u < c1) {           // wave-uniform
-                    s = step(s, u);
-                    fetch(u, cb + u + D < c1 ? cb + u + D : c1 - 1);
-                    if (u == 0 && cb == c0) {   // the composite's loads were issued before this step's: they are in
-                        float4* md = reinterpret_cast<float4*>(msh[g]);
+                if (cb + u < c1) {   // wave-uniform
+                    s = matvec_step<W, NT>(pb[u], s, dl[(cb + u - c0) * 32 + ii], act);
+                    const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
 #pragma unroll
-                        for (int q = 0; q < MQ; ++q) {
-                            const int e = q * 64 + i;
-                            if (e < NT * W / 4) md[e] = mreg[q];
-                        }
-                    }
+                    for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cn * cstride4 + k];
                 }
             }
         }
-        if (i < 32) vg[g][i] = s;
-        // phase 3 re-reads the same rows: start its first fetches now, they land while wave 0 scans the groups
-#pragma unroll
-        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
-    }
-    __syncthreads();
-    // ---- phase 2: wave 0 scans the groups with the composites (rows from LDS)
-    if (g == 0) {
-        float t = 0.f;
-        for (int gg = 0; gg < NG; ++gg) {
-            if (i < 32) sg[gg][i] = t;
-            const float4* mrow = reinterpret_cast<const float4*>(msh[gg] + (size_t)ii * W);
-            float acc0 = vg[gg][ii], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll
-            for (int k = 0; k < W / 4; ++k) {
-                const float4 m4 = mrow[k];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = 4 * k + e;
-                    if (j < NT) {
-                        const float tj = lane_bcast(t, j);
-                        const float pj = f4get(m4, e);
-                        if (e == 0) acc0 = fmaf(pj, tj, acc0);
-                        else if (e == 1) acc1 = fmaf(pj, tj, acc1);
-                        else if (e == 2) acc2 = fmaf(pj, tj, acc2);
-                        else acc3 = fmaf(pj, tj, acc3);
-                    }
-                }
-            }
-            t = act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-        }
-    }
-    __syncthreads();
-    // ---- phase 3: re-scan the group from its start state, writing the chunk start states
-    if (g < NG) {
-        float* ob = out + (size_t)b * NC * 64 + i;   // rows padded to 64 floats: every lane stores
-        s = i < 32 ? sg[g][i] : 0.f;
-        for (int cb = c0; cb < c1; cb += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                if (cb + u < c1) {
-                    const int c = cb + u;
-                    ob[(size_t)c * 64] = s;
-                    s = step(s, u);
-                    fetch(u, c + D < c1 ? c + D : c1 - 1);
-                }
-            }
-        }
-        if (c1 == NP) ob[(size_t)NP * 64] = s;   // the last group also owns the start state of the final chunk
+        if (lane < 32) V2out[((size_t)b * NG + g) * 32 + lane] = s;
     }
 }
 
@@ -1664,27 +1727,26 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     if constexpr (NT <= 24) {
-        if (fast && p.NG > 0 && (flags & GOLF_SS_TWO_LEVEL_SCAN)) {   // opt-in: measured no faster than the flat scan (see above)
+        if (fast && p.NG > 0 && (flags & GOLF_SS_TWO_LEVEL_SCAN)) {   // opt-in (see the kernels above)
             float* MT = (float*)(ws + p.off_mt);
-            float* Madj = (float*)(ws + p.off_madj);
+            float* Vz = (float*)(ws + p.off_madj);                    // [b][NG][32] zero-state group responses
+            float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
+            float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S_{c+1} of the refinement pass
             hipLaunchKernelGGL((lpc_group_composite_kernel<W, NT>), dim3(p.NG, B), dim3(64), 0, st, (const float*)PhiT, MT,
-                               Madj, p.NP, p.GS, p.NG);
+                               p.NP, p.NG);
             GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
-                               (const float*)z, (const float*)MT, S, p.NC, p.NP, p.GS, p.NG);
+            hipLaunchKernelGGL((lpc_group_zscan_kernel<W, NT>), dim3((unsigned)ceil_div(p.NG * B, 4)), dim3(256), 0, st,
+                               (const float*)PhiT, (const float*)z, Vz, p.NP, p.NG, B);
             GOLF_LAUNCH_CHECK();
-            float* dfc = (float*)(ws + p.off_z2);   // defects E_c - S_{c+1} of the refinement sweep
-            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                               ex_stride, gain, a, (const float*)S, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
-                               (const float*)nullptr);
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, kGroup), B), dim3(64), 0, st, ex,
+                               ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
+                               (const float*)MT, (const float*)Vz, (const float*)nullptr, Vd, (const float*)z,
+                               (const float*)nullptr, p.NP, p.NG);
             GOLF_LAUNCH_CHECK();
-            float* dS = (float*)(ws + p.off_lam);    // correction of the chunk start states ([b][c][64], as S)
-            hipLaunchKernelGGL((lpc_hscan_kernel<W, NT>), dim3(B), dim3(64 * p.NG), 0, st, (const float*)PhiT,
-                               (const float*)dfc, (const float*)MT, dS, p.NC, p.NP, p.GS, p.NG);
-            GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 4>), dim3((unsigned)ceil_div(p.NC, 16), B), dim3(64), 0, st, ex,
-                               ex_stride, gain, a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NC,
-                               (const float*)dS);
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, kGroup), B), dim3(64), 0, st, ex,
+                               ex_stride, gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT,
+                               (const float*)MT, (const float*)Vz, (const float*)Vd, (float*)nullptr, (const float*)z,
+                               (const float*)dfc, p.NP, p.NG);
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }
