@@ -891,10 +891,9 @@ __device__ __forceinline__ float matvec_step(const float4* rw, float s, float ad
 }
 
 template <int W, int NT>
-__global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __restrict__ PhiT,
-                                                                 float* __restrict__ MT, int NP, int NG) {
+__device__ __forceinline__ void group_composite_body(const float* __restrict__ PhiT, float* __restrict__ MT, int NP,
+                                                     int NG, int b, int g, int lane) {
     static_assert(NT <= 24, "the 12 K-steps of the product cover state components 0..23");
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int n = lane & 31, kh = lane >> 5;
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     f32x16 P;
@@ -905,40 +904,33 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
     }
     const bool rowok = n < NT;
     const float* base = PhiT + ((size_t)b * NP * NT + (rowok ? n : 0)) * W;
-    // row fragments prefetched PF chunks ahead (a load from L2 takes ~1 us, a product a fraction of that)
-    constexpr int PF = 4;
-    float4 nx[PF][3];
-    auto load = [&](float4 (&dst)[3], int c) {
-        const float* rp = base + (size_t)(c < c1 ? c : c1 - 1) * NT * W;
+    // the whole group's row fragments are loaded up front (16 x 3 float4 per lane: a lone wave has the registers):
+    // the L2 latency is paid once instead of per product
+    float4 fr[kGroup][3];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+        const float* rp = base + (size_t)(c0 + u < c1 ? c0 + u : c1 - 1) * NT * W;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int col = 8 * q + 4 * kh;
-            dst[q] = (rowok && col < NT) ? *reinterpret_cast<const float4*>(rp + (col < W ? col : 0))
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            fr[u][q] = (rowok && col < NT) ? *reinterpret_cast<const float4*>(rp + (col < W ? col : 0))
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    };
-#pragma unroll
-    for (int u = 0; u < PF; ++u) load(nx[u], c0 + u);
+    }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int cb = c0; cb < c1; cb += PF) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (cb + u < c1) {   // wave-uniform
-                float4 a4[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) a4[q] = nx[u][q];
-                load(nx[u], cb + u + PF);
-                // four independent accumulators (3 K-steps each): the 12 MFMAs of a product would otherwise form one
-                // dependent chain of 12 x 64 cycles
-                f32x16 D0 = zero16, D1 = zero16, D2 = zero16, D3 = zero16;
-#define GOLF_MM(ACC, KK) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a4[(KK) / 4], (KK) % 4), P[KK], ACC, 0, 0, 0)
-                GOLF_MM(D0, 0); GOLF_MM(D1, 1); GOLF_MM(D2, 2);  GOLF_MM(D3, 3);
-                GOLF_MM(D0, 4); GOLF_MM(D1, 5); GOLF_MM(D2, 6);  GOLF_MM(D3, 7);
-                GOLF_MM(D0, 8); GOLF_MM(D1, 9); GOLF_MM(D2, 10); GOLF_MM(D3, 11);
+    for (int u = 0; u < kGroup; ++u) {
+        if (c0 + u < c1) {   // wave-uniform
+            // four independent accumulators (3 K-steps each): the 12 MFMAs of a product would otherwise form one
+            // dependent chain of 12 x 64 cycles
+            f32x16 D0 = zero16, D1 = zero16, D2 = zero16, D3 = zero16;
+#define GOLF_MM(ACC, KK) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(fr[u][(KK) / 4], (KK) % 4), P[KK], ACC, 0, 0, 0)
+            GOLF_MM(D0, 0); GOLF_MM(D1, 1); GOLF_MM(D2, 2);  GOLF_MM(D3, 3);
+            GOLF_MM(D0, 4); GOLF_MM(D1, 5); GOLF_MM(D2, 6);  GOLF_MM(D3, 7);
+            GOLF_MM(D0, 8); GOLF_MM(D1, 9); GOLF_MM(D2, 10); GOLF_MM(D3, 11);
 #undef GOLF_MM
 #pragma unroll
-                for (int v = 0; v < 16; ++v) P[v] = (D0[v] + D1[v]) + (D2[v] + D3[v]);
-            }
+            for (int v = 0; v < 16; ++v) P[v] = (D0[v] + D1[v]) + (D2[v] + D3[v]);
         }
     }
     float* mt = MT + ((size_t)b * NG + g) * NT * W;
@@ -950,43 +942,46 @@ __global__ __launch_bounds__(64) void lpc_group_composite_kernel(const float* __
 }
 
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
-// One wave per (utterance, group); four independent waves per workgroup.
 template <int W, int NT>
-__global__ __launch_bounds__(256) void lpc_group_zscan_kernel(const float* __restrict__ PhiT, const float* __restrict__ x,
-                                                              float* __restrict__ V, int NP, int NG, int B) {
-    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (unit >= NG * B) return;   // wave-uniform
-    const int b = unit / NG, g = unit - b * NG, i = threadIdx.x & 63;
+__device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT, const float* __restrict__ x,
+                                                 float* __restrict__ V, int NP, int NG, int b, int g, int i) {
     const bool act = i < NT;
     const int ii = act ? i : 0;
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* xb = x + (size_t)b * NP * W + ii;
-    constexpr int D = 8;
-    float4 buf[D][W / 4];
-    float xc[D];
+    float4 buf[kGroup][W / 4];   // the whole group up front, as above
+    float xc[kGroup];
 #pragma unroll
-    for (int u = 0; u < D; ++u) {
+    for (int u = 0; u < kGroup; ++u) {
         const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
         xc[u] = xb[(size_t)cl * W];
     }
     float s = 0.f;
-    for (int cb = c0; cb < c1; cb += D) {
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-            if (cb + u < c1) {   // wave-uniform
-                s = matvec_step<W, NT>(buf[u], s, xc[u], act);
-                const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
-#pragma unroll
-                for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cn * cstride4 + k];
-                xc[u] = xb[(size_t)cn * W];
-            }
-        }
-    }
+    for (int u = 0; u < kGroup; ++u)
+        if (c0 + u < c1) s = matvec_step<W, NT>(buf[u], s, xc[u], act);   // wave-uniform
     if (i < 32) V[((size_t)b * NG + g) * 32 + i] = s;
+}
+
+// Both pre-passes of the two-level scan in ONE launch (they depend only on the transition kernel's outputs):
+// units [0, NG*B) form the group composites, units [NG*B, 2*NG*B) the groups' zero-state responses; one wave per unit,
+// four independent waves per workgroup.
+template <int W, int NT>
+__global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
+                                                                const float* __restrict__ z, float* __restrict__ MT,
+                                                                float* __restrict__ V, int NP, int NG, int B) {
+    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, nu = NG * B;
+    if (unit < nu) {
+        group_composite_body<W, NT>(PhiT, MT, NP, NG, unit / NG, unit % NG, lane);
+    } else if (unit < 2 * nu) {
+        const int u2 = unit - nu;
+        group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, lane);
+    }
 }
 
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
@@ -999,9 +994,25 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
     const size_t cstride4 = (size_t)NT * W / 4;
-    constexpr int D = 4;
     float t = 0.f;
+    // the wave's own chunk maps: first fetches issued before the fold below, so they are in flight during it
+    constexpr int DC = 6;
+    const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+    const float* xb = x + (size_t)b * NP * W + ii;
+    const float* x2b = x2 ? x2 + (size_t)b * NP * W + ii : nullptr;
+    const int c0 = g * kGroup;
+    float4 pb[DC][W / 4];
+    float xx[DC];
+    auto fetchc = [&](int u, int c) {
+        const int cl = c < NP ? c : NP - 1;
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+        xx[u] = xb[(size_t)cl * W] + (x2b ? x2b[(size_t)cl * W] : 0.f);
+    };
+#pragma unroll
+    for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
     {   // (a) the groups before this one
+        constexpr int D = 4;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
         const float* vb = V + (size_t)b * NG * 32 + ii;
         const float* v2b = V2 ? V2 + (size_t)b * NG * 32 + ii : nullptr;
@@ -1026,29 +1037,14 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
             }
         }
     }
-    {   // (b) the wave's own chunk maps
-        const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
-        const float* xb = x + (size_t)b * NP * W + ii;
-        const float* x2b = x2 ? x2 + (size_t)b * NP * W + ii : nullptr;
-        const int c0 = g * kGroup;
-        float4 pb[D][W / 4];
-        float xx[D];
-        auto fetch = [&](int u, int c) {
-            const int cl = c < NP ? c : NP - 1;
+    {   // (b) the wave's own chunk maps (kGroup = 16 is not a multiple of DC: the slot index runs modulo DC)
 #pragma unroll
-            for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
-            xx[u] = xb[(size_t)cl * W] + (x2b ? x2b[(size_t)cl * W] : 0.f);
-        };
-#pragma unroll
-        for (int u = 0; u < D; ++u) fetch(u, c0 + u);
-        for (int k0 = 0; k0 < kGroup; k0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int c = c0 + k0 + u;
-                if (lane < 32) st[(k0 + u) * 32 + lane] = t;
-                if (c < NP) t = matvec_step<W, NT>(pb[u], t, xx[u], act);   // wave-uniform
-                fetch(u, c + D);
-            }
+        for (int k = 0; k < kGroup; ++k) {
+            const int u = k % DC;
+            const int c = c0 + k;
+            if (lane < 32) st[k * 32 + lane] = t;
+            if (c < NP) t = matvec_step<W, NT>(pb[u], t, xx[u], act);   // wave-uniform
+            if (k + DC < kGroup) fetchc(u, c + DC);
         }
         if (lane < 32) st[kGroup * 32 + lane] = t;
     }
@@ -1732,11 +1728,8 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* Vz = (float*)(ws + p.off_madj);                    // [b][NG][32] zero-state group responses
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
             float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S_{c+1} of the refinement pass
-            hipLaunchKernelGGL((lpc_group_composite_kernel<W, NT>), dim3(p.NG, B), dim3(64), 0, st, (const float*)PhiT, MT,
-                               p.NP, p.NG);
-            GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_group_zscan_kernel<W, NT>), dim3((unsigned)ceil_div(p.NG * B, 4)), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, Vz, p.NP, p.NG, B);
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(2 * p.NG * B, 4)), dim3(256), 0,
+                               st, (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B);
             GOLF_LAUNCH_CHECK();
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, kGroup), B), dim3(64), 0, st, ex,
                                ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
