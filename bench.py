@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--prereplay", type=int, default=16,
                     help="setup: replays of every captured hipGraph before the warm-up steps (graph upload, code objects, "
                          "clocks: instantiation is setup, not a step)")
-    ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "two-level"],
+    ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "flat-scan"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
@@ -117,7 +117,10 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
 
     if workload == "golf-ss-synth":
         def step():
-            return GF.ltv_allpole_ss(source(), gain, a, hop, fast_inference=fast, mode=mode)
+            # --overlap-transitions: the filter's excitation-independent phase (transition matrices + group composites)
+            # on a second stream beside the oscillator -- shortens a lone batch's latency, not the pipelined rate
+            prep = GF.ltv_allpole_prepare(a, hop, t_ss, overlap=True, fast=fast, mode=mode) if overlap else None
+            return GF.ltv_allpole_ss(source(), gain, a, hop, prepared=prep, fast_inference=fast, mode=mode)
     elif workload == "lpc-ss-fwd":
         def step():
             return GF.ltv_allpole_ss(noise, gain, a, hop)

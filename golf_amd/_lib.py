@@ -113,7 +113,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-c", s,
-               "-o", o]
+               "-o", o] + os.environ.get("GOLF_HIPCC_FLAGS", "").split()      # kernel-tuning A/B builds (-DP1F_CHAINS=2 ...)
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -141,7 +141,7 @@ def load():
             raise RuntimeError(
                 f"golf_amd: {LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback by design)")
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(os.environ.get("GOLF_HIP_LIBRARY", LIB_PATH))   # override: an A/B build of the same ABI
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res

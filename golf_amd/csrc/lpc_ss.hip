@@ -83,7 +83,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     if (p->serial) {   // batch-parallel serial path: no transition matrices, no boundary states
         p->off_phi = p->off_phiT = p->off_z = p->off_E = p->off_z2 = p->off_S = p->off_zadj = p->off_lam = 0;
         p->NG = p->GS = 0;
-        p->off_mt = p->off_madj = 0;
+        p->off_mt = p->off_gv = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -101,16 +101,16 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
-    // two-level boundary scan (lpc_group_composite_kernel + lpc_hscan_kernel): worth it from ~48 chunk maps on, and the
-    // composite kernel's 32 x 32 MFMA tile holds up to 24 state components
+    // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
+    // composite product's 32 x 32 MFMA tile holds up to 24 state components
     p->NG = 0;
     p->GS = 0;
-    p->off_mt = p->off_madj = o;
+    p->off_mt = p->off_gv = o;
     if (p->NP >= 48 && p->NT <= 24) {
         p->GS = 16;                                  // = the 16 chunks a wave of the chunk kernels owns
         p->NG = (int)ceil_div(p->NP, p->GS);
         p->off_mt = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
-        p->off_madj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * 32 * 2, 256);   // group responses (z, defects)
+        p->off_gv = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * 32 * 2, 256);   // group responses (z, defects)
     }
     p->total = o;
     return true;
@@ -625,6 +625,9 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
+#ifndef P1F_CHAINS
+#define P1F_CHAINS 2
+#endif
 template <int W, int NT>
 struct P1fGeom {
     static constexpr int KT = 4;
@@ -691,20 +694,30 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
             f32x2 cfp[NP2];
 #pragma unroll
             for (int pp = 0; pp < NP2; ++pp) cfp[pp] = __builtin_elementwise_fma(n2, ddp[pp], a0p[pp]);
-            f32x2 raA = f32x2{0.f, 0.f}, rbA = raA, raB = raA, rbB = raA;
+            // NCH independent accumulation chains per ring (2 x NCH in flight).  Measured: 2 and 4 chains per ring run
+            // the same 41.5 us -- the loop is bound by v_pk_fma_f32 issue (~6.4 cycles each for a lone wave), not by the
+            // dependent-result latency
+            constexpr int NCH = P1F_CHAINS;
+            f32x2 rA[NCH], rB[NCH];
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) rA[u] = rB[u] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = NT - 1; i >= 1; --i) {
                 const float cf = (i & 1) ? cfp[i / 2].y : cfp[i / 2].x;
                 const f32x2 c2 = f32x2{cf, cf};
                 const int slot = (s - 1 - i + 2 * W) % W;
-                if (i & 1) { raA = __builtin_elementwise_fma(c2, hA[slot], raA); raB = __builtin_elementwise_fma(c2, hB[slot], raB); }
-                else       { rbA = __builtin_elementwise_fma(c2, hA[slot], rbA); rbB = __builtin_elementwise_fma(c2, hB[slot], rbB); }
+                rA[i % NCH] = __builtin_elementwise_fma(c2, hA[slot], rA[i % NCH]);
+                rB[i % NCH] = __builtin_elementwise_fma(c2, hB[slot], rB[i % NCH]);
             }
+#pragma unroll
+            for (int st = NCH / 2; st >= 1; st /= 2)
+#pragma unroll
+                for (int u = 0; u < st; ++u) { rA[u] += rA[u + st]; rB[u] += rB[u + st]; }
             const float cf0 = cfp[0].x;
             const f32x2 c0 = f32x2{-cf0, -cf0};
             const int sp = (s - 1 + W) % W;
-            hA[s] = __builtin_elementwise_fma(c0, hA[sp], -(raA + rbA));
-            hB[s] = __builtin_elementwise_fma(c0, hB[sp], -(raB + rbB));
+            hA[s] = __builtin_elementwise_fma(c0, hA[sp], -rA[0]);
+            hB[s] = __builtin_elementwise_fma(c0, hB[sp], -rB[0]);
         }
     }
     // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Two-level boundary scan (round 2; opt-in GOLF_SS_TWO_LEVEL_SCAN).  The flat scan below is 199 dependent 22 x 22
+// Two-level boundary scan (round 2; the default for long utterances with M <= 24; GOLF_SS_FLAT_SCAN selects the flat one).  The flat scan below is 199 dependent 22 x 22
 // matvecs on ONE wave per utterance: 31 us, twice per inference step (38 % of the single-stream step).  The chunk maps
 // of an utterance are cut into groups of 16 -- the 16 chunks one wave of the chunk kernels (lpc_fwdq*) owns:
 //   lpc_group_composite_kernel  M_g = Phi_{c0+15} ... Phi_{c0} for every group, once per step: a chain of 16 exact-fp32
@@ -973,8 +986,13 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
                                                                 const float* __restrict__ z, float* __restrict__ MT,
-                                                                float* __restrict__ V, int NP, int NG, int B) {
-    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                                                                float* __restrict__ V, int NP, int NG, int B,
+                                                                int first, int count) {
+    // [first, first + count): all 2*NG*B units, or only the composites (transitions prepared ahead of the excitation:
+    // golf_ltv_allpole_transitions_f32) / only the zero-state scans (the forward that picks them up)
+    const int rel = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (rel >= count) return;   // wave-uniform; the waves of a workgroup never synchronise with each other
+    const int unit = first + rel;
     const int lane = threadIdx.x & 63, nu = NG * B;
     if (unit < nu) {
         group_composite_body<W, NT>(PhiT, MT, NP, NG, unit / NG, unit % NG, lane);
@@ -1592,8 +1610,22 @@ __global__ __launch_bounds__(64) void lpc_inverse_bwd_a_kernel(const float* __re
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 template <int W, int NT>
+static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStream_t st) {
+    if constexpr (NT <= 24) {
+        if (p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN)) {   // two-level boundary scan: the group composites need only Phi
+            const int nu = p.NG * B;
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, st,
+                               (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
+                               (float*)nullptr, p.NP, p.NG, B, 0, nu);
+            GOLF_LAUNCH_CHECK();
+        }
+    }
+    return GOLF_OK;
+}
+
+template <int W, int NT>
 static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int F, int M, int hop, char* ws,
-                              int fast, hipStream_t st) {
+                              int fast, int flags, hipStream_t st) {
     if (p.NP <= 0) return GOLF_OK;
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
@@ -1603,7 +1635,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
         hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
                            st, a, PhiT, F, M, hop, p.L, p.NP, nq);
         GOLF_LAUNCH_CHECK();
-        return GOLF_OK;
+        return launch_composites<W, NT>(p, B, ws, flags, st);
     }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
     if (kt_env == 1) {
@@ -1622,7 +1654,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
                        (const float*)Phi, PhiT, nq);
     GOLF_LAUNCH_CHECK();
-    return GOLF_OK;
+    return launch_composites<W, NT>(p, B, ws, flags, st);
 }
 
 // CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
@@ -1710,7 +1742,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                     GOLF_LAUNCH_CHECK();
                 }
                 fused_p1 = true;
-            } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, s1)) {
+            } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, flags, s1)) {
                 return rc;
             }
         }
@@ -1723,14 +1755,24 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     if constexpr (NT <= 24) {
-        if (fast && p.NG > 0 && (flags & GOLF_SS_TWO_LEVEL_SCAN)) {   // opt-in (see the kernels above)
+        if (p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN)) {   // two-level boundary scan (see the kernels above)
             float* MT = (float*)(ws + p.off_mt);
-            float* Vz = (float*)(ws + p.off_madj);                    // [b][NG][32] zero-state group responses
+            float* Vz = (float*)(ws + p.off_gv);                    // [b][NG][32] zero-state group responses
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
             float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S_{c+1} of the refinement pass
-            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(2 * p.NG * B, 4)), dim3(256), 0,
-                               st, (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B);
+            // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
+            const int nu = p.NG * B, first = fused_p1 ? 0 : nu, count = fused_p1 ? 2 * nu : nu;
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, st,
+                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first, count);
             GOLF_LAUNCH_CHECK();
+            if (!fast) {   // accurate (fp64-derived) transition matrices: no refinement pass
+                hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, kGroup), B), dim3(64), 0, st,
+                                   ex, ex_stride, gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT,
+                                   (const float*)MT, (const float*)Vz, (const float*)nullptr, (float*)nullptr,
+                                   (const float*)z, (const float*)nullptr, p.NP, p.NG);
+                GOLF_LAUNCH_CHECK();
+                return GOLF_OK;
+            }
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, kGroup), B), dim3(64), 0, st, ex,
                                ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
                                (const float*)MT, (const float*)Vz, (const float*)nullptr, Vd, (const float*)z,
@@ -1899,7 +1941,7 @@ extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, in
                     p.total, ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
-    GOLF_SS_DISPATCH(launch_transitions, p, a, B, T, F, M, hop, (char*)ws, fast, st)
+    GOLF_SS_DISPATCH(launch_transitions, p, a, B, T, F, M, hop, (char*)ws, fast, flags, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_transitions: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

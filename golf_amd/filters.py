@@ -93,7 +93,11 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
         hop = int(a.hop_length)
         F = a.shape[1]
         T = (F - 1) * hop + 1 if n_samples is None else min(int(n_samples), (F - 1) * hop + 1)
-        self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T, overlap=overlap)
+        # fp32 matrices (+ refinement sweep in the forward) unless a gradient may be asked for; a forward that does
+        # need gradients ignores a fast handle and recomputes
+        at, gt = a.as_tensor(), gain.as_tensor()
+        fast = not (torch.is_grad_enabled() and (at.requires_grad or gt.requires_grad))
+        self._prepared = GF.ltv_allpole_prepare(at, hop, T, overlap=overlap, fast=fast)
 
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
         hop = _check_filter_inputs(ex, gain, a)

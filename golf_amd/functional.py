@@ -42,20 +42,22 @@ class PreparedTransitions:
 
 
 def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False,
-                        fast: bool = False) -> PreparedTransitions:
+                        fast: bool = False, mode=None) -> PreparedTransitions:
     """Compute the transition matrices for coefficients ``a`` (B,F,M) and output length ``T`` ahead of the
     excitation; pass the handle to ltv_allpole_ss(..., prepared=handle) (e.g. to filter several signals with the
     same coefficients, or to start the most expensive, excitation-independent phase early).
     ``overlap=True`` launches on a second HIP stream that the forward joins right before its boundary scan.
-    Measured on MI355X at B=32 this does NOT pay with the fp64 matrices: that kernel occupies most SIMDs, so whatever
-    runs beside it slows down by as much as is saved — hence off by default.
+    With the two-level boundary scan the group composites (which need only the matrices) are computed here as well.
+    What it buys is LATENCY of a lone batch (the 40 us transition kernel hides behind the oscillator); with several
+    batches in flight the chip is full either way and the fork/join only costs — off by default.
     ``fast=True`` computes the fp32 matrices of the inference path (the forward then runs its refinement sweep; such a
     handle must not be used when gradients are needed)."""
     _lib.require_device(a)
     lib = _lib.load()
     a = a.detach().contiguous()
     B, F, M = a.shape
-    ws = _workspace(lib.golf_ltv_allpole_workspace_bytes(B, T, F, M, hop), a.device)
+    flags = SS_MODES[mode] | (FAST_TRANSITIONS if fast else 0)
+    ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, flags), a.device)
     cur = torch.cuda.current_stream(a.device)
     side = None
     if overlap:
@@ -64,9 +66,9 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
         ws.record_stream(side)
         a.record_stream(side)
     rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
-                                              FAST_TRANSITIONS if fast else 0, (side or cur).cuda_stream)
+                                              flags, (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
-    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version), side, a, fast)
+    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version, SS_MODES[mode]), side, a, fast)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -121,9 +123,9 @@ class _LTVAllPoleSS(torch.autograd.Function):
                 f"golf_amd: the sample-wise LPC filter has no backward for lpc_order={M}, hop={hop}, frames={F}: training "
                 f"needs >= 2 frames and a ring width W in {[r for r, _ in SS_RINGS]} with hop % W == 0 and lpc_order <= W - 2 "
                 f"(e.g. hop 240 -> orders up to 38, hop 256 -> up to 30, hop 100 -> none)")
-        if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version)
+        if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version, mode)
                 and not (prepared.fast and needs_grad)):
-            ws, flags, side = prepared.ws, HAVE_TRANSITIONS, prepared.stream
+            ws, flags, side = prepared.ws, HAVE_TRANSITIONS | mode, prepared.stream
             if prepared.fast:
                 flags |= FAST_TRANSITIONS
         else:
@@ -168,7 +170,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
         return g_ex, g_gain, g_a, None, None, None, None
 
 
-SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "two-level": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _TWO_LEVEL_SCAN
+SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _FLAT_SCAN
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
@@ -180,7 +182,8 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
     fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
     ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
-    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one."""
+    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one, "flat-scan" is
+    the chunked algorithm with the flat boundary scan instead of the two-level one (A/B)."""
     return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode])
 
 

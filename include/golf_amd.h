@@ -86,10 +86,11 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                large-batch kernel (default from B >= 2048, where the two meet on MI355X).  The backward must be given the flag the forward ran with. */
 #define GOLF_SS_SERIAL 8
 #define GOLF_SS_CHUNKED 16
-/*          GOLF_SS_TWO_LEVEL_SCAN  (with FAST, long utterances, M <= 24) two-level boundary scan: group composites as
- *                exact-fp32 MFMA product chains + a three-phase scan in one launch.  Correct, measured no faster than
- *                the flat scan on MI355X (csrc/lpc_ss.hip): opt-in. */
-#define GOLF_SS_TWO_LEVEL_SCAN 32
+/*          GOLF_SS_FLAT_SCAN  chunk-boundary states by the flat scan (one wave per utterance, NP dependent matvecs)
+ *                instead of the two-level scan that long utterances with M <= 24 take by default (group composites as
+ *                exact-fp32 MFMA product chains + per-group scans spread over the chip + start states derived in the
+ *                chunk kernels): an A/B switch; the two give the same states up to fp32 rounding. */
+#define GOLF_SS_FLAT_SCAN 32
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);

@@ -375,16 +375,22 @@ def test_large_batch_defaults_to_serial_and_matches_chunked():
 @pytest.mark.parametrize("B,F,M,hop", [(3, 520, 12, 24), (2, 1500, 4, 8), (2, 800, 14, 16), (5, 60, 22, 240),
                                        (2, 210, 20, 240)])
 def test_two_level_scan_shapes(B, F, M, hop):
-    """Long utterances at other ring widths / orders through both forward paths and through the opt-in two-level boundary
-    scan (group composites as MFMA product chains + three-phase scan; measured no faster than the flat scan, hence not
-    the default): 60 frames of hop 240 exercise a partial last group, 1500 frames of hop 8 the 8-wide ring."""
+    """Long utterances at other ring widths / orders through both forward paths with the two-level boundary scan (group
+    composites as MFMA product chains, per-group scans, start states derived in the chunk kernels) and with the flat scan
+    (A/B switch), plus the training path: 60 frames of hop 240 exercise a partial last group, 1500 frames of hop 8 the
+    8-wide ring."""
     from oracle import golf_oracle as O
 
     ex, gain, a = smooth_case(B, F, M, hop, seed=F + M, walk=0.02 * (240 / max(hop, 24)) ** 0.5 * 0.3)
     ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
-    for fast in (True, False):
+    for fast in (True, False):      # default: two-level scan where the shape allows it (NP >= 48, M <= 24)
         y = run_fwd(ex, gain, a, hop, fast=fast)
         assert y.shape == ref.shape
-        check(y, ref, f"flat scan B{B} F{F} M{M} hop{hop} fast={fast}")
-    y2 = run_mode(ex, gain, a, hop, "two-level")      # opt-in variant (GOLF_SS_TWO_LEVEL_SCAN)
-    check(y2, ref, f"two-level scan B{B} F{F} M{M} hop{hop}")
+        check(y, ref, f"two-level scan B{B} F{F} M{M} hop{hop} fast={fast}")
+    y2 = run_mode(ex, gain, a, hop, "flat-scan")      # A/B: the flat scan (GOLF_SS_FLAT_SCAN)
+    check(y2, ref, f"flat scan B{B} F{F} M{M} hop{hop}")
+    gy = np.random.default_rng(F).normal(0, 1, ref.shape).astype(np.float32)
+    res = run_mode(ex, gain, a, hop, None, gy)         # training path: fp64 transitions + two-level forward + backward
+    check(res[0], ref, "training forward (two-level scan)")
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+    check(res[3], r_a, "g_a after a two-level forward", 2e-4)

@@ -116,6 +116,30 @@ def test_prefetch_overlap_is_bit_identical():
     assert torch.equal(ag.grad, ag2.grad)
 
 
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("mode", [None, "flat-scan"])
+def test_prefetch_with_two_level_scan_is_bit_identical(fast, mode):
+    """Long utterances (two-level boundary scan): transitions AND group composites prepared on the side stream, the
+    forward then runs only the zero-state halves of the pre-pass -- same bits as the all-in-one forward."""
+    from golf_amd import functional as GF
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=3, T=24000, device="cuda")
+    ex, gain, a = inp["noise"], inp["gain"], inp["a"]
+    y0 = GF.ltv_allpole_ss(ex, gain, a, 240, fast_inference=fast, mode=mode)
+    for overlap in (False, True):
+        prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1], overlap=overlap, fast=fast, mode=mode)
+        y1 = GF.ltv_allpole_ss(ex, gain, a, 240, prep, fast_inference=fast, mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1), overlap
+    # a handle prepared for the other scan is not picked up (its workspace may lack the composites)
+    other = "flat-scan" if mode is None else None
+    prep = GF.ltv_allpole_prepare(a, 240, y0.shape[1], overlap=True, fast=fast, mode=other)
+    y2 = GF.ltv_allpole_ss(ex, gain, a, 240, prep, fast_inference=fast, mode=mode)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y2)
+
+
 def test_room_filter_g14(golden):
     """LTIAcousticFilter (golf_lti_fir_f32 + adjoint + taps gradient) against the reference's own run."""
     from golf_amd.audiotensor import AudioTensor
