@@ -68,8 +68,10 @@ def parse():
                     help="diagnostic: transition kernel and zero-state pass as two launches instead of the fused one")
     ap.add_argument("--fp64-transitions", action="store_true",
                     help="inference with the training path's fp64 transition matrices instead of fp32 + refinement sweep")
-    ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
-                    help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step")
+    ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync", "peer-store"],
+                    help="pipelined: the gather of step k overlaps step k+1 (double-buffered); sync: inside each step; "
+                         "peer-store: no collective -- every step's audio is stored straight into the peers' receive "
+                         "buffers over xGMI (golf_amd.dist.PeerStoreGather; one node, not yet measured across GPUs)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="N>1: stage this many steps' audio per slot and exchange them in ONE all-gather (fewer, larger "
                          "collectives: xGMI is per-link bound and a 6 MB gather per ~70 us step sits at the link rate); "
@@ -420,7 +422,13 @@ def main():
     do_gather = world > 1 and not args.no_gather
     GE = (args.gather_every if args.gather_every > 0 else max(1, min(8, args.steps // S))) if do_gather else 1
     pipelined = args.gather_mode == "pipelined"
-    if do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank (golf_amd.dist.StagedGather)
+    peer_store = do_gather and args.gather_mode == "peer-store"
+    if peer_store:   # per slot: a ring of receive buffers on every rank, filled by the peers' stores
+        from golf_amd.dist import PeerStoreGather
+
+        GE = 1
+        stagers = [PeerStoreGather(B, t_out, depth=4, device=device) for _ in range(S)]
+    elif do_gather:  # per slot: GE staged steps -> one collective of GE*B rows per rank (golf_amd.dist.StagedGather)
         from golf_amd.dist import StagedGather
 
         stagers = [StagedGather(B, t_out, GE, device, world=world) for _ in range(S)]
@@ -587,8 +595,9 @@ def main():
         if world > 1:
             result["exchange"] = {"backend": args.dist_backend, "world_size": world,
                                   "bytes_in_per_rank_per_step": int((world - 1) * B * t_out * 4) if do_gather else 0,
-                                  "bytes_per_collective_per_rank": int(GE * B * t_out * 4) if do_gather else 0,
-                                  "collectives_per_step": (1.0 / GE) if do_gather else 0.0}
+                                  "bytes_per_collective_per_rank": int(GE * B * t_out * 4) if do_gather and not peer_store else 0,
+                                  "collectives_per_step": (1.0 / GE) if do_gather and not peer_store else 0.0,
+                                  "mode": args.gather_mode if do_gather else "none"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(B, 240, 22)
@@ -600,6 +609,9 @@ def main():
         import torch.distributed as dist
 
         dist.barrier()  # ranks > 0 wait for rank 0's profiling pass before tearing the communicator down
+        if peer_store:
+            for st in stagers:
+                st.close()
         dist.destroy_process_group()
 
 

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgolf_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip", "ctrl.hip", "noise_band.hip")
+SOURCES = ("abi.hip", "lpc_ss.hip", "lpc_ff.hip", "glottal_osc.hip", "noise_fir.hip", "ctrl.hip", "noise_band.hip", "peer.hip")
 
 _c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -89,6 +89,14 @@ SIGNATURES = {
     "golf_lti_fir_taps_grad_workspace_bytes": (_sz, [_int] * 3),
     "golf_lti_fir_taps_grad_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _int, _vp, _sz,
                                           _vp]),
+    "golf_peer_alloc": (_int, [_sz, _vp]),
+    "golf_peer_free": (_int, [_vp]),
+    "golf_peer_export": (_int, [_vp, _vp]),
+    "golf_peer_open": (_int, [_vp, _vp]),
+    "golf_peer_close": (_int, [_vp]),
+    "golf_peer_store_f32": (_int, [_c_f32p, _i64, _int, _int, _vp, _i64, _int, _vp]),
+    "golf_peer_signal_u32": (_int, [_vp, _int, ctypes.c_uint32, _vp]),
+    "golf_peer_wait_u32": (_int, [_vp, _int, _int, ctypes.c_uint32, _i64, _vp, _vp]),
 }
 
 ABI_VERSION = 2

@@ -10,7 +10,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-__all__ = ["shard_bounds", "shard_inputs", "gather_audio", "gather_audio_async", "synth_sharded", "StagedGather"]
+__all__ = ["shard_bounds", "shard_inputs", "gather_audio", "gather_audio_async", "synth_sharded", "StagedGather",
+           "PeerStoreGather"]
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int, int]:
@@ -159,3 +160,169 @@ class StagedGather:
         a full group, fewer for the partial group a flush sent)."""
         k = self.every if steps is None else steps
         return self.recv[i][: self.world * k * self.rows].view(self.world, k, self.rows, self.T)
+
+
+class _DeviceView:
+    """Raw device memory as a tensor (torch.as_tensor reads __cuda_array_interface__): the buffers of PeerStoreGather
+    are allocated / IPC-mapped by libgolf_hip.so, not by torch's allocator."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class PeerStoreGather:
+    """The audio exchange as peer-to-peer stores over xGMI instead of an all-gather (flag-gated alternative to
+    StagedGather / gather_audio; include/golf_amd.h golf_peer_*).
+
+    Every rank owns a receive buffer (depth, world, rows, T) and a flag array, both fine-grained device memory exported
+    through HIP IPC and mapped by every other rank of the node.  ``push(y)`` -- on the current stream, no host
+    synchronisation --
+      1. waits until every peer has released the slot this step is about to overwrite (their acknowledgement flags),
+      2. stores the (rows, T) block into slot [step % depth, rank] of EVERY rank's buffer with one kernel (source read
+         once; xGMI is point to point, so the world-1 remote stores run on world-1 different links at once),
+      3. publishes the step's sequence number into each rank's flag array (system-scope release after the stores).
+    ``wait()`` blocks the stream until the oldest outstanding step has arrived from every rank and returns it as a
+    (world, rows, T) view of the local buffer; ``release()`` hands the slot back (acknowledgement to every rank).
+    ``push`` consumes-and-releases the oldest step by itself when ``depth`` steps are outstanding, so a producer loop
+    that never looks at the data (bench.py) cannot overrun; ``flush()`` drains.  Waits are bounded (``timeout_s``): a
+    missing peer raises at the next ``check()`` / ``flush()`` instead of hanging the GPU.
+
+    Needs one process per GPU on ONE node, an initialised process group (any backend: it only carries the 64-byte IPC
+    handles, once) and HSA_ENABLE_IPC_MODE_LEGACY=0.  Exercised with two processes sharing one GPU
+    (tests/test_gpu_peer.py); not yet measured across GPUs."""
+
+    def __init__(self, rows: int, T: int, depth: int = 4, device=None, timeout_s: float = 20.0):
+        import ctypes
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        assert dist.is_initialized(), "PeerStoreGather needs an initialised process group"
+        self.lib = _lib.load()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert self.world <= 16, "at most GOLF_MAX_PEERS = 16 ranks"
+        self.rows, self.T, self.depth = int(rows), int(T), max(1, int(depth))
+        self.device = torch.device(device if device is not None else "cuda")
+        self.timeout_us = int(timeout_s * 1e6)
+        W, D = self.world, self.depth
+        self.slot_elems = self.rows * self.T
+        data_bytes = 4 * D * W * self.slot_elems
+        # flags: [0, D*W) data-arrived sequence numbers (slot, source); [D*W, 2*D*W) slot-released ones (slot, consumer)
+        flag_bytes = 4 * 2 * D * W
+        with torch.cuda.device(self.device):
+            self._local = []
+            for nbytes in (data_bytes, flag_bytes):
+                p = ctypes.c_void_p()
+                _lib.check(self.lib.golf_peer_alloc(nbytes, ctypes.byref(p)), "golf_peer_alloc")
+                self._local.append(p.value)
+            handles = []
+            for ptr in self._local:
+                h = ctypes.create_string_buffer(64)
+                _lib.check(self.lib.golf_peer_export(ptr, h), "golf_peer_export")
+                handles.append(h.raw)
+            everyone = [None] * W
+            dist.all_gather_object(everyone, handles)
+            self._data, self._flags, self._opened = [None] * W, [None] * W, []
+            for r in range(W):
+                if r == self.rank:
+                    self._data[r], self._flags[r] = self._local
+                    continue
+                mapped = []
+                for raw in everyone[r]:
+                    p = ctypes.c_void_p()
+                    _lib.check(self.lib.golf_peer_open(raw, ctypes.byref(p)), "golf_peer_open")
+                    mapped.append(p.value)
+                    self._opened.append(p.value)
+                self._data[r], self._flags[r] = mapped
+        self.recv = torch.as_tensor(_DeviceView(self._local[0], (D, W, self.rows, self.T), "<f4"), device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.pushed = 0       # steps pushed so far; step k uses slot k % depth and sequence number k + 1
+        self.consumed = 0     # steps waited for
+        self.released = 0     # steps released
+        self._PtrArray = ctypes.c_void_p * W
+        dist.barrier()        # every rank has mapped every buffer before the first store
+
+    # ---- addresses ----------------------------------------------------------------------------
+    def _flag_addr(self, owner: int, kind: int, slot: int, who: int) -> int:
+        return self._flags[owner] + 4 * ((kind * self.depth + slot) * self.world + who)
+
+    @property
+    def bytes_out_per_step(self) -> int:
+        """Bytes this rank stores into OTHER ranks' memory per step."""
+        return 4 * self.slot_elems * (self.world - 1)
+
+    # ---- protocol -----------------------------------------------------------------------------
+    def push(self, y: torch.Tensor) -> None:
+        from . import _lib
+
+        assert y.shape == (self.rows, self.T) and y.dtype == torch.float32 and y.stride(1) == 1
+        if self.pushed - self.released >= self.depth:      # the ring is full: consume the oldest step ourselves
+            if self.consumed == self.released:
+                self.wait()
+            self.release()
+        k, W = self.pushed, self.world
+        slot, stream = k % self.depth, _lib.stream_ptr()
+        if k >= self.depth:   # every rank has released what it received in this slot `depth` steps ago
+            _lib.check(self.lib.golf_peer_wait_u32(self._flag_addr(self.rank, 1, slot, 0), W, 1, k - self.depth + 1,
+                                                   self.timeout_us, self.status.data_ptr(), stream), "golf_peer_wait_u32")
+        dst = self._PtrArray(*[self._data[r] + 4 * (slot * W + self.rank) * self.slot_elems for r in range(W)])
+        _lib.check(self.lib.golf_peer_store_f32(y.data_ptr(), y.stride(0), self.rows, self.T, dst, self.T, W, stream),
+                   "golf_peer_store_f32")
+        flags = self._PtrArray(*[self._flag_addr(r, 0, slot, self.rank) for r in range(W)])
+        _lib.check(self.lib.golf_peer_signal_u32(flags, W, k + 1, stream), "golf_peer_signal_u32")
+        self.pushed += 1
+
+    def wait(self) -> torch.Tensor:
+        """Block the current stream until the oldest un-waited step is here from every rank; (world, rows, T) view."""
+        from . import _lib
+
+        assert self.consumed < self.pushed, "nothing outstanding"
+        k = self.consumed
+        slot = k % self.depth
+        _lib.check(self.lib.golf_peer_wait_u32(self._flag_addr(self.rank, 0, slot, 0), self.world, 1, k + 1,
+                                               self.timeout_us, self.status.data_ptr(), _lib.stream_ptr()),
+                   "golf_peer_wait_u32")
+        self.consumed += 1
+        return self.recv[slot]
+
+    def release(self) -> None:
+        """The oldest waited-for step has been read: its slot may be overwritten (acknowledgement to every rank)."""
+        from . import _lib
+
+        assert self.released < self.consumed, "release() follows wait()"
+        k = self.released
+        slot = k % self.depth
+        flags = self._PtrArray(*[self._flag_addr(r, 1, slot, self.rank) for r in range(self.world)])
+        _lib.check(self.lib.golf_peer_signal_u32(flags, self.world, k + 1, _lib.stream_ptr()), "golf_peer_signal_u32")
+        self.released += 1
+
+    def flush(self) -> None:
+        """Wait for and release everything outstanding, then check that no wait timed out (synchronises the stream)."""
+        while self.released < self.pushed:
+            if self.consumed == self.released:
+                self.wait()
+            self.release()
+        self.check()
+
+    def check(self) -> None:
+        st = int(self.status.item())
+        if st:
+            raise RuntimeError(f"PeerStoreGather: rank {self.rank} timed out waiting for rank {st - 1} "
+                               f"(pushed {self.pushed}, consumed {self.consumed})")
+
+    def close(self) -> None:
+        """Unmap the peers' buffers and free the local ones (all ranks, after a barrier: nobody stores any more)."""
+        import torch.distributed as dist
+
+        torch.cuda.synchronize(self.device)
+        dist.barrier()
+        self.recv = None
+        for p in self._opened:
+            self.lib.golf_peer_close(p)
+        self._opened = []
+        dist.barrier()
+        for p in self._local:
+            self.lib.golf_peer_free(p)
+        self._local = []

@@ -343,6 +343,36 @@ int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_stride, cons
                                   const float* hscale, int H, float* g_amp, int B, int Tout,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (e) multi-GPU: push-based exchange of the synthesised audio (north_star: "shards independent utterances across the 8
+ * MI355X ... all-gathering only the synthesized audio").  The reference has no counterpart (it is single-device:
+ * autoencode.py / test_rtf.py); what these replace is the torch.distributed.all_gather_into_tensor that
+ * golf_amd.dist.gather_audio issues.  xGMI is point to point, so instead of a ring collective ONE kernel stores a
+ * step's (rows, T) block into every peer's receive buffer (7 links at once, source read once), then publishes a
+ * sequence number with system scope; the consumer waits for it in-stream.
+ *   golf_peer_alloc     fine-grained device memory, zero-filled (receive buffers and flags: pollable while kernels run)
+ *   golf_peer_export    -> GOLF_PEER_HANDLE_BYTES opaque bytes (hipIpcMemHandle_t) to send to the other processes
+ *   golf_peer_open/close   map / unmap another process's buffer
+ *   golf_peer_store_f32    src (rows, T) -> dst[i] (rows, T) for i < n_dst <= GOLF_MAX_PEERS; dst = HOST array of device
+ *                          pointers (already offset to this rank's slot in each peer's buffer)
+ *   golf_peer_signal_u32   *flags[i] = seq for i < n (release, system scope; ordered after this stream's stores)
+ *   golf_peer_wait_u32     blocks the STREAM until flags[i*stride] >= seq for all i < n (signed distance: sequence numbers
+ *                          may wrap), or sets *status (device int) to 1 + i after timeout_us -- never hangs the GPU
+ * Used by golf_amd.dist.PeerStoreGather (bench.py --gather-mode peer-store).  Exercised with 2 processes on one GPU;
+ * not yet measured on a multi-GPU node -- RCCL's all-gather remains the default exchange. */
+#define GOLF_MAX_PEERS 16
+#define GOLF_PEER_HANDLE_BYTES 64
+int golf_peer_alloc(size_t bytes, void** ptr);
+int golf_peer_free(void* ptr);
+int golf_peer_export(void* ptr, void* handle64);
+int golf_peer_open(const void* handle64, void** ptr);
+int golf_peer_close(void* ptr);
+int golf_peer_store_f32(const float* src, int64_t src_stride, int rows, int T, void* const* dst, int64_t dst_stride,
+                        int n_dst, void* stream);
+int golf_peer_signal_u32(void* const* flags, int n, uint32_t seq, void* stream);
+int golf_peer_wait_u32(const uint32_t* flags, int n, int stride, uint32_t seq, int64_t timeout_us, int* status,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
