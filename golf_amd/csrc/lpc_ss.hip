@@ -128,7 +128,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
 //   MODE 0 (P1z): zero initial state, chunks c < NCQ=NP, final state -> out[(b*NCQ+c)*W + i]
 //   MODE 1 (P3) : initial state S[(b*NCS+c)*64 + i], writes y[b][t]
 //   MODE 2      : initial state S[(b*NCS+c)*64 + i], chunks c < NCQ=NP, final state -> out (refinement sweep)
-//   MODE 3      : as MODE 2 but the defect alone;  MODE 4: as MODE 1 from S + zin (the corrected states)
+//   MODE 3      : as MODE 2 but the defect alone, start states and defects in LDS (two-level scan, LS = true)
 // The body is a device function of ONE wave (its LDS tiles are passed in, its only synchronisation is the wave-level
 // LDS fence) so that it can also run as one of the four independent waves of lpc_p1fz_kernel's workgroups.
 template <int W, int NT, int MODE, bool LS = false>
@@ -142,7 +142,8 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     // lst (two-level scan): the chunk start states of this wave's 16 chunks (+ the next one) in LDS, row stride 32,
     // instead of the scanned states S in HBM; ldl: the defects of MODE 3 are also left in LDS ([16][32])
     constexpr int TPL = quad_tpl(W, NT);
-    constexpr bool WY = MODE == 1 || MODE == 4;   // the passes that write y
+    constexpr bool WY = MODE == 1;   // the pass that writes y
+    static_assert(MODE >= 0 && MODE <= 3 && (MODE != 3 || LS), "MODE 3 exists only with LDS-resident start states");
     constexpr int R = 16;
     using TL = Tile<W, R>;
     const int lq = lane / W, lr = lane % W;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     const BufRow xrow(ex + (size_t)b * ex_stride, T);
     const BufRow yrow(WY ? out + (size_t)b * y_stride : nullptr, WY ? T : 0);
     float w[TPL];
-    if (MODE >= 1 && mine) {   // MODE 1, 2, 3, 4 start from the scanned state (MODE 4: plus its correction zin)
+    if (MODE >= 1 && mine) {   // MODE 1, 2, 3 start from the scanned state
         if constexpr (LS) {   // (LDS and HBM pointers are kept in separate code paths: no pointer selects)
 #pragma unroll
             for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = lst[row * 32 + r * TPL + k];
@@ -161,11 +162,6 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
             const float* sp = S + ((size_t)b * NCS + c) * 64 + r * TPL;
 #pragma unroll
             for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] = sp[k];
-        }
-        if (MODE == 4) {
-            const float* dp = zin + ((size_t)b * NCS + c) * 64 + r * TPL;
-#pragma unroll
-            for (int k = 0; k < TPL; ++k) w[TPL - 1 - k] += dp[k];
         }
     } else {
 #pragma unroll
@@ -260,11 +256,9 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 if (MODE == 2) v += zin[((size_t)b * NCQ + c) * W + i] - S[((size_t)b * NCS + c + 1) * 64 + i];
                 // MODE 3: the defect alone (two-level scan: the second scan propagates only the correction, so that
                 // the rounding of the group composites acts on a quantity that is already second order)
-                if constexpr (MODE == 3 && LS) {
+                if constexpr (MODE == 3) {
                     v -= lst[(row + 1) * 32 + i];
                     ldl[row * 32 + i] = v;
-                } else if constexpr (MODE == 3) {
-                    v -= S[((size_t)b * NCS + c + 1) * 64 + i];
                 }
                 zp[i] = v;
             }
@@ -280,7 +274,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
                                                       int NCS, const float* __restrict__ zin) {
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
-    __shared__ float yt[(MODE == 1 || MODE == 4) ? TL::SIZE : 1];
+    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
     fwdq_body<W, NT, MODE>(ex, ex_stride, gain, a, S, out, y_stride, T, F, M, hop, L, NCQ, NCS, zin, xt, yt,
                            blockIdx.y, blockIdx.x, threadIdx.x);
 }
