@@ -1603,10 +1603,35 @@ __global__ __launch_bounds__(64) void lpc_inverse_bwd_a_kernel(const float* __re
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
+// CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
+static int device_cu_count() {
+    constexpr int kMaxDev = 16;
+    static int cache[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
+// The two-level boundary scan buys latency with (utterance x group) waves whose prologues hold a SIMD's registers
+// (one wave per SIMD).  Measured with 4 batches in flight / one batch alone, two-level vs flat, us per step:
+//   B = 32: 71.5 vs 70.1 / 136 vs 163;  B = 48: 105 vs 96 / 191 vs 212;  B = 64: 134 vs 117 / 205 vs 227;
+//   B = 96: 204 vs 166 / 300 vs 286;  B = 256: 537 vs 437 / 629 vs 515
+// so it is taken while B x NG stays below half the SIMD count (B <= 39 at 2 s), where it costs the pipelined rate ~2 %.
+static bool use_two_level_scan(const SsPlan& p, int B, int flags) {
+    static const long env = [] { const char* e = getenv("GOLF_SS_TWO_LEVEL_WAVES"); return e ? atol(e) : 0L; }();   // dev knob
+    const int64_t cap = env > 0 ? (int64_t)env : (int64_t)2 * device_cu_count();
+    return p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN) && (int64_t)B * p.NG <= cap;
+}
+
 template <int W, int NT>
 static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStream_t st) {
     if constexpr (NT <= 24) {
-        if (p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN)) {   // two-level boundary scan: the group composites need only Phi
+        if (use_two_level_scan(p, B, flags)) {   // two-level boundary scan: the group composites need only Phi
             const int nu = p.NG * B;
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
@@ -1649,20 +1674,6 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
                        (const float*)Phi, PhiT, nq);
     GOLF_LAUNCH_CHECK();
     return launch_composites<W, NT>(p, B, ws, flags, st);
-}
-
-// CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
-static int device_cu_count() {
-    constexpr int kMaxDev = 16;
-    static int cache[kMaxDev] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
-    if (cache[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        cache[dev] = n;
-    }
-    return cache[dev];
 }
 
 // Fork/join helper: `side` runs P1h (needs only `a`) while `st` runs P1z (needs the excitation).
@@ -1749,7 +1760,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     if constexpr (NT <= 24) {
-        if (p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN)) {   // two-level boundary scan (see the kernels above)
+        if (use_two_level_scan(p, B, flags)) {   // two-level boundary scan (see the kernels above)
             float* MT = (float*)(ws + p.off_mt);
             float* Vz = (float*)(ws + p.off_gv);                    // [b][NG][32] zero-state group responses
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects

@@ -87,7 +87,8 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
 #define GOLF_SS_SERIAL 8
 #define GOLF_SS_CHUNKED 16
 /*          GOLF_SS_FLAT_SCAN  chunk-boundary states by the flat scan (one wave per utterance, NP dependent matvecs)
- *                instead of the two-level scan that long utterances with M <= 24 take by default (group composites as
+ *                instead of the two-level scan that long utterances with M <= 24 take by default while the batch is
+ *                small (utterances x groups of 16 chunks <= 2 x the CU count: B <= 39 at 2 s; group composites as
  *                exact-fp32 MFMA product chains + per-group scans spread over the chip + start states derived in the
  *                chunk kernels): an A/B switch; the two give the same states up to fp32 rounding. */
 #define GOLF_SS_FLAT_SCAN 32
