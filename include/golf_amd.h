@@ -64,6 +64,9 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  * most expensive phase.  golf_ltv_allpole_transitions_f32 computes them into `ws` on its own, so a caller that
  * knows `a` before `ex` exists can start it early (optionally on a second HIP stream) or reuse it for several
  * excitations, and then pass GOLF_SS_HAVE_TRANSITIONS to the forward.
+ *   The transitions call also prepares what the forward's boundary scan derives from the matrices alone (the group
+ *   composites of the two-level scan): give BOTH calls the same algorithm flags (GOLF_SS_CHUNKED / _FLAT_SCAN / _FAST_...),
+ *   and size `ws` with golf_ltv_allpole_workspace_bytes_ex for those flags.
  *   flags  GOLF_SS_HAVE_TRANSITIONS  `ws` already holds the transitions for (a,B,T,F,M,hop)
  *          GOLF_SS_FAST_TRANSITIONS  inference mode: transition matrices from fp32 instead of fp64 trajectories
  *                (about 4x cheaper) and the forward runs one refinement sweep over the chunk boundary states
