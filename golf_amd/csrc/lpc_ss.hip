@@ -102,7 +102,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
-    // composite product's 32 x 32 MFMA tile holds up to 24 state components
+    // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
     p->GS = 0;
     p->off_mt = p->off_gv = o;
@@ -897,55 +897,138 @@ __device__ __forceinline__ float matvec_step(const float4* rw, float s, float ad
     return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
 }
 
+// Composite map of a group, M_g = Phi_{c1-1} ... Phi_{c0}, accumulated in DOUBLE precision on the matrix pipe.
+// Why not fp32 (round 2 first built this as an exact-fp32 MFMA product chain, 4.8 us): the entries of a companion-form
+// transition matrix cancel heavily in products (consecutive samples are almost collinear states), so an fp32 chain of 16
+// products comes out with ~1e-4 relative error for benign filters and ~1e-2 when poles sit at radius 0.9999 (first
+// reflection coefficient ~0.98: ordinary voiced speech).  The flat scan never forms products -- it applies Phi_c to actual
+// states, at rounding level -- and a refinement sweep cannot repair a coarse propagator whose error times the
+// dynamics' error growth is of order one: boundary-state error 1.3 (!) instead of 6e-3 on such an utterance, 8e-8 on
+// both for a benign one (numpy emulation; tests/test_gpu_lpc_ss.py::test_ill_conditioned_rows).  With the products
+// accumulated in fp64 and rounded ONCE to fp32 the two-level scan is as accurate as the flat one (3.7e-3 vs 5.9e-3).
+// (A VALU version -- v_fma_f64, maps staged in LDS as doubles, columns split over 2 / 4 / 8 waves -- took 20.6 / 19.2 /
+// 28.6 us for the pre-pass: ~240 dependent-issue instructions per product per wave.)
+// v_mfma_f64_16x16x4_f64: the state space is padded to NTL x 16 (NTL = 1 or 2 tiles).  The columns of M_g are
+// independent, so a wave owns ONE column tile jt and both row tiles: per product NTL x NTL x 4 MFMAs, no exchange with
+// any other wave.  The running product never leaves the accumulators.  D: lane (kq = l / 16, n = l % 16), register v ->
+// tile position p = kq + 4 v (probed on the hardware, tools/ubench/mfma_f64_layout.hip; the f32 16x16x4 instruction has
+// 4 kq + v).  Used as the B operand of K-step s = v, lane kq contributes position kq + 4 s -- so if position p holds state
+// component rho(p) = 4 (p % 4) + p / 4 (a 4 x 4 transpose of the tile's 16 indices), the A operand of step s is column
+// rho(kq + 4 s) = 4 kq + s: element s of ONE contiguous float4 of the lane's row, and the lane's row is rho(m).
+// The permutation costs nothing: it is address arithmetic on the A rows, the identity start and the final store.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <int W, int NT>
-__device__ __forceinline__ void group_composite_body(const float* __restrict__ PhiT, float* __restrict__ MT, int NP,
-                                                     int NG, int b, int g, int lane) {
-    static_assert(NT <= 24, "the 12 K-steps of the product cover state components 0..23");
-    const int n = lane & 31, kh = lane >> 5;
+struct CompGeom {
+    static constexpr int NTL = NT > 16 ? 2 : 1;   // 16-wide tiles of the (padded) state space = waves per group
+    static constexpr int KW = NTL;
+};
+// One product step P <- Phi . P on the matrix pipe; A fragments fr[it][kt] as fetched by comp_fetch / read from LDS.
+template <int NT, int NTL, typename AV>
+__device__ __forceinline__ void comp_product(const AV (&fr)[NTL][NTL], f64x4 (&P)[NTL]) {
+    // one accumulator per (row tile, K tile): NTL x NTL independent chains of 4 MFMAs (a dependent f64 MFMA waits for its
+    // predecessor: two chains of 8 measured ~190 cycles per instruction, four chains of 4 ~130)
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    f64x4 Dn[NTL][NTL];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+        for (int it = 0; it < NTL; ++it)
+#pragma unroll
+            for (int kt = 0; kt < NTL; ++kt) {
+                if (sidx == 0) Dn[it][kt] = zero4;
+                if (16 * kt + sidx < NT)   // step s meets columns 16 kt + 4 kq + s, kq = 0..3
+                    Dn[it][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fr[it][kt][sidx], P[kt][sidx], Dn[it][kt],
+                                                                      0, 0, 0);
+            }
+#pragma unroll
+    for (int it = 0; it < NTL; ++it) {
+        P[it] = Dn[it][0];
+#pragma unroll
+        for (int kt = 1; kt < NTL; ++kt) P[it] += Dn[it][kt];
+    }
+}
+
+// The workgroup of one group: wave (jt, h) multiplies the maps of HALF the chain (h = 0: c0 .. cmid-1, h = 1: cmid ..
+// c1-1) for column tile jt -- 8 dependent products instead of 16, an f64 MFMA being ~130 cycles from one wave --; the
+// h = 1 waves leave their product P_B in LDS (doubles, padded 32 x 32), and after one workgroup barrier the h = 0 waves,
+// which still hold P_A[:, jt] in their accumulators, finish with M[:, jt] = P_B . P_A[:, jt].
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int W, int NT>
+__device__ __forceinline__ void group_composite_wg(const float* __restrict__ PhiT, float* __restrict__ MT, int NP, int NG,
+                                                   int b, int g, double* __restrict__ pb_lds /* [32][32] */) {
+    static_assert(NT <= 32 && W % 4 == 0, "two 16-wide tiles");
+    constexpr int NTL = CompGeom<W, NT>::NTL;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jt = wv & 1, h = wv >> 1;
+    const int m = lane & 15, kq = lane >> 4;
+    const int n = 16 * jt + m;                                        // this lane's column
+    const int rm = 4 * (m & 3) + (m >> 2);                            // rho(m)
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
-    f32x16 P;
+    const int cmid = c0 + kGroup / 2 < c1 ? c0 + kGroup / 2 : c1;
+    const int ca = h ? cmid : c0, cb = h ? c1 : cmid;                 // this wave's part of the chain
+    const bool live = jt < NTL;                                       // orders <= 16 have one column tile
+    f64x4 P[NTL];                                                     // P[kt][v] = P(row 16 kt + 4 kq + v, column n)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int row = 8 * (v / 4) + 4 * kh + (v % 4);
-        P[v] = (row == n && row < NT) ? 1.f : 0.f;
-    }
-    const bool rowok = n < NT;
-    const float* base = PhiT + ((size_t)b * NP * NT + (rowok ? n : 0)) * W;
-    // the whole group's row fragments are loaded up front (16 x 3 float4 per lane: a lone wave has the registers):
-    // the L2 latency is paid once instead of per product
-    float4 fr[kGroup][3];
+    for (int kt = 0; kt < NTL; ++kt)
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) {
-        const float* rp = base + (size_t)(c0 + u < c1 ? c0 + u : c1 - 1) * NT * W;
+        for (int v = 0; v < 4; ++v) P[kt][v] = (16 * kt + 4 * kq + v == n && n < NT) ? 1.0 : 0.0;   // rho(kq + 4 v)
+    if (live) {
+        const float* base = PhiT + (size_t)b * NP * NT * W;
+        // A fragments: row 16 it + rho(m), columns 16 kt + 4 kq .. + 3 of map c (zero outside the NT x W array)
+        constexpr int D = 2;                                          // maps fetched ahead (deeper rings measured slower)
+        f32x4v fr[D][NTL][NTL];
+        auto fetch = [&](int u, int c) {
+            const float* mp = base + (size_t)(c < cb ? c : (cb > ca ? cb - 1 : ca)) * NT * W;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int col = 8 * q + 4 * kh;
-            fr[u][q] = (rowok && col < NT) ? *reinterpret_cast<const float4*>(rp + (col < W ? col : 0))
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < NTL; ++it)
+#pragma unroll
+                for (int kt = 0; kt < NTL; ++kt) {
+                    const int row = 16 * it + rm, col = 16 * kt + 4 * kq;
+                    const f32x4v zf = {0.f, 0.f, 0.f, 0.f};
+                    fr[u][it][kt] = (row < NT && col < W && cb > ca)
+                                        ? *reinterpret_cast<const f32x4v*>(mp + (size_t)row * W + col) : zf;
+                }
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, ca + u);
+#pragma unroll
+        for (int k = 0; k < kGroup / 2; ++k) {
+            const int u = k % D;
+            if (ca + k < cb) {   // wave-uniform
+                comp_product<NT, NTL>(fr[u], P);
+                if (k + D < kGroup / 2) fetch(u, ca + k + D);
+            }
+        }
+        if (h == 1) {   // P_B[rho-position basis -> original row i][column n] for the final product's A operand
+#pragma unroll
+            for (int it = 0; it < NTL; ++it)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pb_lds[(16 * it + 4 * kq + v) * 32 + n] = P[it][v];
         }
     }
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (!live || h == 1) return;
+    {   // M[:, jt] = P_B . P_A[:, jt]: A fragments of P_B from LDS (row 16 it + rho(m), columns 16 kt + 4 kq .. + 3)
+        f64x4 fa[NTL][NTL];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) {
-        if (c0 + u < c1) {   // wave-uniform
-            // four independent accumulators (3 K-steps each): the 12 MFMAs of a product would otherwise form one
-            // dependent chain of 12 x 64 cycles
-            f32x16 D0 = zero16, D1 = zero16, D2 = zero16, D3 = zero16;
-#define GOLF_MM(ACC, KK) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(fr[u][(KK) / 4], (KK) % 4), P[KK], ACC, 0, 0, 0)
-            GOLF_MM(D0, 0); GOLF_MM(D1, 1); GOLF_MM(D2, 2);  GOLF_MM(D3, 3);
-            GOLF_MM(D0, 4); GOLF_MM(D1, 5); GOLF_MM(D2, 6);  GOLF_MM(D3, 7);
-            GOLF_MM(D0, 8); GOLF_MM(D1, 9); GOLF_MM(D2, 10); GOLF_MM(D3, 11);
-#undef GOLF_MM
+        for (int it = 0; it < NTL; ++it)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) P[v] = (D0[v] + D1[v]) + (D2[v] + D3[v]);
-        }
+            for (int kt = 0; kt < NTL; ++kt) {
+                const double* rp = pb_lds + (16 * it + rm) * 32 + 16 * kt + 4 * kq;
+                fa[it][kt] = *reinterpret_cast<const f64x4*>(rp);
+            }
+        comp_product<NT, NTL>(fa, P);
     }
+    // M_g[i][n] rounded once to fp32; columns NT .. W-1 of the rows (never read) are written as zeros
     float* mt = MT + ((size_t)b * NG + g) * NT * W;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int i = 8 * (v / 4) + 4 * kh + (v % 4);   // row of the composite, column n
-        if (i < NT && n < W) mt[(size_t)i * W + n] = P[v];
-    }
+    for (int it = 0; it < NTL; ++it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 16 * it + 4 * kq + v;   // rho(kq + 4 v)
+            if (i < NT && n < W) mt[(size_t)i * W + n] = n < NT ? (float)P[it][v] : 0.f;
+        }
 }
 
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
@@ -958,41 +1041,50 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* xb = x + (size_t)b * NP * W + ii;
-    float4 buf[kGroup][W / 4];   // the whole group up front, as above
-    float xc[kGroup];
-#pragma unroll
-    for (int u = 0; u < kGroup; ++u) {
-        const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
+    // a ring of D maps ahead.  Registers decide how many of the launch's workgroups are resident at once: the 416
+    // composite + 104 scan workgroups of a B = 32 launch need 3 waves per SIMD (<= 168 VGPRs), or the last scan
+    // workgroups only start when the first composites retire.
+    constexpr int D = 4;
+    float4 buf[D][W / 4];
+    float xc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c < c1 ? c : c1 - 1;
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) buf[u][k] = rows[(size_t)cl * cstride4 + k];
         xc[u] = xb[(size_t)cl * W];
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) fetch(u, c0 + u);
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u)
-        if (c0 + u < c1) s = matvec_step<W, NT>(buf[u], s, xc[u], act);   // wave-uniform
+    for (int k = 0; k < kGroup; ++k) {
+        const int u = k % D;
+        if (c0 + k < c1) s = matvec_step<W, NT>(buf[u], s, xc[u], act);   // wave-uniform
+        if (k + D < kGroup) fetch(u, c0 + k + D);
+    }
     if (i < 32) V[((size_t)b * NG + g) * 32 + i] = s;
 }
 
 // Both pre-passes of the two-level scan in ONE launch (they depend only on the transition kernel's outputs):
-// units [0, NG*B) form the group composites, units [NG*B, 2*NG*B) the groups' zero-state responses; one wave per unit,
-// four independent waves per workgroup.
+// workgroups [0, NG*B) form the group composites (4 waves cooperating on one group), the ceil(NG*B / 4) workgroups after
+// them the groups' zero-state responses (one wave per group, four independent waves per workgroup).
+//   [first, first + count) in workgroup units: everything, or only the composites (transitions prepared ahead of the
+//   excitation: golf_ltv_allpole_transitions_f32) / only the zero-state scans (the forward that picks them up).
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
                                                                 const float* __restrict__ z, float* __restrict__ MT,
                                                                 float* __restrict__ V, int NP, int NG, int B,
-                                                                int first, int count) {
-    // [first, first + count): all 2*NG*B units, or only the composites (transitions prepared ahead of the excitation:
-    // golf_ltv_allpole_transitions_f32) / only the zero-state scans (the forward that picks them up)
-    const int rel = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (rel >= count) return;   // wave-uniform; the waves of a workgroup never synchronise with each other
-    const int unit = first + rel;
-    const int lane = threadIdx.x & 63, nu = NG * B;
-    if (unit < nu) {
-        group_composite_body<W, NT>(PhiT, MT, NP, NG, unit / NG, unit % NG, lane);
-    } else if (unit < 2 * nu) {
-        const int u2 = unit - nu;
-        group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, lane);
+                                                                int first) {
+    __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
+    const int blk = first + (int)blockIdx.x, nu = NG * B;
+    if (blk < nu) {
+        // the fold of group g runs over the groups BEFORE it: the last composite is needed only when the final partial
+        // chunk opens a group of its own (NP a multiple of 16)
+        if (blk % NG == NG - 1 && NP % kGroup != 0) return;
+        group_composite_wg<W, NT>(PhiT, MT, NP, NG, blk / NG, blk % NG, pb_lds);
+    } else {
+        const int u2 = (blk - nu) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (u2 < nu) group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, threadIdx.x & 63);
     }
 }
 
@@ -1632,10 +1724,10 @@ template <int W, int NT>
 static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStream_t st) {
     if constexpr (NT <= 24) {
         if (use_two_level_scan(p, B, flags)) {   // two-level boundary scan: the group composites need only Phi
-            const int nu = p.NG * B;
-            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, st,
+            const int nu = p.NG * B;   // composite workgroups only
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)nu), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
-                               (float*)nullptr, p.NP, p.NG, B, 0, nu);
+                               (float*)nullptr, p.NP, p.NG, B, 0);
             GOLF_LAUNCH_CHECK();
         }
     }
@@ -1766,9 +1858,10 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
             float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S_{c+1} of the refinement pass
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
-            const int nu = p.NG * B, first = fused_p1 ? 0 : nu, count = fused_p1 ? 2 * nu : nu;
-            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first, count);
+            const int nu = p.NG * B, nz = (int)ceil_div(nu, 4);
+            const int first = fused_p1 ? 0 : nu, count = fused_p1 ? nu + nz : nz;   // in workgroups
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
+                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first);
             GOLF_LAUNCH_CHECK();
             if (!fast) {   // accurate (fp64-derived) transition matrices: no refinement pass
                 hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)ceil_div(p.NC, kGroup), B), dim3(64), 0, st,

@@ -373,12 +373,13 @@ def test_large_batch_defaults_to_serial_and_matches_chunked():
 
 
 @pytest.mark.parametrize("B,F,M,hop", [(3, 520, 12, 24), (2, 1500, 4, 8), (2, 800, 14, 16), (5, 60, 22, 240),
-                                       (2, 210, 20, 240)])
+                                       (2, 210, 20, 240), (2, 65, 22, 240), (3, 49, 16, 240)])
 def test_two_level_scan_shapes(B, F, M, hop):
     """Long utterances at other ring widths / orders through both forward paths with the two-level boundary scan (group
     composites as MFMA product chains, per-group scans, start states derived in the chunk kernels) and with the flat scan
     (A/B switch), plus the training path: 60 frames of hop 240 exercise a partial last group, 1500 frames of hop 8 the
-    8-wide ring."""
+    8-wide ring, 65 and 49 frames a chunk-map count that is a multiple of 16 (the final partial chunk then opens a group
+    of its own and the last composite, otherwise never formed, is needed)."""
     from oracle import golf_oracle as O
 
     ex, gain, a = smooth_case(B, F, M, hop, seed=F + M, walk=0.02 * (240 / max(hop, 24)) ** 0.5 * 0.3)
@@ -394,3 +395,81 @@ def test_two_level_scan_shapes(B, F, M, hop):
     check(res[0], ref, "training forward (two-level scan)")
     r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
     check(res[3], r_a, "g_a after a two-level forward", 2e-4)
+
+
+def _two_level_sweep_cases(n=10, seed=77):
+    rng = np.random.default_rng(seed)
+    rings = [(8, (2, 4, 6)), (16, (8, 12, 14)), (24, (8, 16, 20, 22))]
+    cases = []
+    for _ in range(n):
+        W, orders = rings[rng.integers(len(rings))]
+        M = int(orders[rng.integers(len(orders))])
+        hop = int(W * rng.integers(1, 11)) if W < 24 else int(rng.choice([24, 48, 120, 240]))
+        L = hop * (240 // hop) if hop < 240 else hop          # chunk length the library picks for these hops
+        chunks = int(rng.integers(49, 140))                   # >= 48 chunk maps: 4 .. 9 groups, the last one partial
+        T = chunks * L - int(rng.integers(0, L))              # ragged end inside the last chunk
+        F = -(-(T - 1) // hop) + 1 + int(rng.integers(0, 3))  # enough frames, sometimes more than needed
+        B = int(rng.choice([1, 2, 3, 5]))
+        cases.append((B, F, M, hop, T))
+    return cases
+
+
+@pytest.mark.parametrize("B,F,M,hop,T", _two_level_sweep_cases())
+def test_two_level_scan_random_shapes(B, F, M, hop, T):
+    """Seeded sweep across ring widths, orders, hops, group counts and ragged ends: inference path (two-level scan) and
+    the flat-scan A/B against the float64 oracle, and against each other far inside the tolerance."""
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=T, seed=T, walk=0.006 * (hop / 24) ** 0.5)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    y = run_fwd(ex, gain, a, hop, fast=True)
+    assert y.shape == ref.shape
+    check(y, ref, f"two-level B{B} F{F} M{M} hop{hop} T{T}")
+    y2 = run_mode(ex, gain, a, hop, "flat-scan")
+    check(y2, ref, f"flat B{B} F{F} M{M} hop{hop} T{T}")
+    check(y, y2, "two-level vs flat", 5e-5)
+
+
+def test_ill_conditioned_rows():
+    """Utterances whose filters sit at the edge of stability (reflection coefficients up to 0.98, pole radius 0.9999 --
+    ordinary for voiced speech) amplify every rounding error ~1e4-fold, so no fp32 path reaches 1e-4 there, the
+    reference's own sequential fp32 recursion included.  What must hold: the default path (two-level boundary scan with
+    double-precision group composites) is no worse than the arithmetic the reference uses -- the sequential fp32
+    recursion (serial kernels) -- by more than a small factor, on every row, and equally accurate on the benign rows.
+    (With fp32 composite products this test fails by two orders of magnitude on rows 10 and 31.)"""
+    from oracle import golf_oracle as O
+
+    B, F, M, hop = 32, 200, 22, 240
+    ex, gain, a = smooth_case(48, F, M, hop, seed=40)          # seed 40: rows 10 and 31 are the hard ones
+    ex, gain, a = ex[:B], gain[:B], a[:B]
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    scale = np.abs(ref).max(1)
+
+    def row_err(y):
+        return np.abs(y - ref).max(1) / scale
+
+    e_seq = row_err(run_mode(ex, gain, a, hop, "serial"))      # sequential fp32: the reference's arithmetic
+    e_two = row_err(run_fwd(ex, gain, a, hop, fast=True))      # default inference path (two-level scan at B = 32)
+    e_flat = row_err(run_mode(ex, gain, a, hop, "flat-scan"))
+    e_acc = row_err(run_fwd(ex, gain, a, hop, fast=False))     # fp64 transitions, two-level, no refinement
+    hard = np.nonzero(e_seq > 1e-4)[0]
+    print("hard rows", hard, "sequential", e_seq[hard], "two-level", e_two[hard], "flat", e_flat[hard], "fp64-Phi", e_acc[hard])
+    assert len(hard) >= 1, "the case is supposed to contain ill-conditioned rows"
+    benign = np.nonzero(e_seq <= 5e-6)[0]                      # rows without error growth: the usual 1e-4 bar, easily
+    assert len(benign) >= 16
+    for name, e in (("two-level", e_two), ("flat", e_flat), ("fp64 transitions", e_acc)):
+        assert e[benign].max() <= 1e-4, (name, e[benign].max())
+        assert np.all(e <= 20 * e_seq + 2e-5), (name, np.nonzero(e > 20 * e_seq + 2e-5)[0], e.max())
+
+
+def test_two_level_switch_point_by_batch():
+    """The library takes the two-level scan while utterances x groups <= 2 x the CU count and the flat scan beyond:
+    batches on both sides of the switch (B = 39 / 40 at 13 groups on 256 CUs) agree with the oracle row by row."""
+    from oracle import golf_oracle as O
+
+    F, M, hop = 200, 22, 240
+    ex, gain, a = smooth_case(40, F, M, hop, seed=3, walk=0.01)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    for B in (39, 40):
+        y = run_fwd(ex[:B], gain[:B], a[:B], hop, fast=True)
+        check(y, ref[:B], f"B={B} at the two-level / flat switch")
