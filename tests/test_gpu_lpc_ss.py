@@ -373,13 +373,15 @@ def test_large_batch_defaults_to_serial_and_matches_chunked():
 
 
 @pytest.mark.parametrize("B,F,M,hop", [(3, 520, 12, 24), (2, 1500, 4, 8), (2, 800, 14, 16), (5, 60, 22, 240),
-                                       (2, 210, 20, 240), (2, 65, 22, 240), (3, 49, 16, 240)])
+                                       (2, 210, 20, 240), (2, 65, 22, 240), (3, 49, 16, 240), (2, 60, 22, 256),
+                                       (2, 400, 22, 40), (2, 80, 16, 160)])
 def test_two_level_scan_shapes(B, F, M, hop):
     """Long utterances at other ring widths / orders through both forward paths with the two-level boundary scan (group
     composites as MFMA product chains, per-group scans, start states derived in the chunk kernels) and with the flat scan
     (A/B switch), plus the training path: 60 frames of hop 240 exercise a partial last group, 1500 frames of hop 8 the
     8-wide ring, 65 and 49 frames a chunk-map count that is a multiple of 16 (the final partial chunk then opens a group
-    of its own and the last composite, otherwise never formed, is needed)."""
+    of its own and the last composite, otherwise never formed, is needed); hops 256 / 40 / 160 select the 32- and 40-wide
+    rings (row strides other than 24 in every map access)."""
     from oracle import golf_oracle as O
 
     ex, gain, a = smooth_case(B, F, M, hop, seed=F + M, walk=0.02 * (240 / max(hop, 24)) ** 0.5 * 0.3)
