@@ -464,6 +464,35 @@ def test_ill_conditioned_rows():
         assert np.all(e <= 20 * e_seq + 2e-5), (name, np.nonzero(e > 20 * e_seq + 2e-5)[0], e.max())
 
 
+def test_ill_conditioned_rows_backward():
+    """The same utterances through the custom backward: the chunked adjoint (fp64 transitions, flat adjoint scan) against
+    the sequential adjoint of the serial kernels -- the arithmetic of a plain fp32 reverse recursion -- both measured
+    against the float64 oracle, row by row."""
+    from oracle import golf_oracle as O
+
+    B, F, M, hop = 32, 200, 22, 240
+    ex, gain, a = smooth_case(48, F, M, hop, seed=40)
+    ex, gain, a = ex[:B], gain[:B], a[:B]
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    gy = (np.random.default_rng(1).normal(0, 1, ref.shape) / np.abs(ref).max(1, keepdims=True)).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+
+    def errs(res):
+        _, g_ex, g_gain, g_a = res
+        e1 = np.abs(g_ex[:, : r_ex.shape[1]] - r_ex).max(1) / (np.abs(r_ex).max(1) + 1e-30)
+        e2 = np.abs(g_gain - r_gain).max(1) / (np.abs(r_gain).max(1) + 1e-30)
+        e3 = np.abs(g_a - r_a).reshape(B, -1).max(1) / (np.abs(r_a).reshape(B, -1).max(1) + 1e-30)
+        return np.maximum(np.maximum(e1, e2), e3)
+
+    e_seq = errs(run_mode(ex, gain, a, hop, "serial", gy))
+    e_chk = errs(run_mode(ex, gain, a, hop, None, gy))
+    hard = np.nonzero(e_seq > 2e-4)[0]
+    print("hard rows", hard, "sequential", e_seq[hard], "chunked", e_chk[hard], "| benign max", e_chk[e_seq <= 2e-5].max())
+    # (measured: 1.3e-2 against 5.7e-4 on the one hard row -- its forward output, 3.7e-3 off, enters the correlations --
+    #  and 1.5e-5 on the benign rows)
+    assert np.all(e_chk <= 40 * e_seq + 2e-4), (np.nonzero(e_chk > 40 * e_seq + 2e-4)[0], e_chk.max())
+
+
 def test_two_level_switch_point_by_batch():
     """The library takes the two-level scan while utterances x groups <= 2 x the CU count and the flat scan beyond:
     batches on both sides of the switch (B = 39 / 40 at 13 groups on 256 CUs) agree with the oracle row by row."""
