@@ -912,9 +912,11 @@ __device__ __forceinline__ float matvec_step(const float4* rw, float s, float ad
 // independent, so a wave owns ONE column tile jt and both row tiles: per product NTL x NTL x 4 MFMAs, no exchange with
 // any other wave.  The running product never leaves the accumulators.  D: lane (kq = l / 16, n = l % 16), register v ->
 // tile position p = kq + 4 v (probed on the hardware, tools/ubench/mfma_f64_layout.hip; the f32 16x16x4 instruction has
-// 4 kq + v).  Used as the B operand of K-step s = v, lane kq contributes position kq + 4 s -- so if position p holds state
-// component rho(p) = 4 (p % 4) + p / 4 (a 4 x 4 transpose of the tile's 16 indices), the A operand of step s is column
-// rho(kq + 4 s) = 4 kq + s: element s of ONE contiguous float4 of the lane's row, and the lane's row is rho(m).
+// 4 kq + v).  Used as the B operand of K-step s = v, lane kq contributes position kq + 4 s -- so the tile's 16 positions
+// may hold the state components in any fixed order rho, as long as the A operand of step s is column rho(kq + 4 s) of row
+// rho(m).  rho(kq + 4 s) = 8 (s / 2) + 2 kq + s % 2: steps 0, 1 cover components 0..7 of the tile and steps 2, 3
+// components 8..15 -- for the second K tile of a 22-component state (components 16..21) steps 2 and 3 meet only padding
+// and are skipped (12 MFMAs per product instead of 16), and the A operand is two contiguous float2 of the lane's row.
 // The permutation costs nothing: it is address arithmetic on the A rows, the identity start and the final store.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <int W, int NT>
@@ -936,7 +938,7 @@ __device__ __forceinline__ void comp_product(const AV (&fr)[NTL][NTL], f64x4 (&P
 #pragma unroll
             for (int kt = 0; kt < NTL; ++kt) {
                 if (sidx == 0) Dn[it][kt] = zero4;
-                if (16 * kt + sidx < NT)   // step s meets columns 16 kt + 4 kq + s, kq = 0..3
+                if (16 * kt + 8 * (sidx / 2) + sidx % 2 < NT)   // step s meets columns 16 kt + 8 (s / 2) + 2 kq + s % 2
                     Dn[it][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fr[it][kt][sidx], P[kt][sidx], Dn[it][kt],
                                                                       0, 0, 0);
             }
@@ -963,19 +965,21 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
     const int jt = wv & 1, h = wv >> 1;
     const int m = lane & 15, kq = lane >> 4;
     const int n = 16 * jt + m;                                        // this lane's column
-    const int rm = 4 * (m & 3) + (m >> 2);                            // rho(m)
+    const int rm = 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1);       // rho(m), m = kq' + 4 s'
+    const int rq = 2 * kq;                                            // rho(kq + 4 v) = 8 (v / 2) + rq + v % 2
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     const int cmid = c0 + kGroup / 2 < c1 ? c0 + kGroup / 2 : c1;
     const int ca = h ? cmid : c0, cb = h ? c1 : cmid;                 // this wave's part of the chain
     const bool live = jt < NTL;                                       // orders <= 16 have one column tile
-    f64x4 P[NTL];                                                     // P[kt][v] = P(row 16 kt + 4 kq + v, column n)
+    f64x4 P[NTL];                                                     // P[kt][v] = P(row 16 kt + rho(kq + 4 v), column n)
 #pragma unroll
     for (int kt = 0; kt < NTL; ++kt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) P[kt][v] = (16 * kt + 4 * kq + v == n && n < NT) ? 1.0 : 0.0;   // rho(kq + 4 v)
+        for (int v = 0; v < 4; ++v) P[kt][v] = (16 * kt + 8 * (v / 2) + rq + v % 2 == n && n < NT) ? 1.0 : 0.0;
     if (live) {
         const float* base = PhiT + (size_t)b * NP * NT * W;
-        // A fragments: row 16 it + rho(m), columns 16 kt + 4 kq .. + 3 of map c (zero outside the NT x W array)
+        // A fragments: row 16 it + rho(m), columns 16 kt + 2 kq + {0, 1} and 16 kt + 8 + 2 kq + {0, 1} of map c (zero
+        // outside the NT x W array)
         constexpr int D = 2;                                          // maps fetched ahead (deeper rings measured slower)
         f32x4v fr[D][NTL][NTL];
         auto fetch = [&](int u, int c) {
@@ -984,10 +988,13 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
             for (int it = 0; it < NTL; ++it)
 #pragma unroll
                 for (int kt = 0; kt < NTL; ++kt) {
-                    const int row = 16 * it + rm, col = 16 * kt + 4 * kq;
-                    const f32x4v zf = {0.f, 0.f, 0.f, 0.f};
-                    fr[u][it][kt] = (row < NT && col < W && cb > ca)
-                                        ? *reinterpret_cast<const f32x4v*>(mp + (size_t)row * W + col) : zf;
+                    const int row = 16 * it + rm, col = 16 * kt + rq;
+                    const float* rp = mp + (size_t)(row < NT ? row : 0) * W;
+                    const bool ok = row < NT && cb > ca;
+                    const float2 lo = (ok && col < W) ? *reinterpret_cast<const float2*>(rp + col) : make_float2(0.f, 0.f);
+                    const float2 hi = (ok && col + 8 < W && 16 * kt + 8 < NT)
+                                          ? *reinterpret_cast<const float2*>(rp + col + 8) : make_float2(0.f, 0.f);
+                    fr[u][it][kt] = f32x4v{lo.x, lo.y, hi.x, hi.y};
                 }
         };
 #pragma unroll
@@ -1004,19 +1011,20 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
 #pragma unroll
             for (int it = 0; it < NTL; ++it)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) pb_lds[(16 * it + 4 * kq + v) * 32 + n] = P[it][v];
+                for (int v = 0; v < 4; ++v) pb_lds[(16 * it + 8 * (v / 2) + rq + v % 2) * 32 + n] = P[it][v];
         }
     }
     __syncthreads();
     if (!live || h == 1) return;
-    {   // M[:, jt] = P_B . P_A[:, jt]: A fragments of P_B from LDS (row 16 it + rho(m), columns 16 kt + 4 kq .. + 3)
+    {   // M[:, jt] = P_B . P_A[:, jt]: A fragments of P_B from LDS (row 16 it + rho(m), the same columns as above)
         f64x4 fa[NTL][NTL];
 #pragma unroll
         for (int it = 0; it < NTL; ++it)
 #pragma unroll
             for (int kt = 0; kt < NTL; ++kt) {
-                const double* rp = pb_lds + (16 * it + rm) * 32 + 16 * kt + 4 * kq;
-                fa[it][kt] = *reinterpret_cast<const f64x4*>(rp);
+                const double* rp = pb_lds + (16 * it + rm) * 32 + 16 * kt + rq;
+                const double2 lo = *reinterpret_cast<const double2*>(rp), hi = *reinterpret_cast<const double2*>(rp + 8);
+                fa[it][kt] = f64x4{lo.x, lo.y, hi.x, hi.y};
             }
         comp_product<NT, NTL>(fa, P);
     }
@@ -1026,7 +1034,7 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
     for (int it = 0; it < NTL; ++it)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int i = 16 * it + 4 * kq + v;   // rho(kq + 4 v)
+            const int i = 16 * it + 8 * (v / 2) + rq + v % 2;   // rho(kq + 4 v)
             if (i < NT && n < W) mt[(size_t)i * W + n] = n < NT ? (float)P[it][v] : 0.f;
         }
 }
