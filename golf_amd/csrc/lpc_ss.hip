@@ -1719,8 +1719,8 @@ static int device_cu_count() {
 
 // The two-level boundary scan buys latency with (utterance x group) waves whose prologues hold a SIMD's registers
 // (one wave per SIMD).  Measured with 4 batches in flight / one batch alone, two-level vs flat, us per step:
-//   B = 32: 69.8 vs 70.1 / 139 vs 163;  B = 48: 105 vs 96 / 191 vs 212;  B = 64: 134 vs 117 / 205 vs 227;
-//   B = 96: 204 vs 166 / 300 vs 286;  B = 256: 537 vs 437 / 629 vs 515
+//   B = 32: 71.9 vs 71.6 / 140 vs 166;  B = 48: 101 vs 94 / 192 vs 214;  B = 64: 132 vs 117 / 212 vs 229;
+//   (with the earlier fp32 composites) B = 96: 204 vs 166 / 300 vs 286;  B = 256: 537 vs 437 / 629 vs 515
 // so it is taken while B x NG stays below half the SIMD count (B <= 39 at 2 s), where it costs the pipelined rate nothing.
 static bool use_two_level_scan(const SsPlan& p, int B, int flags) {
     static const long env = [] { const char* e = getenv("GOLF_SS_TWO_LEVEL_WAVES"); return e ? atol(e) : 0L; }();   // dev knob
