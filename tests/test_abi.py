@@ -52,6 +52,13 @@ def test_argument_checks_without_gpu():
     rc = lib.golf_glottal_osc_fwd_f32(None, 0, 10, 1, None, 2, 8, None, 1, 16, 1, 0, None, 0, None, None, 0, 1, 10,
                                       None, 0, None, None, 0, 0)
     assert rc == -1
+    # peer-exchange entry points: null pointers / too many destinations are refused before anything touches a device
+    assert lib.golf_peer_store_f32(None, 0, 1, 1, None, 0, 1, None) == -1 and b"null" in lib.golf_last_error()
+    import ctypes
+    many = (ctypes.c_void_p * 17)(*([1] * 17))
+    assert lib.golf_peer_signal_u32(many, 17, 1, None) == -1 and b"at most" in lib.golf_last_error()
+    assert lib.golf_peer_wait_u32(None, 1, 1, 1, 0, None, None) == -1
+    assert lib.golf_peer_alloc(0, None) == -1
 
 
 def test_ops_fail_loudly_on_cpu_tensors():
