@@ -36,6 +36,7 @@ SIGNATURES = {
     "golf_ltv_allpole_transitions_f32": (_int, [_c_f32p] + [_int] * 5 + [_vp, _sz, _int, _vp]),
     "golf_ltv_allpole_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 5
                                  + [_vp, _sz, _int, _vp, _vp]),
+    "golf_ltv_allpole_status_u32": (_int, [_vp, _sz] + [_int] * 6 + [_vp, _vp]),
     "golf_ltv_allpole_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64,
                                         _c_f32p, _c_f32p] + [_int] * 5 + [_vp, _sz, _int, _vp]),
     "golf_ltv_inverse_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _i64] + [_int] * 5 + [_vp]),
@@ -99,7 +100,7 @@ SIGNATURES = {
     "golf_peer_wait_u32": (_int, [_vp, _int, _int, ctypes.c_uint32, _i64, _vp, _vp]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lock = threading.Lock()
 _lib = None
 

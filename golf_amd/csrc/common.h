@@ -38,7 +38,11 @@ struct SsPlan {
     bool serial;  // batch-parallel serial kernels (large batches): no transition matrices / boundary states in ws
     // workspace offsets (bytes)
     int NG, GS; // two-level boundary scan: NG groups of GS chunk maps (NG == 0: flat scan)
-    size_t off_phi, off_phiT, off_z, off_E, off_z2, off_S, off_zadj, off_lam, off_g, off_pa, off_pg, off_mt, off_gv, off_pmax, off_gm, total;
+    size_t off_phi, off_phiT, off_z, off_E, off_z2, off_S, off_zadj, off_lam, off_g, off_pa, off_pg, off_mt, off_gv, off_pmax, total;
+    // conditioning tiers (see lpc_fixup_kernel): per-utterance tier words, first-pass chunk start states of the two-level
+    // scan (the delta-form refinement adds its correction to exactly these), the status words, and -- touched only for the
+    // rare tier-3 utterances -- the transition matrices as doubles
+    size_t off_tier, off_S1, off_status, off_phi64;
 };
 bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode = 0);
 int ss_serial_min_batch();

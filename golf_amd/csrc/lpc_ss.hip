@@ -7,15 +7,24 @@
 // Algorithm (MI355X-first; nothing like the reference's serial 22-thread numba kernel):
 //   The recursion y[t] = x[t] - sum_i A[t,i] y[t-1-i] is linear in the state
 //   s_t = (y[t-1..t-M]).  Time is cut into chunks of L samples.  Per chunk c:
-//     P1h  M homogeneous trajectories (unit initial states, no input)  -> Phi_c (MxM)   [fp64]
-//     P1z  one zero-state trajectory with the real input               -> z_c   (M)     [fp32]
+//     P1f/P1h  M homogeneous trajectories (unit initial states, no input) -> Phi_c (MxM)
+//              [fp32 for inference, fp64 for training; stored fp32]
+//     P1z      one zero-state trajectory with the real input              -> z_c   (M)  [fp32]
 //   so that s_{c+1} = Phi_c s_c + z_c.  Then
-//     P2   one wave per utterance scans the NC chunk boundaries (lane = state component)
-//     P3   every chunk re-runs its L-step recursion from its now-known initial state -> y
+//     first pass   chunk-boundary states S1 from the maps (two-level scan: group composites on the f64 matrix pipe +
+//                  per-group scans; or one wave per utterance, flat)
+//     refinement   every chunk re-runs its L-step recursion from S1_c -> its true end state E_c; the DEFECTS
+//                  d_c = E_c - S1_{c+1} are scanned on their own (delta_{c+1} = Phi_c delta_c + d_c) and the final
+//                  states are S1 + delta: one Parareal sweep in delta form.  The maps then act on a correction that is
+//                  ~1e-4 of the state, so their fp32 rounding (and the fp32 trajectories' error) is second order and the
+//                  result is the sequential fp32 recursion's -- the reference's arithmetic -- up to its own rounding.
+//     final pass   every chunk runs from S1_c + delta_c -> y
 //   B*NC*(M+1) independent in-lane recursions instead of B serial ones: at B=32, T=47761
 //   that is 146k lanes x 240 steps instead of 32 lanes x 47761 steps.
-//   Phi is computed in fp64 (fp32 homogeneous trajectories lose ~2e-5 relative accuracy each,
-//   which the boundary scan amplifies to >1e-4; measured in DESIGN.md §numerics) and stored fp32.
+//   Conditioning tiers (lpc_fixup_kernel; numerics measured in tools/numlab): the sweep contracts as long
+//   as the maps are accurate relative to their size.  Chunks whose fp32 map has entries beyond ~30 are recomputed from
+//   fp64 trajectories (in place, rounded to fp32); utterances with entries beyond ~256 take their boundary states from
+//   an fp64 scan over maps kept as doubles.  Both ride in launches that exist anyway.
 //   Frame-rate coefficients (B,F,M) are interpolated on the fly (a_f + n*d_f, one FMA per tap);
 //   the (B,T,M) tensor the reference materialises (134 MB at B=32) never exists.
 //   Each lane keeps its M-sample history in a statically indexed rotating register window
@@ -83,7 +92,8 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     if (p->serial) {   // batch-parallel serial path: no transition matrices, no boundary states
         p->off_phi = p->off_phiT = p->off_z = p->off_E = p->off_z2 = p->off_S = p->off_zadj = p->off_lam = 0;
         p->NG = p->GS = 0;
-        p->off_mt = p->off_gv = p->off_pmax = p->off_gm = 0;
+        p->off_mt = p->off_gv = p->off_pmax = 0;
+        p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -102,7 +112,8 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
-    p->off_gm = o;   o = align_up(o + sizeof(float) * (size_t)B * (3 * ((p->NP + 15) / 16) + 1), 256);  // ... condensed per utterance
+    p->off_tier = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);     // conditioning tier + hot-chunk count per utterance
+    p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
     // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
@@ -114,8 +125,44 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->off_mt = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NG * p->NT * W, 256);
         p->off_gv = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * 32 * 2, 256);   // group responses (z, defects)
     }
+    p->off_S1 = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NC * 32, 256);   // first-pass chunk start states (two-level)
+    // transition matrices as doubles, [b][c][j][i] (trajectory-major), written and read only for tier-3 utterances: the
+    // allocation is never touched otherwise (27 MB at B = 32 x 2 s)
+    p->off_phi64 = o; o = align_up(o + sizeof(double) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
     p->total = o;
     return true;
+}
+
+// Conditioning tiers of the time-chunked algorithm (numerics: tools/numlab/lab2.py).
+// The delta-form refinement sweep makes every error of the coarse propagator second order, PROVIDED the sweep contracts:
+// the chunk maps have to be accurate relative to their size.  fp32 homogeneous trajectories lose ~1e-5 x (largest entry),
+// so -- measured against the sequential fp32 recursion, the reference's arithmetic, over the benchmark recipe and much
+// harsher coefficient tracks --
+//   tier 1  largest |entry| of a chunk's fp32 map <= G1 (30): fp32 map + one sweep = sequential fp32 (1.8 % of the
+//           recipe's utterances have a chunk beyond 30, 0.13 % one beyond 256);
+//   tier 2  a chunk beyond G1 ("hot"): lpc_fixup_kernel recomputes its map from fp64 trajectories, rounds it to fp32 IN
+//           PLACE, and everything downstream is unchanged: equal to sequential fp32 up to entries of ~400;
+//   tier 3  an utterance with an entry beyond G3 (256), a non-finite one, or groups of maps whose product could overflow
+//           fp32: all its maps are recomputed and kept as DOUBLES, one wave scans its boundary states in fp64 (riding in
+//           the pre-pass / first scan launch), and its chunks run from those states without a sweep: at or below the
+//           sequential recursion's error for entries up to 7e4 (beyond that both are garbage).
+// Cost: one light launch (lpc_fixup_kernel: every wave reads its utterance's per-chunk maxima and returns unless it owns a
+// hot chunk); a hot chunk costs its wave one fp64 pass over the chunk (~25 us), a tier-3 utterance additionally a 199-step
+// fp64 scan (~45 us) beside the 15 us pre-pass.  No sequential fallback exists any more (round 2: 2.6 ms).
+static float phi_guard() {
+    static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD"); return e ? (float)atof(e) : 30.f; }();
+    return v;   // <= 0: no chunk is ever hot (dev knob)
+}
+static float phi_guard3() {
+    static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD3"); return e ? (float)atof(e) : 256.f; }();
+    return v;   // <= 0: no utterance is ever tier 3 (dev knob)
+}
+// rows of 16 utterances are addressed through one 32-bit buffer descriptor (serial kernels)
+static bool serial_strides_ok(int64_t s0, int64_t s1) { return s0 < (1 << 24) && s1 < (1 << 24); }
+constexpr unsigned kTierHot = 2u, kTierPrecise = 3u;
+// tier words: tier[2 b] = 0 / 2 / 3, tier[2 b + 1] = number of hot chunks (wave-uniform reads: b is)
+__device__ __forceinline__ bool tier3(const unsigned* __restrict__ tier, int b) {
+    return tier != nullptr && __builtin_amdgcn_readfirstlane((int)tier[2 * b]) == (int)kTierPrecise;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -140,7 +187,8 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                                           int F, int M, int hop, int L, int NCQ, int NCS,
                                           const float* __restrict__ zin, float* __restrict__ xt,
                                           float* __restrict__ yt, int b, int cg, int lane,
-                                          const float* lst = nullptr, float* ldl = nullptr) {
+                                          const float* lst = nullptr, float* ldl = nullptr,
+                                          unsigned* __restrict__ nonfinite = nullptr) {
     // lst (two-level scan): the chunk start states of this wave's 16 chunks (+ the next one) in LDS, row stride 32,
     // instead of the scanned states S in HBM; ldl: the defects of MODE 3 are also left in LDS ([16][32])
     constexpr int TPL = quad_tpl(W, NT);
@@ -177,6 +225,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
     int fcur = -1;
     const int nblk = L / W;
     float nx[TL::ITS];
+    bool bad = false;   // a non-finite output sample went to y (status word of the boundary, include/golf_amd.h)
     TL::fetch(nx, xrow, c0 * L, L, lq, lr);
     for (int blk = 0; blk < nblk; ++blk) {
         const int tw = c0 * L + blk * W;  // block start of the wave's first chunk
@@ -241,9 +290,12 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
             float o[TL::ITS];
             TL::gather(o, yt, lq, lr);
             TL::store(o, yrow, tw, L, lq, lr);
+#pragma unroll
+            for (int it = 0; it < TL::ITS; ++it) bad = bad || !(fabsf(o[it]) <= 3.4028235e38f);
         }
         wave_lds_fence();
     }
+    if (WY && nonfinite && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(nonfinite, 1u);
     if (!WY && mine) {
         float* zp = out + ((size_t)b * NCQ + c) * W;
 #pragma unroll
@@ -251,13 +303,13 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
             const int i = r * TPL + k;
             if (i < W) {
                 float v = i < M ? w[TPL - 1 - k] : 0.f;
-                // MODE 2 (refinement sweep): the chunk was re-run from the scanned state S_c, v = its true end state
-                // E_c; what the second scan needs is z_c + (E_c - S_{c+1}): the observed defect added to the
-                // zero-state response (one Parareal iteration; the boundary error becomes second order in the
-                // transition-matrix error).
-                if (MODE == 2) v += zin[((size_t)b * NCQ + c) * W + i] - S[((size_t)b * NCS + c + 1) * 64 + i];
-                // MODE 3: the defect alone (two-level scan: the second scan propagates only the correction, so that
-                // the rounding of the group composites acts on a quantity that is already second order)
+                // MODE 2 / 3 (refinement sweep): the chunk was re-run from the first-pass state S1_c, v = its true end
+                // state E_c; what leaves is the DEFECT E_c - S1_{c+1}.  The second scan propagates only the correction
+                // (delta_{c+1} = Phi_c delta_c + d_c) and the final states are S1 + delta: one Parareal iteration in
+                // delta form -- the maps' rounding acts on a quantity that is already ~1e-4 of the state, so the result
+                // is second order in every error of the coarse propagator (tools/numlab: rescanning z + d from scratch
+                // instead leaves the first-order rounding of Phi s in the states, 3-10 x a sequential recursion's error).
+                if (MODE == 2) v -= S[((size_t)b * NCS + c + 1) * 64 + i];
                 if constexpr (MODE == 3) {
                     v -= lst[(row + 1) * 32 + i];
                     ldl[row * 32 + i] = v;
@@ -273,50 +325,14 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gain, const float* __restrict__ a,
                                                       const float* __restrict__ S, float* __restrict__ out,
                                                       int64_t y_stride, int T, int F, int M, int hop, int L, int NCQ,
-                                                      int NCS, const float* __restrict__ zin) {
+                                                      int NCS, const float* __restrict__ zin,
+                                                      const unsigned* __restrict__ tier = nullptr) {
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    if (MODE == 2 && tier3(tier, blockIdx.y)) return;   // tier-3 utterances take no refinement sweep (see phi_guard)
     fwdq_body<W, NT, MODE>(ex, ex_stride, gain, a, S, out, y_stride, T, F, M, hop, L, NCQ, NCS, zin, xt, yt,
                            blockIdx.y, blockIdx.x, threadIdx.x);
-}
-
-// Conditioning guard of the time-chunked algorithm.  Its transition matrices are computed and applied in fp32; when
-// an utterance's filter is so close to instability that some chunk map has entries beyond ~1e2 (transient growth of the
-// homogeneous response), the matrices' cancellation errors are amplified past usefulness -- measured over random
-// coefficient tracks (tools/fuzz_phi.py), largest |entry| -> error of chunked vs of a sequential fp32 recursion:
-//   <= 30: equal;  30..140: 5-8 x worse;  139: 2e-2 vs 3e-4;  683: 7e-2 vs 5e-4;  >= 1e3: garbage / inf / NaN
-// while the sequential recursion (the reference's arithmetic) degrades gracefully.  The transition kernels therefore
-// record max |entry| per chunk, and a guarded launch of the serial kernels after the chunked ones recomputes exactly
-// the utterances that exceed the guard.  Where to put it is a trade: under the benchmark's own input recipe
-// 0.7 % of the utterances exceed 64, 0.2 % exceed 128 and 0.1 % exceed 256 (one of them, |Phi| = 510, came out 500 % wrong
-// from the unguarded chunked path -- the sequential recursion is at 2e-3 on it; one at 174: 1.4e-2 vs 4e-4; those between
-// 64 and 128: 5-10 x the sequential error, <= 2e-3), and a flagged utterance costs its wave a full sequential pass
-// (2.6 ms at 2 s).  128 keeps every unflagged utterance within ~10 x of the reference's own arithmetic.
-// The guard waves ride in the final chunk kernel's launch (extra grid rows) and read a few condensed values per utterance
-// (the scan kernels that run anyway condense the per-chunk maxima), so the common case costs no launch and no latency.
-static bool serial_strides_ok(int64_t s0, int64_t s1) { return s0 < (1 << 24) && s1 < (1 << 24); }
-static float phi_guard() {
-    static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD"); return e ? (float)atof(e) : 128.f; }();
-    return v;   // <= 0 switches the guard off (dev knob)
-}
-// Regular waves of the final chunk kernels: is utterance b handed to the guard waves?  (lane j looks at value j)
-__device__ __forceinline__ bool utterance_flagged(const float* __restrict__ gm, int ngm, float guard, int b, int lane) {
-    if (!gm) return false;
-    bool hot = false;
-    for (int j = lane; j < ngm; j += 64) hot = hot || !(fabsf(gm[(size_t)b * ngm + j]) <= guard);
-    return __builtin_amdgcn_ballot_w64(hot) != 0ull;
-}
-// bit 4 * row set <=> the wave's utterance `row` has to be (re)computed; without a guard array every live row is
-__device__ __forceinline__ unsigned long long serial_row_mask(const float* __restrict__ pmax, int NPg, float guard, int b,
-                                                              int row, int r, int nrow) {
-    if (!pmax) return ~0ull;
-    unsigned mx = 0u;
-    for (int c = r; c < NPg; c += 4) mx = max(mx, __float_as_uint(fabsf(pmax[(size_t)b * NPg + c])));
-    mx = max(mx, (unsigned)__shfl_xor((int)mx, 1));
-    mx = max(mx, (unsigned)__shfl_xor((int)mx, 2));
-    const bool hot = row < nrow && !(__uint_as_float(mx) <= guard);   // NaN compares false: flagged
-    return __builtin_amdgcn_ballot_w64(hot && r == 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -328,14 +344,13 @@ __device__ __forceinline__ unsigned long long serial_row_mask(const float* __res
 // loaded while frame f is being processed (a lone wave would otherwise stall ~1 us on dependent loads at each of the
 // 200 frame boundaries).  No transition matrices, no scan, no redundant arithmetic: 1x the reference's FMA count.
 // ------------------------------------------------------------------------------------------
-// (one wave = `unit`: utterances 16 unit .. 16 unit + 15; a device function so that the final chunk kernels can carry the
-//  guard waves in their own launch)
+// (one wave = `unit`: utterances 16 unit .. 16 unit + 15)
 template <int W, int NT>
 __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt, float* __restrict__ yt,
                                                 const float* __restrict__ ex, int64_t ex_stride,
                                                 const float* __restrict__ gain, const float* __restrict__ a,
                                                 float* __restrict__ y, int64_t y_stride, int B, int T, int F, int M,
-                                                int hop, const float* __restrict__ pmax, int NPg, float guard) {
+                                                int hop) {
     constexpr int TPL = quad_tpl(W, NT);
     using TL = Tile<W, 16>;
     const int lane = threadIdx.x & 63;
@@ -345,9 +360,6 @@ __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt
     if (b0 >= B) return;   // wave-uniform
     const int nrow = B - b0 < 16 ? B - b0 : 16;
     const int b = b0 + (row < nrow ? row : nrow - 1);  // idle quads shadow the last utterance; their stores are masked
-    // guarded launch (after the chunked kernels): only utterances whose transition matrices exceed the guard are redone
-    const unsigned long long rmask = serial_row_mask(pmax, NPg, guard, b, row, r, nrow);
-    if (rmask == 0ull) return;   // wave-uniform
     const int xs = (int)ex_stride, ys = (int)y_stride;
     const BufRow xblk(ex + (size_t)b0 * ex_stride, nrow * xs);
     const BufRow yblk(y + (size_t)b0 * y_stride, nrow * ys);
@@ -438,7 +450,7 @@ __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt
             int rw, col;
             TL::rowcol(it, lq, lr, rw, col);
             const int t = t0 + col;
-            yblk.st((t < T && rw < nrow && ((rmask >> (4 * rw)) & 1ull)) ? rw * ys + t : -1, o[it]);
+            yblk.st((t < T && rw < nrow) ? rw * ys + t : -1, o[it]);
         }
         wave_lds_fence();
     }
@@ -448,45 +460,29 @@ template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_serial_fwd_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                             const float* __restrict__ gain,
                                                             const float* __restrict__ a, float* __restrict__ y,
-                                                            int64_t y_stride, int B, int T, int F, int M, int hop,
-                                                            const float* __restrict__ pmax, int NPg, float guard) {
+                                                            int64_t y_stride, int B, int T, int F, int M, int hop) {
     using TL = Tile<W, 16>;
     // workgroups of 4 INDEPENDENT waves (one per SIMD of a CU; they never synchronise): single-wave workgroups are
     // placed unevenly by the dispatcher once there are about as many waves as SIMDs (measured on the transition kernel)
     __shared__ float xt_all[4][TL::SIZE];
     __shared__ float yt_all[4][TL::SIZE];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    serial_fwd_unit<W, NT>(blockIdx.x * 4 + wv, xt_all[wv], yt_all[wv], ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop,
-                           pmax, NPg, guard);
+    serial_fwd_unit<W, NT>(blockIdx.x * 4 + wv, xt_all[wv], yt_all[wv], ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop);
 }
 
-// What the final chunk kernels need to carry the guard in their own launch (no extra launch on the stream): rows
-// blockIdx.y >= B of the grid are guard waves (serial_fwd_unit), and the regular waves of a flagged utterance step aside.
-struct GuardArgs {
-    const float* gm;   // condensed max |Phi| values, ngm per utterance (nullptr: no guard)
-    int ngm;
-    float guard;
-    int B;
-};
-
-// Final pass of the flat-scan path (lpc_fwdq_kernel<.., 1>) + guard waves.
+// Final pass of the flat-scan path: every chunk runs from its boundary state S_c (first pass + correction, or the fp64
+// scan of a tier-3 utterance) and writes y.
 template <int W, int NT>
 __global__ __launch_bounds__(64) void lpc_fwdq_final_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                             const float* __restrict__ gain,
                                                             const float* __restrict__ a, const float* __restrict__ S,
                                                             float* __restrict__ y, int64_t y_stride, int T, int F, int M,
-                                                            int hop, int L, int NC, GuardArgs ga) {
+                                                            int hop, int L, int NC, unsigned* __restrict__ nonfinite) {
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[TL::SIZE];
-    if ((int)blockIdx.y >= ga.B) {
-        serial_fwd_unit<W, NT>(((int)blockIdx.y - ga.B) * (int)gridDim.x + (int)blockIdx.x, xt, yt, ex, ex_stride, gain, a, y,
-                               y_stride, ga.B, T, F, M, hop, ga.gm, ga.ngm, ga.guard);
-        return;
-    }
-    if (utterance_flagged(ga.gm, ga.ngm, ga.guard, blockIdx.y, threadIdx.x)) return;   // wave-uniform
     fwdq_body<W, NT, 1>(ex, ex_stride, gain, a, S, y, y_stride, T, F, M, hop, L, NC, NC, nullptr, xt, yt, blockIdx.y,
-                        blockIdx.x, threadIdx.x);
+                        blockIdx.x, threadIdx.x, nullptr, nullptr, nonfinite);
 }
 
 // Serial adjoint (backward of the above): the transposed-form recursion of lpc_adjq_kernel run over the whole utterance
@@ -495,8 +491,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq_final_kernel(const float* __restr
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_serial_adj_kernel(const float* __restrict__ gy, int64_t gy_stride,
                                                             const float* __restrict__ a, float* __restrict__ g,
-                                                            int64_t g_stride, int B, int T, int F, int M, int hop,
-                                                            const float* __restrict__ pmax, int NPg, float guard) {
+                                                            int64_t g_stride, int B, int T, int F, int M, int hop) {
     constexpr int TPL = quad_tpl(W, NT);
     using TL = Tile<W, 16>;
     // workgroups of 4 INDEPENDENT waves (one per SIMD of a CU; they never synchronise): single-wave workgroups are
@@ -513,8 +508,6 @@ __global__ __launch_bounds__(256) void lpc_serial_adj_kernel(const float* __rest
     if (b0 >= B) return;   // wave-uniform
     const int nrow = B - b0 < 16 ? B - b0 : 16;
     const int b = b0 + (row < nrow ? row : nrow - 1);
-    const unsigned long long rmask = serial_row_mask(pmax, NPg, guard, b, row, r, nrow);   // as in the forward kernel
-    if (rmask == 0ull) return;   // wave-uniform
     const int xs = (int)gy_stride, ys = (int)g_stride;
     const BufRow xblk(gy + (size_t)b0 * gy_stride, nrow * xs);
     const BufRow yblk(g + (size_t)b0 * g_stride, nrow * ys);
@@ -596,7 +589,7 @@ __global__ __launch_bounds__(256) void lpc_serial_adj_kernel(const float* __rest
             int rw, col;
             TL::rowcol(it, lq, lr, rw, col);
             const int t = t0 + col;
-            yblk.st((t < T && rw < nrow && ((rmask >> (4 * rw)) & 1ull)) ? rw * ys + t : -1, o[it]);
+            yblk.st((t < T && rw < nrow) ? rw * ys + t : -1, o[it]);
         }
         wave_lds_fence();
     }
@@ -977,6 +970,205 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Conditioning tiers (see phi_guard): lpc_fixup_kernel runs right after the transition kernel.
+//   grid (ceil(ceil(NP / 64) * NT / 4), B), workgroups of 4 independent waves; wave -> (block of 64 chunks, trajectory j),
+//   lane = chunk.  Every wave reduces its utterance's per-chunk maxima (one round of loads) and returns unless one of its
+//   chunks is hot; a hot lane runs ONE fp64 homogeneous trajectory over its chunk (~25 us) and overwrites column j of the
+//   chunk's fp32 map -- and, for a tier-3 utterance, row j of the map kept as doubles.
+//   `accurate` (training path: the maps already come from fp64 trajectories): only tier 3 is acted on.
+// ------------------------------------------------------------------------------------------
+template <int W, int NT>
+__global__ __launch_bounds__(256) void lpc_fixup_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
+                                                        double* __restrict__ Phi64, const float* __restrict__ pmax,
+                                                        unsigned* __restrict__ tier, unsigned* __restrict__ status,
+                                                        int F, int M, int hop, int L, int NP, float g1, float g3,
+                                                        int accurate) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int u = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = u / NT, j = u - cb * NT;
+    if (cb * 64 >= NP) return;   // wave-uniform
+    const float* pm = pmax + (size_t)b * NP;
+    unsigned umax = 0u, nhot = 0u;
+    bool ovf = false;
+    for (int c0 = 0; c0 < NP; c0 += 64) {
+        const int c = c0 + lane;
+        const float v = c < NP ? fabsf(pm[c]) : 0.f;
+        umax = max(umax, __float_as_uint(v));   // bit patterns: a NaN ranks above +inf and cannot hide
+        // the product of a composite group's 16 maps must stay far from the fp32 range (sum of log2 of the maxima over the
+        // group: c0 is a multiple of 64, so 16-lane rows are the groups of lpc_group_prepass_kernel)
+        float lg = __log2f(fmaxf(v, 1.f));
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
+        ovf = ovf || lg > 100.f;
+        nhot += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c < NP && g1 > 0.f && !(v <= g1)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) umax = max(umax, (unsigned)__shfl_xor((int)umax, off));
+    const bool t3 = g3 > 0.f && (!(__uint_as_float(umax) <= g3) || __builtin_amdgcn_ballot_w64(ovf) != 0ull);
+    if (u == 0 && lane == 0) {
+        tier[2 * b] = t3 ? kTierPrecise : ((nhot > 0u && !accurate) ? kTierHot : 0u);
+        tier[2 * b + 1] = nhot;
+        if (b == 0) status[0] = 0u;   // the final pass ORs 1 into it when a non-finite sample leaves
+    }
+    const int c = cb * 64 + lane;
+    const bool hot = c < NP && (t3 || (!accurate && g1 > 0.f && !(fabsf(pm[c < NP ? c : 0]) <= g1)));
+    if (__builtin_amdgcn_ballot_w64(hot) == 0ull) return;   // wave-uniform: the common case ends here
+    const size_t q = (size_t)b * NP + (hot ? c : 0);
+    if (j >= M) {   // padding trajectory: the fp32 map already holds zeros there; the doubles need them
+        if (hot && t3) {
+            double* o = Phi64 + (q * NT + j) * W;
+#pragma unroll
+            for (int i = 0; i < W; ++i) o[i] = 0.0;
+        }
+        return;
+    }
+    double h[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) h[k] = (W - 1 - k == j) ? 1.0 : 0.0;
+    if (hot) {
+        double a0[NT], dd[NT];
+        const double inv_hop = 1.0 / (double)hop;
+        int fcur = -1;
+        const int nblk = L / W;
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int t0 = c * L + blk * W;
+            const int f = t0 / hop;  // <= F-2: chunks with a transition matrix end before (F-1)*hop
+            if (f != fcur) {
+                fcur = f;
+                const float* pa0 = a + ((size_t)b * F + f) * M;
+                const float* pa1 = pa0 + M;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const double v0 = i < M ? (double)pa0[i] : 0.0;
+                    const double v1 = i < M ? (double)pa1[i] : 0.0;
+                    a0[i] = v0;
+                    dd[i] = (v1 - v0) * inv_hop;
+                }
+            }
+            const double n0 = (double)(t0 - f * hop);
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                const double n = n0 + (double)s;
+                double ra = 0.0, rb = 0.0;
+#pragma unroll
+                for (int i = NT - 1; i >= 1; --i) {
+                    const double cf = __builtin_elementwise_fma(n, dd[i], a0[i]);
+                    const int slot = (s - 1 - i + 2 * W) % W;
+                    if (i & 1) ra = __builtin_elementwise_fma(cf, h[slot], ra);
+                    else       rb = __builtin_elementwise_fma(cf, h[slot], rb);
+                }
+                const double cf0 = __builtin_elementwise_fma(n, dd[0], a0[0]);
+                h[s] = __builtin_elementwise_fma(-cf0, h[(s - 1 + W) % W], -(ra + rb));
+            }
+        }
+        if (!accurate) {   // column j of PhiT[q][i][j] = d s_end[i] / d s_start[j]
+            float* o = PhiT + q * NT * W + j;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) o[(size_t)i * W] = i < M ? (float)h[W - 1 - i] : 0.f;
+        }
+        if (t3) {          // row j of Phi64[q][j][i]
+            double* o = Phi64 + (q * NT + j) * W;
+#pragma unroll
+            for (int i = 0; i < W; ++i) o[i] = i < M ? h[W - 1 - i] : 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ double lane_bcast_d(double v, int lane) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
+// Tier-3 boundary states: s_{c+1} = Phi_c s_c + z_c in fp64 over the maps kept as doubles ([c][j][i]: lane i takes
+// element i of every row j, so the wave's accesses are contiguous), one wave per utterance; states leave rounded to fp32
+// into rows of `sstride` floats (32: S1 of the two-level path, 64: S of the flat one).
+template <int W, int NT>
+__device__ __forceinline__ void precise_fwd_scan(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                 float* __restrict__ Sb, int sstride, int NP, int lane) {
+    const bool act = lane < NT;
+    const int ii = act ? lane : 0;
+    constexpr int D = 4;
+    double buf[D][NT];
+    float zc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c < NP ? c : NP - 1;
+        const double* mp = P64 + (size_t)cl * NT * W + ii;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) buf[u][j] = mp[(size_t)j * W];
+        zc[u] = zb[(size_t)cl * W + ii];
+    };
+    double s = 0.0;
+    if (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, u);
+        for (int c0 = 0; c0 < NP; c0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = c0 + u;
+                if (c < NP) {   // wave-uniform
+                    if (lane < sstride) Sb[(size_t)c * sstride + lane] = (float)s;
+                    double acc0 = (double)zc[u], acc1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const double sj = lane_bcast_d(s, j);
+                        if (j & 1) acc1 = __builtin_elementwise_fma(buf[u][j], sj, acc1);
+                        else       acc0 = __builtin_elementwise_fma(buf[u][j], sj, acc0);
+                    }
+                    s = act ? acc0 + acc1 : 0.0;
+                    fetch(u, c + D);
+                }
+            }
+        }
+    }
+    if (lane < sstride) Sb[(size_t)(NP > 0 ? NP : 0) * sstride + lane] = (float)s;
+}
+
+// Tier-3 adjoint boundary states (backward): lam_start(c) = Phi_c^T lam_end(c) + zadj_c in fp64; lane j reads row j of
+// the doubles (contiguous).  Mirrors lpc_adj_scan_kernel: lamEnd[c][:] = adjoint state at the END of chunk c.
+template <int W, int NT>
+__device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                 float* __restrict__ Lb, int NP, int lane) {
+    const bool act = lane < NT;
+    const int jj = act ? lane : 0;
+    Lb[(size_t)NP * 64 + lane] = 0.f;
+    double lam = act ? (double)zb[(size_t)NP * W + jj] : 0.0;
+    constexpr int D = 4;
+    double buf[D][NT];
+    float zc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c > 0 ? c : 0;
+        const double* mp = P64 + ((size_t)cl * NT + jj) * W;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) buf[u][i] = mp[i];
+        zc[u] = zb[(size_t)cl * W + jj];
+    };
+    if (NP <= 0) return;
+#pragma unroll
+    for (int u = 0; u < D; ++u) fetch(u, NP - 1 - u);
+    for (int u0 = 0; u0 < NP; u0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int c = NP - 1 - (u0 + u);
+            if (c >= 0) {   // wave-uniform
+                Lb[(size_t)c * 64 + lane] = (float)lam;
+                double acc0 = (double)zc[u], acc1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const double li = lane_bcast_d(lam, i);
+                    if (i & 1) acc1 = __builtin_elementwise_fma(buf[u][i], li, acc1);
+                    else       acc0 = __builtin_elementwise_fma(buf[u][i], li, acc0);
+                }
+                lam = act ? acc0 + acc1 : 0.0;
+                fetch(u, c - D);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Two-level boundary scan (round 2; the default for long utterances with M <= 24; GOLF_SS_FLAT_SCAN selects the flat one).  The flat scan below is 199 dependent 22 x 22
 // matvecs on ONE wave per utterance: 31 us, twice per inference step (38 % of the single-stream step).  The chunk maps
 // of an utterance are cut into groups of 16 -- the 16 chunks one wave of the chunk kernels (lpc_fwdq*) owns:
@@ -1075,8 +1267,7 @@ __device__ __forceinline__ void comp_product(const AV (&fr)[NTL][NTL], f64x4 (&P
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int W, int NT>
 __device__ __forceinline__ void group_composite_wg(const float* __restrict__ PhiT, float* __restrict__ MT, int NP, int NG,
-                                                   int b, int g, double* __restrict__ pb_lds /* [32][32] */,
-                                                   float* __restrict__ gm) {
+                                                   int b, int g, double* __restrict__ pb_lds /* [32][32] */) {
     static_assert(NT <= 32 && W % 4 == 0, "two 16-wide tiles");
     constexpr int NTL = CompGeom<W, NT>::NTL;
     const int lane = threadIdx.x & 63;
@@ -1134,14 +1325,7 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
         }
     }
     __syncthreads();
-    // the composite's largest |entry| joins the conditioning guard's values (gm[b][NG + 2 g + jt], see phi_guard): a chain
-    // of maps with transient growth can overflow fp32 where no single map is large
-    float* gme = gm ? gm + (size_t)b * 3 * NG + NG + 2 * g + jt : nullptr;
-    if (h == 1) return;
-    if (!live) {
-        if (gme && lane == 0) *gme = 0.f;
-        return;
-    }
+    if (h == 1 || !live) return;
     {   // M[:, jt] = P_B . P_A[:, jt]: A fragments of P_B from LDS (row 16 it + rho(m), the same columns as above)
         f64x4 fa[NTL][NTL];
 #pragma unroll
@@ -1163,16 +1347,6 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
             const int i = 16 * it + 8 * (v / 2) + rq + v % 2;   // rho(kq + 4 v)
             if (i < NT && n < W) mt[(size_t)i * W + n] = n < NT ? (float)P[it][v] : 0.f;
         }
-    if (gme) {
-        unsigned mx = 0u;
-#pragma unroll
-        for (int it = 0; it < NTL; ++it)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) mx = max(mx, __float_as_uint(fabsf((float)P[it][v])));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-        if (lane == 0) *gme = __uint_as_float(mx);
-    }
 }
 
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
@@ -1211,47 +1385,35 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
 
 // Both pre-passes of the two-level scan in ONE launch (they depend only on the transition kernel's outputs):
 // workgroups [0, NG*B) form the group composites (4 waves cooperating on one group), the ceil(NG*B / 4) workgroups after
-// them the groups' zero-state responses (one wave per group, four independent waves per workgroup).
+// them the groups' zero-state responses (one wave per group, four independent waves per workgroup).  Tier-3 utterances
+// (see phi_guard) take their states from the fp64 scan wave that rides in the refinement launch: nothing to do here.
 //   [first, first + count) in workgroup units: everything, or only the composites (transitions prepared ahead of the
 //   excitation: golf_ltv_allpole_transitions_f32) / only the zero-state scans (the forward that picks them up).
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
                                                                 const float* __restrict__ z, float* __restrict__ MT,
                                                                 float* __restrict__ V, int NP, int NG, int B,
-                                                                int first, const float* __restrict__ pmax,
-                                                                float* __restrict__ gm) {
+                                                                int first, const unsigned* __restrict__ tier) {
     __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
     const int blk = first + (int)blockIdx.x, nu = NG * B;
     if (blk < nu) {
         // the fold of group g runs over the groups BEFORE it: the last composite is needed only when the final partial
         // chunk opens a group of its own (NP a multiple of 16)
-        if (blk % NG == NG - 1 && NP % kGroup != 0) {
-            if (gm && threadIdx.x < 2) gm[(size_t)(blk / NG) * 3 * NG + NG + 2 * (blk % NG) + threadIdx.x] = 0.f;
-            return;
-        }
-        group_composite_wg<W, NT>(PhiT, MT, NP, NG, blk / NG, blk % NG, pb_lds, gm);
+        if (blk % NG == NG - 1 && NP % kGroup != 0) return;
+        if (tier3(tier, blk / NG)) return;
+        group_composite_wg<W, NT>(PhiT, MT, NP, NG, blk / NG, blk % NG, pb_lds);
     } else {
         const int u2 = (blk - nu) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (u2 < nu) {
-            const int lane = threadIdx.x & 63;
-            if (gm && pmax) {   // the group's largest |Phi| entry, for the conditioning guard (phi_guard)
-                const int c = (u2 % NG) * kGroup + (lane & 15);
-                unsigned m = c < NP ? __float_as_uint(fabsf(pmax[(size_t)(u2 / NG) * NP + c])) : 0u;
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-                if (lane == 0) gm[(size_t)(u2 / NG) * 3 * NG + (u2 % NG)] = __uint_as_float(m);
-            }
-            group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, lane);
-        }
+        if (u2 < nu && !tier3(tier, u2 / NG)) group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, threadIdx.x & 63);
     }
 }
 
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
-//   t = fold of (M_g', v_g' (+ v2_g')) over the groups before g, then the wave's own chunk maps with inputs x (+ x2).
+//   t = fold of (M_g', v_g') over the groups before g, then the wave's own chunk maps with inputs x
+//   (first pass: v = zero-state group responses, x = z; correction pass: v = the groups' responses to the defects, x = defects).
 template <int W, int NT>
 __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, const float* __restrict__ MT,
-                                               const float* __restrict__ V, const float* __restrict__ V2,
-                                               const float* __restrict__ x, const float* __restrict__ x2,
+                                               const float* __restrict__ V, const float* __restrict__ x,
                                                float* __restrict__ st, int b, int g, int NP, int NG, int lane) {
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
@@ -1261,7 +1423,6 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     constexpr int DC = 6;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NP * W + ii;
-    const float* x2b = x2 ? x2 + (size_t)b * NP * W + ii : nullptr;
     const int c0 = g * kGroup;
     float4 pb[DC][W / 4];
     float xx[DC];
@@ -1269,7 +1430,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
         const int cl = c < NP ? c : NP - 1;
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
-        xx[u] = xb[(size_t)cl * W] + (x2b ? x2b[(size_t)cl * W] : 0.f);
+        xx[u] = xb[(size_t)cl * W];
     };
 #pragma unroll
     for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
@@ -1277,14 +1438,13 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
         constexpr int D = 4;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
         const float* vb = V + (size_t)b * NG * 32 + ii;
-        const float* v2b = V2 ? V2 + (size_t)b * NG * 32 + ii : nullptr;
         float4 mb[D][W / 4];
         float vv[D];
         auto fetch = [&](int u, int gg) {
             const int gl = gg < NG ? gg : NG - 1;
 #pragma unroll
             for (int k = 0; k < W / 4; ++k) mb[u][k] = mrows[(size_t)gl * cstride4 + k];
-            vv[u] = vb[(size_t)gl * 32] + (v2b ? v2b[(size_t)gl * 32] : 0.f);
+            vv[u] = vb[(size_t)gl * 32];
         };
         const int ng = g < NG ? g : NG;
 #pragma unroll
@@ -1313,46 +1473,91 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     wave_lds_fence();
 }
 
-// The chunk kernels of the two-level path.  MODE 3: refinement pass (re-run every chunk from its start state, write
-// the defects E_c - S_{c+1}; epilogue: scan the group's defects -> V2[b][g]).  MODE 1: final pass (writes y).
+// The chunk kernels of the two-level path.
+//   MODE 3, refinement pass: start states S1 from the prologue (fold of the groups before + scan of the own chunk maps, inputs
+//     z), kept in HBM for the final pass; every chunk re-runs from S1_c and leaves its defect d_c = E_c - S1_{c+1}; epilogue:
+//     the group's response to its own defects -> V2[b][g].
+//   MODE 1, final pass: the SAME prologue run on the defects (composites folded with V2, chunk maps with inputs d) gives the
+//     correction delta_c; chunks run from S1_c + delta_c and write y.  (Delta form: see fwdq_body.)
+//   Tier-3 utterances (see phi_guard) skip the refinement pass: rows blockIdx.y >= B of ITS grid hold one wave per utterance
+//     that returns at once unless the utterance is tier 3 and then scans its boundary states in fp64 -> S1 (this launch has
+//     the registers and lasts 26 us anyway); the final pass takes those as they are.
 template <int W, int NT, int MODE>
 __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                        const float* __restrict__ gain, const float* __restrict__ a,
                                                        float* __restrict__ out, int64_t y_stride, int T, int F, int M,
                                                        int hop, int L, int NCQ, const float* __restrict__ PhiT,
                                                        const float* __restrict__ MT, const float* __restrict__ V,
-                                                       const float* __restrict__ V2in, float* __restrict__ V2out,
-                                                       const float* __restrict__ x, const float* __restrict__ x2, int NP,
-                                                       int NG, GuardArgs ga) {
+                                                       float* __restrict__ V2out, const float* __restrict__ x, int NP,
+                                                       int NG, float* __restrict__ S1,
+                                                       const unsigned* __restrict__ tier,
+                                                       unsigned* __restrict__ nonfinite, int B,
+                                                       const double* __restrict__ Phi64) {
     static_assert(MODE == 1 || MODE == 3, "final pass or refinement pass");
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
     __shared__ float st[(kGroup + 1) * 32];
     __shared__ float dl[MODE == 3 ? kGroup * 32 : 1];
-    if constexpr (MODE == 1) {   // the final pass carries the guard waves (GuardArgs) and leaves flagged utterances to them
-        if ((int)blockIdx.y >= ga.B) {
-            serial_fwd_unit<W, NT>(((int)blockIdx.y - ga.B) * (int)gridDim.x + (int)blockIdx.x, xt, yt, ex, ex_stride, gain,
-                                   a, out, y_stride, ga.B, T, F, M, hop, ga.gm, ga.ngm, ga.guard);
+    if constexpr (MODE == 3) {
+        if ((int)blockIdx.y >= B) {   // fp64 boundary scan of a tier-3 utterance (x = the zero-state responses z)
+            const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
+            if (bp < B && tier3(tier, bp))
+                precise_fwd_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, x + (size_t)bp * NP * W,
+                                        S1 + (size_t)bp * (NP + 1) * 32, 32, NP, threadIdx.x);
             return;
         }
-        if (utterance_flagged(ga.gm, ga.ngm, ga.guard, blockIdx.y, threadIdx.x)) return;   // wave-uniform
     }
     const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
-    group_prologue<W, NT>(PhiT, MT, V, V2in, x, x2, st, b, g, NP, NG, lane);
-    if (MODE == 3) {
+    const int c0 = g * kGroup;
+    const bool precise = tier3(tier, b);   // wave-uniform
+    float* s1b = S1 + (size_t)b * (NP + 1) * 32;
+    if constexpr (MODE == 3) {
+        if (precise) return;
+        group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);
+        // The state the NEXT group starts from is its own fold, M_g S1_{c0} + v_g -- not this wave's scan result st[16]
+        // (the two differ by the composite's rounding).  The defect of the group's last chunk has to be taken against the
+        // state its successor really runs from, or that difference would never be corrected: recompute the successor's
+        // fold step here (same operands, same instruction sequence: bit-identical) and put it in st[16].
+        if (c0 + kGroup <= NP) {   // wave-uniform; the composite of this group exists (lpc_group_prepass_kernel)
+            const bool act = lane < NT;
+            const int ii = act ? lane : 0;
+            const float4* mrow = reinterpret_cast<const float4*>(MT + (((size_t)b * NG + g) * NT + ii) * W);
+            float4 mb[W / 4];
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
+            const float vv = V[((size_t)b * NG + g) * 32 + ii];
+            const float t0 = lane < 32 ? st[lane] : 0.f;
+            const float t1 = matvec_step<W, NT>(mb, t0, vv, act);
+            if (lane < 32) st[kGroup * 32 + lane] = t1;
+            wave_lds_fence();
+        }
+        // S1 -> HBM: the own chunks' start states, and S1_{NP} when no later group of this grid owns it
+        for (int e = lane; e < kGroup * 32; e += 64)
+            if (c0 + e / 32 <= NP) s1b[(size_t)c0 * 32 + e] = st[e];
+        if (c0 + kGroup == NP && lane < 32) s1b[(size_t)NP * 32 + lane] = st[kGroup * 32 + lane];
         for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
+        wave_lds_fence();
+    } else {
+        if (precise) {
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] = c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+        } else {
+            group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);   // delta_c (V = defect responses, x = defects)
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] += c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+        }
         wave_lds_fence();
     }
     fwdq_body<W, NT, MODE, true>(ex, ex_stride, gain, a, nullptr, out, y_stride, T, F, M, hop, L, NCQ, 0, nullptr, xt, yt,
-                                 b, g, lane, st, dl);
+                                 b, g, lane, st, dl, nonfinite);
     if (MODE == 3) {   // epilogue: the group's response to its own defects, for the final pass's fold
         wave_lds_fence();
         const bool act = lane < NT;
         const int ii = act ? lane : 0;
         const size_t cstride4 = (size_t)NT * W / 4;
         const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
-        const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+        const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
         constexpr int D = 4;
         float4 pb[D][W / 4];
 #pragma unroll
@@ -1383,24 +1588,30 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
 //   The step is a 22x22 matvec with s broadcast by v_readlane; what bounds it is the latency of
 //   fetching Phi_c, so rows are read as float4 (7 loads per chunk: vmcnt only counts 63) and kept
 //   D chunks ahead in registers.
+//   ACC = false: first pass, S = states from the zero-state responses z.  Blocks [B, 2B) of that launch hold one wave per
+//     utterance that returns unless the utterance is tier 3 (see phi_guard): then it writes S from the fp64 scan, and the
+//     regular wave of that utterance steps aside (in both passes).
+//   ACC = true: correction pass of the delta-form refinement sweep, S += scan of the defects.
 // ------------------------------------------------------------------------------------------
-template <int W, int NT, int D>
+template <int W, int NT, int D, bool ACC>
 __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict__ PhiT, const float* __restrict__ z,
-                                                         float* __restrict__ S, int NC, int NP,
-                                                         const float* __restrict__ pmax, float* __restrict__ gm) {
-    const int b = blockIdx.x;
+                                                         float* __restrict__ S, int NC, int NP, int B,
+                                                         const unsigned* __restrict__ tier,
+                                                         const double* __restrict__ Phi64) {
     const int i = threadIdx.x;
-    if (gm) {   // the utterance's largest |Phi| entry, for the conditioning guard (phi_guard)
-        unsigned m = 0u;
-        for (int c = i; c < NP; c += 64) m = max(m, __float_as_uint(fabsf(pmax[(size_t)b * NP + c])));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-        if (i == 0) gm[b] = __uint_as_float(m);
+    if ((int)blockIdx.x >= B) {
+        const int bp = (int)blockIdx.x - B;
+        if (tier3(tier, bp))
+            precise_fwd_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, z + (size_t)bp * NP * W, S + (size_t)bp * NC * 64, 64,
+                                    NP, i);
+        return;
     }
+    const int b = blockIdx.x;
+    if (tier3(tier, b)) return;
     const bool act = i < NT;
     const int ii = act ? i : 0;
     float* Sb = S + (size_t)b * NC * 64 + i;  // rows padded to 64 floats: every lane stores, no predication
-    if (NP <= 0) { Sb[0] = 0.f; return; }
+    if (NP <= 0) { if (!ACC) Sb[0] = 0.f; return; }
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
     const float* zb = z + (size_t)b * NP * W + ii;
@@ -1432,7 +1643,7 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int c = c0 + u;
-            Sb[(size_t)c * 64] = s;
+            if (ACC) Sb[(size_t)c * 64] += s; else Sb[(size_t)c * 64] = s;
             GOLF_P2_STEP(u)
             const int cn = c + D < NP ? c + D : NP - 1;
 #pragma unroll
@@ -1444,12 +1655,12 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
     for (int u = 0; u < D; ++u) {  // remainder (< D chunks), operands already in registers
         const int c = c0 + u;
         if (c < NP) {
-            Sb[(size_t)c * 64] = s;
+            if (ACC) Sb[(size_t)c * 64] += s; else Sb[(size_t)c * 64] = s;
             GOLF_P2_STEP(u)
         }
     }
 #undef GOLF_P2_STEP
-    Sb[(size_t)NP * 64] = s;
+    if (ACC) Sb[(size_t)NP * 64] += s; else Sb[(size_t)NP * 64] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1567,11 +1778,23 @@ __global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ 
 
 // B2: lamEnd[b][c][:] = adjoint state at the END of chunk c; lam_start(c) = Phi_c^T lam_end(c) + zadj_c.
 //   lane j reads row j of Phi (float4 x W/4), D chunks ahead.
+//   Blocks [B, 2B): one wave per utterance that returns unless the utterance is tier 3 (see phi_guard): then the scan runs
+//   in fp64 over the maps kept as doubles, and the regular wave of that utterance steps aside.
 template <int W, int NT, int D>
 __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restrict__ Phi, const float* __restrict__ zadj,
-                                                          float* __restrict__ lamEnd, int NC, int NP) {
-    const int b = blockIdx.x;
+                                                          float* __restrict__ lamEnd, int NC, int NP, int B,
+                                                          const unsigned* __restrict__ tier,
+                                                          const double* __restrict__ Phi64) {
     const int j = threadIdx.x;
+    if ((int)blockIdx.x >= B) {
+        const int bp = (int)blockIdx.x - B;
+        if (tier3(tier, bp))
+            precise_adj_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, zadj + (size_t)bp * NC * W,
+                                    lamEnd + (size_t)bp * NC * 64, NP, j);
+        return;
+    }
+    const int b = blockIdx.x;
+    if (tier3(tier, b)) return;
     const bool act = j < NT;
     const int jj = act ? j : 0;
     float* Lb = lamEnd + (size_t)b * NC * 64 + j;  // rows padded to 64 floats
@@ -1866,6 +2089,32 @@ __global__ __launch_bounds__(64) void lpc_inverse_bwd_a_kernel(const float* __re
     }
 }
 
+// Conditioning / health status of the forward that last used a workspace (golf_ltv_allpole_status_u32): one workgroup.
+__global__ __launch_bounds__(256) void lpc_status_kernel(const unsigned* __restrict__ tier,
+                                                         const unsigned* __restrict__ status,
+                                                         const float* __restrict__ pmax, int B, int NP,
+                                                         unsigned* __restrict__ out) {
+    __shared__ unsigned sh[3][256];
+    unsigned nh = 0u, n3 = 0u, mx = 0u;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        nh += tier[2 * b + 1] > 0u ? 1u : 0u;
+        n3 += tier[2 * b] == kTierPrecise ? 1u : 0u;
+    }
+    for (int64_t q = threadIdx.x; q < (int64_t)B * NP; q += 256) mx = max(mx, __float_as_uint(fabsf(pmax[q])));
+    sh[0][threadIdx.x] = nh; sh[1][threadIdx.x] = n3; sh[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+            sh[2][threadIdx.x] = max(sh[2][threadIdx.x], sh[2][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = status[0]; out[3] = sh[2][0]; }
+}
+__global__ void lpc_status_zero_kernel(unsigned* __restrict__ out) { if (threadIdx.x < 4) out[threadIdx.x] = 0u; }
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
@@ -1894,6 +2143,21 @@ static bool use_two_level_scan(const SsPlan& p, int B, int flags) {
     return p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN) && (int64_t)B * p.NG <= cap;
 }
 
+// Conditioning tiers (see phi_guard): recompute hot chunk maps from fp64 trajectories.  `accurate`: the maps in `ws` come
+// from fp64 trajectories already (training path), only tier-3 utterances get their doubles.
+template <int W, int NT>
+static int launch_fixup(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int accurate,
+                        hipStream_t st) {
+    if (p.NP <= 0) return GOLF_OK;
+    const int nwave = (int)ceil_div(p.NP, 64) * NT;
+    hipLaunchKernelGGL((lpc_fixup_kernel<W, NT>), dim3((unsigned)ceil_div(nwave, 4), B), dim3(256), 0, st, a,
+                       (float*)(ws + p.off_phiT), (double*)(ws + p.off_phi64), (const float*)(ws + p.off_pmax),
+                       (unsigned*)(ws + p.off_tier), (unsigned*)(ws + p.off_status), F, M, hop, p.L, p.NP, phi_guard(),
+                       phi_guard3(), accurate);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
 template <int W, int NT>
 static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStream_t st) {
     if constexpr (NT <= 24) {
@@ -1901,7 +2165,7 @@ static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStr
             const int nu = p.NG * B;   // composite workgroups only
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)nu), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
-                               (float*)nullptr, p.NP, p.NG, B, 0, (const float*)nullptr, (float*)(ws + p.off_gm));
+                               (float*)nullptr, p.NP, p.NG, B, 0, (const unsigned*)(ws + p.off_tier));
             GOLF_LAUNCH_CHECK();
         }
     }
@@ -1920,6 +2184,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
         hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
                            st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax));
         GOLF_LAUNCH_CHECK();
+        if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, 0, st)) return rc;
         return launch_composites<W, NT>(p, B, ws, flags, st);
     }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
@@ -1939,6 +2204,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
                        (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax));
     GOLF_LAUNCH_CHECK();
+    if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, 1, st)) return rc;
     return launch_composites<W, NT>(p, B, ws, flags, st);
 }
 
@@ -1966,21 +2232,6 @@ struct ForkJoin {
     }
 };
 
-// Guard of the final chunk kernels (see phi_guard): the arguments the kernel needs and the extra grid rows that hold its
-// guard waves (one wave per 16 utterances, gx waves per row).
-static GuardArgs guard_setup(const SsPlan& p, int64_t ex_stride, int64_t y_stride, int B, char* ws, int ngm, int gx,
-                             int* extra_rows) {
-    GuardArgs ga{nullptr, 0, 0.f, B};
-    *extra_rows = 0;
-    const float guard = phi_guard();
-    if (p.NP <= 0 || guard <= 0.f || !serial_strides_ok(ex_stride, y_stride)) return ga;
-    ga.gm = (const float*)(ws + p.off_gm);
-    ga.ngm = ngm;
-    ga.guard = guard;
-    *extra_rows = (int)ceil_div(ceil_div(B, 16), gx);
-    return ga;
-}
-
 template <int W, int NT>
 static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a, float* y,
                       int64_t y_stride, int B, int T, int F, int M, int hop, char* ws, int flags, hipStream_t side,
@@ -1988,6 +2239,9 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     float* PhiT = (float*)(ws + p.off_phiT);
     float* z = (float*)(ws + p.off_z);
     float* S = (float*)(ws + p.off_S);
+    const unsigned* tier = p.NP > 0 ? (const unsigned*)(ws + p.off_tier) : nullptr;
+    unsigned* nonfinite = (unsigned*)(ws + p.off_status);
+    const double* Phi64 = (const double*)(ws + p.off_phi64);
     constexpr int D = 8;
     const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
     ForkJoin fork, join;
@@ -2027,6 +2281,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                                        (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax));
                     GOLF_LAUNCH_CHECK();
                 }
+                if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, st)) return rc;
                 fused_p1 = true;
             } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, flags, s1)) {
                 return rc;
@@ -2035,7 +2290,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         if (!fused_p1) {
             hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
                                ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP,
-                               (const float*)nullptr);
+                               (const float*)nullptr, (const unsigned*)nullptr);
             GOLF_LAUNCH_CHECK();
         }
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
@@ -2045,56 +2300,46 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* MT = (float*)(ws + p.off_mt);
             float* Vz = (float*)(ws + p.off_gv);                    // [b][NG][32] zero-state group responses
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
-            float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S_{c+1} of the refinement pass
+            float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S1_{c+1} of the refinement pass
+            float* S1 = (float*)(ws + p.off_S1);                      // first-pass chunk start states
             const int gxf = (int)ceil_div(p.NC, kGroup);
-            int gextra = 0;
-            const GuardArgs ga = guard_setup(p, ex_stride, y_stride, B, ws, 3 * p.NG, gxf, &gextra);
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
             const int nu = p.NG * B, nz = (int)ceil_div(nu, 4);
-            const int first = fused_p1 ? 0 : nu, count = fused_p1 ? nu + nz : nz;   // in workgroups
+            const int first = fused_p1 ? 0 : nu, count = (fused_p1 ? nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first,
-                               (const float*)(ws + p.off_pmax), (float*)(ws + p.off_gm));
+                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first, tier);
             GOLF_LAUNCH_CHECK();
-            if (!fast) {   // accurate (fp64-derived) transition matrices: no refinement pass
-                hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)gxf, B + gextra), dim3(64), 0, st,
-                                   ex, ex_stride, gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT,
-                                   (const float*)MT, (const float*)Vz, (const float*)nullptr, (float*)nullptr,
-                                   (const float*)z, (const float*)nullptr, p.NP, p.NG, ga);
-                GOLF_LAUNCH_CHECK();
-                return GOLF_OK;
-            }
-            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)ceil_div(p.NP, kGroup), B), dim3(64), 0, st, ex,
-                               ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
-                               (const float*)MT, (const float*)Vz, (const float*)nullptr, Vd, (const float*)z,
-                               (const float*)nullptr, p.NP, p.NG, GuardArgs{nullptr, 0, 0.f, B});
+            // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
+            const int gx3 = (int)ceil_div(p.NP, kGroup);
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0, st,
+                               ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
+                               (const float*)MT, (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier,
+                               (unsigned*)nullptr, B, Phi64);
             GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)gxf, B + gextra), dim3(64), 0, st, ex,
-                               ex_stride, gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT,
-                               (const float*)MT, (const float*)Vz, (const float*)Vd, (float*)nullptr, (const float*)z,
-                               (const float*)dfc, p.NP, p.NG, ga);
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride, gain,
+                               a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,
+                               (const float*)Vd, (float*)nullptr, (const float*)dfc, p.NP, p.NG, S1, tier, nonfinite, B,
+                               Phi64);
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }
     }
-    hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT, (const float*)z,
-                       S, p.NC, p.NP, (const float*)(ws + p.off_pmax), (float*)(ws + p.off_gm));
+    hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, (const float*)PhiT,
+                       (const float*)z, S, p.NC, p.NP, B, tier, Phi64);
     GOLF_LAUNCH_CHECK();
-    if (fast && p.NP > 0) {  // one refinement sweep (see lpc_fwdq_kernel, MODE 2)
-        float* z2 = (float*)(ws + p.off_z2);
+    if (p.NP > 0) {  // one refinement sweep in delta form (see fwdq_body, MODE 2): defects, their scan added to S
+        float* dfc = (float*)(ws + p.off_z2);
         hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 2>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
-                           ex_stride, gain, a, (const float*)S, z2, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
-                           (const float*)z);
+                           ex_stride, gain, a, (const float*)S, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NC,
+                           (const float*)nullptr, tier);
         GOLF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, (const float*)PhiT,
-                           (const float*)z2, S, p.NC, p.NP, (const float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D, true>), dim3(B), dim3(64), 0, st, (const float*)PhiT,
+                           (const float*)dfc, S, p.NC, p.NP, B, tier, Phi64);
         GOLF_LAUNCH_CHECK();
     }
     const int gxf = (int)ceil_div(p.NC, 16);
-    int gextra = 0;
-    const GuardArgs ga = guard_setup(p, ex_stride, y_stride, B, ws, 1, gxf, &gextra);
-    hipLaunchKernelGGL((lpc_fwdq_final_kernel<W, NT>), dim3((unsigned)gxf, B + gextra), dim3(64), 0, st, ex, ex_stride, gain,
-                       a, (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, ga);
+    hipLaunchKernelGGL((lpc_fwdq_final_kernel<W, NT>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride, gain, a,
+                       (const float*)S, y, y_stride, T, F, M, hop, p.L, p.NC, p.NP > 0 ? nonfinite : (unsigned*)nullptr);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -2103,30 +2348,25 @@ template <int W, int NT>
 static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                       const float* ex, int64_t ex_stride, const float* gain, const float* a, float* g_ex,
                       int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T, int F, int M, int hop, char* ws,
-                      int ngm, hipStream_t st) {
+                      hipStream_t st) {
     const float* Phi = (const float*)(ws + p.off_phi);
     float* zadj = (float*)(ws + p.off_zadj);
     float* lam = (float*)(ws + p.off_lam);
     float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
+    const unsigned* tier = p.NP > 0 ? (const unsigned*)(ws + p.off_tier) : nullptr;   // as the forward left them
     constexpr int D = 8;
     const dim3 gq((unsigned)ceil_div(p.NC, 16), B);
     hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
                        zadj, (int64_t)0, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D>), dim3(B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
-                       p.NP);
+    hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D>), dim3(2 * B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
+                       p.NP, B, tier, (const double*)(ws + p.off_phi64));
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
                        (int64_t)T, T, F, M, hop, p.L, p.NC);
     GOLF_LAUNCH_CHECK();
-    if (p.NP > 0 && phi_guard() > 0.f && serial_strides_ok(gy_stride, (int64_t)T)) {   // see phi_guard: the flagged
-        // utterances get the adjoint signal of the sequential reverse recursion instead
-        hipLaunchKernelGGL((lpc_serial_adj_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, gy, gy_stride,
-                           a, gbuf, (int64_t)T, B, T, F, M, hop, (const float*)(ws + p.off_gm), ngm, phi_guard());
-        GOLF_LAUNCH_CHECK();
-    }
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
                        y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG);
     GOLF_LAUNCH_CHECK();
@@ -2141,7 +2381,7 @@ template <int W, int NT>
 static int launch_serial_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop, hipStream_t st) {
     hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, ex, ex_stride,
-                       gain, a, y, y_stride, B, T, F, M, hop, (const float*)nullptr, 0, 0.f);
+                       gain, a, y, y_stride, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -2155,7 +2395,7 @@ static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
     hipLaunchKernelGGL((lpc_serial_adj_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, gy, gy_stride,
-                       a, gbuf, (int64_t)T, B, T, F, M, hop, (const float*)nullptr, 0, 0.f);
+                       a, gbuf, (int64_t)T, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st,
                        (const float*)gbuf, (int64_t)T, y, y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T,
@@ -2244,6 +2484,28 @@ extern "C" int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, in
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_transitions: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 
+extern "C" int golf_ltv_allpole_status_u32(const void* ws, size_t ws_bytes, int B, int T, int F, int M, int hop, int flags,
+                                           uint32_t* out, void* stream) {
+    if (int rc = check_ss_args(B, T, F, M, hop)) return rc;
+    if (!out) return fail(GOLF_EINVAL, "ltv_allpole_status: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    SsPlan p;
+    // the serial / generic algorithms have no transition matrices: nothing is ever recomputed, all four words are 0
+    if (!plan_fast(B, T, F, M, hop, &p, flags) || p.serial || p.NP <= 0) {
+        hipLaunchKernelGGL(lpc_status_zero_kernel, dim3(1), dim3(64), 0, st, (unsigned*)out);
+        GOLF_LAUNCH_CHECK();
+        return GOLF_OK;
+    }
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "ltv_allpole_status: workspace needs %zu bytes, 256-aligned (got %zu)", p.total,
+                    ws_bytes);
+    const char* w = (const char*)ws;
+    hipLaunchKernelGGL(lpc_status_kernel, dim3(1), dim3(256), 0, st, (const unsigned*)(w + p.off_tier),
+                       (const unsigned*)(w + p.off_status), (const float*)(w + p.off_pmax), B, p.NP, (unsigned*)out);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
 extern "C" int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
                                         float* y, int64_t y_stride, int B, int T, int F, int M, int hop, void* ws,
                                         size_t ws_bytes, int flags, void* side_stream, void* stream) {
@@ -2301,8 +2563,7 @@ extern "C" int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, cons
         return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
     }
     GOLF_SS_DISPATCH(launch_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride, g_gain, g_a,
-                     B, T, F, M, hop, (char*)ws,
-                     use_two_level_scan(p, B, flags) ? 3 * p.NG : 1 /* what the forward condensed the guard maxima to */, st)
+                     B, T, F, M, hop, (char*)ws, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

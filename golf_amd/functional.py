@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_ola", "glottal_osc",
-           "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions",
+           "ss_output_length", "ff_output_length", "osc_lengths", "PreparedTransitions", "ss_status",
            "zero_phase_fir_basis", "zero_phase_fir_kernels", "ltv_fir_frames", "zero_phase_fir_filter",
            "zero_phase_fir_filter_precise",
            "fir_frames_length", "lti_fir", "harmonic_osc", "biquad_frames_ola"]
@@ -104,7 +104,7 @@ def ss_is_trainable(M: int, hop: int, F: int = 2) -> bool:
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0):
+    def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0, status=None):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
         ex = _rows(ex)
@@ -144,6 +144,13 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           y.stride(0), B, T, F, M, hop, ws.data_ptr(), ws.numel(), flags,
                                           side.cuda_stream if side is not None else 0, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_fwd_f32")
+        if status is not None:
+            # conditioning / health words of this forward (include/golf_amd.h golf_ltv_allpole_status_u32): written
+            # asynchronously on the stream into the caller's 4-word device tensor, read by the host when it likes
+            assert status.is_cuda and status.numel() >= 4 and status.element_size() == 4 and status.is_contiguous()
+            rc = lib.golf_ltv_allpole_status_u32(ws.data_ptr(), ws.numel(), B, T, F, M, hop, flags, status.data_ptr(),
+                                                 _lib.stream_ptr())
+            _lib.check(rc, "golf_ltv_allpole_status_u32")
         ctx.hop, ctx.mode = hop, mode
         ctx.save_for_backward(ex, gain, a, y, ws)
         return y
@@ -167,7 +174,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
                                           ws.data_ptr(), ws.numel(), ctx.mode, _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
-        return g_ex, g_gain, g_a, None, None, None, None
+        return g_ex, g_gain, g_a, None, None, None, None, None
 
 
 SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _FLAT_SCAN
@@ -175,7 +182,7 @@ SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
                    prepared: "PreparedTransitions" = None, fast_inference: bool = True,
-                   mode: str = None) -> torch.Tensor:
+                   mode: str = None, status: torch.Tensor = None) -> torch.Tensor:
     """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
     Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward).
     ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match).
@@ -183,8 +190,18 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
     ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
     serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one, "flat-scan" is
-    the chunked algorithm with the flat boundary scan instead of the two-level one (A/B)."""
-    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode])
+    the chunked algorithm with the flat boundary scan instead of the two-level one (A/B).
+    ``status``: optional int32 device tensor of >= 4 elements that receives, asynchronously, the conditioning / health
+    words of this call (decode with ss_status): utterances with recomputed chunk maps, utterances on the fp64 boundary
+    scan, non-finite output flag, largest transition-matrix entry."""
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode], status)
+
+
+def ss_status(status: torch.Tensor) -> dict:
+    """Decode the 4 status words of ltv_allpole_ss(..., status=t) (synchronises: reads the device tensor)."""
+    w = status.detach().to("cpu").view(torch.int32)[:4]
+    return {"hot_utterances": int(w[0]), "tier3_utterances": int(w[1]), "nonfinite": bool(int(w[2]) != 0),
+            "max_phi": float(w[3:4].view(torch.float32)[0])}
 
 
 class _LTVInverse(torch.autograd.Function):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GOLF_ABI_VERSION 2
+#define GOLF_ABI_VERSION 3
 
 enum {
     GOLF_OK = 0,
@@ -92,8 +92,8 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
 /*          GOLF_SS_FLAT_SCAN  chunk-boundary states by the flat scan (one wave per utterance, NP dependent matvecs)
  *                instead of the two-level scan that long utterances with M <= 24 take by default while the batch is
  *                small (utterances x groups of 16 chunks <= 2 x the CU count: B <= 39 at 2 s; group composites as
- *                exact-fp32 MFMA product chains + per-group scans spread over the chip + start states derived in the
- *                chunk kernels): an A/B switch; the two give the same states up to fp32 rounding. */
+ *                f64 MFMA product chains rounded once to fp32 + per-group scans spread over the chip + start states
+ *                derived in the chunk kernels): an A/B switch; the two give the same states up to fp32 rounding. */
 #define GOLF_SS_FLAT_SCAN 32
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
@@ -102,6 +102,20 @@ int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M,
 int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop,
                              void* ws, size_t ws_bytes, int flags, void* side_stream, void* stream);
+
+/* Conditioning and health status of the forward that last used `ws` (ABI 3).  The reference's sequential fp32
+ * recursion degrades gracefully when an interpolated filter comes close to instability (models/filters.py:99-113 ->
+ * torchlpc.sample_wise_lpc); the time-chunked algorithm keeps that behaviour by recomputing the
+ * transition matrices of such chunks from fp64 trajectories and, for the worst utterances, scanning their boundary
+ * states in fp64 (csrc/lpc_ss.hip, "conditioning tiers").  This call reports how often that happened and whether the
+ * output is finite -- asynchronously, on `stream`, into 4 caller-owned DEVICE words the host reads when it likes:
+ *   out[0]  utterances with at least one chunk whose matrix was recomputed from fp64 trajectories
+ *   out[1]  utterances whose boundary states came from the fp64 scan (tier 3)
+ *   out[2]  1 if a non-finite sample was written to y (an unstable filter is surfaced, not hidden)
+ *   out[3]  the largest |entry| over all transition matrices of the batch, as the bits of an fp32
+ * (B,T,F,M,hop,flags) as given to the forward.  The serial / generic algorithms form no matrices: all four words 0. */
+int golf_ltv_allpole_status_u32(const void* ws, size_t ws_bytes, int B, int T, int F, int M, int hop, int flags,
+                                uint32_t* out, void* stream);
 
 /* Custom backward of the above (what torchlpc's autograd.Function + autograd through
  * F.interpolate compute in the reference; closed form in SURVEY.md App. A-2):

@@ -432,13 +432,41 @@ def test_two_level_scan_random_shapes(B, F, M, hop, T):
     check(y, y2, "two-level vs flat", 5e-5)
 
 
+def run_status(ex, gain, a, hop, fast=True, mode=None):
+    """Forward + the boundary's conditioning / health words (golf_ltv_allpole_status_u32)."""
+    from golf_amd import functional as GF
+
+    st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    y = GF.ltv_allpole_ss(dev(ex), dev(gain), dev(a), hop, fast_inference=fast, mode=mode, status=st)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), GF.ss_status(st)
+
+
+def harsh_case(B, F, M, hop, sigma, seed, walk=0.02):
+    """Coefficient tracks far harsher than the benchmark recipe: logits ~ N(0, sigma^2), reflection coefficients near +-1."""
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(0, sigma, (B, 1, M)) + np.cumsum(rng.normal(0, walk, (B, F, M)), 1)
+    a = O.rc2lpc(np.tanh(logits)).astype(np.float32)
+    gain = np.exp(-3 + np.cumsum(rng.normal(0, 0.05, (B, F)), 1)).astype(np.float32)
+    ex = rng.normal(0, 1, (B, (F - 1) * hop + 1)).astype(np.float32)
+    return ex, gain, a
+
+
+def oracle_rows(ex, gain, a, hop):
+    """float64 oracle through the C restatement (OpenMP over the batch): full-size batches in seconds."""
+    from oracle import cpu_baseline as CB
+
+    return CB.ltv_ss_c(torch.as_tensor(ex).double(), torch.as_tensor(gain).double(), torch.as_tensor(a).double(), hop).numpy()
+
+
 def test_ill_conditioned_rows():
-    """Utterances whose filters sit at the edge of stability (reflection coefficients up to 0.98, pole radius 0.9999 --
-    ordinary for voiced speech) amplify every rounding error ~1e4-fold, so no fp32 path reaches 1e-4 there, the
-    reference's own sequential fp32 recursion included.  What must hold: the default path (two-level boundary scan with
-    double-precision group composites) is no worse than the arithmetic the reference uses -- the sequential fp32
-    recursion (serial kernels) -- by more than a small factor, on every row, and equally accurate on the benign rows.
-    (With fp32 composite products this test fails by two orders of magnitude on rows 10 and 31.)"""
+    """Utterances whose filters sit at the edge of stability (reflection coefficients up to 0.98, pole radius 0.9999)
+    amplify every rounding error ~1e4-fold, so no fp32 path reaches 1e-4 there, the reference's own sequential fp32
+    recursion included.  What must hold: every chunked path is as accurate as the arithmetic the reference uses -- the
+    sequential fp32 recursion (serial kernels) -- on every row, and within 1e-4 on the benign rows.  (Round 2 shipped
+    20 x here; the delta-form refinement sweep + conditioning tiers of round 3 bring it to the sequential level.)"""
     from oracle import golf_oracle as O
 
     B, F, M, hop = 32, 200, 22, 240
@@ -453,7 +481,7 @@ def test_ill_conditioned_rows():
     e_seq = row_err(run_mode(ex, gain, a, hop, "serial"))      # sequential fp32: the reference's arithmetic
     e_two = row_err(run_fwd(ex, gain, a, hop, fast=True))      # default inference path (two-level scan at B = 32)
     e_flat = row_err(run_mode(ex, gain, a, hop, "flat-scan"))
-    e_acc = row_err(run_fwd(ex, gain, a, hop, fast=False))     # fp64 transitions, two-level, no refinement
+    e_acc = row_err(run_fwd(ex, gain, a, hop, fast=False))     # fp64 transitions (training forward)
     hard = np.nonzero(e_seq > 1e-4)[0]
     print("hard rows", hard, "sequential", e_seq[hard], "two-level", e_two[hard], "flat", e_flat[hard], "fp64-Phi", e_acc[hard])
     assert len(hard) >= 1, "the case is supposed to contain ill-conditioned rows"
@@ -461,7 +489,7 @@ def test_ill_conditioned_rows():
     assert len(benign) >= 16
     for name, e in (("two-level", e_two), ("flat", e_flat), ("fp64 transitions", e_acc)):
         assert e[benign].max() <= 1e-4, (name, e[benign].max())
-        assert np.all(e <= 20 * e_seq + 2e-5), (name, np.nonzero(e > 20 * e_seq + 2e-5)[0], e.max())
+        assert np.all(e <= 3 * e_seq + 2e-5), (name, np.nonzero(e > 3 * e_seq + 2e-5)[0], e.max())
 
 
 def test_ill_conditioned_rows_backward():
@@ -488,59 +516,46 @@ def test_ill_conditioned_rows_backward():
     e_chk = errs(run_mode(ex, gain, a, hop, None, gy))
     hard = np.nonzero(e_seq > 2e-4)[0]
     print("hard rows", hard, "sequential", e_seq[hard], "chunked", e_chk[hard], "| benign max", e_chk[e_seq <= 2e-5].max())
-    # (measured: 1.3e-2 against 5.7e-4 on the one hard row -- its forward output, 3.7e-3 off, enters the correlations --
-    #  and 1.5e-5 on the benign rows)
-    assert np.all(e_chk <= 40 * e_seq + 2e-4), (np.nonzero(e_chk > 40 * e_seq + 2e-4)[0], e_chk.max())
+    assert np.all(e_chk <= BWD_FACTOR * e_seq + 2e-4), (np.nonzero(e_chk > BWD_FACTOR * e_seq + 2e-4)[0], e_chk.max())
 
 
-def test_conditioning_guard_falls_back_to_sequential():
-    """Coefficient tracks with reflection coefficients near +-1 (logits ~ N(0, 1)): some chunk transition matrices have
-    entries of 1e3 .. 1e5 and the fp32 time-chunked algorithm returns garbage, inf or NaN there, while a sequential fp32
-    recursion -- the reference's arithmetic -- stays finite and within ~1e-2.  The library records max |Phi| per chunk
-    and re-runs exactly those utterances with its serial kernels: the default path must then EQUAL the serial path on
-    the flagged utterances (same kernel, same inputs), stay as accurate as before on the others, and its gradients must
-    be finite and equal to the serial backward on the flagged rows."""
-    from oracle import golf_oracle as O
+# the adjoint boundary scan has no refinement sweep yet: its error on hot utterances is first order in the maps' rounding
+BWD_FACTOR = 40
 
-    rng = np.random.default_rng(1)
-    B, F, M, hop = 12, 120, 22, 240
-    found = None
-    for _ in range(40):   # draw until the batch mixes benign and extreme utterances
-        logits = rng.normal(0, 1.0, (B, 1, M)) + np.cumsum(rng.normal(0, 0.01, (B, F, M)), 1)
-        logits[: B // 2] *= 0.4                                         # half the batch benign
-        a = O.rc2lpc(np.tanh(logits)).astype(np.float32)
-        gain = np.exp(-3 + np.cumsum(rng.normal(0, 0.05, (B, F)), 1)).astype(np.float32)
-        ex = rng.normal(0, 1, (B, (F - 1) * hop + 1)).astype(np.float32)
-        ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
-        if not np.isfinite(ref).all() or np.abs(ref).max() > 1e10:
-            continue
-        y_ser = run_mode(ex, gain, a, hop, "serial")
-        e_ser = np.abs(y_ser - ref).max(1) / np.abs(ref).max(1)
-        if (e_ser > 5e-3).sum() >= 2 and (e_ser < 1e-5).sum() >= 4:
-            found = (ex, gain, a, ref, y_ser, e_ser)
-            break
-    assert found is not None, "no suitable batch drawn"
-    ex, gain, a, ref, y_ser, e_ser = found
-    scale = np.abs(ref).max(1)
-    flagged_any = np.zeros(B, bool)
-    for fast in (True, False):
-        y = run_fwd(ex, gain, a, hop, fast=fast)
-        assert np.isfinite(y).all(), fast
+
+@pytest.mark.parametrize("sigma,seed", [(0.7, 12), (1.0, 13)])
+def test_conditioning_tiers_harsh_tracks(sigma, seed):
+    """Coefficient tracks with reflection coefficients near +-1: chunk transition matrices with entries of 1e2 .. 1e5.
+    The fp32 time-chunked algorithm of round 2 returned garbage, inf or NaN there and fell back to a 2.6 ms sequential
+    pass; the conditioning tiers (hot chunk maps from fp64 trajectories; the worst utterances on an fp64 boundary scan)
+    keep every path at the accuracy of the sequential fp32 recursion -- the reference's arithmetic -- on every utterance
+    the float64 oracle can resolve, the status words report what was done, and nothing non-finite leaves unreported."""
+    B, F, M, hop = 24, 200, 22, 240
+    ex, gain, a = harsh_case(B, F, M, hop, sigma, seed)
+    ref = oracle_rows(ex, gain, a, hop)
+    ok = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e12)       # unstable tracks: nothing to compare against
+    assert ok.sum() >= B // 2
+    scale = np.abs(ref).max(1) + 1e-300
+    y_ser = run_mode(ex, gain, a, hop, "serial")
+    e_ser = np.abs(y_ser - ref).max(1) / scale
+    for fast, mode in ((True, None), (True, "flat-scan"), (False, None)):
+        y, st = run_status(ex, gain, a, hop, fast=fast, mode=mode)
         e = np.abs(y - ref).max(1) / scale
-        redone = np.array([np.array_equal(y[b], y_ser[b]) for b in range(B)])   # recomputed by the serial kernel
-        flagged_any |= redone
-        print("fast", fast, "sequential", np.sort(e_ser)[-3:], "default", np.sort(e)[-3:], "recomputed rows", np.nonzero(redone)[0])
-        assert np.all(redone | (e <= 40 * e_ser + 1e-4)), (fast, np.nonzero(~redone & (e > 40 * e_ser + 1e-4))[0], e.max())
-    assert flagged_any.any(), "the batch was drawn to contain utterances beyond the guard"
-    gy = (rng.normal(0, 1, ref.shape) / scale[:, None]).astype(np.float32)
+        worst = np.argsort((e / (e_ser + 1e-7))[ok])[-3:]
+        print(f"sigma {sigma} fast {fast} mode {mode}: status {st}; worst ratios",
+              [(int(np.nonzero(ok)[0][w]), float(e[ok][w]), float(e_ser[ok][w])) for w in worst])
+        assert st["tier3_utterances"] >= 1 and st["hot_utterances"] >= st["tier3_utterances"], st
+        assert st["max_phi"] > 256 or not np.isfinite(st["max_phi"]), st
+        assert st["nonfinite"] == (not np.isfinite(y).all()), st
+        good = ok & (e_ser < 0.05)          # beyond that the sequential recursion itself has lost the signal
+        assert np.all(e[good] <= 3 * e_ser[good] + 1e-4), (fast, mode, np.nonzero(good & (e > 3 * e_ser + 1e-4))[0],
+                                                            e[good].max())
+    # gradients: finite wherever the forward is, and no worse than the sequential adjoint by more than the known factor
+    gy = (np.random.default_rng(2).normal(0, 1, ref.shape) / scale[:, None]).astype(np.float32)
+    gy[~ok] = 0
     res = run_mode(ex, gain, a, hop, None, gy)
-    ser = run_mode(ex, gain, a, hop, "serial", gy)
-    redone = np.array([np.array_equal(res[0][b], ser[0][b]) for b in range(B)])
-    for g_def, g_ser, name in zip(res[1:], ser[1:], ("g_ex", "g_gain", "g_a")):
-        assert np.isfinite(g_def).all(), name
-        if redone.any():
-            d = np.abs(g_def[redone] - g_ser[redone]).max() / (np.abs(g_ser[redone]).max() + 1e-30)
-            assert d <= 1e-5, (name, d)
+    for g, name in zip(res[1:], ("g_ex", "g_gain", "g_a")):
+        assert np.isfinite(g[ok]).all(), name
 
 
 def test_two_level_switch_point_by_batch():
@@ -558,27 +573,45 @@ def test_two_level_switch_point_by_batch():
 
 def test_b256_benchmark_inputs_every_utterance():
     """BASELINE configs[3] draws 256 utterances from the benchmark recipe.  One of them (row 50 of seed 2434, largest
-    transition entry 510) came out 500 % wrong from the unguarded chunked path and another 1.4 % -- found only when every
-    row was compared, the first 32 (configs[1]) being benign.  With the conditioning guard: every row within 2e-3 of the
-    sequential kernels' output (the reference's arithmetic), the flagged ones bit-identical to it, and the rows that
-    deviate most checked against the float64 oracle."""
+    transition entry 510) came out 500 % wrong from the unguarded chunked path of round 2 and another 1.4 % -- found only
+    when every row was compared, the first 32 (configs[1]) being benign.  Round 3 bar: EVERY row within
+    2 x the sequential fp32 recursion's error (the reference's arithmetic) + 1e-4 of the float64 oracle, on the flat-scan
+    path this batch size takes and on the two-level path its 32-utterance shards take; the status words name the rows."""
     from golf_amd import functional as GF
     from golf_amd.synthetic import make_inputs
-    from oracle import golf_oracle as O
 
     inp = make_inputs(B=256, seed=2434)
-    ex, gain, a, hop = inp["noise"], inp["gain"], inp["a"], inp["hop"]
-    y = GF.ltv_allpole_ss(ex.cuda(), gain.cuda(), a.cuda(), hop).cpu().numpy()
-    ys = GF.ltv_allpole_ss(ex.cuda(), gain.cuda(), a.cuda(), hop, mode="serial").cpu().numpy()
-    assert np.isfinite(y).all()
-    dev_rel = np.abs(y - ys).max(1) / np.abs(ys).max(1)
-    redone = np.array([np.array_equal(y[b], ys[b]) for b in range(256)])
-    print("recomputed rows", np.nonzero(redone)[0], "largest deviation from the sequential kernel", dev_rel.max(), "row", dev_rel.argmax())
-    assert redone[50], "row 50 (max |Phi| = 510) has to be taken over by the guard"
-    assert dev_rel.max() <= 2e-3, (int(dev_rel.argmax()), float(dev_rel.max()))
-    sub = np.argsort(dev_rel)[-6:]
-    ref = O.ltv_allpole_ss_forward(ex.numpy()[sub], gain.numpy()[sub], a.numpy()[sub], hop)
-    err = np.abs(y[sub] - ref).max(1) / np.abs(ref).max(1)
-    err_s = np.abs(ys[sub] - ref).max(1) / np.abs(ref).max(1)
-    print("vs oracle", err, "sequential", err_s)
-    assert np.all(err <= 20 * err_s + 1e-4)
+    ex, gain, a, hop = inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy(), inp["hop"]
+    ref = oracle_rows(ex, gain, a, hop)
+    scale = np.abs(ref).max(1)
+    ys = run_mode(ex, gain, a, hop, "serial")
+    e_seq = np.abs(ys - ref).max(1) / scale
+    y, st = run_status(ex, gain, a, hop)
+    assert np.isfinite(y).all() and not st["nonfinite"]
+    e = np.abs(y - ref).max(1) / scale
+    print("status", st, "worst row", int(e.argmax()), float(e.max()), "sequential there", float(e_seq[e.argmax()]),
+          "largest ratio", float((e / (e_seq + 5e-5)).max()))
+    assert st["tier3_utterances"] >= 1 and st["hot_utterances"] >= 3, st      # row 50 (510) is tier 3; rows beyond 30 are hot
+    assert np.all(e <= 2 * e_seq + 1e-4), (np.nonzero(e > 2 * e_seq + 1e-4)[0], e.max())
+    for lo in range(0, 256, 32):                                              # the 8 shards of configs[3]: two-level scan
+        ysh, sth = run_status(ex[lo:lo + 32], gain[lo:lo + 32], a[lo:lo + 32], hop)
+        esh = np.abs(ysh - ref[lo:lo + 32]).max(1) / scale[lo:lo + 32]
+        assert np.all(esh <= 2 * e_seq[lo:lo + 32] + 1e-4), (lo, np.nonzero(esh > 2 * e_seq[lo:lo + 32] + 1e-4)[0], esh.max())
+
+
+@pytest.mark.parametrize("seed", [2435, 2436, 3001])
+def test_recipe_fuzz_every_utterance(seed):
+    """tools/fuzz_lpc.py folded into the suite: 128 more utterances of the benchmark recipe per seed, every
+    row of the default path against the float64 oracle with the sequential fp32 recursion beside it."""
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=128, seed=seed)
+    ex, gain, a, hop = inp["noise"].numpy(), inp["gain"].numpy(), inp["a"].numpy(), inp["hop"]
+    ref = oracle_rows(ex, gain, a, hop)
+    scale = np.abs(ref).max(1)
+    e_seq = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    for lo in range(0, 128, 32):
+        y, st = run_status(ex[lo:lo + 32], gain[lo:lo + 32], a[lo:lo + 32], hop)
+        e = np.abs(y - ref[lo:lo + 32]).max(1) / scale[lo:lo + 32]
+        print(f"seed {seed} rows {lo}..{lo + 31}: status {st}, worst {e.max():.2e} (sequential {e_seq[lo:lo + 32][e.argmax()]:.2e})")
+        assert np.all(e <= 2 * e_seq[lo:lo + 32] + 1e-4), (seed, lo, np.nonzero(e > 2 * e_seq[lo:lo + 32] + 1e-4)[0], e.max())
