@@ -84,6 +84,10 @@ def parse():
                          "clocks: instantiation is setup, not a step)")
     ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "flat-scan"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
+    ap.add_argument("--recipe-stream", type=int, default=-1,
+                    help="also time a stream of this many consecutive recipe batches (seeds 2434, 2435, ...: benign and hot "
+                         "ones alike, each its own captured graph) through the same S streams; -1: 64 for the default "
+                         "single-GPU golf-ss-synth run, 0 otherwise")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
@@ -183,9 +187,7 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
             dec.room_filter.kernel.copy_(inp["room_kernel"])
         split_sizes, trsfms, keys = dec.split_sizes_and_trsfms
         flat = [n for grp in split_sizes for n in grp]
-        torch.manual_seed(2434)
-        h = torch.randn(B, a.shape[1], sum(flat), device=phase.device) * 0.3
-        h[..., 64 + 256] -= 3.0   # log-gain channel
+        h = logits_workload_encoder_output(inp, flat, phase.device)
         ph = AudioTensor(phase)
 
         @torch.no_grad()
@@ -259,6 +261,54 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
 
     y = step()
     return step, int(y.shape[0] * y.shape[1]), y.shape[1]
+
+
+def logits_workload_encoder_output(inp, flat, device):
+    """Stand-in for the encoder output (B, F, 343) of golf-ss-decoder-logits: random heads for the table-selection
+    network and the noise filter, and the RECIPE's smooth tracks in the end filter's channels -- log-gain and
+    the LPC logits that .ctrl turns into reflection coefficients.  (Rounds 1-2 filled those with white noise per frame:
+    SURVEY 8d forbids exactly that -- interpolating unrelated stable frames is unstable -- and every utterance then had
+    transition-matrix entries of 1e13.)"""
+    B, F = inp["gain"].shape
+    g = torch.Generator(device="cpu").manual_seed(2434)
+    h = (torch.randn(B, F, sum(flat), generator=g) * 0.3).to(device)
+    n_lpc = inp["logits"].shape[-1]
+    assert flat[-2:] == [1, n_lpc] or list(flat[-2:]) == [1, n_lpc], flat
+    h[..., -n_lpc:] = inp["logits"]
+    h[..., -n_lpc - 1] = inp["log_gain"]
+    return h
+
+
+def conditioning_of(workload, inp, device):
+    """Conditioning / health words of the sample-wise filter on one slot's coefficient tracks (golf_ltv_allpole_status_u32):
+    how many of its utterances had chunk maps recomputed from fp64 trajectories (hot), how many ran on the fp64 boundary
+    scan (tier 3), whether the output is finite, the largest transition-matrix entry.  One extra filter call outside every
+    timed region.  None for workloads without the sample-wise filter."""
+    from golf_amd import functional as GF
+
+    if "ss" not in workload and workload != "lpc-ss-fast":
+        return None
+    gain, a, hop = inp["gain"], inp["a"], inp["hop"]
+    if workload == "golf-ss-decoder-logits":   # the coefficient tracks the decoder derives from its logits
+        from golf_amd.audiotensor import AudioTensor
+        from golf_amd.synthetic import make_decoder
+
+        dec = make_decoder(injected_noise=inp["noise"]).to(device).eval()
+        split_sizes, trsfms, keys = dec.split_sizes_and_trsfms
+        flat = [n for grp in split_sizes for n in grp]
+        h = logits_workload_encoder_output(inp, flat, device)
+        pieces = [AudioTensor(t.squeeze(2) if t.shape[2] == 1 else t, hop) for t in torch.split(h, flat, dim=2)]
+        i = 0
+        for key, grp, fn in zip(keys, split_sizes, trsfms):
+            if key == "end_filter_params":
+                g_at, a_at = fn(*pieces[i:i + len(grp)])
+                gain, a = g_at.as_tensor().contiguous(), a_at.as_tensor().contiguous()
+            i += len(grp)
+    st = torch.zeros(4, dtype=torch.int32, device=device)
+    with torch.no_grad():
+        GF.ltv_allpole_ss(inp["noise"], gain, a, hop, status=st)
+    torch.cuda.synchronize()
+    return GF.ss_status(st)
 
 
 def device_kernel_times(step, n=20):
@@ -410,13 +460,17 @@ def main():
                 for k, v in shard_inputs(inp_all, rank, world).items()}
 
     steps_fn, samples, t_out = [], None, None
+    slot_cond = []   # per in-flight slot: the filter's conditioning words on that slot's coefficient tracks
     for i in range(S):
         if i > 0 and args.shared_inputs:
             steps_fn.append(steps_fn[0])
+            slot_cond.append(slot_cond[0])
             continue
-        fn, samples, t_out = make_step(args.workload, slot_inputs(i), osc, ss, ff, fast=not args.fp64_transitions,
+        inp_i = slot_inputs(i)
+        fn, samples, t_out = make_step(args.workload, inp_i, osc, ss, ff, fast=not args.fp64_transitions,
                                        overlap=args.overlap_transitions, mode=args.lpc_mode)
         steps_fn.append(fn)
+        slot_cond.append(conditioning_of(args.workload, inp_i, device))
     step = steps_fn[0]
 
     do_gather = world > 1 and not args.no_gather
@@ -526,6 +580,70 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * samples / (elapsed / args.steps)
 
+    # ---- conditioning of the slots' filters, per rank (N > 1: the first SCALE run must be readable)
+    cond_ranks = None
+    if slot_cond and slot_cond[0] is not None:
+        mine = torch.tensor([[c["hot_utterances"], c["tier3_utterances"], int(c["nonfinite"])] for c in slot_cond],
+                            device=device, dtype=torch.int32)
+        if world > 1:
+            import torch.distributed as dist
+
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            cond_ranks = [t.cpu().tolist() for t in allr]
+        else:
+            cond_ranks = [mine.cpu().tolist()]
+
+    # ---- a stream of consecutive recipe batches: the headline's S slots are S fixed batches; a serving
+    # loop sees every batch of the recipe, the hot ones included.  N batches, each its own graph, replayed round-robin on
+    # the same S streams.
+    recipe_stream = None
+    n_rs = args.recipe_stream if args.recipe_stream >= 0 else (64 if (world == 1 and args.workload == "golf-ss-synth"
+                                                                      and B == 32 and use_graphs) else 0)
+    if n_rs > 0 and use_graphs and world == 1:
+        rs_graphs, rs_cond = [], []
+        for k in range(n_rs):
+            inp_k = make_inputs(B=B, device=device, with_noise_filter="decoder" in args.workload, seed=2434 + k)
+            fn_k, _, _ = make_step(args.workload, inp_k, osc, ss, ff, fast=not args.fp64_transitions, mode=args.lpc_mode)
+            warm = torch.cuda.Stream(device=device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                fn_k()
+            torch.cuda.current_stream().wait_stream(warm)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yk = fn_k()
+            rs_graphs.append((g, yk))
+            rs_cond.append(conditioning_of(args.workload, inp_k, device))
+        torch.cuda.synchronize()
+
+        def rs_region():
+            for rep_i in range(max(1, args.steps // n_rs)):
+                for k in range(n_rs):
+                    with torch.cuda.stream(streams[k % S]):
+                        rs_graphs[k][0].replay()
+
+        for _ in range(2):
+            rs_region()
+        torch.cuda.synchronize()
+        rs_times = []
+        for _ in range(max(3, args.repeats)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs_region()
+            torch.cuda.synchronize()
+            rs_times.append((time.perf_counter() - t0) / (max(1, args.steps // n_rs) * n_rs))
+        rs_med = sorted(rs_times)[len(rs_times) // 2]
+        hot_b = [k for k, c in enumerate(rs_cond) if c and c["hot_utterances"] > 0]
+        recipe_stream = {
+            "batches": n_rs, "seeds": [2434, 2434 + n_rs - 1], "us_per_step": round(rs_med * 1e6, 2),
+            "value": samples / rs_med, "unit": "audio samples/s",
+            "hot_utterances": int(sum(c["hot_utterances"] for c in rs_cond if c)),
+            "tier3_utterances": int(sum(c["tier3_utterances"] for c in rs_cond if c)),
+            "batches_with_hot_utterances": len(hot_b), "nonfinite_batches": int(sum(c["nonfinite"] for c in rs_cond if c)),
+            "note": "latency of each batch alone (cold / hot / tier 3): tools/recipe_latency.py -> profiles/"}
+        del rs_graphs
+
     result = None
     collective_step = world > 1 and args.workload == "golf-ss-train-step"   # DDP: every rank must take every step
     if rank != 0 and collective_step:
@@ -543,7 +661,7 @@ def main():
         graph_us = event_time_us(graphs[0].replay) if use_graphs else None   # the same as one hipGraph launch
         traffic = None
         try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed
-            for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
                 fn = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(fn):
                     continue
@@ -558,6 +676,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/ (separate rocprofv3 --pmc passes, not measured in this run)",
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "path_frac": round(PATH_BYTES[args.workload] * samples / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "path_frac_single_stream": round(PATH_BYTES[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
@@ -592,12 +711,28 @@ def main():
             "roofline": roofline,
             "stages_us": stages,
         }
+        if cond_ranks is not None:
+            # conditioning of the sample-wise filter on the slots' inputs: [hot utterances, tier-3 utterances, non-finite]
+            # per slot, per rank (golf_ltv_allpole_status_u32; csrc/lpc_ss.hip "conditioning tiers")
+            result["conditioning"] = {
+                "flagged_utterances_per_slot": [[c[0] for c in r] for r in cond_ranks],
+                "tier3_utterances_per_slot": [[c[1] for c in r] for r in cond_ranks],
+                "nonfinite_per_slot": [[c[2] for c in r] for r in cond_ranks],
+                "max_phi_per_slot_rank0": [None if c is None else round(c["max_phi"], 2) for c in slot_cond],
+                "thresholds": {"hot_utterance_G1": float(os.environ.get("GOLF_SS_PHI_GUARD", 30)),
+                               "hot_chunk_G2": float(os.environ.get("GOLF_SS_PHI_GUARD2", 16)),
+                               "tier3_G3": float(os.environ.get("GOLF_SS_PHI_GUARD3", 256))}}
+        if recipe_stream is not None:
+            result["recipe_stream"] = recipe_stream
         if world > 1:
             result["exchange"] = {"backend": args.dist_backend, "world_size": world,
                                   "bytes_in_per_rank_per_step": int((world - 1) * B * t_out * 4) if do_gather else 0,
                                   "bytes_per_collective_per_rank": int(GE * B * t_out * 4) if do_gather and not peer_store else 0,
                                   "collectives_per_step": (1.0 / GE) if do_gather and not peer_store else 0.0,
-                                  "mode": args.gather_mode if do_gather else "none"}
+                                  "mode": args.gather_mode if do_gather else "none",
+                                  # hot utterances cost their rank ~13 us more per step: the ranks a synchronous gather waits for
+                                  "flagged_utterances_per_rank": None if cond_ranks is None else [sum(c[0] for c in r) for r in cond_ranks],
+                                  "tier3_utterances_per_rank": None if cond_ranks is None else [sum(c[1] for c in r) for r in cond_ranks]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(B, 240, 22)

@@ -42,7 +42,7 @@ struct SsPlan {
     // conditioning tiers (see lpc_fixup_kernel): per-utterance tier words, first-pass chunk start states of the two-level
     // scan (the delta-form refinement adds its correction to exactly these), the status words, and -- touched only for the
     // rare tier-3 utterances -- the transition matrices as doubles
-    size_t off_tier, off_S1, off_status, off_phi64;
+    size_t off_tier, off_S1, off_status, off_phi64, off_fixcnt;
 };
 bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode = 0);
 int ss_serial_min_batch();

@@ -93,7 +93,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->off_phi = p->off_phiT = p->off_z = p->off_E = p->off_z2 = p->off_S = p->off_zadj = p->off_lam = 0;
         p->NG = p->GS = 0;
         p->off_mt = p->off_gv = p->off_pmax = 0;
-        p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = 0;
+        p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = p->off_fixcnt = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -114,6 +114,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
     p->off_tier = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);     // conditioning tier + hot-chunk count per utterance
     p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
+    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);   // fix-up units completed / claimed per utterance
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
     // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
@@ -140,8 +141,11 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
 // harsher coefficient tracks --
 //   tier 1  largest |entry| of a chunk's fp32 map <= G1 (30): fp32 map + one sweep = sequential fp32 (1.8 % of the
 //           recipe's utterances have a chunk beyond 30, 0.13 % one beyond 256);
-//   tier 2  a chunk beyond G1 ("hot"): lpc_fixup_kernel recomputes its map from fp64 trajectories, rounds it to fp32 IN
-//           PLACE, and everything downstream is unchanged: equal to sequential fp32 up to entries of ~400;
+//   tier 2  an utterance with a chunk beyond G1: lpc_fixup_kernel recomputes the maps of its chunks beyond G2 (10) from
+//           fp64 trajectories, rounds them to fp32 IN PLACE, and everything downstream is unchanged: equal to sequential
+//           fp32 up to entries of ~400.  (Why the second threshold: inside a long stretch of 15..30 the fp32 maps' errors
+//           are amplified by the hot neighbours -- over 2048 utterances of the recipe "chunks beyond 30 only" left one at
+//           3.5 x the sequential error, "beyond 10 where some chunk is beyond 30" none above 1.2 x.)
 //   tier 3  an utterance with an entry beyond G3 (256), a non-finite one, or groups of maps whose product could overflow
 //           fp32: all its maps are recomputed and kept as DOUBLES, one wave scans its boundary states in fp64 (riding in
 //           the pre-pass / first scan launch), and its chunks run from those states without a sweep: at or below the
@@ -153,12 +157,21 @@ static float phi_guard() {
     static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD"); return e ? (float)atof(e) : 30.f; }();
     return v;   // <= 0: no chunk is ever hot (dev knob)
 }
+static float phi_guard2() {
+    static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD2"); return e ? (float)atof(e) : 16.f; }();
+    return v;   // chunks of an utterance that has a chunk beyond G1 are hot from G2 on
+}
 static float phi_guard3() {
     static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD3"); return e ? (float)atof(e) : 256.f; }();
     return v;   // <= 0: no utterance is ever tier 3 (dev knob)
 }
 // rows of 16 utterances are addressed through one 32-bit buffer descriptor (serial kernels)
 static bool serial_strides_ok(int64_t s0, int64_t s1) { return s0 < (1 << 24) && s1 < (1 << 24); }
+// diagnostic A/B switch (bench): no fix-up launch at all, every utterance is treated as tier 1 (status words are then void)
+static bool no_fixup() {
+    static const bool v = [] { const char* e = getenv("GOLF_SS_NO_FIXUP"); return e && atoi(e) != 0; }();
+    return v;
+}
 constexpr unsigned kTierHot = 2u, kTierPrecise = 3u;
 // tier words: tier[2 b] = 0 / 2 / 3, tier[2 b + 1] = number of hot chunks (wave-uniform reads: b is)
 __device__ __forceinline__ bool tier3(const unsigned* __restrict__ tier, int b) {
@@ -715,7 +728,7 @@ struct P1fGeom {
 template <int W, int NT>
 __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
                                          int L, int NP, int nq, float* __restrict__ tile_all, int blk_id,
-                                         float* __restrict__ pmax) {
+                                         float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0) {
     // Workgroups of P1F_WPB = 4 independent waves: there are fewer waves than SIMDs (637 for B=32) and every wave is
     // FMA-issue bound, so two waves sharing a SIMD double the kernel.  With single-wave workgroups the dispatcher's
     // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
@@ -728,6 +741,8 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     float* tile = tile_all + wv * (CPP * NT * LDT);
     const int cl = lane / NG, grp = lane - cl * NG;
     const int q0 = (blk_id * P1F_WPB + wv) * CPW;
+    if (fixcnt && blk_id == 0 && wv == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
+        for (int e = lane; e < 2 * B; e += 64) fixcnt[e] = 0u;
     if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
@@ -850,9 +865,10 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
 template <int W, int NT>
 __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
                                                                int F, int M, int hop, int L, int NP, int nq,
-                                                               float* __restrict__ pmax) {
+                                                               float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
+                                                               int B) {
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
-    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax);
+    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B);
 }
 
 // `upw` zero-state units (16 chunks of one utterance each) per wave, one after the other: the host picks upw so that the
@@ -884,12 +900,13 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __r
                                                                 const float* __restrict__ a, float* __restrict__ z,
                                                                 float* __restrict__ PhiT, int T, int F, int M, int hop,
                                                                 int L, int NP, int nq, int nblk_f, int ncg, int B,
-                                                                int upw, float* __restrict__ pmax) {
+                                                                int upw, float* __restrict__ pmax,
+                                                                unsigned* __restrict__ fixcnt) {
     using TL = Tile<W, 16>;
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
     __shared__ float xt[P1F_WPB][TL::SIZE];
     if ((int)blockIdx.x < nblk_f) {
-        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax);
+        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B);
     } else {
         p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_f, xt);
     }
@@ -920,9 +937,12 @@ __global__ __launch_bounds__(256) void lpc_p1hz_kernel(const float* __restrict__
 // 27 MB of coalesced traffic instead of ~3 M scattered 4-byte stores inside the trajectory kernel: -28 us there).
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restrict__ Phi, float* __restrict__ PhiT,
-                                                            int nq, float* __restrict__ pmax) {
+                                                            int nq, float* __restrict__ pmax,
+                                                            unsigned* __restrict__ fixcnt, int B) {
     __shared__ float t[4][NT * (W + 1)];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (fixcnt && blockIdx.x == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
+        for (int e = threadIdx.x; e < 2 * B; e += 256) fixcnt[e] = 0u;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
     const float* src = Phi + (size_t)q * NT * W;
@@ -970,26 +990,23 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Conditioning tiers (see phi_guard): lpc_fixup_kernel runs right after the transition kernel.
-//   grid (ceil(ceil(NP / 64) * NT / 4), B), workgroups of 4 independent waves; wave -> (block of 64 chunks, trajectory j),
-//   lane = chunk.  Every wave reduces its utterance's per-chunk maxima (one round of loads) and returns unless one of its
-//   chunks is hot; a hot lane runs ONE fp64 homogeneous trajectory over its chunk (~25 us) and overwrites column j of the
-//   chunk's fp32 map -- and, for a tier-3 utterance, row j of the map kept as doubles.
+// Conditioning tiers (see phi_guard): the fix-up of hot chunk maps.
+//   Decision: every wave that needs it derives its utterance's tier from the per-chunk maxima the transition kernel left
+//   (a few loads + wave reductions; all waves arrive at the same answer, nothing is communicated).
+//   Work: unit = (chunk c, trajectory j), one QUAD of lanes per unit, 16 units per wave -- the tap-parallel systolic
+//   recursion of fwdq_body in fp64 (lane r owns taps [r TPL, (r+1) TPL) and a TPL-deep window; per step TPL coefficient +
+//   TPL dot FMAs, a 2-stage DPP butterfly, a 1-lane DPP shift): ~13 us per chunk instead of ~25 us with one lane per
+//   trajectory.  A unit's quad ends with column j of the chunk's map: overwrites it in the fp32 map (rounded once) and,
+//   for a tier-3 utterance, stores row j of the map kept as doubles.
+//   Units are enumerated densely over ALL chunks (u = c NT + j) and dealt round-robin to the utterance's fix-up waves; a
+//   wave skips a pass none of whose 16 units is hot, so a cluster of hot chunks spreads over consecutive waves.
 //   `accurate` (training path: the maps already come from fp64 trajectories): only tier 3 is acted on.
 // ------------------------------------------------------------------------------------------
-template <int W, int NT>
-__global__ __launch_bounds__(256) void lpc_fixup_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
-                                                        double* __restrict__ Phi64, const float* __restrict__ pmax,
-                                                        unsigned* __restrict__ tier, unsigned* __restrict__ status,
-                                                        int F, int M, int hop, int L, int NP, float g1, float g3,
-                                                        int accurate) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int u = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cb = u / NT, j = u - cb * NT;
-    if (cb * 64 >= NP) return;   // wave-uniform
-    const float* pm = pmax + (size_t)b * NP;
-    unsigned umax = 0u, nhot = 0u;
+struct UttTier { bool t2, t3; unsigned nhot; };
+
+__device__ __forceinline__ UttTier utterance_tier(const float* __restrict__ pm, int NP, int lane, float g1, float g2,
+                                                  float g3, int accurate) {
+    unsigned umax = 0u;
     bool ovf = false;
     for (int c0 = 0; c0 < NP; c0 += 64) {
         const int c = c0 + lane;
@@ -1000,34 +1017,105 @@ __global__ __launch_bounds__(256) void lpc_fixup_kernel(const float* __restrict_
         float lg = __log2f(fmaxf(v, 1.f));
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
-        ovf = ovf || lg > 100.f;
-        nhot += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c < NP && g1 > 0.f && !(v <= g1)));
+        ovf = ovf || lg > 120.f;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) umax = max(umax, (unsigned)__shfl_xor((int)umax, off));
-    const bool t3 = g3 > 0.f && (!(__uint_as_float(umax) <= g3) || __builtin_amdgcn_ballot_w64(ovf) != 0ull);
-    if (u == 0 && lane == 0) {
-        tier[2 * b] = t3 ? kTierPrecise : ((nhot > 0u && !accurate) ? kTierHot : 0u);
-        tier[2 * b + 1] = nhot;
-        if (b == 0) status[0] = 0u;   // the final pass ORs 1 into it when a non-finite sample leaves
+    UttTier d;
+    d.t3 = g3 > 0.f && (!(__uint_as_float(umax) <= g3) || __builtin_amdgcn_ballot_w64(ovf) != 0ull);
+    d.t2 = !accurate && g1 > 0.f && !(__uint_as_float(umax) <= g1);   // some chunk beyond G1: chunks beyond G2 are hot
+    d.nhot = 0u;
+    if (d.t3) {
+        d.nhot = (unsigned)NP;
+    } else if (d.t2) {
+        for (int c0 = 0; c0 < NP; c0 += 64)
+            d.nhot += (unsigned)__builtin_popcountll(
+                __builtin_amdgcn_ballot_w64(c0 + lane < NP && !(fabsf(pm[c0 + lane < NP ? c0 + lane : 0]) <= g2)));
     }
-    const int c = cb * 64 + lane;
-    const bool hot = c < NP && (t3 || (!accurate && g1 > 0.f && !(fabsf(pm[c < NP ? c : 0]) <= g1)));
-    if (__builtin_amdgcn_ballot_w64(hot) == 0ull) return;   // wave-uniform: the common case ends here
-    const size_t q = (size_t)b * NP + (hot ? c : 0);
-    if (j >= M) {   // padding trajectory: the fp32 map already holds zeros there; the doubles need them
-        if (hot && t3) {
-            double* o = Phi64 + (q * NT + j) * W;
-#pragma unroll
-            for (int i = 0; i < W; ++i) o[i] = 0.0;
+    return d;
+}
+
+// 64-bit DPP = two 32-bit DPP moves (v_add_f64 takes no DPP operand).  bound_ctrl: no `old` value has to be materialised.
+template <int CTRL>
+__device__ __forceinline__ double dppd(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+struct FixArgs {
+    const float* a;      // (B, F, M) coefficients
+    float* PhiT;         // fp32 maps [b][c][i][j]
+    double* Phi64;       // maps as doubles [b][c][j][i] (tier 3 only)
+    const float* pmax;   // largest |entry| per chunk, from the transition kernel
+    unsigned* tier;      // [b][2]: tier, hot chunks
+    unsigned* status;    // [0] non-finite output, [1] a wait for the fix-up timed out
+    unsigned* fixcnt;    // [b]: fix-up units completed, [B + b]: units claimed (zeroed by the transition kernel)
+    int F, M, hop, L, NP, B;
+    float g1, g2, g3;
+    int accurate;
+};
+
+// One wave of utterance b's fix-up.  Units (hot chunk, trajectory) are CLAIMED 16 at a time from a per-utterance counter, so
+// any number of waves can share the work in any order: the workgroups that lead the grid guarantee that it gets done
+// (they are resident or finished before any wave that waits for them starts), the ones that trail the grid only make it
+// faster when there is room for them.  `hotlist`: the wave's own LDS scratch for the compact list of hot chunks.
+constexpr int kHotListMax = 1024;   // chunks per utterance the compact list holds (ushort); longer utterances enumerate all chunks
+template <int W, int NT>
+__device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes_tier, unsigned short* __restrict__ hotlist) {
+    constexpr int TPL = quad_tpl(W, NT);
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 2, r = lane & 3;
+    const int NP = fa.NP, M = fa.M, F = fa.F, hop = fa.hop, L = fa.L;
+    const float* pm = fa.pmax + (size_t)b * NP;
+    const UttTier d = utterance_tier(pm, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
+    if (writes_tier && lane == 0) {
+        fa.tier[2 * b] = d.t3 ? kTierPrecise : (d.t2 ? kTierHot : 0u);
+        fa.tier[2 * b + 1] = d.nhot;
+        if (b == 0) { fa.status[0] = 0u; fa.status[1] = 0u; }   // the final pass ORs 1 into [0] when a non-finite sample leaves
+    }
+    if (d.nhot == 0u) return;   // wave-uniform: the common case ends here
+    const bool listed = NP <= kHotListMax;
+    if (listed) {   // compact list of the hot chunks (every wave builds its own: a few ballots)
+        int base = 0;
+        for (int c0 = 0; c0 < NP; c0 += 64) {
+            const int c = c0 + lane;
+            const bool h = c < NP && (d.t3 || !(fabsf(pm[c < NP ? c : 0]) <= fa.g2));
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
+            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (h) hotlist[base + pre] = (unsigned short)c;
+            base += __builtin_popcountll(m);
         }
-        return;
+        wave_lds_fence();
     }
-    double h[W];
+    const int total = (listed ? (int)d.nhot : NP) * NT;   // units: (listed chunk, trajectory)
+    unsigned done = 0u;
+    for (;;) {
+        int k0 = 0;
+        if (lane == 0) k0 = (int)atomicAdd(fa.fixcnt + fa.B + b, 16u);   // claim counters follow the B done counters
+        k0 = __builtin_amdgcn_readfirstlane(k0);
+        if (k0 >= total) break;
+        const int k = k0 + row;
+        const bool live = k < total;
+        done += (unsigned)((total - k0 < 16) ? total - k0 : 16);
+        const int h = live ? k / NT : 0, j = live ? k - h * NT : 0;
+        const int c = listed ? (int)hotlist[h] : h;
+        const bool hot = live && (listed || d.t3 || !(fabsf(pm[c]) <= fa.g2));
+        if (!hot) continue;   // whole quads
+        const size_t q = (size_t)b * NP + c;
+        double* o64 = fa.Phi64 + (q * NT + j) * W;
+        if (d.t3)
+            for (int i = 4 * TPL + r; i < W; i += 4) o64[i] = 0.0;
+        if (j >= M) {   // padding trajectory: the fp32 map already holds zeros there; the doubles need them
+            if (d.t3) {
 #pragma unroll
-    for (int k = 0; k < W; ++k) h[k] = (W - 1 - k == j) ? 1.0 : 0.0;
-    if (hot) {
-        double a0[NT], dd[NT];
+                for (int kk = 0; kk < TPL; ++kk) o64[r * TPL + kk] = 0.0;
+            }
+            continue;
+        }
+        double w[TPL], a0[TPL], dd[TPL];
+#pragma unroll
+        for (int kk = 0; kk < TPL; ++kk) w[TPL - 1 - kk] = (r * TPL + kk == j) ? 1.0 : 0.0;
         const double inv_hop = 1.0 / (double)hop;
         int fcur = -1;
         const int nblk = L / W;
@@ -1036,43 +1124,83 @@ __global__ __launch_bounds__(256) void lpc_fixup_kernel(const float* __restrict_
             const int f = t0 / hop;  // <= F-2: chunks with a transition matrix end before (F-1)*hop
             if (f != fcur) {
                 fcur = f;
-                const float* pa0 = a + ((size_t)b * F + f) * M;
+                const float* pa0 = fa.a + ((size_t)b * F + f) * M;
                 const float* pa1 = pa0 + M;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const double v0 = i < M ? (double)pa0[i] : 0.0;
-                    const double v1 = i < M ? (double)pa1[i] : 0.0;
-                    a0[i] = v0;
-                    dd[i] = (v1 - v0) * inv_hop;
+                for (int kk = 0; kk < TPL; ++kk) {
+                    const int i = r * TPL + kk;
+                    const double v0 = i < M ? (double)pa0[i < M ? i : 0] : 0.0;
+                    const double v1 = i < M ? (double)pa1[i < M ? i : 0] : 0.0;
+                    a0[kk] = -v0;                       // NEGATED coefficients: the tap sum is the new sample itself
+                    dd[kk] = (v0 - v1) * inv_hop;
                 }
             }
             const double n0 = (double)(t0 - f * hop);
 #pragma unroll
             for (int s = 0; s < W; ++s) {
                 const double n = n0 + (double)s;
-                double ra = 0.0, rb = 0.0;
+                double cf[TPL];
 #pragma unroll
-                for (int i = NT - 1; i >= 1; --i) {
-                    const double cf = __builtin_elementwise_fma(n, dd[i], a0[i]);
-                    const int slot = (s - 1 - i + 2 * W) % W;
-                    if (i & 1) ra = __builtin_elementwise_fma(cf, h[slot], ra);
-                    else       rb = __builtin_elementwise_fma(cf, h[slot], rb);
+                for (int kk = 0; kk < TPL; ++kk) cf[kk] = __builtin_elementwise_fma(n, dd[kk], a0[kk]);
+                double pa = 0.0, pb = 0.0;
+#pragma unroll
+                for (int kk = TPL - 1; kk >= 1; --kk) {
+                    const int slot = (s - 1 - kk + 4 * TPL) % TPL;
+                    if (kk & 1) pa = __builtin_elementwise_fma(cf[kk], w[slot], pa);
+                    else        pb = __builtin_elementwise_fma(cf[kk], w[slot], pb);
                 }
-                const double cf0 = __builtin_elementwise_fma(n, dd[0], a0[0]);
-                h[s] = __builtin_elementwise_fma(-cf0, h[(s - 1 + W) % W], -(ra + rb));
+                double part = __builtin_elementwise_fma(cf[0], w[(s - 1 + TPL) % TPL], pa + pb);
+                part += dppd<DPP_XOR1>(part);
+                part += dppd<DPP_XOR2>(part);       // = y[t] (homogeneous: no input), in every lane of the quad
+                const double inc = dppd<DPP_SHR1>(w[s % TPL]);
+                w[s % TPL] = r == 0 ? part : inc;   // lane 0 takes y, the others their left neighbour's oldest
+                // (a DPP bank mask cannot do this select: banks are lanes 4i..4i+3 of a row, not lane % 4)
             }
         }
-        if (!accurate) {   // column j of PhiT[q][i][j] = d s_end[i] / d s_start[j]
-            float* o = PhiT + q * NT * W + j;
+        // this lane holds entries i = r TPL + kk of column j: d s_end[i] / d s_start[j]
+        if (!fa.accurate) {
+            float* o = fa.PhiT + q * NT * W + j;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) o[(size_t)i * W] = i < M ? (float)h[W - 1 - i] : 0.f;
+            for (int kk = 0; kk < TPL; ++kk) {
+                const int i = r * TPL + kk;
+                if (i < NT) o[(size_t)i * W] = i < M ? (float)w[TPL - 1 - kk] : 0.f;
+            }
         }
-        if (t3) {          // row j of Phi64[q][j][i]
-            double* o = Phi64 + (q * NT + j) * W;
+        if (d.t3) {
 #pragma unroll
-            for (int i = 0; i < W; ++i) o[i] = i < M ? h[W - 1 - i] : 0.0;
+            for (int kk = 0; kk < TPL; ++kk) {
+                const int i = r * TPL + kk;
+                o64[i] = i < M ? w[TPL - 1 - kk] : 0.0;
+            }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0 && done) atomicAdd(fa.fixcnt + b, done);
+}
+
+// Waves of the SAME launch that read an utterance's maps after its fix-up (the composite and zero-state workgroups of
+// lpc_group_prepass_kernel): wait until all units have reported.  The leading fix-up workgroups precede every waiter in
+// the grid, so they are resident or done when a waiter starts: no deadlock; a bounded spin, so no hang either way.
+__device__ __forceinline__ void wait_for_fixup(const FixArgs& fa, int b, unsigned nhot, int NT) {
+    const unsigned expected = (fa.NP <= kHotListMax ? nhot : (unsigned)fa.NP) * (unsigned)NT;
+    unsigned it = 0u;
+    while (__hip_atomic_load(fa.fixcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++it > (1u << 16)) {
+            if ((threadIdx.x & 63) == 0) atomicOr(fa.status + 1, 1u);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// The fix-up as a launch of its own (flat-scan path, transitions prepared without the two-level scan):
+// grid (KF, B), 4 independent waves per workgroup.
+template <int W, int NT>
+__global__ __launch_bounds__(256) void lpc_fixup_kernel(FixArgs fa) {
+    __shared__ unsigned short hotlist[4][kHotListMax];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    fixup_wave<W, NT>(fa, blockIdx.y, blockIdx.x == 0 && wv == 0, hotlist[wv]);
 }
 
 __device__ __forceinline__ double lane_bcast_d(double v, int lane) {
@@ -1383,29 +1511,68 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
     if (i < 32) V[((size_t)b * NG + g) * 32 + i] = s;
 }
 
-// Both pre-passes of the two-level scan in ONE launch (they depend only on the transition kernel's outputs):
-// workgroups [0, NG*B) form the group composites (4 waves cooperating on one group), the ceil(NG*B / 4) workgroups after
-// them the groups' zero-state responses (one wave per group, four independent waves per workgroup).  Tier-3 utterances
-// (see phi_guard) take their states from the fp64 scan wave that rides in the refinement launch: nothing to do here.
-//   [first, first + count) in workgroup units: everything, or only the composites (transitions prepared ahead of the
-//   excitation: golf_ltv_allpole_transitions_f32) / only the zero-state scans (the forward that picks them up).
+// Both pre-passes of the two-level scan AND the fix-up of hot chunk maps in ONE launch (they depend only on the transition
+// kernel's outputs).  Workgroup ranges, in grid order (`parts` bit 0: fix-up + composites, bit 1: zero-state scans):
+//   B*KF1               leading fix-up workgroups (fixup_wave; 4 independent waves each): every wave derives its utterance's
+//                       tier and returns at once unless the utterance has hot chunks.  Few (KF1 per utterance): they are
+//                       what GUARANTEES the fix-up (a waiter never starts before them), not what makes it fast;
+//   ceil(NG*B / 4)      the groups' zero-state responses (one wave per group, four independent waves per workgroup);
+//   NG*B                group composites (4 waves cooperating on one group);
+//   B*KF2               trailing fix-up workgroups: the same waves again, claiming units from the same counters -- they make
+//                       a hot utterance's fix-up ~one 13 us pass, and cost a cold batch nothing (they start after everything
+//                       else has been dispatched and return after one load).
+// A composite / zero-state wave looks at its OWN group's 16 chunk maxima first: nothing beyond G2 there (the common case)
+// -> its maps are final, go ahead.  Otherwise it derives the utterance's tier like the fix-up waves do: tier 2 waits until
+// the utterance's units have all reported (wait_for_fixup), tier 3 steps aside (its states come from the fp64 scan wave in
+// the refinement launch).  So a batch without hot chunks pays neither a launch nor a wait for the conditioning machinery
+// (as a launch of its own the fix-up cost 4 us of latency and 6 us/step of the pipelined rate; with all its workgroups
+// leading this grid, 7 us), and a hot one pays about one fix-up pass inside this launch.
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
                                                                 const float* __restrict__ z, float* __restrict__ MT,
                                                                 float* __restrict__ V, int NP, int NG, int B,
-                                                                int first, const unsigned* __restrict__ tier) {
+                                                                int parts, FixArgs fa, int KF1, int KF2) {
     __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
-    const int blk = first + (int)blockIdx.x, nu = NG * B;
-    if (blk < nu) {
+    static_assert(sizeof(double) * 32 * 32 >= sizeof(unsigned short) * 4 * kHotListMax, "the fix-up waves' lists reuse pb_lds");
+    const bool fix = fa.pmax != nullptr && (parts & 1);   // (no fix-up at all: diagnostic switch GOLF_SS_NO_FIXUP)
+    const int nu = NG * B;
+    const int nf1 = fix ? B * KF1 : 0, nz = (parts & 2) ? (nu + 3) / 4 : 0, nc = (parts & 1) ? nu : 0;
+    int blk = (int)blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blk < nf1) {
+        fixup_wave<W, NT>(fa, blk / KF1, blk % KF1 == 0 && wv == 0, reinterpret_cast<unsigned short*>(pb_lds) + wv * kHotListMax);
+        return;
+    }
+    blk -= nf1;
+    if (blk >= nz + nc) {   // trailing fix-up workgroups
+        blk -= nz + nc;
+        if (fix) fixup_wave<W, NT>(fa, blk / KF2, false, reinterpret_cast<unsigned short*>(pb_lds) + wv * kHotListMax);
+        return;
+    }
+    const bool comp = blk >= nz;
+    int b, g;
+    if (comp) {
+        blk -= nz;
         // the fold of group g runs over the groups BEFORE it: the last composite is needed only when the final partial
         // chunk opens a group of its own (NP a multiple of 16)
         if (blk % NG == NG - 1 && NP % kGroup != 0) return;
-        if (tier3(tier, blk / NG)) return;
-        group_composite_wg<W, NT>(PhiT, MT, NP, NG, blk / NG, blk % NG, pb_lds);
+        b = blk / NG; g = blk % NG;
     } else {
-        const int u2 = (blk - nu) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (u2 < nu && !tier3(tier, u2 / NG)) group_zscan_body<W, NT>(PhiT, z, V, NP, NG, u2 / NG, u2 % NG, threadIdx.x & 63);
+        const int u2 = blk * 4 + wv;
+        if (u2 >= nu) return;
+        b = u2 / NG; g = u2 % NG;
     }
+    if (fa.pmax) {
+        const int c = g * kGroup + (lane & 15);
+        const float v = c < NP ? fabsf(fa.pmax[(size_t)b * NP + c]) : 0.f;
+        if (__builtin_amdgcn_ballot_w64(!(v <= fa.g2)) != 0ull) {   // a chunk of this group may have been recomputed
+            const UttTier d = utterance_tier(fa.pmax + (size_t)b * NP, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
+            if (d.t3) return;
+            if (d.nhot > 0u && !fa.accurate) wait_for_fixup(fa, b, d.nhot, NT);
+        }
+    }
+    if (comp) group_composite_wg<W, NT>(PhiT, MT, NP, NG, b, g, pb_lds);
+    else      group_zscan_body<W, NT>(PhiT, z, V, NP, NG, b, g, lane);
 }
 
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
@@ -2143,33 +2310,73 @@ static bool use_two_level_scan(const SsPlan& p, int B, int flags) {
     return p.NG > 0 && !(flags & GOLF_SS_FLAT_SCAN) && (int64_t)B * p.NG <= cap;
 }
 
-// Conditioning tiers (see phi_guard): recompute hot chunk maps from fp64 trajectories.  `accurate`: the maps in `ws` come
-// from fp64 trajectories already (training path), only tier-3 utterances get their doubles.
+// Conditioning tiers (see phi_guard): the arguments of the fix-up.  `accurate`: the maps in `ws` come from fp64
+// trajectories already (training path), only tier-3 utterances get their doubles.
+static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, char* ws, int accurate) {
+    FixArgs fa;
+    fa.a = a;
+    fa.PhiT = (float*)(ws + p.off_phiT);
+    fa.Phi64 = (double*)(ws + p.off_phi64);
+    fa.pmax = no_fixup() ? nullptr : (const float*)(ws + p.off_pmax);
+    fa.tier = (unsigned*)(ws + p.off_tier);
+    fa.status = (unsigned*)(ws + p.off_status);
+    fa.fixcnt = (unsigned*)(ws + p.off_fixcnt);
+    fa.F = F; fa.M = M; fa.hop = hop; fa.L = p.L; fa.NP = p.NP;
+    fa.B = 0;   // set by the caller
+    fa.g1 = phi_guard(); fa.g2 = phi_guard2(); fa.g3 = phi_guard3();
+    fa.accurate = accurate;
+    static const bool nowait = [] { const char* e = getenv("GOLF_SS_FIXUP_NOWAIT"); return e && atoi(e) != 0; }();   // dev knob (A/B timing only: wrong for hot batches)
+    if (nowait) fa.g3 = -12345.f;
+    return fa;
+}
+// fix-up workgroups (4 waves of 16 units) per utterance: KF1 lead the grid (the guarantee), KF2 trail it (the speed);
+// together at most one pass over all units of an utterance
+static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2) {
+    static const int e1 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF1"); return e ? atoi(e) : 0; }();   // dev knobs
+    static const int e2 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF2"); return e ? atoi(e) : -1; }();
+    const int64_t all = ceil_div((int64_t)p.NP * NT, 64);   // workgroups that cover every unit in one pass
+    int k1 = e1 > 0 ? e1 : 6;
+    if (k1 > all) k1 = (int)(all < 1 ? 1 : all);
+    int64_t k2 = e2 >= 0 ? e2 : 42;
+    if (k1 + k2 > all) k2 = all - k1 > 0 ? all - k1 : 0;
+    *kf1 = k1;
+    *kf2 = (int)k2;
+}
+
+// ... as a launch of its own (flat-scan path)
 template <int W, int NT>
 static int launch_fixup(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int accurate,
                         hipStream_t st) {
-    if (p.NP <= 0) return GOLF_OK;
-    const int nwave = (int)ceil_div(p.NP, 64) * NT;
-    hipLaunchKernelGGL((lpc_fixup_kernel<W, NT>), dim3((unsigned)ceil_div(nwave, 4), B), dim3(256), 0, st, a,
-                       (float*)(ws + p.off_phiT), (double*)(ws + p.off_phi64), (const float*)(ws + p.off_pmax),
-                       (unsigned*)(ws + p.off_tier), (unsigned*)(ws + p.off_status), F, M, hop, p.L, p.NP, phi_guard(),
-                       phi_guard3(), accurate);
+    if (p.NP <= 0 || no_fixup()) return GOLF_OK;
+    int k1, k2;
+    fixup_kf(p, NT, &k1, &k2);
+    FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate);
+    fa.B = B;
+    hipLaunchKernelGGL((lpc_fixup_kernel<W, NT>), dim3((unsigned)(k1 + k2), B), dim3(256), 0, st, fa);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
 
+// Transitions prepared ahead of the excitation: what the forward's boundary scan derives from the matrices alone -- the
+// fix-up of hot chunk maps and, with the two-level scan, the group composites (one launch).
 template <int W, int NT>
-static int launch_composites(const SsPlan& p, int B, char* ws, int flags, hipStream_t st) {
+static int launch_composites(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int accurate,
+                             int flags, hipStream_t st) {
     if constexpr (NT <= 24) {
-        if (use_two_level_scan(p, B, flags)) {   // two-level boundary scan: the group composites need only Phi
-            const int nu = p.NG * B;   // composite workgroups only
-            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)nu), dim3(256), 0, st,
+        if (use_two_level_scan(p, B, flags)) {
+            FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate);
+            fa.B = B;
+            int k1, k2;
+            fixup_kf(p, NT, &k1, &k2);
+            const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B;
+            hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)(nf + nu)), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
-                               (float*)nullptr, p.NP, p.NG, B, 0, (const unsigned*)(ws + p.off_tier));
+                               (float*)nullptr, p.NP, p.NG, B, 1, fa, k1, k2);
             GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
         }
     }
-    return GOLF_OK;
+    return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, st);
 }
 
 template <int W, int NT>
@@ -2182,10 +2389,10 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
         constexpr int CPW = 64 / ((NT + 3) / 4);
         hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
-                           st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax));
+                           st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
+                           (unsigned*)(ws + p.off_fixcnt), B);
         GOLF_LAUNCH_CHECK();
-        if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, 0, st)) return rc;
-        return launch_composites<W, NT>(p, B, ws, flags, st);
+        return launch_composites<W, NT>(p, a, B, F, M, hop, ws, 0, flags, st);
     }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
     if (kt_env == 1) {
@@ -2202,10 +2409,9 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     }
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
-                       (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax));
+                       (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt), B);
     GOLF_LAUNCH_CHECK();
-    if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, 1, st)) return rc;
-    return launch_composites<W, NT>(p, B, ws, flags, st);
+    return launch_composites<W, NT>(p, a, B, F, M, hop, ws, 1, flags, st);
 }
 
 // Fork/join helper: `side` runs P1h (needs only `a`) while `st` runs P1z (needs the excitation).
@@ -2239,7 +2445,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     float* PhiT = (float*)(ws + p.off_phiT);
     float* z = (float*)(ws + p.off_z);
     float* S = (float*)(ws + p.off_S);
-    const unsigned* tier = p.NP > 0 ? (const unsigned*)(ws + p.off_tier) : nullptr;
+    const unsigned* tier = p.NP > 0 && !no_fixup() ? (const unsigned*)(ws + p.off_tier) : nullptr;
     unsigned* nonfinite = (unsigned*)(ws + p.off_status);
     const double* Phi64 = (const double*)(ws + p.off_phi64);
     constexpr int D = 8;
@@ -2264,7 +2470,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                     const int nblk_z = (int)ceil_div(nunit, 4 * upw);
                     hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
                                        0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
-                                       B, upw, (float*)(ws + p.off_pmax));
+                                       B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt));
                     GOLF_LAUNCH_CHECK();
                 } else {
                     constexpr int KT = 3, NG = (NT + KT - 1) / KT;
@@ -2278,10 +2484,10 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                                        upw);
                     GOLF_LAUNCH_CHECK();
                     hipLaunchKernelGGL((lpc_transpose_kernel<W, NT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), 0, st,
-                                       (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax));
+                                       (const float*)Phi, PhiT, nq, (float*)(ws + p.off_pmax),
+                                       (unsigned*)(ws + p.off_fixcnt), B);
                     GOLF_LAUNCH_CHECK();
                 }
-                if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, st)) return rc;
                 fused_p1 = true;
             } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, flags, s1)) {
                 return rc;
@@ -2304,10 +2510,14 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* S1 = (float*)(ws + p.off_S1);                      // first-pass chunk start states
             const int gxf = (int)ceil_div(p.NC, kGroup);
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
-            const int nu = p.NG * B, nz = (int)ceil_div(nu, 4);
-            const int first = fused_p1 ? 0 : nu, count = (fused_p1 ? nu : 0) + nz;   // in workgroups
+            FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1);
+            fa.B = B;
+            int k1, k2;
+            fixup_kf(p, NT, &k1, &k2);
+            const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B, nz = (int)ceil_div(nu, 4);
+            const int parts = fused_p1 ? 3 : 2, count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, first, tier);
+                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2);
             GOLF_LAUNCH_CHECK();
             // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
             const int gx3 = (int)ceil_div(p.NP, kGroup);
@@ -2324,6 +2534,8 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             return GOLF_OK;
         }
     }
+    if (fused_p1)   // (otherwise launch_transitions / the caller's transitions call ran it)
+        if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, st)) return rc;
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, (const float*)PhiT,
                        (const float*)z, S, p.NC, p.NP, B, tier, Phi64);
     GOLF_LAUNCH_CHECK();
@@ -2355,7 +2567,7 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
-    const unsigned* tier = p.NP > 0 ? (const unsigned*)(ws + p.off_tier) : nullptr;   // as the forward left them
+    const unsigned* tier = p.NP > 0 && !no_fixup() ? (const unsigned*)(ws + p.off_tier) : nullptr;   // as the forward left them
     constexpr int D = 8;
     const dim3 gq((unsigned)ceil_div(p.NC, 16), B);
     hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,

@@ -11,7 +11,7 @@ def matvec32(Mx, s):
     return (Mx @ s).astype(f32)
 
 
-def solve(ex, gain, a, T, hop, L, thr, sweeps, two_level, Phi32=None, Phi64=None, per_chunk=True, ret=False):
+def solve(ex, gain, a, T, hop, L, thr, sweeps, two_level, Phi32=None, Phi64=None, per_chunk=True, ret=False, thr2=None):
     F, M = a.shape
     NC = -(-T // L); NP = NC - 1
     if Phi32 is None: Phi32 = lab.phi_all(a, NP, L, hop, 32)
@@ -20,6 +20,8 @@ def solve(ex, gain, a, T, hop, L, thr, sweeps, two_level, Phi32=None, Phi64=None
     mx = np.where(np.isfinite(mx), mx, np.inf)
     if per_chunk:
         hot = mx > thr
+        if thr2 is not None and hot.any():   # an utterance with a hot chunk: its other chunks are hot from thr2 on
+            hot = mx > thr2
     else:
         hot = np.full(NP, mx.max() > thr)
     Phi = np.where(hot[:, None, None], Phi64, Phi32).astype(f32)
