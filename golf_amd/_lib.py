@@ -50,6 +50,9 @@ SIGNATURES = {
                                            _c_f32p, _c_f32p] + [_int] * 7 + [_vp, _vp, _sz, _vp]),
     "golf_biquad_frames_ola_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64] + [_int] * 9
                                        + [_vp, _sz, _vp]),
+    "golf_biquad_frames_bwd_workspace_bytes": (_sz, [_int] * 7),
+    "golf_biquad_frames_ola_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64,
+                                              _c_f32p, _c_f32p, _c_f32p] + [_int] * 9 + [_vp, _sz, _vp]),
     "golf_rc2lpc_fwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
     "golf_rc2lpc_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),
     "golf_sos2lpc_fwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, ctypes.c_float, _int, _vp]),

@@ -622,6 +622,152 @@ extern "C" int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, c
     return fail(GOLF_EUNSUPPORTED, "lti_frames_bwd: need M <= 38 and hop >= ring width (M=%d hop=%d)", M, hop);
 }
 
+// ---- backward of the cascade (the reference is differentiable through its K lfilter calls,
+// models/lpc.py:115-118).  One wave per frame; both cascades are laid across lanes like the forward's:
+//   phase 1  re-runs the forward cascade and keeps EVERY section's output in LDS: Y[0] = the gain-scaled input frame,
+//            Y[k+1] = output of section k (the correlations of phase 2 need them);
+//   phase 2  the adjoint cascade: the adjoint of an LTI all-pole section is the same section run BACKWARDS in time,
+//            u_{k-1}[n] = (u_k[n] - a1 u_{k-1}[n+1] - a2 u_{k-1}[n+2]) / a0, fed at the last section with
+//            u_K = window * g_q of the frame; lane k takes its input from lane k+1's previous output (row_shl:1) and
+//            accumulates d/d(a0,a1,a2) of its section = -sum_n u_{k-1}[n] * y_k[n - i];
+//   lane 0's output u_0 is the gradient w.r.t. the scaled input frame: stored (times the frame gain in gain mode 1) for the
+//   overlap-add kernel below; gain mode 1 also reduces g_gain[b,f] = sum_n u_0[n] x[n] here.
+#define DPP_ROW_SHL1 0x101
+__global__ __launch_bounds__(64) void ff_biquad_bwd_kernel(const float* __restrict__ gq, int64_t gq_stride,
+                                                           const float* __restrict__ ex, int64_t ex_stride,
+                                                           const float* __restrict__ gain, const float* __restrict__ bq,
+                                                           const float* __restrict__ window, float* __restrict__ ufr,
+                                                           float* __restrict__ g_bq, float* __restrict__ g_gain_f,
+                                                           int Tx, int Ty, int F, int K, int hop, int Wl, int pad,
+                                                           int nfr, int gain_mode) {
+    extern __shared__ __attribute__((aligned(16))) float bqb_lds[];
+    const int WS = Wl + 4;
+    float* Y = bqb_lds;                    // [(K+1)][WS], row k at Y + k*WS + 2 (two zeros in front: y[-1], y[-2])
+    float* U = bqb_lds + (size_t)(K + 1) * WS;   // [WS]: u_K on the way in, u_0 on the way out
+    const int lane = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+    const int k = lane;
+    const float* gb = gain + (size_t)b * F;
+    const float inv_hop = 1.0f / (float)hop;
+    const int tb = f * hop - pad;          // input sample of frame position 0
+    for (int i = lane; i < (K + 1) * WS; i += 64) Y[i] = 0.f;
+    wave_lds_fence();
+    for (int n = lane; n < Wl; n += 64) {
+        const int t = tb + n;
+        float xv = (t >= 0 && t < Tx) ? ex[(size_t)b * ex_stride + t] : 0.f;
+        float G = 1.f;
+        if (gain_mode == 0) {
+            int ft = max(t, 0) / hop;
+            ft = max(min(ft, F - 2), 0);
+            G = fmaf((float)(t - ft * hop), (gb[min(ft + 1, F - 1)] - gb[ft]) * inv_hop, gb[ft]);
+        } else {
+            G = gb[f];
+        }
+        Y[2 + n] = xv * G;
+        const int to = tb + n;              // output sample index of frame position n: f*hop - pad + n
+        U[n] = (to >= 0 && to < Ty) ? window[n] * gq[(size_t)b * gq_stride + to] : 0.f;
+    }
+    float a1 = 0.f, a2 = 0.f, ia0 = 1.f;
+    if (k < K) {
+        const float* c = bq + (((size_t)b * F + f) * K + k) * 3;
+        ia0 = 1.0f / c[0];
+        a1 = c[1] * ia0;
+        a2 = c[2] * ia0;
+    }
+    wave_lds_fence();
+    // ---- phase 1: forward cascade, lane k = section k filters sample m - k at step m
+    {
+        float s1 = 0.f, s2 = 0.f, outp = 0.f;
+        for (int m = 0; m < Wl + K - 1; ++m) {
+            const float sh = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, outp), DPP_ROW_SHR1, 0xF, 0xF, true));
+            const int n = m - k;
+            const bool on = k < K && n >= 0 && n < Wl;
+            const float in = k == 0 ? Y[2 + (on ? n : 0)] : sh;
+            const float y = on ? fmaf(ia0, in, fmaf(-a1, s1, -a2 * s2)) : 0.f;
+            if (on) { s2 = s1; s1 = y; Y[(size_t)(k + 1) * WS + 2 + n] = y; }
+            outp = y;
+        }
+    }
+    wave_lds_fence();
+    // ---- phase 2: adjoint cascade in reverse time, lane k = section k handles sample Wl-1 - (m - (K-1-k)) at step m
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    {
+        float s1 = 0.f, s2 = 0.f, outp = 0.f;
+        const float* yk = Y + (size_t)(k < K ? k + 1 : 0) * WS + 2;   // this section's OUTPUT
+        for (int m = 0; m < Wl + K - 1; ++m) {
+            const float sh = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, outp), DPP_ROW_SHL1, 0xF, 0xF, true));
+            const int n = Wl - 1 - (m - (K - 1 - k));
+            const bool on = k < K && n >= 0 && n < Wl;
+            const float in = k == K - 1 ? U[on ? n : 0] : sh;
+            const float u = on ? fmaf(ia0, in, fmaf(-a1, s1, -a2 * s2)) : 0.f;   // (a1, a2 already divided by a0)
+            if (on) {
+                s2 = s1; s1 = u;
+                g0 = fmaf(-u, yk[n], g0);
+                g1 = fmaf(-u, yk[n - 1], g1);
+                g2 = fmaf(-u, yk[n - 2], g2);
+            }
+            outp = u;
+            // lane 0's outputs replace U behind the read front of lane K-1 (it is K-1 samples ahead): no hazard, U[n] of
+            // lane K-1 at this step has index n - (K-1) < n of lane 0
+            if (on && k == 0) U[n] = u;
+        }
+    }
+    if (k < K) {
+        float* o = g_bq + (((size_t)b * F + f) * K + k) * 3;
+        o[0] = g0; o[1] = g1; o[2] = g2;
+    }
+    wave_lds_fence();
+    // ---- u_0 -> frame gradient store; gain mode 1: g_gain[b,f] = sum_n u_0[n] * x[n]
+    float gg = 0.f;
+    const float gf = gain_mode == 1 ? gb[f] : 1.f;
+    float* uo = ufr + ((size_t)b * nfr + f) * Wl;
+    for (int n = lane; n < Wl; n += 64) {
+        const float u0 = U[n];
+        uo[n] = u0 * gf;
+        const int t = tb + n;
+        if (gain_mode == 1 && t >= 0 && t < Tx) gg = fmaf(u0, ex[(size_t)b * ex_stride + t], gg);
+    }
+    if (gain_mode == 1) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) gg += __shfl_xor(gg, off);
+        if (lane == 0) g_gain_f[(size_t)b * F + f] = gg;
+    }
+}
+
+// overlap-add of the frame gradients: g_x[b,t] = sum_f ufr[b,f,t - f*hop + pad]; gain mode 0 multiplies by up(gain)[t]
+// (g_ex) and also writes g_x * ex (the host folds it onto the gain frames: up^T).
+__global__ void ff_biquad_bwd_ola_kernel(const float* __restrict__ ufr, const float* __restrict__ ex, int64_t ex_stride,
+                                         const float* __restrict__ gain, float* __restrict__ g_ex, int64_t g_ex_stride,
+                                         float* __restrict__ gxe, int B, int Tx, int F, int hop, int Wl, int pad, int nfr,
+                                         int gain_mode) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * Tx) return;
+    const int b = (int)(idx / Tx), t = (int)(idx - (int64_t)b * Tx);
+    const int m = t + pad;
+    int fhi = m / hop;
+    if (fhi > nfr - 1) fhi = nfr - 1;
+    int flo = (m - Wl + hop) / hop;
+    if (m - Wl + 1 <= 0) flo = 0;
+    if (flo < 0) flo = 0;
+    float acc = 0.f;
+    for (int f = flo; f <= fhi; ++f) {
+        const int k = m - f * hop;
+        if (k < 0 || k >= Wl) continue;
+        acc += ufr[((size_t)b * nfr + f) * Wl + k];
+    }
+    if (gain_mode == 0) {
+        int ft = t / hop;
+        ft = max(min(ft, F - 2), 0);
+        const float* gb = gain + (size_t)b * F;
+        const float G = fmaf((float)(t - ft * hop), (gb[min(ft + 1, F - 1)] - gb[ft]) / (float)hop, gb[ft]);
+        g_ex[(size_t)b * g_ex_stride + t] = acc * G;
+        gxe[(size_t)b * Tx + t] = acc * ex[(size_t)b * ex_stride + t];
+    } else {
+        g_ex[(size_t)b * g_ex_stride + t] = acc;
+    }
+}
+
 extern "C" int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float* gain,
                                               const float* biquads, const float* window, float* y, int64_t y_stride,
                                               int B, int Tx, int F, int K, int hop, int W, int pad, int gain_mode,
@@ -653,6 +799,51 @@ extern "C" int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride
     const int64_t n = (int64_t)B * Ty;
     hipLaunchKernelGGL(ff_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)wf, window, y,
                        y_stride, B, Ty, hop, W, nfr, pad);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
+extern "C" size_t golf_biquad_frames_bwd_workspace_bytes(int B, int Tx, int F, int K, int hop, int W, int pad) {
+    if (B < 1 || Tx < 1 || F < 1 || K < 1 || hop < 1 || W < 1 || pad < 0 || Tx + 2 * pad < W) return 0;
+    const int nfr = (Tx + 2 * pad - W) / hop + 1;
+    return align_up(sizeof(float) * (size_t)B * nfr * W, 256) + align_up(sizeof(float) * (size_t)B * Tx, 256);
+}
+
+extern "C" int golf_biquad_frames_ola_bwd_f32(const float* gq, int64_t gq_stride, const float* ex, int64_t ex_stride,
+                                              const float* gain, const float* biquads, const float* window, float* g_ex,
+                                              int64_t g_ex_stride, float* g_gain_frames, float* g_biquads, float* gx_ex,
+                                              int B, int Tx, int F, int K, int hop, int W, int pad, int gain_mode, int Ty,
+                                              void* ws, size_t ws_bytes, void* stream) {
+    if (B < 1 || Tx < 1 || F < 1 || K < 1 || hop < 1 || W < 1 || pad < 0 || (gain_mode != 0 && gain_mode != 1))
+        return fail(GOLF_EINVAL, "biquad_frames_bwd: bad size / mode");
+    if (!gq || !ex || !gain || !biquads || !window || !g_ex || !g_biquads || (gain_mode == 1 && !g_gain_frames) ||
+        (gain_mode == 0 && !gx_ex))
+        return fail(GOLF_EINVAL, "biquad_frames_bwd: null pointer");
+    if (K > BQ_ROW) return fail(GOLF_EUNSUPPORTED, "biquad_frames_bwd: %d sections > %d (one DPP row per frame)", K, BQ_ROW);
+    if (Tx + 2 * pad < W) return fail(GOLF_EINVAL, "biquad_frames_bwd: signal shorter than one frame");
+    const int nfr = (Tx + 2 * pad - W) / hop + 1;
+    const int ty = (nfr - 1) * hop + W - 2 * pad;
+    if (nfr > F) return fail(GOLF_EINVAL, "biquad_frames_bwd: %d frames vs %d coefficient frames", nfr, F);
+    if (ty != Ty || ty < 1) return fail(GOLF_EINVAL, "biquad_frames_bwd: Ty=%d, expected %d", Ty, ty);
+    if (gq_stride < Ty || ex_stride < Tx || g_ex_stride < Tx) return fail(GOLF_EINVAL, "biquad_frames_bwd: row stride too small");
+    const size_t need = golf_biquad_frames_bwd_workspace_bytes(B, Tx, F, K, hop, W, pad);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "biquad_frames_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", need, ws_bytes);
+    const size_t lds = sizeof(float) * (size_t)(K + 2) * (W + 4);
+    if (lds > 64 * 1024) return fail(GOLF_EUNSUPPORTED, "biquad_frames_bwd: %d sections x window %d exceed the LDS staging", K, W);
+    hipStream_t st = (hipStream_t)stream;
+    float* ufr = (float*)ws;
+    // frames beyond nfr own no samples: their coefficient / gain gradients are zero
+    if (hipMemsetAsync(g_biquads, 0, sizeof(float) * (size_t)B * F * K * 3, st) != hipSuccess)
+        return fail((int)hipErrorUnknown, "biquad_frames_bwd: memset failed");
+    if (gain_mode == 1 && hipMemsetAsync(g_gain_frames, 0, sizeof(float) * (size_t)B * F, st) != hipSuccess)
+        return fail((int)hipErrorUnknown, "biquad_frames_bwd: memset failed");
+    hipLaunchKernelGGL(ff_biquad_bwd_kernel, dim3((unsigned)nfr, B), dim3(64), lds, st, gq, gq_stride, ex, ex_stride, gain,
+                       biquads, window, ufr, g_biquads, g_gain_frames, Tx, Ty, F, K, hop, W, pad, nfr, gain_mode);
+    GOLF_LAUNCH_CHECK();
+    const int64_t n = (int64_t)B * Tx;
+    hipLaunchKernelGGL(ff_biquad_bwd_ola_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)ufr, ex,
+                       ex_stride, gain, g_ex, g_ex_stride, gx_ex, B, Tx, F, hop, W, pad, nfr, gain_mode);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -979,32 +979,64 @@ def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, 
 # ------------------------------------------------------------------------------------------------
 # frame-wise all-pole synthesis as a cascade of biquads (reference models/lpc.py:94-131)
 # ------------------------------------------------------------------------------------------------
+class _BiquadFramesOLA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ex, gain, biquads, window, hop, pad, frame_gain):
+        _lib.require_device(ex, gain, biquads, window)
+        lib = _lib.load()
+        ex = _rows(ex)
+        gain, biquads, window = gain.contiguous(), biquads.contiguous(), window.contiguous()
+        B, Tx0 = ex.shape
+        F, K = biquads.shape[1], biquads.shape[2]
+        W = window.numel()
+        Tx = Tx0 if frame_gain else min(Tx0, (F - 1) * hop + 1)
+        nfr = (Tx + 2 * pad - W) // hop + 1
+        if nfr < 1 or nfr > F:
+            raise _lib.GolfError(f"biquad_frames_ola: {nfr} frames for {F} coefficient frames")
+        Ty = (nfr - 1) * hop + W - 2 * pad
+        y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
+        ws = _workspace(B * nfr * W * 4 + 256, ex.device)
+        rc = lib.golf_biquad_frames_ola_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), biquads.data_ptr(),
+                                                window.data_ptr(), y.data_ptr(), y.stride(0), B, Tx, F, K, hop, W, pad,
+                                                1 if frame_gain else 0, Ty, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_biquad_frames_ola_fwd_f32")
+        ctx.geom = (hop, pad, bool(frame_gain), Tx, nfr, Ty)
+        ctx.save_for_backward(ex, gain, biquads, window)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, gain, biquads, window = ctx.saved_tensors
+        hop, pad, frame_gain, Tx, nfr, Ty = ctx.geom
+        lib = _lib.load()
+        B, Tx0 = ex.shape
+        F, K = biquads.shape[1], biquads.shape[2]
+        W = window.numel()
+        # the overlap-add of the window (the normaliser of the forward), on the output samples
+        norm = torch.nn.functional.conv_transpose1d(window.new_ones(1, 1, nfr), window.view(1, 1, W), stride=hop)
+        norm = norm.view(-1)[pad: pad + Ty]
+        gq = _rows((gy.float() / norm).contiguous())
+        g_ex = torch.zeros(B, Tx0, dtype=torch.float32, device=ex.device)
+        g_bq = torch.empty_like(biquads)
+        g_gain_f = torch.empty_like(gain)
+        gxe = torch.empty(B, Tx, dtype=torch.float32, device=ex.device)
+        ws = _workspace(lib.golf_biquad_frames_bwd_workspace_bytes(B, Tx, F, K, hop, W, pad), ex.device)
+        rc = lib.golf_biquad_frames_ola_bwd_f32(gq.data_ptr(), gq.stride(0), ex.data_ptr(), ex.stride(0), gain.data_ptr(),
+                                                biquads.data_ptr(), window.data_ptr(), g_ex.data_ptr(), g_ex.stride(0),
+                                                g_gain_f.data_ptr(), g_bq.data_ptr(), gxe.data_ptr(), B, Tx, F, K, hop, W,
+                                                pad, 1 if frame_gain else 0, Ty, ws.data_ptr(), ws.numel(),
+                                                _lib.stream_ptr())
+        _lib.check(rc, "golf_biquad_frames_ola_bwd_f32")
+        g_gain = g_gain_f if frame_gain else upsample_adjoint(gxe, hop, F)
+        return g_ex, g_gain, g_bq, None, None, None, None
+
+
 def biquad_frames_ola(ex: torch.Tensor, gain: torch.Tensor, biquads: torch.Tensor, window: torch.Tensor, hop: int,
                       pad: int = None, frame_gain: bool = True) -> torch.Tensor:
     """ex (B,Tx), gain (B,F), biquads (B,F,K,3) -> (B,Ty): every frame through its K sections 1/(a0+a1 z^-1+a2 z^-2),
     windowed overlap-add.  ``pad`` defaults to (W-hop)//2 and ``frame_gain`` to True (BatchSecondOrderLPCSynth);
-    pad = W//2, frame_gain=False is LTVMinimumPhaseFilter's convention.  Inference only (no backward): train through
-    the direct form (biquads2lpc + lti_frames_ola)."""
-    _lib.require_device(ex, gain, biquads, window)
-    if any(t.requires_grad for t in (ex, gain, biquads)) and torch.is_grad_enabled():
-        raise NotImplementedError("golf_amd: the cascaded-biquad kernel is forward-only; use biquads2lpc + "
-                                  "lti_frames_ola (LTVMinimumPhaseFilter) when gradients are needed")
-    lib = _lib.load()
-    ex = _rows(ex)
-    gain, biquads, window = gain.contiguous(), biquads.contiguous(), window.contiguous()
-    B, Tx0 = ex.shape
-    F, K = biquads.shape[1], biquads.shape[2]
+    pad = W//2, frame_gain=False is LTVMinimumPhaseFilter's convention.  Differentiable w.r.t. ex, gain and biquads
+    (custom HIP backward: the cascade's adjoint is the reversed cascade on the reversed signal)."""
     W = window.numel()
     pad = (W - hop) // 2 if pad is None else pad
-    Tx = Tx0 if frame_gain else min(Tx0, (F - 1) * hop + 1)
-    nfr = (Tx + 2 * pad - W) // hop + 1
-    if nfr < 1 or nfr > F:
-        raise _lib.GolfError(f"biquad_frames_ola: {nfr} frames for {F} coefficient frames")
-    Ty = (nfr - 1) * hop + W - 2 * pad
-    y = torch.empty(B, Ty, dtype=torch.float32, device=ex.device)
-    ws = _workspace(B * nfr * W * 4 + 256, ex.device)
-    rc = lib.golf_biquad_frames_ola_fwd_f32(ex.data_ptr(), ex.stride(0), gain.data_ptr(), biquads.data_ptr(),
-                                            window.data_ptr(), y.data_ptr(), y.stride(0), B, Tx, F, K, hop, W, pad,
-                                            1 if frame_gain else 0, Ty, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-    _lib.check(rc, "golf_biquad_frames_ola_fwd_f32")
-    return y
+    return _BiquadFramesOLA.apply(ex, gain, biquads, window, int(hop), int(pad), bool(frame_gain))

@@ -2,9 +2,10 @@
 
 ``BatchSecondOrderLPCSynth`` (reference models/lpc.py:94-131) is the reference's statement of the *cascaded-biquad*
 all-pole filter: every frame runs through K second-order sections.  Here the cascade is a systolic pipeline across
-the lanes of a DPP row (golf_biquad_frames_ola_fwd_f32, csrc/lpc_ff.hip).  Inference only; training goes through the
-direct form (``golf_amd.filters.LTVMinimumPhaseFilter``), to which a cascade is converted by
-``golf_amd.utils.biquads2lpc``.
+the lanes of a DPP row (golf_biquad_frames_ola_fwd_f32, csrc/lpc_ff.hip), and so is its backward
+(golf_biquad_frames_ola_bwd_f32: the adjoint of a cascade is the reversed cascade on the reversed signal), so the module is
+differentiable w.r.t. the excitation, the gains and the section coefficients like the reference's (autograd through its K
+lfilter calls, models/lpc.py:115-118).
 """
 from __future__ import annotations
 
@@ -30,6 +31,4 @@ class BatchSecondOrderLPCSynth(nn.Module):
         assert ex.ndim == 2
         assert gain.ndim == 2
         assert biquads.ndim == 4 and biquads.shape[-1] == 3
-        with torch.no_grad():
-            return GF.biquad_frames_ola(ex, gain, biquads, self._window, self.hop_length, pad=self.padding,
-                                        frame_gain=True)
+        return GF.biquad_frames_ola(ex, gain, biquads, self._window, self.hop_length, pad=self.padding, frame_gain=True)

@@ -187,6 +187,21 @@ int golf_biquad_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const flo
                                    int hop, int W, int pad, int gain_mode, int Ty, void* ws, size_t ws_bytes,
                                    void* stream);
 
+/* Backward of the cascade (the reference's is autograd through its K lfilter calls, models/lpc.py:115-118; closed form in
+ * oracle/golf_oracle.py::biquad_frames_ola_backward, pinned by the reference's own gradients in tests/golden/g26):
+ *   g_q = gy / norm (the caller divides: norm = overlap-add of the window);  per frame, u_K = window * g_q and
+ *   u_{k-1} = section k run BACKWARDS in time on u_k;  g_biquads[b,f,k,i] = -sum_n u_{k-1}[n] * y_k[n-i] (y_k = the section's
+ *   output, recomputed);  the frames' u_0 are overlap-added:
+ *   gain_mode 1: g_ex = that sum (each frame scaled by its gain), g_gain_frames[b,f] = sum_n u_0[n] * x_f[n];
+ *   gain_mode 0: g_ex = sum * up(gain), and gx_ex (B,Tx) = sum * ex for the caller to fold onto the gain frames (up^T).
+ *   g_ex (B,Tx), g_biquads (B,F,K,3) are fully overwritten; ws: golf_biquad_frames_bwd_workspace_bytes(). */
+size_t golf_biquad_frames_bwd_workspace_bytes(int B, int Tx, int F, int K, int hop, int W, int pad);
+int golf_biquad_frames_ola_bwd_f32(const float* gq, int64_t gq_stride, const float* ex, int64_t ex_stride,
+                                   const float* gain, const float* biquads, const float* window, float* g_ex,
+                                   int64_t g_ex_stride, float* g_gain_frames, float* g_biquads, float* gx_ex,
+                                   int B, int Tx, int F, int K, int hop, int W, int pad, int gain_mode, int Ty,
+                                   void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a-2: control transform of the LPC filters, logits -> direct-form coefficients.
  * Replaces rc2lpc(tanh(logits) * max_abs_value), models/filters.py:91-97 + models/utils.py:581-593 (a Python loop of

@@ -1018,3 +1018,75 @@ def biquad_frames_ola_forward(ex, gain, biquads, hop: int, window: np.ndarray, p
         acc[:, f * hop : f * hop + W] += v * window
         norm[f * hop : f * hop + W] += window
     return acc[:, pad : full - pad] / norm[pad : full - pad]
+
+
+def biquad_frames_ola_backward(gy, ex, gain, biquads, hop: int, window: np.ndarray, pad: int | None = None,
+                               frame_gain: bool = True):
+    """Closed-form backward of biquad_frames_ola_forward (the reference differentiates through its K lfilter calls,
+    models/lpc.py:115-118; pinned by the reference's own autograd gradients in tests/golden/g26).
+    Per frame: u_K = window * gy/norm;  u_{k-1}[n] = (u_k[n] - a1 u_{k-1}[n+1] - a2 u_{k-1}[n+2]) / a0 (section k run
+    backwards in time);  d/d a_i of section k = -sum_n u_{k-1}[n] y_k[n-i] with y_k the section's output;  u_0 is the
+    gradient w.r.t. the (gain-scaled) input frame.  Returns (g_ex, g_gain, g_biquads)."""
+    ex = np.asarray(ex, dtype=np.float64)
+    gain = np.asarray(gain, dtype=np.float64)
+    bq = np.asarray(biquads, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    gy = np.asarray(gy, dtype=np.float64)
+    W = window.shape[0]
+    pad = (W - hop) // 2 if pad is None else pad
+    B, F = gain.shape
+    if frame_gain:
+        x = ex
+    else:
+        G = linear_upsample(gain, hop, axis=1)
+        T = min(ex.shape[1], G.shape[1])
+        x = ex[:, :T] * G[:, :T]
+    xp = np.pad(x, ((0, 0), (pad, pad)))
+    nfr = (xp.shape[1] - W) // hop + 1
+    full = (nfr - 1) * hop + W
+    K = bq.shape[2]
+    norm = np.zeros(full)
+    for f in range(nfr):
+        norm[f * hop: f * hop + W] += window
+    gq_full = np.zeros((B, full))
+    gq_full[:, pad: full - pad] = gy / norm[pad: full - pad]
+    g_xp = np.zeros_like(xp)
+    g_gain = np.zeros_like(gain)
+    g_bq = np.zeros_like(bq)
+    for f in range(nfr):
+        v = xp[:, f * hop: f * hop + W].copy()
+        if frame_gain:
+            v *= gain[:, f: f + 1]
+        ys = []
+        for k in range(K):   # forward, keeping every section's output (two leading zeros: y[-1], y[-2])
+            a0, a1, a2 = bq[:, f, k, 0], bq[:, f, k, 1], bq[:, f, k, 2]
+            y = np.zeros((B, W + 2))
+            for n in range(W):
+                y[:, n + 2] = (v[:, n] - a1 * y[:, n + 1] - a2 * y[:, n]) / a0
+            ys.append(y)
+            v = y[:, 2:]
+        u = gq_full[:, f * hop: f * hop + W] * window
+        for k in range(K - 1, -1, -1):
+            a0, a1, a2 = bq[:, f, k, 0], bq[:, f, k, 1], bq[:, f, k, 2]
+            un = np.zeros((B, W + 2))     # un[:, n] = u_{k-1}[n], two trailing zeros
+            for n in range(W - 1, -1, -1):
+                un[:, n] = (u[:, n] - a1 * un[:, n + 1] - a2 * un[:, n + 2]) / a0
+            y = ys[k]
+            for i in range(3):
+                g_bq[:, f, k, i] = -(un[:, :W] * y[:, 2 - i: 2 - i + W]).sum(1)
+            u = un[:, :W]
+        frame = xp[:, f * hop: f * hop + W]
+        if frame_gain:
+            g_gain[:, f] = (u * frame).sum(1)
+            g_xp[:, f * hop: f * hop + W] += u * gain[:, f: f + 1]
+        else:
+            g_xp[:, f * hop: f * hop + W] += u
+    g_x = g_xp[:, pad: xp.shape[1] - pad]
+    g_ex = np.zeros_like(ex)
+    if frame_gain:
+        g_ex[:, : g_x.shape[1]] = g_x
+    else:
+        T = g_x.shape[1]
+        g_ex[:, :T] = g_x * G[:, :T]
+        g_gain = _upsample_adjoint(g_x * ex[:, :T], hop, F)
+    return g_ex, g_gain, g_bq

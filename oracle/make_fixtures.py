@@ -777,4 +777,25 @@ res = rbq.get_biquads(fake, torch.zeros(1, 10))
 d.update(bq_logits=bq_logits, bq_voicing=res[0], bq_harm_log_gain=res[1], bq_harm_biquads=res[2], bq_noise_log_gain=res[3],
          bq_noise_biquads=res[4], bq_table_select_weight=res[5])
 save("g24_noiseband_ckpt_biquads", **d)
+# ----------------------------------------------------------------------------- g26 gradients of the biquad cascade (a-6)
+# BatchSecondOrderLPCSynth is differentiable through its K lfilter calls (models/lpc.py:115-118): the reference's own
+# autograd gradients w.r.t. ex, gain and the section coefficients, in float64 through its own glue (the lfilter stand-in
+# above is an autograd-able loop of the same difference equation).  Own generator: g1..g24 stay bit-identical.
+rng26 = np.random.default_rng(26)
+d = {}
+for tag, (B, F, K, hop, W, T) in (("a", (2, 9, 3, 8, 32, 64)), ("b", (1, 6, 5, 16, 48, 80))):
+    logits = torch.from_numpy(rng26.normal(0, 1, (B, F, K, 2)).astype(np.float32)).double()
+    bq = ru.get_logits2biquads("coef", 0.95)(logits).clone()
+    bq[..., 0] = torch.from_numpy(rng26.uniform(0.8, 1.25, (B, F, K)))       # a0 != 1 as well
+    bq.requires_grad_(True)
+    gain = torch.exp(torch.from_numpy(rng26.normal(-1, 0.3, (B, F)).astype(np.float32)).double()).requires_grad_(True)
+    ex = torch.from_numpy(rng26.normal(0, 1, (B, T)).astype(np.float32)).double().requires_grad_(True)
+    syn = rlpc.BatchSecondOrderLPCSynth(hop_length=hop, window_size=W, window="hanning").double()
+    y = syn(ex, gain, bq)
+    gy = torch.from_numpy(rng26.normal(0, 1, tuple(y.shape)).astype(np.float32)).double()
+    (y * gy).sum().backward()
+    d.update({f"{tag}_ex": ex.detach(), f"{tag}_gain": gain.detach(), f"{tag}_biquads": bq.detach(), f"{tag}_hop": hop,
+              f"{tag}_W": W, f"{tag}_y": y.detach(), f"{tag}_gy": gy, f"{tag}_g_ex": ex.grad, f"{tag}_g_gain": gain.grad,
+              f"{tag}_g_biquads": bq.grad})
+save("g26_biquad_cascade_grads", **d)
 print("done")

@@ -249,3 +249,60 @@ def test_ff_ill_conditioned_rows():
     err = np.abs(y - ref).max(1) / np.abs(ref).max(1)
     print("worst rows", np.argsort(err)[-3:], np.sort(err)[-3:])
     assert err.max() <= 3e-4 and np.sort(err)[-2] <= 1e-4, (int(err.argmax()), float(err.max()))
+
+
+def _bq_grads(ex, gain, bq, win, gy, hop, pad=None, frame_gain=True):
+    from golf_amd import functional as GF
+
+    t = [dev(v).requires_grad_(True) for v in (ex, gain, bq)]
+    y = GF.biquad_frames_ola(t[0], t[1], t[2], dev(win), hop, pad=pad, frame_gain=frame_gain)
+    (y * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    return (y.detach().cpu().numpy(),) + tuple(v.grad.cpu().numpy() for v in t)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_biquad_cascade_grads_golden_g26(golden, tag):
+    """Backward of the cascaded-biquad synthesiser (row a-6) against the reference's own autograd gradients."""
+    g = golden("g26_biquad_cascade_grads")
+    hop, W = int(g[f"{tag}_hop"]), int(g[f"{tag}_W"])
+    win = torch.hann_window(W).numpy()
+    y, g_ex, g_gain, g_bq = _bq_grads(g[f"{tag}_ex"], g[f"{tag}_gain"], g[f"{tag}_biquads"], win, g[f"{tag}_gy"], hop)
+    check(y, g[f"{tag}_y"], f"g26{tag} y", 2e-5)
+    check(g_ex, g[f"{tag}_g_ex"], f"g26{tag} g_ex", 5e-5)
+    check(g_gain, g[f"{tag}_g_gain"], f"g26{tag} g_gain", 5e-5)
+    check(g_bq, g[f"{tag}_g_biquads"], f"g26{tag} g_biquads", 5e-5)
+
+
+@pytest.mark.parametrize("frame_gain", [True, False])
+def test_biquad_cascade_grads_config_size(frame_gain):
+    """The same at the GOLF-ff frame shape (11 sections = order 22, window 960, hop 240), both gain conventions, against
+    the float64 closed form; and through the drop-in module (BatchSecondOrderLPCSynth is differentiable like the
+    reference's)."""
+    from golf_amd.utils import get_logits2biquads
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(11)
+    B, F, K, hop, W = 2, 12, 11, 240, 960
+    logits = torch.from_numpy(rng.normal(0, 0.7, (B, F, K, 2)).astype(np.float32))
+    bq = get_logits2biquads("coef", 0.95)(logits).numpy().astype(np.float32)
+    gain = np.exp(rng.normal(-1, 0.3, (B, F))).astype(np.float32)
+    pad = (W - hop) // 2 if frame_gain else W // 2
+    Tx = (F - 1) * hop + W - 2 * pad if frame_gain else (F - 1) * hop + 1
+    ex = rng.normal(0, 1, (B, Tx)).astype(np.float32)
+    win = torch.hann_window(W).numpy()
+    ref = O.biquad_frames_ola_forward(ex, gain, bq, hop, win, pad=pad, frame_gain=frame_gain)
+    gy = (rng.normal(0, 1, ref.shape) / np.abs(ref).max()).astype(np.float32)
+    r_ex, r_gain, r_bq = O.biquad_frames_ola_backward(gy, ex, gain, bq, hop, win, pad=pad, frame_gain=frame_gain)
+    y, g_ex, g_gain, g_bq = _bq_grads(ex, gain, bq, win, gy, hop, pad=pad, frame_gain=frame_gain)
+    check(y, ref, "cascade y")
+    check(g_ex, r_ex, "cascade g_ex")
+    check(g_gain, r_gain, "cascade g_gain")
+    check(g_bq, r_bq, "cascade g_biquads")
+    if frame_gain:
+        from golf_amd.lpc import BatchSecondOrderLPCSynth
+
+        m = BatchSecondOrderLPCSynth(hop_length=hop, window_size=W, window="hanning").cuda()
+        t = [dev(v).requires_grad_(True) for v in (ex, gain, bq)]
+        (m(*t) * dev(gy)).sum().backward()
+        check(t[2].grad.cpu().numpy(), r_bq, "module g_biquads")

@@ -615,3 +615,38 @@ def test_recipe_fuzz_every_utterance(seed):
         e = np.abs(y - ref[lo:lo + 32]).max(1) / scale[lo:lo + 32]
         print(f"seed {seed} rows {lo}..{lo + 31}: status {st}, worst {e.max():.2e} (sequential {e_seq[lo:lo + 32][e.argmax()]:.2e})")
         assert np.all(e <= 2 * e_seq[lo:lo + 32] + 1e-4), (seed, lo, np.nonzero(e > 2 * e_seq[lo:lo + 32] + 1e-4)[0], e.max())
+
+
+def test_speech_lpc_tracks_g25(golden):
+    """Analysis filters of real speech: order-22 autocorrelation LPC tracks (Hann 960, hop 240) of the six
+    ground-truth clips the reference ships, cut into 2 s utterances (oracle/make_lpc_tracks.py -> g25, arrays only).
+    The default path is within 1e-4 of the float64 oracle on every utterance, forward and gradients, and the conditioning
+    machinery has nothing to do: no hot utterance (largest transition-matrix entry 20.5 < 30) -- the synthetic recipe is
+    harsher than these filters, where 2.3 % of the utterances are hot."""
+    from oracle import golf_oracle as O
+
+    g = golden("g25_speech_lpc_tracks")
+    a, gain, hop = g["a"], g["gain"], int(g["hop"])
+    U, F, M = a.shape
+    rng = np.random.default_rng(25)
+    ex = rng.normal(0, 1, (U, (F - 1) * hop + 1)).astype(np.float32)
+    gain = (gain / gain.max()).astype(np.float32)           # (scale only: the clips' level is irrelevant here)
+    ref = oracle_rows(ex, gain, a, hop)
+    y, st = run_status(ex, gain, a, hop)
+    scale = np.abs(ref).max(1)
+    e = np.abs(y - ref).max(1) / scale
+    e_seq = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    print("speech tracks: status", st, "worst", float(e.max()), "sequential fp32 worst", float(e_seq.max()))
+    assert st["hot_utterances"] == 0 and st["tier3_utterances"] == 0 and not st["nonfinite"], st
+    assert 15.0 < st["max_phi"] < 30.0, st                   # 20.5 in float64 (oracle/make_lpc_tracks.py's own report)
+    assert e.max() <= 1e-4, (int(e.argmax()), float(e.max()))
+    y_acc = run_fwd(ex, gain, a, hop, fast=False)
+    assert (np.abs(y_acc - ref).max(1) / scale).max() <= 1e-4
+    # gradients on a few utterances (the float64 closed-form backward is slow in numpy)
+    sel = [0, 9, 16]
+    gy = (rng.normal(0, 1, ref[sel].shape) / scale[sel, None]).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex[sel], gain[sel], a[sel], hop)
+    _, g_ex, g_gain, g_a = run_bwd(ex[sel], gain[sel], a[sel], gy, hop)
+    check(g_ex[:, : r_ex.shape[1]], r_ex, "speech tracks g_ex")
+    check(g_gain, r_gain, "speech tracks g_gain")
+    check(g_a, r_a, "speech tracks g_a")
