@@ -254,7 +254,7 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
 
         def step():
             y = GF.ltv_allpole_ss(GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True, add=noise), gain_g, a_g,
-                                  hop, mode=mode)
+                                  hop, mode=mode, fast_inference=fast)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y

@@ -94,6 +94,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->NG = p->GS = 0;
         p->off_mt = p->off_gv = p->off_pmax = 0;
         p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = p->off_fixcnt = 0;
+        p->off_mtT = p->off_L1 = p->off_wadj = p->off_dadj = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -127,6 +128,12 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->off_gv = o; o = align_up(o + sizeof(float) * (size_t)B * p->NG * 32 * 2, 256);   // group responses (z, defects)
     }
     p->off_S1 = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NC * 32, 256);   // first-pass chunk start states (two-level)
+    // backward, two-level adjoint scan: transposed composites, first-pass adjoint states L1 (rows -1 .. NP), group responses
+    // (zadj, defects), defects
+    p->off_mtT = o;  o = align_up(o + sizeof(float) * (size_t)B * (p->NG > 0 ? p->NG : 1) * p->NT * W, 256);
+    p->off_L1 = o;   o = align_up(o + sizeof(float) * (size_t)B * (p->NC + 1) * 32, 256);
+    p->off_wadj = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NG > 0 ? p->NG : 1) * 32 * 2, 256);
+    p->off_dadj = o; o = align_up(o + sizeof(float) * (size_t)B * p->NC * W, 256);
     // transition matrices as doubles, [b][c][j][i] (trajectory-major), written and read only for tier-3 utterances: the
     // allocation is never touched otherwise (27 MB at B = 32 x 2 s)
     p->off_phi64 = o; o = align_up(o + sizeof(double) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
@@ -728,7 +735,8 @@ struct P1fGeom {
 template <int W, int NT>
 __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
                                          int L, int NP, int nq, float* __restrict__ tile_all, int blk_id,
-                                         float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0) {
+                                         float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0,
+                                         float* __restrict__ Phi = nullptr) {
     // Workgroups of P1F_WPB = 4 independent waves: there are fewer waves than SIMDs (637 for B=32) and every wave is
     // FMA-issue bound, so two waves sharing a SIMD double the kernel.  With single-wave workgroups the dispatcher's
     // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
@@ -831,6 +839,29 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
         }
         wave_lds_fence();
     }
+    // Training (GOLF_SS_TRAINING): the backward's adjoint scan reads the maps in the other orientation, Phi[q][j][i] -- rows
+    // j = this lane's four trajectories, W contiguous floats each: direct float4 stores.
+    if (Phi && live) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + u;
+            if (j < NT) {
+                float4* o = reinterpret_cast<float4*>(Phi + ((size_t)q * NT + j) * W);
+#pragma unroll
+                for (int i4 = 0; i4 < W / 4; ++i4) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * i4 + e;
+                        const f32x2 ha = hA[(W - 1 - i + W) % W], hb = hB[(W - 1 - i + W) % W];
+                        const float x = u == 0 ? ha.x : (u == 1 ? ha.y : (u == 2 ? hb.x : hb.y));
+                        v[e] = (i < M && j < M) ? x : 0.f;
+                    }
+                    o[i4] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
     // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
     // Copy-out through the wave's LDS tile, CPP chunks per pass: CPP chunks x NT rows x W floats are contiguous in PhiT.
     constexpr int RW4 = W / 4;
@@ -866,9 +897,9 @@ template <int W, int NT>
 __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
                                                                int F, int M, int hop, int L, int NP, int nq,
                                                                float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
-                                                               int B) {
+                                                               int B, float* __restrict__ Phi) {
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
-    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B);
+    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
 }
 
 // `upw` zero-state units (16 chunks of one utterance each) per wave, one after the other: the host picks upw so that the
@@ -901,12 +932,12 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __r
                                                                 float* __restrict__ PhiT, int T, int F, int M, int hop,
                                                                 int L, int NP, int nq, int nblk_f, int ncg, int B,
                                                                 int upw, float* __restrict__ pmax,
-                                                                unsigned* __restrict__ fixcnt) {
+                                                                unsigned* __restrict__ fixcnt, float* __restrict__ Phi) {
     using TL = Tile<W, 16>;
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
     __shared__ float xt[P1F_WPB][TL::SIZE];
     if ((int)blockIdx.x < nblk_f) {
-        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B);
+        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
     } else {
         p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_f, xt);
     }
@@ -1046,6 +1077,7 @@ __device__ __forceinline__ double dppd(double v) {
 struct FixArgs {
     const float* a;      // (B, F, M) coefficients
     float* PhiT;         // fp32 maps [b][c][i][j]
+    float* Phi;          // the same maps as [b][c][j][i] (training with fp32 trajectories: the backward's orientation), or null
     double* Phi64;       // maps as doubles [b][c][j][i] (tier 3 only)
     const float* pmax;   // largest |entry| per chunk, from the transition kernel
     unsigned* tier;      // [b][2]: tier, hot chunks
@@ -1165,6 +1197,14 @@ __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes
                 const int i = r * TPL + kk;
                 if (i < NT) o[(size_t)i * W] = i < M ? (float)w[TPL - 1 - kk] : 0.f;
             }
+            if (fa.Phi) {
+                float* o2 = fa.Phi + (q * NT + j) * W;
+#pragma unroll
+                for (int kk = 0; kk < TPL; ++kk) {
+                    const int i = r * TPL + kk;
+                    if (i < W) o2[i] = i < M ? (float)w[TPL - 1 - kk] : 0.f;
+                }
+            }
         }
         if (d.t3) {
 #pragma unroll
@@ -1258,10 +1298,10 @@ __device__ __forceinline__ void precise_fwd_scan(const double* __restrict__ P64,
 // the doubles (contiguous).  Mirrors lpc_adj_scan_kernel: lamEnd[c][:] = adjoint state at the END of chunk c.
 template <int W, int NT>
 __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64, const float* __restrict__ zb,
-                                                 float* __restrict__ Lb, int NP, int lane) {
+                                                 float* __restrict__ Lb, int lstride, int NP, int lane) {
     const bool act = lane < NT;
     const int jj = act ? lane : 0;
-    Lb[(size_t)NP * 64 + lane] = 0.f;
+    if (lane < lstride) Lb[(size_t)NP * lstride + lane] = 0.f;
     double lam = act ? (double)zb[(size_t)NP * W + jj] : 0.0;
     constexpr int D = 4;
     double buf[D][NT];
@@ -1281,7 +1321,7 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
         for (int u = 0; u < D; ++u) {
             const int c = NP - 1 - (u0 + u);
             if (c >= 0) {   // wave-uniform
-                Lb[(size_t)c * 64 + lane] = (float)lam;
+                if (lane < lstride) Lb[(size_t)c * lstride + lane] = (float)lam;
                 double acc0 = (double)zc[u], acc1 = 0.0;
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
@@ -1395,7 +1435,8 @@ __device__ __forceinline__ void comp_product(const AV (&fr)[NTL][NTL], f64x4 (&P
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int W, int NT>
 __device__ __forceinline__ void group_composite_wg(const float* __restrict__ PhiT, float* __restrict__ MT, int NP, int NG,
-                                                   int b, int g, double* __restrict__ pb_lds /* [32][32] */) {
+                                                   int b, int g, double* __restrict__ pb_lds /* [32][32] */,
+                                                   float* __restrict__ MTt = nullptr) {
     static_assert(NT <= 32 && W % 4 == 0, "two 16-wide tiles");
     constexpr int NTL = CompGeom<W, NT>::NTL;
     const int lane = threadIdx.x & 63;
@@ -1474,6 +1515,8 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
         for (int v = 0; v < 4; ++v) {
             const int i = 16 * it + 8 * (v / 2) + rq + v % 2;   // rho(kq + 4 v)
             if (i < NT && n < W) mt[(size_t)i * W + n] = n < NT ? (float)P[it][v] : 0.f;
+            // training: the transposed copy, for the backward's two-level adjoint scan (rows of M_g^T are what its lanes read)
+            if (MTt && i < W && n < NT) MTt[(((size_t)b * NG + g) * NT + n) * W + i] = i < NT ? (float)P[it][v] : 0.f;
         }
 }
 
@@ -1531,7 +1574,8 @@ template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
                                                                 const float* __restrict__ z, float* __restrict__ MT,
                                                                 float* __restrict__ V, int NP, int NG, int B,
-                                                                int parts, FixArgs fa, int KF1, int KF2) {
+                                                                int parts, FixArgs fa, int KF1, int KF2,
+                                                                float* __restrict__ MTt) {
     __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
     static_assert(sizeof(double) * 32 * 32 >= sizeof(unsigned short) * 4 * kHotListMax, "the fix-up waves' lists reuse pb_lds");
     const bool fix = fa.pmax != nullptr && (parts & 1);   // (no fix-up at all: diagnostic switch GOLF_SS_NO_FIXUP)
@@ -1554,8 +1598,9 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
     if (comp) {
         blk -= nz;
         // the fold of group g runs over the groups BEFORE it: the last composite is needed only when the final partial
-        // chunk opens a group of its own (NP a multiple of 16)
-        if (blk % NG == NG - 1 && NP % kGroup != 0) return;
+        // chunk opens a group of its own (NP a multiple of 16) -- and by the backward's adjoint fold, which runs over the
+        // groups ABOVE (training: MTt given)
+        if (blk % NG == NG - 1 && NP % kGroup != 0 && !MTt) return;
         b = blk / NG; g = blk % NG;
     } else {
         const int u2 = blk * 4 + wv;
@@ -1571,7 +1616,7 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
             if (d.nhot > 0u && !fa.accurate) wait_for_fixup(fa, b, d.nhot, NT);
         }
     }
-    if (comp) group_composite_wg<W, NT>(PhiT, MT, NP, NG, b, g, pb_lds);
+    if (comp) group_composite_wg<W, NT>(PhiT, MT, NP, NG, b, g, pb_lds, MTt);
     else      group_zscan_body<W, NT>(PhiT, z, V, NP, NG, b, g, lane);
 }
 
@@ -1835,33 +1880,41 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
 //     g[t] = gy[t] + lam[0];   lam[k] <- lam[k+1] - A[t,k] g[t]
 //   lane r of a quad holds lam[r*TPL .. r*TPL+TPL-1] in a ring p[(k + step) % TPL]; per sample lane 0 forms g and
 //   broadcasts it (DPP), every lane pulls lam[(r+1)*TPL] from its right neighbour (DPP shift) and does TPL FMAs.
+//   L(c) := the adjoint state at the END of chunk c (= at the start of chunk c+1); L(NP) = 0; lam_start(c) = L(c-1).
 //   MODE 0 (B1): lam_end = 0, lam at chunk start -> zadj[(b*NC+c)*W + k]
-//   MODE 1 (B3): lam_end from lamEnd[(b*NC+c)*64 + k], writes g[b][t] (the adjoint signal dL/dy_total)
+//   MODE 1 (B3): lam_end = L(c), writes g[b][t] (the adjoint signal dL/dy_total)
+//   MODE 2     : refinement sweep of the flat scan: lam_end = L1(c) from HBM, out = the DEFECT lam_start(c) - L1(c-1)
+//   MODE 3     : the same with the states in LDS (two-level scan, LS = true): lst[k+1] = L1(c0+k), lst[0] = L1(c0-1)
+//   Where the states come from: lamEnd[(b*NC+c)*64 + k] (HBM; LS = false) or lst[(row+1)*32 + k] (LDS; LS = true).
+//   A device function of ONE wave, like fwdq_body.
 // ------------------------------------------------------------------------------------------
-template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ gy, int64_t gy_stride,
-                                                      const float* __restrict__ a, const float* __restrict__ lamEnd,
-                                                      float* __restrict__ out, int64_t g_stride, int T, int F, int M,
-                                                      int hop, int L, int NC) {
+template <int W, int NT, int MODE, bool LS = false>
+__device__ __forceinline__ void adjq_body(const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ a,
+                                          const float* __restrict__ lamEnd, float* __restrict__ out, int64_t g_stride,
+                                          int T, int F, int M, int hop, int L, int NC, int NCQ,
+                                          float* __restrict__ xt, float* __restrict__ yt, int b, int cg, int lane,
+                                          const float* lst = nullptr, float* ldl = nullptr) {
     constexpr int TPL = quad_tpl(W, NT);
     constexpr int R = 16;
     using TL = Tile<W, R>;
-    __shared__ float xt[TL::SIZE];
-    __shared__ float yt[TL::SIZE];
-    const int b = blockIdx.y, cg = blockIdx.x;
-    const int lane = threadIdx.x;
+    static_assert(MODE >= 0 && MODE <= 3 && (MODE != 3 || LS), "MODE 3 exists only with LDS-resident states");
     const int lq = lane / W, lr = lane % W;
     const int row = lane >> 2, r = lane & 3;
     const int c0 = cg * R;
     const int c = c0 + row;
-    const bool mine = c < NC;
+    const bool mine = c < NCQ;
     const BufRow gyrow(gy + (size_t)b * gy_stride, T);
     const BufRow grow(MODE == 1 ? out + (size_t)b * g_stride : nullptr, MODE == 1 ? T : 0);
     float p[TPL];
-    if (MODE == 1 && mine) {
-        const float* lp = lamEnd + ((size_t)b * NC + c) * 64 + r * TPL;
+    if (MODE >= 1 && mine) {
+        if constexpr (LS) {
 #pragma unroll
-        for (int k = 0; k < TPL; ++k) p[k] = lp[k];
+            for (int k = 0; k < TPL; ++k) p[k] = lst[(row + 1) * 32 + r * TPL + k];
+        } else {
+            const float* lp = lamEnd + ((size_t)b * NC + c) * 64 + r * TPL;
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) p[k] = lp[k];
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < TPL; ++k) p[k] = 0.f;
@@ -1879,7 +1932,7 @@ __global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ 
     for (; blk >= 0; --blk) {
         const int tw = c0 * L + blk * W;
         TL::scatter(xt, nx, lq, lr);
-        __syncthreads();
+        wave_lds_fence();
         float gin[W];
         TL::rows_load(gin, xt, row);
         TL::fetch(nx, gyrow, tw - W, L, lq, lr);  // prefetch the earlier block (before 0: hardware returns 0)
@@ -1926,20 +1979,227 @@ __global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ 
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
-            __syncthreads();
+            wave_lds_fence();
             float o[TL::ITS];
             TL::gather(o, yt, lq, lr);
             TL::store(o, grow, tw, L, lq, lr);
         }
-        __syncthreads();
+        wave_lds_fence();
     }
-    if (MODE == 0 && mine) {
+    if (MODE != 1 && mine) {
         float* zp = out + ((size_t)b * NC + c) * W;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
             const int i = r * TPL + k;
-            if (i < W) zp[i] = i < NT ? p[k] : 0.f;
+            if (i < W) {
+                float v = i < NT ? p[k] : 0.f;
+                // refinement sweep (see fwdq_body): the defect of this chunk's start state against the state the chunk
+                // below really starts from; chunk 0 has no chunk below (its defect feeds nothing)
+                if (MODE == 2) v = c >= 1 ? v - lamEnd[((size_t)b * NC + c - 1) * 64 + i] : 0.f;
+                if constexpr (MODE == 3) v = c >= 1 ? v - lst[row * 32 + i] : 0.f;
+                if (MODE != 2 && ldl) ldl[row * 32 + i] = v;   // (the two-level kernels' epilogue scans these)
+                zp[i] = v;
+            }
         }
+    }
+}
+
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ gy, int64_t gy_stride,
+                                                      const float* __restrict__ a, const float* __restrict__ lamEnd,
+                                                      float* __restrict__ out, int64_t g_stride, int T, int F, int M,
+                                                      int hop, int L, int NC, const unsigned* __restrict__ tier = nullptr) {
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    if (MODE == 2 && tier3(tier, blockIdx.y)) return;   // tier-3 utterances take no refinement sweep
+    adjq_body<W, NT, MODE>(gy, gy_stride, a, lamEnd, out, g_stride, T, F, M, hop, L, NC, NC, xt, yt, blockIdx.y, blockIdx.x,
+                           threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-level ADJOINT boundary scan (round 3): the mirror of lpc_fwdq2_kernel for the backward.
+//   L(c-1) = Phi_c^T L(c) + zadj_c runs from the top chunk down.  Groups are the forward's (chunks 16 g .. 16 g + 15), so
+//   the forward's composites serve transposed: through group g, L(16 g - 1) = M_g^T L(16 g + 15) + w_g.
+//   lpc_adjq2_kernel<0>  local adjoints zadj_c of the wave's 16 chunks (B1) + epilogue: the group's response w_g to its own
+//                        zadj (16-step scan from zero with Phi_c^T) -> Wz[b][g]
+//   lpc_adjq2_kernel<3>  refinement: prologue = fold of (M_g'^T, w_g') over the groups ABOVE (top state L(NP-1) = zadj_NP),
+//                        then the own chunks' scan -> L1 (kept in HBM); chunks re-run from L1(c), defects
+//                        d_c = lam_start(c) - L1(c-1) (the bottom chunk's against the state the group below really starts
+//                        from: one more fold step, bit-identical to that group's own); epilogue: response to the defects -> Wd
+//   lpc_adjq2_kernel<1>  final: the same prologue on (Wd, defects, top state 0) = the correction delta; chunks run from
+//                        L1 + delta and write g.
+//   Tier-3 utterances: the fp64 scan wave (precise_adj_scan) rides in the refinement launch's extra rows and writes L1.
+//   st layout (LDS, 17 rows of 32): st[k+1] = L(c0+k), st[0] = L(c0-1).
+// ------------------------------------------------------------------------------------------
+template <int W, int NT>
+__device__ __forceinline__ void adj_group_prologue(const float* __restrict__ Phi, const float* __restrict__ MTt,
+                                                   const float* __restrict__ Wv, const float* __restrict__ x, int NC,
+                                                   bool with_top, float* __restrict__ st, int b, int g, int NP, int NG,
+                                                   int lane) {
+    const bool act = lane < NT;
+    const int ii = act ? lane : 0;
+    const size_t cstride4 = (size_t)NT * W / 4;
+    const int c0 = g * kGroup;
+    const int gt = NG - 1;                                   // top group with chunk maps
+    const int ct = c0 + kGroup - 1 < NP - 1 ? c0 + kGroup - 1 : NP - 1;   // top chunk map of this group (if any)
+    // the wave's own chunk maps (rows of Phi: lane j holds row j = column j of Phi^T), first fetches before the fold
+    constexpr int DC = 6;
+    const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + ii) * W);
+    const float* xb = x + (size_t)b * NC * W + ii;
+    float4 pb[DC][W / 4];
+    float xx[DC];
+    auto fetchc = [&](int u, int c) {
+        const int cl = c < 0 ? 0 : (c < NP ? c : NP - 1);
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+        xx[u] = xb[(size_t)cl * W];
+    };
+#pragma unroll
+    for (int u = 0; u < DC; ++u) fetchc(u, ct - u);
+    // state entering the top group: L(NP-1) = zadj_NP (first pass) or 0 (correction pass)
+    float t = (with_top && act) ? x[((size_t)b * NC + NP) * W + ii] : 0.f;
+    if (g < gt) {   // (a) the groups above this one, from the top down
+        constexpr int D = 4;
+        const float4* mrows = reinterpret_cast<const float4*>(MTt + ((size_t)b * NG * NT + ii) * W);
+        const float* vb = Wv + (size_t)b * NG * 32 + ii;
+        float4 mb[D][W / 4];
+        float vv[D];
+        auto fetch = [&](int u, int gg) {
+            const int gl = gg > g ? gg : g + 1;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[u][k] = mrows[(size_t)gl * cstride4 + k];
+            vv[u] = vb[(size_t)gl * 32];
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, gt - u);
+        for (int gb = gt; gb > g; gb -= D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (gb - u > g) {   // wave-uniform
+                    t = matvec_step<W, NT>(mb[u], t, vv[u], act);
+                    fetch(u, gb - u - D);
+                }
+            }
+        }
+    }
+    // (b) the own chunks, top down: st[k+1] = L(c0+k); rows above the top chunk map hold L = 0 except ... the top state
+    for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
+    wave_lds_fence();
+    if (c0 <= NP - 1) {
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int u = k % DC;
+            const int c = ct - k;
+            if (c >= c0) {   // wave-uniform
+                if (lane < 32) st[(c - c0 + 1) * 32 + lane] = t;
+                t = matvec_step<W, NT>(pb[u], t, xx[u], act);
+                if (k + DC < kGroup) fetchc(u, c - DC);
+            }
+        }
+        if (lane < 32) st[lane] = t;   // L(c0-1) by the own scan (replaced by the fold value of the group below in MODE 3)
+    }
+    wave_lds_fence();
+}
+
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__ gy, int64_t gy_stride,
+                                                       const float* __restrict__ a, float* __restrict__ out,
+                                                       int64_t g_stride, int T, int F, int M, int hop, int L, int NC,
+                                                       const float* __restrict__ Phi, const float* __restrict__ MTt,
+                                                       const float* __restrict__ Wv, float* __restrict__ Wout,
+                                                       const float* __restrict__ x, int NP, int NG,
+                                                       float* __restrict__ L1, const unsigned* __restrict__ tier, int B,
+                                                       const double* __restrict__ Phi64) {
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "local adjoints, final pass or refinement pass");
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    __shared__ float st[(kGroup + 1) * 32];
+    __shared__ float dl[kGroup * 32];
+    if constexpr (MODE == 3) {
+        if ((int)blockIdx.y >= B) {   // fp64 adjoint boundary scan of a tier-3 utterance (x = zadj) -> L1 rows c+1
+            const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
+            if (bp < B && tier3(tier, bp))
+                precise_adj_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, x + (size_t)bp * NC * W,
+                                        L1 + (size_t)bp * (NC + 1) * 32 + 32, 32, NP, threadIdx.x);
+            return;
+        }
+    }
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int c0 = g * kGroup;
+    const bool precise = tier3(tier, b);   // wave-uniform
+    float* l1b = L1 + (size_t)b * (NC + 1) * 32;   // row c+1 = L1(c), c = -1 .. NP
+    const bool act = lane < NT;
+    const int ii = act ? lane : 0;
+    if constexpr (MODE == 0) {
+        for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
+        wave_lds_fence();
+        adjq_body<W, NT, 0>(gy, gy_stride, a, nullptr, out, 0, T, F, M, hop, L, NC, NC, xt, yt, b, g, lane, nullptr, dl);
+        if (g >= NG || precise) return;   // a group without chunk maps (it holds only the final partial chunk)
+    } else if constexpr (MODE == 3) {
+        if (precise) return;
+        adj_group_prologue<W, NT>(Phi, MTt, Wv, x, NC, true, st, b, g, NP, NG, lane);
+        if (g >= 1) {   // the state the group BELOW really starts from: its fold step M_g^T L1(c0+15) + w_g, recomputed here
+            const float4* mrow = reinterpret_cast<const float4*>(MTt + (((size_t)b * NG + g) * NT + ii) * W);
+            float4 mb[W / 4];
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
+            const float vv = Wv[((size_t)b * NG + g) * 32 + ii];
+            const int ktop = (c0 + kGroup - 1 < NP - 1 ? kGroup - 1 : NP - 1 - c0);   // row of the group's top chunk map
+            const float tin = lane < 32 ? st[(ktop + 1) * 32 + lane] : 0.f;
+            const float t1 = matvec_step<W, NT>(mb, tin, vv, act);
+            if (lane < 32) st[lane] = t1;
+            wave_lds_fence();
+        }
+        for (int e = lane; e < kGroup * 32; e += 64)   // L1 -> HBM: rows c0+k+1 of this group (c0+k <= NP)
+            if (c0 + e / 32 <= NP) l1b[(size_t)(c0 + 1) * 32 + e] = st[32 + e];
+        for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
+        wave_lds_fence();
+        adjq_body<W, NT, 3, true>(gy, gy_stride, a, nullptr, out, 0, T, F, M, hop, L, NC, NP, xt, yt, b, g, lane, st, dl);
+    } else {
+        if (precise) {
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)   // rows 0 .. NP of L1 hold L(-1) .. L(NP-1); L(NP) = 0
+                st[e] = c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
+        } else {
+            adj_group_prologue<W, NT>(Phi, MTt, Wv, x, NC, false, st, b, g, NP, NG, lane);   // delta (Wv = Wd, x = defects)
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] += c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
+        }
+        wave_lds_fence();
+        adjq_body<W, NT, 1, true>(gy, gy_stride, a, nullptr, out, g_stride, T, F, M, hop, L, NC, NC, xt, yt, b, g, lane, st,
+                                  nullptr);
+        return;
+    }
+    // epilogue (MODE 0 / 3): the group's response to its own inputs (zadj_c / defects d_c), scanned from zero, top down
+    {
+        wave_lds_fence();
+        const size_t cstride4 = (size_t)NT * W / 4;
+        const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + ii) * W);
+        const int ct = c0 + kGroup - 1 < NP - 1 ? c0 + kGroup - 1 : NP - 1;
+        constexpr int D = 4;
+        float4 pbuf[D][W / 4];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int cl = ct - u > c0 ? ct - u : c0;
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) pbuf[u][k] = rows[(size_t)cl * cstride4 + k];
+        }
+        float s = 0.f;
+        for (int cb = ct; cb >= c0; cb -= D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = cb - u;
+                if (c >= c0) {   // wave-uniform
+                    const float xi = dl[(c - c0) * 32 + ii];   // zadj_c (MODE 0) / defect d_c (MODE 3), left in LDS by the body
+                    s = matvec_step<W, NT>(pbuf[u], s, xi, act);
+                    const int cn = c - D > c0 ? c - D : c0;
+#pragma unroll
+                    for (int k = 0; k < W / 4; ++k) pbuf[u][k] = rows[(size_t)cn * cstride4 + k];
+                }
+            }
+        }
+        if (lane < 32) Wout[((size_t)b * NG + g) * 32 + lane] = s;
     }
 }
 
@@ -1947,7 +2207,9 @@ __global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ 
 //   lane j reads row j of Phi (float4 x W/4), D chunks ahead.
 //   Blocks [B, 2B): one wave per utterance that returns unless the utterance is tier 3 (see phi_guard): then the scan runs
 //   in fp64 over the maps kept as doubles, and the regular wave of that utterance steps aside.
-template <int W, int NT, int D>
+//   ACC: correction pass of the delta-form refinement sweep -- zadj holds the defects, lamEnd += their scan (the top state,
+//   L(NP-1), is exact and gets no correction).
+template <int W, int NT, int D, bool ACC>
 __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restrict__ Phi, const float* __restrict__ zadj,
                                                           float* __restrict__ lamEnd, int NC, int NP, int B,
                                                           const unsigned* __restrict__ tier,
@@ -1955,9 +2217,9 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
     const int j = threadIdx.x;
     if ((int)blockIdx.x >= B) {
         const int bp = (int)blockIdx.x - B;
-        if (tier3(tier, bp))
+        if (!ACC && tier3(tier, bp))
             precise_adj_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, zadj + (size_t)bp * NC * W,
-                                    lamEnd + (size_t)bp * NC * 64, NP, j);
+                                    lamEnd + (size_t)bp * NC * 64, 64, NP, j);
         return;
     }
     const int b = blockIdx.x;
@@ -1967,8 +2229,8 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
     float* Lb = lamEnd + (size_t)b * NC * 64 + j;  // rows padded to 64 floats
     const float* zb = zadj + (size_t)b * NC * W + jj;
     // last chunk (c = NP) has no transition matrix and lam_end = 0
-    Lb[(size_t)NP * 64] = 0.f;
-    float lam = act ? zb[(size_t)NP * W] : 0.f;
+    if (!ACC) Lb[(size_t)NP * 64] = 0.f;
+    float lam = (act && !ACC) ? zb[(size_t)NP * W] : 0.f;
     if (NP <= 0) return;
     const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + jj) * W);
     const size_t cstride4 = (size_t)NT * W / 4;
@@ -2000,7 +2262,7 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int c = NP - 1 - (u0 + u);
-            Lb[(size_t)c * 64] = lam;
+            if (ACC) Lb[(size_t)c * 64] += lam; else Lb[(size_t)c * 64] = lam;
             GOLF_B2_STEP(u)
             const int cn = c - D > 0 ? c - D : 0;
 #pragma unroll
@@ -2012,7 +2274,7 @@ __global__ __launch_bounds__(64) void lpc_adj_scan_kernel(const float* __restric
     for (int u = 0; u < D; ++u) {
         const int c = NP - 1 - (u0 + u);
         if (c >= 0) {
-            Lb[(size_t)c * 64] = lam;
+            if (ACC) Lb[(size_t)c * 64] += lam; else Lb[(size_t)c * 64] = lam;
             GOLF_B2_STEP(u)
         }
     }
@@ -2312,10 +2574,11 @@ static bool use_two_level_scan(const SsPlan& p, int B, int flags) {
 
 // Conditioning tiers (see phi_guard): the arguments of the fix-up.  `accurate`: the maps in `ws` come from fp64
 // trajectories already (training path), only tier-3 utterances get their doubles.
-static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, char* ws, int accurate) {
+static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, char* ws, int accurate, int training = 0) {
     FixArgs fa;
     fa.a = a;
     fa.PhiT = (float*)(ws + p.off_phiT);
+    fa.Phi = (training && !accurate) ? (float*)(ws + p.off_phi) : nullptr;
     fa.Phi64 = (double*)(ws + p.off_phi64);
     fa.pmax = no_fixup() ? nullptr : (const float*)(ws + p.off_pmax);
     fa.tier = (unsigned*)(ws + p.off_tier);
@@ -2346,11 +2609,11 @@ static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2) {
 // ... as a launch of its own (flat-scan path)
 template <int W, int NT>
 static int launch_fixup(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int accurate,
-                        hipStream_t st) {
+                        int training, hipStream_t st) {
     if (p.NP <= 0 || no_fixup()) return GOLF_OK;
     int k1, k2;
     fixup_kf(p, NT, &k1, &k2);
-    FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate);
+    FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate, training);
     fa.B = B;
     hipLaunchKernelGGL((lpc_fixup_kernel<W, NT>), dim3((unsigned)(k1 + k2), B), dim3(256), 0, st, fa);
     GOLF_LAUNCH_CHECK();
@@ -2362,21 +2625,23 @@ static int launch_fixup(const SsPlan& p, const float* a, int B, int F, int M, in
 template <int W, int NT>
 static int launch_composites(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int accurate,
                              int flags, hipStream_t st) {
+    const int training = (accurate || (flags & GOLF_SS_TRAINING)) ? 1 : 0;   // the backward follows: keep what it needs
     if constexpr (NT <= 24) {
         if (use_two_level_scan(p, B, flags)) {
-            FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate);
+            FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate, training);
             fa.B = B;
             int k1, k2;
             fixup_kf(p, NT, &k1, &k2);
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B;
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)(nf + nu)), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
-                               (float*)nullptr, p.NP, p.NG, B, 1, fa, k1, k2);
+                               (float*)nullptr, p.NP, p.NG, B, 1, fa, k1, k2,
+                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr);
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }
     }
-    return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, st);
+    return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, training, st);
 }
 
 template <int W, int NT>
@@ -2390,7 +2655,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
         constexpr int CPW = 64 / ((NT + 3) / 4);
         hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
                            st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
-                           (unsigned*)(ws + p.off_fixcnt), B);
+                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
         GOLF_LAUNCH_CHECK();
         return launch_composites<W, NT>(p, a, B, F, M, hop, ws, 0, flags, st);
     }
@@ -2450,6 +2715,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     const double* Phi64 = (const double*)(ws + p.off_phi64);
     constexpr int D = 8;
     const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
+    const int training = (!fast || (flags & GOLF_SS_TRAINING)) ? 1 : 0;   // the backward follows: keep what it needs
     ForkJoin fork, join;
     bool fused_p1 = false;
     if (p.NP > 0) {
@@ -2470,7 +2736,8 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                     const int nblk_z = (int)ceil_div(nunit, 4 * upw);
                     hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
                                        0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
-                                       B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt));
+                                       B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
+                                       training ? (float*)(ws + p.off_phi) : (float*)nullptr);
                     GOLF_LAUNCH_CHECK();
                 } else {
                     constexpr int KT = 3, NG = (NT + KT - 1) / KT;
@@ -2510,14 +2777,15 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* S1 = (float*)(ws + p.off_S1);                      // first-pass chunk start states
             const int gxf = (int)ceil_div(p.NC, kGroup);
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
-            FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1);
+            FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1, training);
             fa.B = B;
             int k1, k2;
             fixup_kf(p, NT, &k1, &k2);
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B, nz = (int)ceil_div(nu, 4);
             const int parts = fused_p1 ? 3 : 2, count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2);
+                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2,
+                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr);
             GOLF_LAUNCH_CHECK();
             // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
             const int gx3 = (int)ceil_div(p.NP, kGroup);
@@ -2535,7 +2803,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         }
     }
     if (fused_p1)   // (otherwise launch_transitions / the caller's transitions call ran it)
-        if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, st)) return rc;
+        if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, training, st)) return rc;
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, (const float*)PhiT,
                        (const float*)z, S, p.NC, p.NP, B, tier, Phi64);
     GOLF_LAUNCH_CHECK();
@@ -2560,25 +2828,60 @@ template <int W, int NT>
 static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                       const float* ex, int64_t ex_stride, const float* gain, const float* a, float* g_ex,
                       int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T, int F, int M, int hop, char* ws,
-                      hipStream_t st) {
+                      int flags, hipStream_t st) {
     const float* Phi = (const float*)(ws + p.off_phi);
     float* zadj = (float*)(ws + p.off_zadj);
     float* lam = (float*)(ws + p.off_lam);
     float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
+    float* dadj = (float*)(ws + p.off_dadj);
     const unsigned* tier = p.NP > 0 && !no_fixup() ? (const unsigned*)(ws + p.off_tier) : nullptr;   // as the forward left them
+    const double* Phi64 = (const double*)(ws + p.off_phi64);
     constexpr int D = 8;
     const dim3 gq((unsigned)ceil_div(p.NC, 16), B);
-    hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
-                       zadj, (int64_t)0, T, F, M, hop, p.L, p.NC);
-    GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D>), dim3(2 * B), dim3(64), 0, st, Phi, (const float*)zadj, lam, p.NC,
-                       p.NP, B, tier, (const double*)(ws + p.off_phi64));
-    GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
-                       (int64_t)T, T, F, M, hop, p.L, p.NC);
-    GOLF_LAUNCH_CHECK();
+    bool done = false;
+    if constexpr (NT <= 24) {
+        if (p.NP > 0 && use_two_level_scan(p, B, flags)) {   // two-level adjoint scan + refinement sweep (see lpc_adjq2_kernel)
+            const float* MTt = (const float*)(ws + p.off_mtT);   // written by the (training) forward's pre-pass
+            float* Wz = (float*)(ws + p.off_wadj);
+            float* Wd = Wz + (size_t)B * p.NG * 32;
+            float* L1 = (float*)(ws + p.off_L1);
+            hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, zadj, (int64_t)0, T, F, M,
+                               hop, p.L, p.NC, Phi, MTt, (const float*)nullptr, Wz, (const float*)nullptr, p.NP, p.NG, L1,
+                               tier, B, Phi64);
+            GOLF_LAUNCH_CHECK();
+            const int gx3 = (int)ceil_div(p.NP, kGroup);
+            hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 3>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0, st,
+                               gy, gy_stride, a, dadj, (int64_t)0, T, F, M, hop, p.L, p.NC, Phi, MTt, (const float*)Wz, Wd,
+                               (const float*)zadj, p.NP, p.NG, L1, tier, B, Phi64);
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, gbuf, (int64_t)T, T, F, M,
+                               hop, p.L, p.NC, Phi, MTt, (const float*)Wd, (float*)nullptr, (const float*)dadj, p.NP, p.NG,
+                               L1, tier, B, Phi64);
+            GOLF_LAUNCH_CHECK();
+            done = true;
+        }
+    }
+    if (!done) {   // flat adjoint scan, with the same refinement sweep in delta form
+        hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
+                           zadj, (int64_t)0, T, F, M, hop, p.L, p.NC, (const unsigned*)nullptr);
+        GOLF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, Phi, (const float*)zadj, lam,
+                           p.NC, p.NP, B, tier, Phi64);
+        GOLF_LAUNCH_CHECK();
+        if (p.NP > 0) {
+            hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 2>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, dadj,
+                               (int64_t)0, T, F, M, hop, p.L, p.NC, tier);
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D, true>), dim3(B), dim3(64), 0, st, Phi, (const float*)dadj, lam,
+                               p.NC, p.NP, B, tier, Phi64);
+            GOLF_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)lam, gbuf,
+                           (int64_t)T, T, F, M, hop, p.L, p.NC, (const unsigned*)nullptr);
+        GOLF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
                        y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG);
     GOLF_LAUNCH_CHECK();
@@ -2775,7 +3078,7 @@ extern "C" int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, cons
         return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
     }
     GOLF_SS_DISPATCH(launch_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride, g_gain, g_a,
-                     B, T, F, M, hop, (char*)ws, st)
+                     B, T, F, M, hop, (char*)ws, flags, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

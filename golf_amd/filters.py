@@ -93,11 +93,11 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
         hop = int(a.hop_length)
         F = a.shape[1]
         T = (F - 1) * hop + 1 if n_samples is None else min(int(n_samples), (F - 1) * hop + 1)
-        # fp32 matrices (+ refinement sweep in the forward) unless a gradient may be asked for; a forward that does
-        # need gradients ignores a fast handle and recomputes
-        at, gt = a.as_tensor(), gain.as_tensor()
-        fast = not (torch.is_grad_enabled() and (at.requires_grad or gt.requires_grad))
-        self._prepared = GF.ltv_allpole_prepare(at, hop, T, overlap=overlap, fast=fast)
+        # the fp32 matrices of the inference path serve training too (ABI 3: the backward runs its own refinement sweep);
+        # with grad mode on the handle also keeps what the backward reads -- whichever decoder input ends up requiring a
+        # gradient (a frozen filter under a trainable source included: ADVICE r2), the forward can pick it up
+        self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T, overlap=overlap, fast=True,
+                                                training=torch.is_grad_enabled())
 
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
         hop = _check_filter_inputs(ex, gain, a)

@@ -17,6 +17,7 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
 
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
+TRAINING = 64            # GOLF_SS_TRAINING
 FORK_TRANSITIONS = False
 SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
@@ -37,12 +38,12 @@ class PreparedTransitions:
     """Handle returned by ltv_allpole_prepare: the workspace with the transition matrices in flight on the side
     stream, plus the shape key they are valid for."""
 
-    def __init__(self, ws, key, stream, a, fast=False):
-        self.ws, self.key, self.stream, self.a, self.fast = ws, key, stream, a, fast
+    def __init__(self, ws, key, stream, a, fast=False, training=False):
+        self.ws, self.key, self.stream, self.a, self.fast, self.training = ws, key, stream, a, fast, training
 
 
 def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False,
-                        fast: bool = False, mode=None) -> PreparedTransitions:
+                        fast: bool = False, mode=None, training: bool = False) -> PreparedTransitions:
     """Compute the transition matrices for coefficients ``a`` (B,F,M) and output length ``T`` ahead of the
     excitation; pass the handle to ltv_allpole_ss(..., prepared=handle) (e.g. to filter several signals with the
     same coefficients, or to start the most expensive, excitation-independent phase early).
@@ -50,13 +51,13 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
     With the two-level boundary scan the group composites (which need only the matrices) are computed here as well.
     What it buys is LATENCY of a lone batch (the 40 us transition kernel hides behind the oscillator); with several
     batches in flight the chip is full either way and the fork/join only costs — off by default.
-    ``fast=True`` computes the fp32 matrices of the inference path (the forward then runs its refinement sweep; such a
-    handle must not be used when gradients are needed)."""
+    ``fast=True`` computes the fp32 matrices of the inference path; ``training=True`` (implied by ``fast=False``) also keeps
+    what the backward reads, so the handle serves a forward whose gradients are needed."""
     _lib.require_device(a)
     lib = _lib.load()
     a = a.detach().contiguous()
     B, F, M = a.shape
-    flags = SS_MODES[mode] | (FAST_TRANSITIONS if fast else 0)
+    flags = SS_MODES[mode] | (FAST_TRANSITIONS if fast else 0) | (TRAINING if (fast and training) else 0)
     ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, flags), a.device)
     cur = torch.cuda.current_stream(a.device)
     side = None
@@ -68,7 +69,8 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
     rc = lib.golf_ltv_allpole_transitions_f32(a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(),
                                               flags, (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
-    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version, SS_MODES[mode]), side, a, fast)
+    return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version, SS_MODES[mode]), side, a, fast,
+                               training or not fast)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -124,15 +126,17 @@ class _LTVAllPoleSS(torch.autograd.Function):
                 f"needs >= 2 frames and a ring width W in {[r for r, _ in SS_RINGS]} with hop % W == 0 and lpc_order <= W - 2 "
                 f"(e.g. hop 240 -> orders up to 38, hop 256 -> up to 30, hop 100 -> none)")
         if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version, mode)
-                and not (prepared.fast and needs_grad)):
+                and not (prepared.fast and needs_grad and not prepared.training)):
             ws, flags, side = prepared.ws, HAVE_TRANSITIONS | mode, prepared.stream
             if prepared.fast:
-                flags |= FAST_TRANSITIONS
+                flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0)
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
             flags = mode
-            if not needs_grad and fast_inference:
-                flags |= FAST_TRANSITIONS  # fp32 transitions + one refinement sweep (inference only)
+            if fast_inference:
+                # fp32 transition matrices (hot chunks recomputed from fp64 trajectories) + one refinement sweep; with a
+                # gradient pending the forward also keeps the adjoint-orientation maps for the backward's own sweep
+                flags |= FAST_TRANSITIONS | (TRAINING if needs_grad else 0)
             if SPLIT_P1:
                 flags |= 4                # GOLF_SS_SPLIT_P1 (diagnostic): two launches instead of the fused one
             if FORK_TRANSITIONS:

@@ -72,8 +72,8 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                (about 4x cheaper) and the forward runs one refinement sweep over the chunk boundary states
  *                (re-run the chunks from the scanned states, rescan with the observed end-state defects), which
  *                makes the result second order in the matrix error: same accuracy as a sequential fp32 recursion.
- *                The matrices left in `ws` are then only fp32-accurate: the host binding never sets FAST when a
- *                gradient is required (golf_ltv_allpole_bwd_f32 expects the fp64-derived matrices).
+ *                (ABI 2 required the fp64-derived matrices for the backward; since ABI 3 the backward runs its own refinement
+ *                sweep and accepts either: see GOLF_SS_TRAINING.)
  *   side_stream  optional second hipStream_t (may be NULL): without HAVE_TRANSITIONS the forward forks the
  *                transition kernel onto it (event fork/join) so it overlaps the excitation-dependent phase;
  *                with HAVE_TRANSITIONS the forward joins it (event wait) right before the boundary scan. */
@@ -95,6 +95,12 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                f64 MFMA product chains rounded once to fp32 + per-group scans spread over the chip + start states
  *                derived in the chunk kernels): an A/B switch; the two give the same states up to fp32 rounding. */
 #define GOLF_SS_FLAT_SCAN 32
+/*          GOLF_SS_TRAINING  golf_ltv_allpole_bwd_f32 will follow on this workspace: the forward also keeps what the backward's
+ *                two-level adjoint scan reads (the transition matrices in the adjoint's orientation, the group composites
+ *                transposed).  Implied without GOLF_SS_FAST_TRANSITIONS.  With FAST | TRAINING the training step runs on the
+ *                fp32 transition matrices of the inference path (hot chunks recomputed from fp64 trajectories, one refinement
+ *                sweep in the forward AND in the backward): same accuracy class, ~28 us less per B = 32 step (ABI 3). */
+#define GOLF_SS_TRAINING 64
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);

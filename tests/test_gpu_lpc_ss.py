@@ -519,8 +519,8 @@ def test_ill_conditioned_rows_backward():
     assert np.all(e_chk <= BWD_FACTOR * e_seq + 2e-4), (np.nonzero(e_chk > BWD_FACTOR * e_seq + 2e-4)[0], e_chk.max())
 
 
-# the adjoint boundary scan has no refinement sweep yet: its error on hot utterances is first order in the maps' rounding
-BWD_FACTOR = 40
+# (round 2: 40; the adjoint scan now runs the same delta-form refinement sweep as the forward)
+BWD_FACTOR = 3
 
 
 @pytest.mark.parametrize("sigma,seed", [(0.7, 12), (1.0, 13)])
@@ -650,3 +650,26 @@ def test_speech_lpc_tracks_g25(golden):
     check(g_ex[:, : r_ex.shape[1]], r_ex, "speech tracks g_ex")
     check(g_gain, r_gain, "speech tracks g_gain")
     check(g_a, r_a, "speech tracks g_a")
+
+
+@pytest.mark.parametrize("B,F,M,hop", [(3, 60, 22, 240), (2, 130, 12, 24), (40, 20, 22, 240)])
+def test_bwd_both_transition_precisions(B, F, M, hop):
+    """The training step runs on the inference path's fp32 transition matrices by default (GOLF_SS_FAST_TRANSITIONS |
+    GOLF_SS_TRAINING: forward and backward each do a refinement sweep); ``fast_inference=False`` keeps the fp64-trajectory
+    path.  Both against the float64 oracle: two-level scans (long utterances, B <= 39) and flat ones (short / B = 40)."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    ex, gain, a = smooth_case(B, F, M, hop, seed=B * 7 + F)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    gy = (np.random.default_rng(3).normal(0, 1, ref.shape) / np.abs(ref).max(1, keepdims=True)).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+    for fast in (True, False):
+        t = [dev(v).requires_grad_(True) for v in (ex, gain, a)]
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, fast_inference=fast)
+        (y * dev(gy)).sum().backward()
+        torch.cuda.synchronize()
+        check(y.detach().cpu().numpy(), ref, f"fast={fast} y")
+        check(t[0].grad.cpu().numpy()[:, : r_ex.shape[1]], r_ex, f"fast={fast} g_ex")
+        check(t[1].grad.cpu().numpy(), r_gain, f"fast={fast} g_gain")
+        check(t[2].grad.cpu().numpy(), r_a, f"fast={fast} g_a")

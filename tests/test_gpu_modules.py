@@ -108,7 +108,8 @@ def test_prefetch_overlap_is_bit_identical():
     assert torch.equal(y2, y2_ref) and not torch.equal(y2, y0)
     # backward through a prepared forward
     ag = a.clone().requires_grad_(True)
-    prep = GF.ltv_allpole_prepare(ag, 240, y0.shape[1], overlap=True)
+    # (the training step runs on the inference path's fp32 matrices: the handle must keep what the backward reads)
+    prep = GF.ltv_allpole_prepare(ag, 240, y0.shape[1], overlap=True, fast=True, training=True)
     GF.ltv_allpole_ss(ex, gain, ag, 240, prep).square().sum().backward()
     ag2 = a.clone().requires_grad_(True)
     GF.ltv_allpole_ss(ex, gain, ag2, 240).square().sum().backward()
