@@ -75,11 +75,12 @@ SIGNATURES = {
                                        _vp, _sz, _vp]),
     "golf_harmonic_osc_workspace_bytes": (_sz, [_int] * 5),
     "golf_harmonic_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _c_f32p,
-                                         _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),
+                                         _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _int, _int, _c_f32p]),
     "golf_harmonic_osc_dphase_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _c_f32p,
-                                         _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp]),
+                                         _int, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _int, _int, _c_f32p]),
     "golf_harmonic_osc_bwd_amp_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _int, _int, _c_f32p, _int, _int,
-                                             _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz, _vp]),
+                                             _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz, _vp, _c_f32p, _int, _int,
+                                             _c_f32p]),
     "golf_zero_phase_fir_row_stride": (_int, [_int]),
     "golf_zero_phase_fir_basis_bytes": (_sz, [_int]),
     "golf_zero_phase_fir_basis_f32": (_int, [_int, _vp, _sz, _vp]),

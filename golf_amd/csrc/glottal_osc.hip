@@ -1009,6 +1009,23 @@ __device__ __forceinline__ HarmSample harm_sample(const float* __restrict__ pb, 
     r.p = fmaf((float)k, (p1 - p0) / (float)P, p0);
     return r;
 }
+// Optional phase terms of HarmonicOscillator.forward (models/synth.py:434-440): harmonic h runs at
+//   h * (Phi(t) + up(phase_offset)(t)) + initial_phase[b, h]   (cycles).
+struct HarmPhase {
+    const float* poff;   // (B, Fo) at hop po_hop, linearly upsampled; or null
+    int Fo, po_hop;
+    const float* phi0;   // (B, H) cycles; or null
+};
+// the offset as a Q0.64 fraction of a cycle (any real value: only its fractional part matters)
+__device__ __forceinline__ u64 harm_offset_q64(const HarmPhase& hp, int b, int t) {
+    if (!hp.poff) return 0;
+    int f = 0;
+    float w = 0.f;
+    if (hp.Fo >= 2) { f = min(t / hp.po_hop, hp.Fo - 2); w = (float)(t - f * hp.po_hop) / (float)hp.po_hop; }
+    const float v0 = hp.poff[(size_t)b * hp.Fo + f], v1 = hp.poff[(size_t)b * hp.Fo + (hp.Fo >= 2 ? f + 1 : f)];
+    const double x = (double)fmaf(w, v1 - v0, v0);
+    return (u64)((x - floor(x)) * 18446744073709551616.0);
+}
 // sin and cos of 2*pi*(x / 2^64)
 __device__ __forceinline__ void harm_sincos(u64 x, float& s, float& c) {
     const float rev = (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);  // top 24 bits: exact in fp32, [0,1)
@@ -1023,7 +1040,7 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
     int ntile, int Tp, int P, const float* __restrict__ amp, int Fa, int amp_hop, const float* __restrict__ tscale,
     int Fs, int ts_hop, const float* __restrict__ hscale, int H, float* __restrict__ out, int64_t out_stride, int Tout,
-    int nrows_lds) {
+    int nrows_lds, HarmPhase hp) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     __shared__ u64 toff[256];
     __shared__ u64 twsum[4];
@@ -1040,7 +1057,13 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
     }
     float* hs = hsm;                     // [H] per-harmonic scale (used directly when there is no amplitude tensor)
     float* rows = hsm + ((H + 3) & ~3);  // [nrows_lds][H] amplitude rows, per-harmonic scale already folded in
+    float* ph0 = rows + (size_t)(amp ? nrows_lds : 1) * H;   // [2][H] cos / sin of 2 pi initial_phase (only if given)
     for (int h = tid; h < H; h += HARM_THREADS) hs[h] = hscale ? hscale[h] : 1.0f;
+    if (hp.phi0)
+        for (int h = tid; h < H; h += HARM_THREADS) {
+            const float x = hp.phi0[(size_t)b * H + h];
+            sincospif(2.0f * (x - floorf(x)), &ph0[H + h], &ph0[h]);
+        }
     const float* pb = phase + (size_t)b * phase_stride;
     const u64* cb = Cloc + (size_t)b * Tp;
     const double scale_a = 18446744073709551616.0, scale_d = scale_a / (double)P;
@@ -1056,7 +1079,8 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
     __syncthreads();
     const int t = t_lo + tid;
     if (t >= Tout) return;
-    const HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+    HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+    sm.Phi += harm_offset_q64(hp, b, t);   // the harmonics multiply Phi + offset: wraps exactly, like Phi itself
     int fa = 0;
     float wa = 0.f;
     if (Fa >= 2) { fa = min(t / amp_hop, Fa - 2); wa = (float)(t - fa * amp_hop) * inv_ah; }
@@ -1087,8 +1111,14 @@ __global__ __launch_bounds__(HARM_THREADS) void harm_kernel(
             if (h <= H) {  // uniform
                 const float a0 = r0[h - 1];
                 const float a = fmaf(wa, r1[h - 1] - a0, a0);
-                if (DERIV) acc = h <= hl ? fmaf(a * (float)h, c, acc) : acc;
-                else       acc = h <= hl ? fmaf(a, s, acc) : acc;
+                float se = s, ce = c;   // sin / cos of 2 pi (h (Phi + offset) + initial_phase[h])
+                if (hp.phi0) {          // uniform
+                    const float cp = ph0[h - 1], sp = ph0[H + h - 1];
+                    se = fmaf(s, cp, c * sp);
+                    ce = fmaf(c, cp, -s * sp);
+                }
+                if (DERIV) acc = h <= hl ? fmaf(a * (float)h, ce, acc) : acc;
+                else       acc = h <= hl ? fmaf(a, se, acc) : acc;
                 const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
                 s = sn;
                 c = cn;
@@ -1109,7 +1139,7 @@ __global__ __launch_bounds__(64) void harm_bwd_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Cloc, const u64* __restrict__ Ttot,
     int ntile, int Tp, int P, int Fa, int amp_hop, const float* __restrict__ tscale, int Fs, int ts_hop,
     const float* __restrict__ hscale, int H, const float* __restrict__ g_out, int64_t g_out_stride,
-    float* __restrict__ part, int nseg, int Tout) {
+    float* __restrict__ part, int nseg, int Tout, HarmPhase hp) {
     __shared__ u64 toff[256];
     const int lane = threadIdx.x, sg = blockIdx.x, b = blockIdx.y;
     {   // exclusive prefix of the phase tile totals, 4 passes of one wave
@@ -1138,7 +1168,8 @@ __global__ __launch_bounds__(64) void harm_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < HARM_ANCHOR; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
         for (int t = t_lo + lane; t < t_hi; t += 64) {
-            const HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+            HarmSample sm = harm_sample(pb, cb, toff, t, Tp, P, scale_a, scale_d);
+            sm.Phi += harm_offset_q64(hp, b, t);
             const float wa = Fa >= 2 ? (float)(t - t_lo) * inv_ah : 0.f;
             float ts = 1.0f;
             if (tscale) {
@@ -1156,7 +1187,14 @@ __global__ __launch_bounds__(64) void harm_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < HARM_ANCHOR; ++i) {
                 const int h = h0 + i;
-                const float v = (h <= H && (float)h * sm.p < 0.5f) ? s : 0.f;
+                float se = s;
+                if (hp.phi0 && h <= H) {   // sin(2 pi (h Phi + initial_phase[h])); two loads per term: the rare path
+                    float sp, cp;
+                    const float x = hp.phi0[(size_t)b * H + h - 1];
+                    sincospif(2.0f * (x - floorf(x)), &sp, &cp);
+                    se = fmaf(s, cp, c * sp);
+                }
+                const float v = (h <= H && (float)h * sm.p < 0.5f) ? se : 0.f;
                 a0[i] = fmaf(g0, v, a0[i]);
                 a1[i] = fmaf(g1, v, a1[i]);
                 const float sn = fmaf(s, rc, c * rs), cn = fmaf(c, rc, -s * rs);
@@ -1427,29 +1465,40 @@ template <bool DERIV>
 static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                             const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                             const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout, void* ws,
-                            size_t ws_bytes, void* stream);
+                            size_t ws_bytes, void* stream, HarmPhase hp);
+static int harm_phase_check(const char* who, const float* phase_offset, int Fo, int po_hop, int Tout) {
+    if (phase_offset && (Fo < 1 || po_hop < 1 || (Fo >= 2 && (int64_t)(Fo - 1) * po_hop + 1 < Tout) || (Fo == 1 && Tout > 1 && po_hop == 1)))
+        return fail(GOLF_EINVAL, "%s: phase_offset (%d frames at hop %d) does not cover %d samples", who, Fo, po_hop, Tout);
+    return GOLF_OK;
+}
 
 extern "C" int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                          const float* amp, int Fa, int amp_hop, const float* tscale, int Fs,
                                          int ts_hop, const float* hscale, int H, float* out, int64_t out_stride, int B,
-                                         int Tout, void* ws, size_t ws_bytes, void* stream) {
+                                         int Tout, void* ws, size_t ws_bytes, void* stream, const float* phase_offset,
+                                         int Fo, int po_hop, const float* initial_phase) {
+    if (int rc = harm_phase_check("harmonic_osc_fwd", phase_offset, Fo, po_hop, Tout)) return rc;
     return harmonic_osc_run<false>("harmonic_osc_fwd", phase, phase_stride, Tp, phase_hop, amp, Fa, amp_hop, tscale, Fs,
-                                   ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream);
+                                   ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream,
+                                   HarmPhase{phase_offset, Fo, po_hop, initial_phase});
 }
 
 extern "C" int golf_harmonic_osc_dphase_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                             const float* amp, int Fa, int amp_hop, const float* tscale, int Fs,
                                             int ts_hop, const float* hscale, int H, float* out, int64_t out_stride,
-                                            int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
+                                            int B, int Tout, void* ws, size_t ws_bytes, void* stream,
+                                            const float* phase_offset, int Fo, int po_hop, const float* initial_phase) {
+    if (int rc = harm_phase_check("harmonic_osc_dphase", phase_offset, Fo, po_hop, Tout)) return rc;
     return harmonic_osc_run<true>("harmonic_osc_dphase", phase, phase_stride, Tp, phase_hop, amp, Fa, amp_hop, tscale,
-                                  Fs, ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream);
+                                  Fs, ts_hop, hscale, H, out, out_stride, B, Tout, ws, ws_bytes, stream,
+                                  HarmPhase{phase_offset, Fo, po_hop, initial_phase});
 }
 
 template <bool DERIV>
 static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                             const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                             const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout, void* ws,
-                            size_t ws_bytes, void* stream) {
+                            size_t ws_bytes, void* stream, HarmPhase hp) {
     HarmGeom g;
     harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp ? amp_hop : HARM_THREADS, &g,
               amp ? Fa : 0, H > 0 ? H : 1);
@@ -1462,10 +1511,10 @@ static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_s
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, 1, g.ntile, B, st)) return rc;
-    const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H);
+    const size_t lds = sizeof(float) * (((H + 3) & ~3) + (size_t)(amp ? g.nrows : 1) * H + (hp.phi0 ? 2 * (size_t)H : 0));
     hipLaunchKernelGGL(harm_kernel<DERIV>, dim3((unsigned)ceil_div(Tout, HARM_THREADS), B), dim3(HARM_THREADS), lds, st,
                        phase, phase_stride, (const u64*)Cw, (const u64*)Ttot, g.ntile, Tp, g.P, amp, amp ? Fa : 1,
-                       amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, Tout, g.nrows);
+                       amp ? amp_hop : 1, tscale, Fs, ts_hop, hscale, H, out, out_stride, Tout, g.nrows, hp);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -1473,7 +1522,9 @@ static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_s
 extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_stride, const float* phase,
                                              int64_t phase_stride, int Tp, int phase_hop, int Fa, int amp_hop,
                                              const float* tscale, int Fs, int ts_hop, const float* hscale, int H,
-                                             float* g_amp, int B, int Tout, void* ws, size_t ws_bytes, void* stream) {
+                                             float* g_amp, int B, int Tout, void* ws, size_t ws_bytes, void* stream,
+                                             const float* phase_offset, int Fo, int po_hop, const float* initial_phase) {
+    if (int rc = harm_phase_check("harmonic_osc_bwd_amp", phase_offset, Fo, po_hop, Tout)) return rc;
     HarmGeom g;
     harm_geom(B > 0 ? B : 1, Tp > 0 ? Tp : 1, phase_hop > 0 ? phase_hop : 1, amp_hop > 0 ? amp_hop : 1, &g, Fa,
               H > 0 ? H : 1);
@@ -1492,7 +1543,7 @@ extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_s
     const int nseg = Fa > 1 ? Fa - 1 : 1;
     hipLaunchKernelGGL(harm_bwd_kernel, dim3((unsigned)nseg, B), dim3(64), 0, st, phase, phase_stride, (const u64*)Cw,
                        (const u64*)Ttot, g.ntile, Tp, g.P, Fa, amp_hop, tscale, Fs, ts_hop, hscale, H, g_out,
-                       g_out_stride, part, nseg, Tout);
+                       g_out_stride, part, nseg, Tout, HarmPhase{phase_offset, Fo, po_hop, initial_phase});
     GOLF_LAUNCH_CHECK();
     const int n = B * Fa * H;
     hipLaunchKernelGGL(harm_bwd_combine_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)part,

@@ -881,8 +881,9 @@ def _up_len(n: int, hop: int) -> int:
 
 class _HarmonicOsc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop):
-        _lib.require_device(phase, amp, tscale, hscale)
+    def forward(ctx, phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop, phase_offset=None, po_hop=1,
+                initial_phase=None):
+        _lib.require_device(phase, amp, tscale, hscale, phase_offset, initial_phase)
         lib = _lib.load()
         phase = _rows(phase)
         B, Tp = phase.shape
@@ -900,62 +901,82 @@ class _HarmonicOsc(torch.autograd.Function):
             Tout = min(Tout, _up_len(Fs, ts_hop))
         if hscale is not None:
             hscale = hscale.contiguous()
+        Fo = 1
+        if phase_offset is not None:
+            phase_offset = phase_offset.contiguous()
+            Fo = phase_offset.shape[1]
+            Tout = min(Tout, _up_len(Fo, po_hop))
+        if initial_phase is not None:
+            initial_phase = initial_phase.contiguous()
+            if tuple(initial_phase.shape) != (B, H):
+                raise _lib.GolfError(f"harmonic_osc: initial_phase {tuple(initial_phase.shape)} for B={B}, H={H}")
         out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
         ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa if amp is not None else 0, H),
                         phase.device)
         rc = lib.golf_harmonic_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, _lib.ptr(amp), Fa, amp_hop,
                                            _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(),
-                                           out.stride(0), B, Tout, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                           out.stride(0), B, Tout, ws.data_ptr(), ws.numel(), _lib.stream_ptr(),
+                                           _lib.ptr(phase_offset), Fo, po_hop, _lib.ptr(initial_phase))
         _lib.check(rc, "golf_harmonic_osc_fwd_f32")
-        ctx.save_for_backward(phase, tscale, hscale, amp)
+        ctx.save_for_backward(phase, tscale, hscale, amp, phase_offset, initial_phase)
         ctx.geom = (H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, amp is not None)
+        ctx.po = (Fo, po_hop)
         return out
 
     @staticmethod
-    def _run(lib, name, phase, amp, tscale, hscale, geom):
+    def _run(lib, name, phase, amp, tscale, hscale, geom, phase_offset=None, po=(1, 1), initial_phase=None):
         H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = geom
         B, Tp = phase.shape
         out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
         ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa if has_amp else 0, H), phase.device)
         rc = getattr(lib, name)(phase.data_ptr(), phase.stride(0), Tp, phase_hop, _lib.ptr(amp), Fa, amp_hop,
                                 _lib.ptr(tscale), Fs, ts_hop, _lib.ptr(hscale), H, out.data_ptr(), out.stride(0), B, Tout,
-                                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                ws.data_ptr(), ws.numel(), _lib.stream_ptr(), _lib.ptr(phase_offset), po[0], po[1],
+                                _lib.ptr(initial_phase))
         _lib.check(rc, name)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        phase, tscale, hscale, amp = ctx.saved_tensors
+        phase, tscale, hscale, amp, phase_offset, initial_phase = ctx.saved_tensors
         H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = ctx.geom
+        if ctx.needs_input_grad[10]:
+            raise NotImplementedError("golf_amd: no gradient w.r.t. the harmonic oscillator's initial_phase (a constant in "
+                                      "every reference call site, models/synth.py:411)")
         if ctx.needs_input_grad[3]:
             raise NotImplementedError("golf_amd: the per-harmonic scale of the harmonic oscillator is a constant "
                                       "(SawToothOscillator's 1/h buffer)")
         lib = _lib.load()
         g_out = _rows(g_out.float())
         B, Tp = phase.shape
-        g_phase = g_amp = g_ts = None
+        g_phase = g_amp = g_ts = g_po = None
         if has_amp and ctx.needs_input_grad[1]:
             g_amp = torch.empty(B, Fa, H, dtype=torch.float32, device=phase.device)
             ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa, H), phase.device)
             rc = lib.golf_harmonic_osc_bwd_amp_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(),
                                                    phase.stride(0), Tp, phase_hop, Fa, amp_hop, _lib.ptr(tscale), Fs,
                                                    ts_hop, _lib.ptr(hscale), H, g_amp.data_ptr(), B, Tout,
-                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr(), _lib.ptr(phase_offset),
+                                                   ctx.po[0], ctx.po[1], _lib.ptr(initial_phase))
             _lib.check(rc, "golf_harmonic_osc_bwd_amp_f32")
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[8]:
             # out depends on the phase input through Phi = cumsum(up(phase)) (the Nyquist mask is piecewise constant):
             # g_phase = up^T( reverse-cumsum( g_out * d out / d Phi ) ), the derivative bank from the same kernel
             d = _HarmonicOsc._run(lib, "golf_harmonic_osc_dphase_f32", phase, amp if has_amp else None, tscale, hscale,
-                                  ctx.geom)
+                                  ctx.geom, phase_offset, ctx.po, initial_phase)
             g_inst = (g_out[:, :Tout] * d).double()
-            g_up = torch.flip(torch.cumsum(torch.flip(g_inst, [1]), 1), [1]).float()
-            g_phase = upsample_adjoint(g_up, phase_hop, Tp)
+            if ctx.needs_input_grad[0]:
+                g_up = torch.flip(torch.cumsum(torch.flip(g_inst, [1]), 1), [1]).float()
+                g_phase = upsample_adjoint(g_up, phase_hop, Tp)
+            if ctx.needs_input_grad[8]:   # the offset enters every harmonic's phase like Phi does, without the cumsum
+                g_po = upsample_adjoint(g_inst.float(), ctx.po[1], ctx.po[0])
         if tscale is not None and ctx.needs_input_grad[2]:
             # out = up(tscale) * S: S is the same kernel without the per-sample scale
             geom = (H, phase_hop, amp_hop, ts_hop, Fa, 1, Tout, has_amp)
-            S = _HarmonicOsc._run(lib, "golf_harmonic_osc_fwd_f32", phase, amp if has_amp else None, None, hscale, geom)
+            S = _HarmonicOsc._run(lib, "golf_harmonic_osc_fwd_f32", phase, amp if has_amp else None, None, hscale, geom,
+                                  phase_offset, ctx.po, initial_phase)
             g_ts = upsample_adjoint(g_out[:, :Tout] * S, ts_hop, Fs)
-        return g_phase, g_amp, g_ts, None, None, None, None, None
+        return g_phase, g_amp, g_ts, None, None, None, None, None, g_po, None, None
 
 
 def upsample_adjoint(v: torch.Tensor, hop: int, F: int) -> torch.Tensor:
@@ -974,10 +995,12 @@ def upsample_adjoint(v: torch.Tensor, hop: int, F: int) -> torch.Tensor:
 
 
 def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, tscale=None, ts_hop: int = 1,
-                 hscale=None) -> torch.Tensor:
-    """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h] * sin(2 pi h cumsum(p)[t]),
-    p = up(phase); differentiable w.r.t. ``amp``, ``phase`` and ``tscale``."""
-    return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop)
+                 hscale=None, phase_offset=None, po_hop: int = 1, initial_phase=None) -> torch.Tensor:
+    """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h]
+                      * sin(2 pi (h (cumsum(p)[t] + up(phase_offset)[t]) + initial_phase[b,h])),   p = up(phase);
+    differentiable w.r.t. ``amp``, ``phase``, ``tscale`` and ``phase_offset`` (reference models/synth.py:403-446)."""
+    return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop, phase_offset, int(po_hop),
+                              initial_phase)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -265,16 +265,18 @@ class HarmonicOscillator(OscillatorInterface):
     def _run(self, phase: AudioTensor, num_harmonics: int, amplitudes: AudioTensor = None, tscale: AudioTensor = None,
              hscale: Tensor = None, initial_phase=None, phase_offset=None) -> AudioTensor:
         assert phase.ndim == 2, phase.shape
-        if initial_phase is not None or phase_offset is not None:
-            raise NotImplementedError("golf_amd: initial_phase / phase_offset are not supported by the fused harmonic "
-                                      "oscillator (no shipped config passes them)")
+        if initial_phase is not None and isinstance(initial_phase, AudioTensor):
+            initial_phase = initial_phase.as_tensor()
         if self.check_ranges:
             assert torch.all(phase >= 0) and torch.all(phase <= 0.5)
         y = GF.harmonic_osc(phase.as_tensor(), num_harmonics, phase_hop=int(phase.hop_length),
                             amp=None if amplitudes is None else amplitudes.as_tensor(),
                             amp_hop=1 if amplitudes is None else int(amplitudes.hop_length),
                             tscale=None if tscale is None else tscale.as_tensor(),
-                            ts_hop=1 if tscale is None else int(tscale.hop_length), hscale=hscale)
+                            ts_hop=1 if tscale is None else int(tscale.hop_length), hscale=hscale,
+                            phase_offset=None if phase_offset is None else phase_offset.as_tensor(),
+                            po_hop=1 if phase_offset is None else int(phase_offset.hop_length),
+                            initial_phase=initial_phase)
         return AudioTensor(y)
 
     def forward(self, phase: AudioTensor, amplitudes: AudioTensor, initial_phase=None, phase_offset=None) -> AudioTensor:

@@ -364,23 +364,29 @@ int golf_noise_band_bwd_f32(const float* g_out, int64_t g_out_stride, const floa
  *   The (B,T,H) tensors of the reference are never formed; the phase is exact (64-bit fixed point, as in the
  *   wavetable oscillator), sin(h theta) by a rotation recurrence re-anchored from the exact phase every 32 harmonics.
  * Backward w.r.t. A (g_amp (B,Fa,H) fully overwritten); golf_harmonic_osc_dphase_f32 serves the gradient w.r.t. the phase.
+ *   Optional phase terms (ABI 3; models/synth.py:434-440): harmonic h runs at h * (Phi + up(phase_offset)) + initial_phase[b,h];
+ *   phase_offset (B,Fo) cycles at hop po_hop (linear upsampling, must cover Tout samples), initial_phase (B,H) cycles;
+ *   either may be NULL.  d out / d phase_offset(t) is what golf_harmonic_osc_dphase_f32 returns.
  * ------------------------------------------------------------------------------------------- */
 /* Fa = amplitude frames (0 if amp is NULL); sized for the forward and the backward */
 size_t golf_harmonic_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fa, int H);
 int golf_harmonic_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                               const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                               const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
-                              void* ws, size_t ws_bytes, void* stream);
+                              void* ws, size_t ws_bytes, void* stream,
+                              const float* phase_offset, int Fo, int po_hop, const float* initial_phase);
 /* d out / d Phi(t) (Phi = the running phase in cycles): 2 pi sum_h [h p < 0.5] amp(t,h) h cos(2 pi h Phi(t)); the
  * gradient w.r.t. the phase input is the transposed upsampling of the reverse cumulative sum of g_out * this (host). */
 int golf_harmonic_osc_dphase_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                               const float* amp, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                               const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout,
-                              void* ws, size_t ws_bytes, void* stream);
+                              void* ws, size_t ws_bytes, void* stream,
+                              const float* phase_offset, int Fo, int po_hop, const float* initial_phase);
 int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_stride, const float* phase, int64_t phase_stride,
                                   int Tp, int phase_hop, int Fa, int amp_hop, const float* tscale, int Fs, int ts_hop,
                                   const float* hscale, int H, float* g_amp, int B, int Tout,
-                                  void* ws, size_t ws_bytes, void* stream);
+                                  void* ws, size_t ws_bytes, void* stream,
+                                  const float* phase_offset, int Fo, int po_hop, const float* initial_phase);
 
 /* ---------------------------------------------------------------------------------------------
  * (e) multi-GPU: push-based exchange of the synthesised audio (north_star: "shards independent utterances across the 8

@@ -943,16 +943,24 @@ def golf_ss_decoder(phase, phase_hop, weight, weight_hop, table, noise, log_mag,
 # --------------------------------------------------------------------------------------
 # a-11  harmonic oscillator bank (DDSP / NHV / WORLD / MLSA / SawSing / PULF baselines)
 # --------------------------------------------------------------------------------------
-def _harmonic_terms(phase, phase_hop, n_harm, n_out):
+def _harmonic_terms(phase, phase_hop, n_harm, n_out, phase_offset=None, po_hop=1, initial_phase=None, deriv=False):
     up = linear_upsample(np.asarray(phase, dtype=np.float64), phase_hop, axis=1)[:, :n_out]   # cycles / sample
     h = np.arange(1, n_harm + 1, dtype=np.float64)
     inst = np.cumsum(up, axis=1)[:, :, None] * h                         # cumsum(h * up) = h * cumsum(up)
+    if phase_offset is not None:                                         # synth.py:429-432: + up(offset) * h
+        po = linear_upsample(np.asarray(phase_offset, dtype=np.float64), po_hop, axis=1)[:, :n_out]
+        inst = inst + po[:, :, None] * h
+    if initial_phase is not None:                                        # synth.py:434-435: + initial_phase[b, h]
+        inst = inst + np.asarray(initial_phase, dtype=np.float64)[:, None, :]
     mask = (up[:, :, None] * h) < 0.5                                    # anti-aliasing: synth.py:440
+    if deriv:                                                            # d sin(2 pi (h Phi + ..)) / d Phi
+        return 2.0 * np.pi * h * np.cos(2.0 * np.pi * inst), mask
     return np.sin(2.0 * np.pi * inst), mask
 
 
-def harmonic_oscillator_forward(phase, phase_hop: int, amplitudes, amp_hop: int) -> np.ndarray:
-    """HarmonicOscillator.forward, models/synth.py:403-446 (initial_phase = phase_offset = None):
+def harmonic_oscillator_forward(phase, phase_hop: int, amplitudes, amp_hop: int, phase_offset=None, po_hop: int = 1,
+                                initial_phase=None) -> np.ndarray:
+    """HarmonicOscillator.forward, models/synth.py:403-446 (optional phase_offset (B,Fo) at po_hop, initial_phase (B,H)):
     harmonic h runs at h * up(phase) cycles per sample, phase = inclusive cumsum, amplitudes (B,Fa,H) at ``amp_hop``
     are linearly upsampled, zeroed where h * up(phase) >= 0.5, out[t] = sum_h sin(2 pi phase_h[t]) * amp[t,h];
     length = min((Tp-1)*phase_hop+1, (Fa-1)*amp_hop+1)  (mixed-hop truncation, utils.py:230-232)."""
@@ -960,8 +968,22 @@ def harmonic_oscillator_forward(phase, phase_hop: int, amplitudes, amp_hop: int)
     A = linear_upsample(amplitudes, amp_hop, axis=1)
     N = (np.asarray(phase).shape[1] - 1) * phase_hop + 1 if phase_hop > 1 else np.asarray(phase).shape[1]
     n_out = min(N, A.shape[1])
-    sines, mask = _harmonic_terms(phase, phase_hop, amplitudes.shape[-1], n_out)
+    if phase_offset is not None:
+        n_out = min(n_out, (np.asarray(phase_offset).shape[1] - 1) * po_hop + 1 if po_hop > 1 else np.asarray(phase_offset).shape[1])
+    sines, mask = _harmonic_terms(phase, phase_hop, amplitudes.shape[-1], n_out, phase_offset, po_hop, initial_phase)
     return np.einsum("bth,bth->bt", sines * mask, A[:, :n_out])
+
+
+def harmonic_oscillator_backward_offset(gy, phase, phase_hop: int, amplitudes, amp_hop: int, phase_offset, po_hop: int,
+                                        initial_phase=None) -> np.ndarray:
+    """d/d phase_offset of harmonic_oscillator_forward: up^T( gy * sum_h amp * mask * 2 pi h cos(2 pi phase_h) )."""
+    amplitudes = np.asarray(amplitudes, dtype=np.float64)
+    gy = np.asarray(gy, dtype=np.float64)
+    n_out = gy.shape[1]
+    A = linear_upsample(amplitudes, amp_hop, axis=1)[:, :n_out]
+    dcos, mask = _harmonic_terms(phase, phase_hop, amplitudes.shape[-1], n_out, phase_offset, po_hop, initial_phase, deriv=True)
+    d = np.einsum("bth,bth->bt", dcos * mask, A)
+    return _upsample_adjoint(gy * d, po_hop, np.asarray(phase_offset).shape[1])
 
 
 def harmonic_oscillator_backward_amp(gy, phase, phase_hop: int, amplitudes_shape, amp_hop: int) -> np.ndarray:

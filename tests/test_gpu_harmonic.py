@@ -183,3 +183,51 @@ def test_additive_synth_trains_through_f0():
     ref = ts.grad[:, :n] * (0.5 * (0.5 / phase.detach()[:, :n]) ** -1.5 * 0.5 / phase.detach()[:, :n] ** 2)
     emax, el2 = rel_err(ref.cpu().numpy(), p2.grad[:, :n].cpu().numpy())
     assert emax < 1e-4 and el2 < 1e-4, (emax, el2)
+
+
+@pytest.mark.parametrize("tag", ["t", "r"])
+def test_harmonic_phase_terms_golden_g27(golden, tag):
+    """initial_phase (B,H) and phase_offset (an AudioTensor at its own hop) of HarmonicOscillator.forward,
+    models/synth.py:429-435: the drop-in module against the reference's values and its autograd gradients w.r.t. the
+    amplitudes and the offset."""
+    from golf_amd.audiotensor import AudioTensor
+    from golf_amd.synth import HarmonicOscillator
+
+    g = golden("g27_harmonic_phase_terms")
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    amp = dev(g[f"{tag}_amp"]).requires_grad_(True)
+    off = dev(g[f"{tag}_offset"]).requires_grad_(True)
+    osc = HarmonicOscillator().cuda()
+    y = osc(AudioTensor(dev(g[f"{tag}_phase"]), int(g[f"{tag}_phase_hop"])), AudioTensor(amp, int(g[f"{tag}_amp_hop"])),
+            initial_phase=dev(g[f"{tag}_initial_phase"]),
+            phase_offset=AudioTensor(off, int(g[f"{tag}_offset_hop"]))).as_tensor()
+    (y * dev(g[f"{tag}_gy"])).sum().backward()
+    torch.cuda.synchronize()
+    for name, got, want in (("y", y.detach(), g[f"{tag}_y"]), ("g_amp", amp.grad, g[f"{tag}_g_amp"]),
+                            ("g_offset", off.grad, g[f"{tag}_g_offset"])):
+        got = got.cpu().numpy()
+        err = np.abs(got - want).max() / np.abs(want).max()
+        print(f"g27{tag} {name}: rel-max {err:.2e}")
+        assert got.shape == want.shape and err <= 1e-4, (name, err)
+
+
+def test_harmonic_phase_terms_full_size():
+    """The same at the DDSP shape (155 harmonics, 2 s) against the float64 oracle; an integer phase offset changes nothing."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(8)
+    B, T, H, hop = 2, 9601, 155, 240
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    phase = (rng.uniform(100, 400, (B, 1)) * (1 + 0.02 * np.sin(np.arange(T) / 700.0)) / 24000).astype(np.float32)
+    amp = rng.uniform(0, 1, (B, (T - 1) // hop + 1, H)).astype(np.float32)
+    off = rng.uniform(-2, 2, (B, (T - 1) // hop + 1)).astype(np.float32)
+    ip = rng.uniform(0, 1, (B, H)).astype(np.float32)
+    ref = O.harmonic_oscillator_forward(phase, 1, amp, hop, off, hop, ip)
+    y = GF.harmonic_osc(dev(phase), H, 1, dev(amp), hop, phase_offset=dev(off), po_hop=hop, initial_phase=dev(ip))
+    err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("harmonic bank with phase terms vs oracle:", err)
+    assert err <= 1e-4
+    y0 = GF.harmonic_osc(dev(phase), H, 1, dev(amp), hop)
+    y1 = GF.harmonic_osc(dev(phase), H, 1, dev(amp), hop, phase_offset=dev(np.full_like(off, 3.0)), po_hop=hop)
+    assert (y0 - y1).abs().max() <= 1e-5 * y0.abs().max()
