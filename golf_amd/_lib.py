@@ -67,6 +67,9 @@ SIGNATURES = {
     "golf_wavetable_lookup_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
     "golf_wavetable_lookup_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64,
                                              _c_f32p, _int, _int, _vp]),
+    "golf_phase_accumulate_workspace_bytes": (_sz, [_int] * 2),
+    "golf_phase_accumulate_f32": (_int, [_c_f32p, _i64, _int, _int, _int, _c_f32p, _i64, _c_f32p, _i64, _int, _int, _vp,
+                                         _sz, _vp]),
     "golf_decimate_fir_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
     "golf_decimate_fir_adj_f32": (_int, [_c_f32p, _i64, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _vp]),
     "golf_noise_band_workspace_bytes": (_sz, [_int] * 3),

@@ -1551,3 +1551,80 @@ extern "C" int golf_harmonic_osc_bwd_amp_f32(const float* g_out, int64_t g_out_s
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
+
+
+// =============================================================================================
+// Running phase of the general (fully differentiable) table oscillators, golf_amd.functional.wavetable_osc:
+//   wrapped[b,n] = frac( cumsum( up(phase / os) )[n] + phase_offset[b,n] ),  n < N = (Tp-1)*phase_hop*os + 1 (Tp if hop*os == 1)
+// Replaces F.interpolate + torch.cumsum + % 1 of IndexedGlottalFlowTable.forward, models/synth.py:239-255, with the same
+// exact 64-bit fixed-point prefix the fused oscillator uses (osc_phase_tile_kernel): one thread per fine sample.
+// =============================================================================================
+namespace golf {
+__global__ __launch_bounds__(256) void osc_wrapped_phase_kernel(const float* __restrict__ phase, int64_t phase_stride,
+                                                                const u64* __restrict__ Cloc,
+                                                                const u64* __restrict__ Ttot, int ntile, int Tp, int P,
+                                                                int os, const float* __restrict__ poff,
+                                                                int64_t poff_stride, float* __restrict__ out,
+                                                                int64_t out_stride, int N) {
+    __shared__ u64 toff[256];
+    __shared__ u64 twsum[4];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    {   // exclusive prefix of the phase tile totals (as in harm_kernel)
+        const u64 v = tid < ntile ? Ttot[(size_t)b * ntile + tid] : 0;
+        const u64 incl = wave_incl_scan(v, tid & 63);
+        if ((tid & 63) == 63) twsum[tid >> 6] = incl;
+        toff[tid] = incl - v;
+        __syncthreads();
+        u64 base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += twsum[w];
+        toff[tid] += base;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (n >= N) return;
+    const float* pb = phase + (size_t)b * phase_stride;
+    const double scale_a = 18446744073709551616.0 / (double)os, scale_d = scale_a / (double)P;
+    const int j = n / P, k = n - j * P;
+    const int jc = j < Tp - 1 ? j : Tp - 1;
+    const int jn = jc + 1 < Tp ? jc + 1 : Tp - 1;
+    const u64 a = osc_fix_a(pb[jc], scale_a), d = osc_fix_d(pb[jc], pb[jn], scale_d);
+    u64 Phi = Cloc[(size_t)b * Tp + jc] + toff[min(jc / OSC_SCAN_TILE, 255)] + (u64)(k + 1) * a + d * ((u64)k * (u64)(k + 1) / 2);
+    if (poff) {
+        const double x = (double)poff[(size_t)b * poff_stride + n];
+        Phi += (u64)((x - floor(x)) * 18446744073709551616.0);
+    }
+    out[(size_t)b * out_stride + n] = (float)((double)Phi * 5.421010862427522e-20);   // * 2^-64
+}
+}  // namespace golf
+
+extern "C" size_t golf_phase_accumulate_workspace_bytes(int B, int Tp) {
+    if (B < 1 || Tp < 1) return 0;
+    const int ntile = (int)golf::ceil_div(Tp, OSC_SCAN_TILE);
+    return golf::align_up(sizeof(u64) * (size_t)B * Tp, 256) + golf::align_up(sizeof(u64) * (size_t)B * ntile, 256);
+}
+
+extern "C" int golf_phase_accumulate_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop, int os,
+                                         const float* phase_offset, int64_t offset_stride, float* wrapped,
+                                         int64_t wrapped_stride, int B, int N, void* ws, size_t ws_bytes, void* stream) {
+    using namespace golf;
+    if (!phase || !wrapped || B < 1 || Tp < 1 || phase_hop < 1 || os < 1 || N < 1)
+        return fail(GOLF_EINVAL, "phase_accumulate: bad argument");
+    const int P = phase_hop * os;
+    const int Nmax = P > 1 ? (Tp - 1) * P + 1 : Tp;
+    if (N > Nmax) return fail(GOLF_EINVAL, "phase_accumulate: N=%d exceeds the upsampled length %d", N, Nmax);
+    if (phase_stride < Tp || wrapped_stride < N || (phase_offset && offset_stride < N))
+        return fail(GOLF_EINVAL, "phase_accumulate: row stride too small");
+    const size_t need = golf_phase_accumulate_workspace_bytes(B, Tp);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255))
+        return fail(GOLF_EWORKSPACE, "phase_accumulate: workspace needs %zu bytes, 256-aligned (got %zu)", need, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int ntile = (int)ceil_div(Tp, OSC_SCAN_TILE);
+    u64* Cw = (u64*)ws;
+    u64* Ttot = (u64*)((char*)ws + align_up(sizeof(u64) * (size_t)B * Tp, 256));
+    if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, P, os, ntile, B, st)) return rc;
+    hipLaunchKernelGGL(osc_wrapped_phase_kernel, dim3((unsigned)ceil_div(N, 256), B), dim3(256), 0, st, phase, phase_stride,
+                       (const u64*)Cw, (const u64*)Ttot, ntile, Tp, P, os, phase_offset, offset_stride, wrapped,
+                       wrapped_stride, N);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}

@@ -567,18 +567,53 @@ def linear_upsample(z: torch.Tensor, hop: int) -> torch.Tensor:
     return torch.nn.functional.interpolate(z[:, None], n, mode="linear", align_corners=True)[:, 0]
 
 
+class _PhaseAccumulate(torch.autograd.Function):
+    """wrapped = frac(cumsum(up(phase / os)) + offset) on the device (golf_phase_accumulate_f32: the exact 64-bit fixed-point
+    prefix of the fused oscillator).  Backward: d wrapped / d inst = 1, so g_phase = up^T(reverse cumsum(g)) / os and
+    g_offset = g -- what autograd does through cumsum and F.interpolate in the reference (models/synth.py:239-255)."""
+
+    @staticmethod
+    def forward(ctx, phase, phase_offset, phase_hop, os):
+        _lib.require_device(phase, phase_offset)
+        lib = _lib.load()
+        phase = _rows(phase.float())
+        B, Tp = phase.shape
+        P = phase_hop * os
+        N = (Tp - 1) * P + 1 if P > 1 else Tp
+        if phase_offset is not None:   # AudioTensor addition truncates to the shorter operand (utils.py:230-232)
+            phase_offset = _rows(phase_offset.float())
+            N = min(N, phase_offset.shape[1])
+        out = torch.empty(B, N, dtype=torch.float32, device=phase.device)
+        ws = _workspace(lib.golf_phase_accumulate_workspace_bytes(B, Tp), phase.device)
+        rc = lib.golf_phase_accumulate_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, os, _lib.ptr(phase_offset),
+                                           0 if phase_offset is None else phase_offset.stride(0), out.data_ptr(),
+                                           out.stride(0), B, N, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "golf_phase_accumulate_f32")
+        ctx.geom = (Tp, P, os, N, phase_offset is not None and phase_offset.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Tp, P, os, N, off_len = ctx.geom
+        g_phase = g_off = None
+        if ctx.needs_input_grad[0]:
+            g_up = torch.flip(torch.cumsum(torch.flip(g.double(), [1]), 1), [1]).float()
+            g_phase = upsample_adjoint(g_up, P, Tp) / os
+        if ctx.needs_input_grad[1]:
+            g_off = g.new_zeros(g.shape[0], off_len)
+            g_off[:, :N] = g
+        return g_phase, g_off, None, None
+
+
 def instantaneous_phase(phase: torch.Tensor, phase_hop: int, oversampling: int = 1, phase_offset: torch.Tensor = None):
     """(wrapped phase (B,N) float32 in [0,1], per-sample increment (B,N)): phase/os upsampled to the (oversampled) sample
-    rate, accumulated in float64 (the reference: float32 cumsum, models/synth.py:250-251; 2^-44 cycles of resolution
-    here) plus the optional offset, wrapped.  Plain tensor ops, so autograd carries d/d phase and d/d phase_offset
-    (reverse cumulative sum, the transposed upsampling) exactly as in the reference."""
+    rate and accumulated exactly on the device (the reference: float32 cumsum, models/synth.py:250-251) plus the optional
+    offset, wrapped; differentiable w.r.t. phase and phase_offset (custom backward: reverse cumulative sum + transposed
+    upsampling, as in the reference).  The increment is a plain linear upsampling (it only scales the equal-energy factor)."""
+    wrapped = _PhaseAccumulate.apply(phase, phase_offset, int(phase_hop), int(oversampling))
     ph = phase / oversampling if oversampling > 1 else phase
-    up = linear_upsample(ph, phase_hop * oversampling)
-    inst = torch.cumsum(up.double(), 1)
-    if phase_offset is not None:   # AudioTensor addition truncates to the shorter operand (utils.py:230-232)
-        n = min(inst.shape[1], phase_offset.shape[1])
-        inst, up = inst[:, :n] + phase_offset[:, :n].double(), up[:, :n]
-    return torch.remainder(inst, 1.0).float(), up
+    up = linear_upsample(ph, phase_hop * oversampling)[:, : wrapped.shape[1]]
+    return wrapped, up
 
 
 def wavetable_osc(phase: torch.Tensor, phase_hop: int, tables: torch.Tensor, table_hop: int, oversampling: int = 1,

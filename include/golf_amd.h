@@ -274,6 +274,16 @@ int golf_wavetable_lookup_bwd_f32(const float* g_out, int64_t g_out_stride, cons
                                   const float* tables, int K, int L, int hop_t, float* g_wrapped,
                                   int64_t g_wrapped_stride, float* g_tables, int B, int N, void* stream);
 
+/* The running phase of those general table oscillators (ABI 3):
+ *   wrapped[b,n] = frac( cumsum(up(phase / os))[n] + phase_offset[b,n] ),   n < N <= (Tp-1)*phase_hop*os + 1
+ * Replaces F.interpolate + torch.cumsum (float32 in the reference) + % 1 of IndexedGlottalFlowTable.forward,
+ * models/synth.py:239-255, with the exact 64-bit fixed-point prefix of the fused oscillator.  phase_offset (B,>=N) at the
+ * fine rate, or NULL.  The gradient w.r.t. phase is the transposed upsampling of the reverse cumulative sum (host). */
+size_t golf_phase_accumulate_workspace_bytes(int B, int Tp);
+int golf_phase_accumulate_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop, int os,
+                              const float* phase_offset, int64_t offset_stride, float* wrapped, int64_t wrapped_stride,
+                              int B, int N, void* ws, size_t ws_bytes, void* stream);
+
 /* The oscillator's decimator on its own (kazane.Decimate(os) stand-in, models/synth.py:208,262; taps are an input):
  *   out[b,o] = sum_k taps[k] * x[b, o*os + k - (K-1)/2], zero padded, Tout = (N-1)/os + 1, K odd, os in [2,64];
  * golf_decimate_fir_adj_f32 is its transpose (g_x (B,N) dense, fully overwritten). */
