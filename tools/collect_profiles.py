@@ -3,7 +3,7 @@ usage: python tools/collect_profiles.py [r02]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -11,6 +11,8 @@ import rocpd_summary
 
 for f in glob.glob(os.path.join(SRC, "bench_*.json")):
     shutil.copy(f, os.path.join(DST, RND + "_" + os.path.basename(f)))
+if os.path.exists(os.path.join(SRC, "recipe_latency.txt")):
+    shutil.copy(os.path.join(SRC, "recipe_latency.txt"), os.path.join(DST, RND + "_recipe_latency.txt"))
 if os.path.exists(os.path.join(SRC, "train_step_profile.json")):
     shutil.copy(os.path.join(SRC, "train_step_profile.json"), os.path.join(DST, RND + "_train_step_profile.json"))
 for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh

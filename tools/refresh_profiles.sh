@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): every bench line, rocprofv3 kernel traces and the
 # separate HBM-counter passes that profiles/ is built from (tools/collect_profiles.py turns the output into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RND=${ROUND_TAG:-r02}
+RND=${ROUND_TAG:-r03}
 O=$R/gpurun_out/$RND
 rm -rf $O; mkdir -p $O
 cd $R
@@ -28,6 +28,8 @@ b --workload golf-ss-decoder-logits --no-cpu-baseline > $O/bench_decoder_logits.
 b --fp64-transitions --no-cpu-baseline > $O/bench_fp64_transitions.json
 b --workload golf-ss-train-step --batch 64 --steps 20 --warmup 5 > $O/bench_train_step.json
 python tools/train_step_profile.py 64 > $O/train_step_profile.json 2>/dev/null
+python tools/recipe_latency.py 64 2>/dev/null | grep seed > $O/recipe_latency.txt   # one batch alone, per recipe seed, with its conditioning words
+b --batch 16384 --workload osc-only --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b16384_osc_only.json
 prof() { out=$1; shift; (cd /tmp && rocprofv3 --kernel-trace -d $O/$out -- python $R/bench.py --no-cpu-baseline --steps 50 --warmup 10 "$@" > $O/$out.log 2>&1); }
 prof trace_synth
 prof trace_synth_single --streams 1 --no-graphs
