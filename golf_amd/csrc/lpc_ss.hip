@@ -1358,6 +1358,13 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the chunk kernels
+// prefetch depths of the two-level prologues (maps fetched ahead of the matvec that uses them): chunk maps / composites
+#ifndef GOLF_GP_DC
+#define GOLF_GP_DC 6
+#endif
+#ifndef GOLF_GP_D
+#define GOLF_GP_D 4
+#endif
 
 // s' = rows . s + add with the state broadcast by v_readlane (lane i = component i, `rw` = row i of the matrix)
 template <int W, int NT>
@@ -1632,7 +1639,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     const size_t cstride4 = (size_t)NT * W / 4;
     float t = 0.f;
     // the wave's own chunk maps: first fetches issued before the fold below, so they are in flight during it
-    constexpr int DC = 6;
+    constexpr int DC = GOLF_GP_DC;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NP * W + ii;
     const int c0 = g * kGroup;
@@ -1647,7 +1654,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 #pragma unroll
     for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
     {   // (a) the groups before this one
-        constexpr int D = 4;
+        constexpr int D = GOLF_GP_D;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
         const float* vb = V + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
@@ -2044,7 +2051,7 @@ __device__ __forceinline__ void adj_group_prologue(const float* __restrict__ Phi
     const int gt = NG - 1;                                   // top group with chunk maps
     const int ct = c0 + kGroup - 1 < NP - 1 ? c0 + kGroup - 1 : NP - 1;   // top chunk map of this group (if any)
     // the wave's own chunk maps (rows of Phi: lane j holds row j = column j of Phi^T), first fetches before the fold
-    constexpr int DC = 6;
+    constexpr int DC = GOLF_GP_DC;
     const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NC * W + ii;
     float4 pb[DC][W / 4];
@@ -2060,7 +2067,7 @@ __device__ __forceinline__ void adj_group_prologue(const float* __restrict__ Phi
     // state entering the top group: L(NP-1) = zadj_NP (first pass) or 0 (correction pass)
     float t = (with_top && act) ? x[((size_t)b * NC + NP) * W + ii] : 0.f;
     if (g < gt) {   // (a) the groups above this one, from the top down
-        constexpr int D = 4;
+        constexpr int D = GOLF_GP_D;
         const float4* mrows = reinterpret_cast<const float4*>(MTt + ((size_t)b * NG * NT + ii) * W);
         const float* vb = Wv + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
