@@ -613,7 +613,7 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 yk = fn_k()
-            rs_graphs.append((g, yk))
+            rs_graphs.append((g, yk, fn_k, inp_k))   # the closure owns the inputs the graph reads: keep it alive
             rs_cond.append(conditioning_of(args.workload, inp_k, device))
         torch.cuda.synchronize()
 
