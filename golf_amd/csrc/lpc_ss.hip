@@ -879,6 +879,15 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
                 v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
                 v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
                 if (jb + 3 < W) *reinterpret_cast<float4*>(trow + (size_t)i * LDT) = v;
+                // columns no trajectory group covers (4 NG .. W-1, e.g. W = 8 with NT <= 4, W = 24 with NT = 20): zeros, not
+                // whatever the tile held -- the group composites read whole rows, and garbage x 0 is NaN when the garbage is
+                if constexpr (4 * NG < W) {
+                    if (grp == NG - 1) {
+#pragma unroll
+                        for (int cc = 4 * NG; cc < W; cc += 4)
+                            *reinterpret_cast<float4*>(trow - jb + cc + (size_t)i * LDT) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
             }
         }
         wave_lds_fence();
@@ -1477,9 +1486,10 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
                     const int row = 16 * it + rm, col = 16 * kt + rq;
                     const float* rp = mp + (size_t)(row < NT ? row : 0) * W;
                     const bool ok = row < NT && cb > ca;
-                    const float2 lo = (ok && col < W) ? *reinterpret_cast<const float2*>(rp + col) : make_float2(0.f, 0.f);
-                    const float2 hi = (ok && col + 8 < W && 16 * kt + 8 < NT)
-                                          ? *reinterpret_cast<const float2*>(rp + col + 8) : make_float2(0.f, 0.f);
+                    // (columns >= NT are padding: zero by construction, and not trusted -- NT and col are even)
+                    const float2 lo = (ok && col < NT) ? *reinterpret_cast<const float2*>(rp + col) : make_float2(0.f, 0.f);
+                    const float2 hi = (ok && col + 8 < NT) ? *reinterpret_cast<const float2*>(rp + col + 8)
+                                                           : make_float2(0.f, 0.f);
                     fr[u][it][kt] = f32x4v{lo.x, lo.y, hi.x, hi.y};
                 }
         };
@@ -1584,20 +1594,20 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
                                                                 int parts, FixArgs fa, int KF1, int KF2,
                                                                 float* __restrict__ MTt) {
     __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
-    static_assert(sizeof(double) * 32 * 32 >= sizeof(unsigned short) * 4 * kHotListMax, "the fix-up waves' lists reuse pb_lds");
+    __shared__ unsigned short hot_lds[4][kHotListMax];   // the fix-up waves' lists (an array of its own: no type punning)
     const bool fix = fa.pmax != nullptr && (parts & 1);   // (no fix-up at all: diagnostic switch GOLF_SS_NO_FIXUP)
     const int nu = NG * B;
     const int nf1 = fix ? B * KF1 : 0, nz = (parts & 2) ? (nu + 3) / 4 : 0, nc = (parts & 1) ? nu : 0;
     int blk = (int)blockIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blk < nf1) {
-        fixup_wave<W, NT>(fa, blk / KF1, blk % KF1 == 0 && wv == 0, reinterpret_cast<unsigned short*>(pb_lds) + wv * kHotListMax);
+        fixup_wave<W, NT>(fa, blk / KF1, blk % KF1 == 0 && wv == 0, hot_lds[wv]);
         return;
     }
     blk -= nf1;
     if (blk >= nz + nc) {   // trailing fix-up workgroups
         blk -= nz + nc;
-        if (fix) fixup_wave<W, NT>(fa, blk / KF2, false, reinterpret_cast<unsigned short*>(pb_lds) + wv * kHotListMax);
+        if (fix) fixup_wave<W, NT>(fa, blk / KF2, false, hot_lds[wv]);
         return;
     }
     const bool comp = blk >= nz;

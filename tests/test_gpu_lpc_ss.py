@@ -673,3 +673,99 @@ def test_bwd_both_transition_precisions(B, F, M, hop):
         check(t[0].grad.cpu().numpy()[:, : r_ex.shape[1]], r_ex, f"fast={fast} g_ex")
         check(t[1].grad.cpu().numpy(), r_gain, f"fast={fast} g_gain")
         check(t[2].grad.cpu().numpy(), r_a, f"fast={fast} g_a")
+
+
+def _harsh_shape_cases(n=14, seed=505):
+    rng = np.random.default_rng(seed)
+    rings = [(8, (2, 4, 6)), (16, (8, 12, 14)), (24, (8, 16, 20, 22)), (32, (26, 30)), (40, (32, 38))]
+    cases = []
+    for k in range(n):
+        W, orders = rings[k % len(rings)]
+        M = int(orders[rng.integers(len(orders))]) - int(rng.integers(0, 2))
+        hop = int(W * rng.integers(1, 11)) if W < 24 else int(rng.choice([W, 2 * W, 5 * W, 10 * W]))
+        if hop > 480:
+            hop = W
+        L = hop * (240 // hop) if hop < 240 else hop
+        chunks = int(rng.choice([3, 20, 60, 130]))                 # flat scans (short) and two-level ones (>= 48 chunk maps)
+        T = chunks * L - int(rng.integers(0, L))
+        F = -(-(T - 1) // hop) + 1 + int(rng.integers(0, 2))
+        B = int(rng.choice([1, 3, 6]))
+        cases.append((B, max(F, 2), max(M, 1), hop, max(T, 2), float(rng.choice([0.7, 1.0]))))
+    return cases
+
+
+@pytest.mark.parametrize("B,F,M,hop,T,sigma", _harsh_shape_cases())
+def test_conditioning_tiers_random_shapes(B, F, M, hop, T, sigma):
+    """tools/fuzz_lpc.py folded into the suite: every ring width, orders below the instance's, chunk lengths that are not
+    the hop, short (flat scan) and long (two-level) utterances -- on coefficient tracks harsh enough to make chunks hot and
+    utterances tier 3.  Forward of both scan variants and both transition precisions against the float64 oracle with the
+    sequential recursion beside it; gradients finite and, where the sequential adjoint has a signal left, close to it."""
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(T + M)
+    logits = rng.normal(0, sigma, (B, 1, M)) + np.cumsum(rng.normal(0, 0.02 * (hop / 240) ** 0.5, (B, F, M)), 1)
+    a = O.rc2lpc(np.tanh(logits)).astype(np.float32)
+    gain = np.exp(-3 + np.cumsum(rng.normal(0, 0.05, (B, F)), 1)).astype(np.float32)
+    ex = rng.normal(0, 1, (B, T)).astype(np.float32)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    ok = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e12)
+    if not ok.any():
+        pytest.skip("every track of this draw is unstable")
+    scale = np.abs(ref).max(1) + 1e-300
+    e_seq = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    good = ok & (e_seq < 0.05)
+    for fast, mode in ((True, None), (True, "flat-scan"), (False, None)):
+        y, st = run_status(ex, gain, a, hop, fast=fast, mode=mode)
+        e = np.abs(y - ref).max(1) / scale
+        print(f"B{B} F{F} M{M} hop{hop} T{T} sigma{sigma} fast={fast} mode={mode}: {st} worst {e[good].max() if good.any() else 0:.2e} "
+              f"(sequential {e_seq[good].max() if good.any() else 0:.2e})")
+        assert st["nonfinite"] == (not np.isfinite(y).all()), st
+        assert np.all(e[good] <= 3 * e_seq[good] + 1e-4), (fast, mode, np.nonzero(good & (e > 3 * e_seq + 1e-4))[0], e[good].max())
+    gy = (rng.normal(0, 1, ref.shape) / scale[:, None]).astype(np.float32)
+    gy[~ok] = 0
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy[good], ex[good], gain[good], a[good], hop) if good.any() else (None,) * 3
+    res = run_mode(ex, gain, a, hop, None, gy)
+    ser = run_mode(ex, gain, a, hop, "serial", gy)
+    for g, name in zip(res[1:], ("g_ex", "g_gain", "g_a")):
+        assert np.isfinite(g[ok]).all(), name
+    if good.any():
+        def gerr(r, ref_g):
+            r = r[good].reshape(int(good.sum()), -1)[:, : ref_g.reshape(int(good.sum()), -1).shape[1]]
+            ref_g = ref_g.reshape(int(good.sum()), -1)
+            return np.abs(r - ref_g).max(1) / (np.abs(ref_g).max(1) + 1e-30)
+        for got, sq, want, name in zip(res[1:], ser[1:], (r_ex, r_gain, r_a), ("g_ex", "g_gain", "g_a")):
+            e_c, e_s = gerr(got, want), gerr(sq, want)
+            assert np.all(e_c <= 4 * e_s + 3e-4), (name, e_c.max(), e_s.max())
+
+
+@pytest.mark.parametrize("B,F,M,hop,T", [(3, 249, 2, 80, 19630), (2, 277, 20, 120, 32849), (3, 585, 4, 32, 18674),
+                                         (2, 240, 4, 64, 15154), (2, 200, 22, 240, 47000), (2, 130, 13, 160, 20500)])
+@pytest.mark.parametrize("poison", [0xFF, 0x7F])
+def test_poisoned_workspace(B, F, M, hop, T, poison, monkeypatch):
+    """The workspace arrives uninitialised: fill it with NaN bit patterns before every call.  Nothing the kernels read may
+    be something they did not write -- including the padding columns of the chunk maps' rows (orders whose trajectory
+    groups do not cover the ring width, e.g. M = 2, 4, 20: round 3 found the group composites multiplying stale LDS
+    contents by zero), every scan variant, both transition precisions, forward and backward."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    def poisoned(nbytes, device):
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        t.fill_(poison)
+        return t
+
+    monkeypatch.setattr(GF, "_workspace", poisoned)
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=T, seed=T, walk=0.006 * (hop / 24) ** 0.5)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    for rep in range(3):
+        check(run_fwd(ex, gain, a, hop, fast=True), ref, f"fast rep{rep}")
+    check(run_fwd(ex, gain, a, hop, fast=False), ref, "fp64 transitions")
+    check(run_mode(ex, gain, a, hop, "flat-scan"), ref, "flat scan")
+    rng = np.random.default_rng(T)
+    gy = rng.normal(0, 1, ref.shape).astype(np.float32)
+    r_ex, r_gain, r_a = O.ltv_allpole_ss_backward(gy, ex, gain, a, hop)
+    for mode in (None, "flat-scan"):
+        res = run_mode(ex, gain, a, hop, mode, gy)
+        check(res[1][:, : r_ex.shape[1]], r_ex, f"{mode} g_ex")
+        check(res[2], r_gain, f"{mode} g_gain")
+        check(res[3], r_a, f"{mode} g_a")
