@@ -253,8 +253,9 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
         gy = torch.randn(B, 47761, device=phase.device)
 
         def step():
+            prep = GF.ltv_allpole_prepare(a_g, hop, t_ss, overlap=True, fast=fast, mode=mode, training=True) if overlap else None
             y = GF.ltv_allpole_ss(GF.glottal_osc(phase, w_g, table, taps, 1, w_hop, 4, True, add=noise), gain_g, a_g,
-                                  hop, mode=mode, fast_inference=fast)
+                                  hop, prepared=prep, mode=mode, fast_inference=fast)
             gain_g.grad = a_g.grad = w_g.grad = None
             y.backward(gy[:, : y.shape[1]])
             return y

@@ -2311,12 +2311,17 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
                                                             int64_t g_ex_stride, float* __restrict__ pa,
                                                             float* __restrict__ pg, int T, int F, int NT, int W,
                                                             int hop, int seg, int NSEG) {
-    __shared__ float gs_[4][256 + 4], ge_[4][256 + 4], ys_[4][256 + 64 + 4];
+    // per wave: (g, n g) pairs, ex and y (with 64 samples of history) of the segment.  One loop serves every lane: tap
+    // lanes correlate the pairs with y[t-1-k], the gain lane with ex[t] -- two packed FMAs per two samples and lane
+    // (first version: scalar FMAs, the n-weights formed in the loop and a second, divergent loop for the gain lane:
+    // 24 instructions per four samples where this has 8; 17.6 us -> see DESIGN.md)
+    __shared__ __attribute__((aligned(16))) f32x2 gp_[4][256 + 4];
+    __shared__ float es_[4][256 + 4], ys_[4][256 + 64 + 4];
     const int wv = threadIdx.x >> 6, k = threadIdx.x & 63;
     const int sg = blockIdx.x * 4 + wv, b = blockIdx.y;
     if (sg >= NSEG) return;  // whole wave
-    float* gs = gs_[wv];
-    float* ge = ge_[wv];  // g*ex
+    f32x2* gp = gp_[wv];
+    float* es = es_[wv];
     float* ys = ys_[wv];
     const int ts = sg * seg;
     const int len = (ts + seg <= T ? seg : T - ts);  // 1..256
@@ -2330,13 +2335,14 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     const float* eb = ex + (size_t)b * ex_stride;
     for (int u = k; u < 256; u += 64) {
         float gv = 0.f, ev = 0.f;
+        const float n = (float)(nbase + u);
         if (u < len) {
             gv = gb[ts + u];
             ev = eb[ts + u];
-            g_ex[(size_t)b * g_ex_stride + ts + u] = gv * fmaf((float)(nbase + u), dg, g0);
+            g_ex[(size_t)b * g_ex_stride + ts + u] = gv * fmaf(n, dg, g0);
         }
-        gs[u] = gv;      // zero padded to a multiple of 4 and beyond
-        ge[u] = gv * ev;
+        gp[u] = f32x2{gv, gv * n};   // zero beyond the segment
+        es[u] = ev;
     }
     for (int u = k; u < 256 + 64; u += 64) {  // ys[u] = y[ts - 64 + u]
         const int t = ts - 64 + u;
@@ -2344,7 +2350,6 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     }
     __builtin_amdgcn_s_waitcnt(0);  // single wave owns its LDS rows
     __builtin_amdgcn_wave_barrier();
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     const int len4 = (len + 3) & ~3;
     // Lanes kk = 0..NT-1 own one tap each, lane NT the gain: with NT + 1 <= 32 the two halves of the wave take the
     // two halves of the segment (first version: 23 of 64 lanes busy for the whole segment, 27 us).
@@ -2352,28 +2357,20 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     const int half = split ? k >> 5 : 0, kk = split ? k & 31 : k;
     const int tmid = split ? ((len4 / 4 + 1) / 2) * 4 : len4;
     const int tb = half ? tmid : 0, te = half ? len4 : tmid;
-    if (kk < NT) {
-        const float* yk = ys + 63 - kk;  // yk[t] = y[ts + t - 1 - kk]
+    f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    if (kk <= NT) {
+        const float* yk = kk < NT ? ys + 63 - kk : es;  // yk[t] = y[ts + t - 1 - kk]  /  ex[ts + t]
         for (int t = tb; t < te; t += 4) {
-            const float4 gv = *reinterpret_cast<const float4*>(gs + t);
-            const float n = (float)(nbase + t);
+            const f32x4v p01 = *reinterpret_cast<const f32x4v*>(gp + t), p23 = *reinterpret_cast<const f32x4v*>(gp + t + 2);
             const float y0 = yk[t], y1 = yk[t + 1], y2 = yk[t + 2], y3 = yk[t + 3];
-            a0 = fmaf(gv.x, y0, a0);              b0 = fmaf(gv.y, y1, b0);
-            a0 = fmaf(gv.z, y2, a0);              b0 = fmaf(gv.w, y3, b0);
-            a1 = fmaf(gv.x * n, y0, a1);          b1 = fmaf(gv.y * (n + 1.f), y1, b1);
-            a1 = fmaf(gv.z * (n + 2.f), y2, a1);  b1 = fmaf(gv.w * (n + 3.f), y3, b1);
-        }
-    } else if (kk == NT) {
-        for (int t = tb; t < te; t += 4) {
-            const float4 gv = *reinterpret_cast<const float4*>(ge + t);
-            const float n = (float)(nbase + t);
-            a0 += gv.x + gv.z;
-            b0 += gv.y + gv.w;
-            a1 = fmaf(gv.x, n, a1);          b1 = fmaf(gv.y, n + 1.f, b1);
-            a1 = fmaf(gv.z, n + 2.f, a1);    b1 = fmaf(gv.w, n + 3.f, b1);
+            acc[0] = __builtin_elementwise_fma(f32x2{p01[0], p01[1]}, f32x2{y0, y0}, acc[0]);
+            acc[1] = __builtin_elementwise_fma(f32x2{p01[2], p01[3]}, f32x2{y1, y1}, acc[1]);
+            acc[2] = __builtin_elementwise_fma(f32x2{p23[0], p23[1]}, f32x2{y2, y2}, acc[2]);
+            acc[3] = __builtin_elementwise_fma(f32x2{p23[2], p23[3]}, f32x2{y3, y3}, acc[3]);
         }
     }
-    float v0 = a0 + b0, v1 = a1 + b1;
+    const f32x2 accs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float v0 = accs.x, v1 = accs.y;
     if (split) {
         v0 += __shfl_down(v0, 32);
         v1 += __shfl_down(v1, 32);

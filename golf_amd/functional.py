@@ -49,8 +49,10 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
     same coefficients, or to start the most expensive, excitation-independent phase early).
     ``overlap=True`` launches on a second HIP stream that the forward joins right before its boundary scan.
     With the two-level boundary scan the group composites (which need only the matrices) are computed here as well.
-    What it buys is LATENCY of a lone batch (the 40 us transition kernel hides behind the oscillator); with several
-    batches in flight the chip is full either way and the fork/join only costs — off by default.
+    Off by default: the HIP fork/join (two event record/wait pairs) measured ~25 us of latency on ROCm 7.2 -- more than the
+    ~20 us of the transition kernel that the oscillator can hide at B = 32 (round 3: one batch alone 161 us forked vs 137 us
+    on one stream; training 370 vs 283) -- and with several batches in flight the chip is full either way.  It pays when
+    much more work precedes the filter on the main stream than the join costs (a long encoder).
     ``fast=True`` computes the fp32 matrices of the inference path; ``training=True`` (implied by ``fast=False``) also keeps
     what the backward reads, so the handle serves a forward whose gradients are needed."""
     _lib.require_device(a)
