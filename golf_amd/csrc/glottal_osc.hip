@@ -63,6 +63,25 @@ __device__ __forceinline__ u64 osc_fix_a(float p, double scale_a) {   // scale_a
 __device__ __forceinline__ u64 osc_fix_d(float p0, float p1, double scale_d) {  // scale_d = 2^64 / (os*P)
     return (u64)__double2ll_rn(((double)p1 - (double)p0) * scale_d);   // signed, two's complement
 }
+// The same two numbers by exponent arithmetic when os and P are powers of two (the fused kernels: os = P = 4).  A float
+// is m 2^(e-150): p 2^(64 - log2 os) is a shift of the mantissa -- exact, and equal to osc_fix_a's rounded double product
+// whenever that product is an integer (p >= 2^-39 cycles per sample; below that this truncates where that rounds to
+// nearest, 2^-64 of a cycle; denormal increments count as 0).  Round 2 spent ~8 double-precision instructions per
+// conversion (v_ldexp_f64, v_floor_f64, v_rndne_f64, two v_cvt_u32_f64 ...), a quarter of osc_fused_kernel's issue cycles;
+// this is 8 integer ones.
+__device__ __forceinline__ u64 osc_fix_a_pow2(float p, int log2os) {
+    // mantissa (hidden bit included) at the top of a 64-bit word, shifted down by what the exponent says:
+    // p = 1.m 2^(e-127)  ->  p 2^(64 - log2os) = (1.m 2^63) >> (126 + log2os - e)
+    const unsigned bits = __float_as_uint(p);
+    const int e = (int)((bits >> 23) & 0xffu);
+    int sft = 126 + log2os - e;                                        // 0 .. 63 for 2^-63 os <= p < 2 / os ... clamp the rest
+    sft = sft < 0 ? 0 : (sft > 63 ? 63 : sft);
+    const unsigned hi = (int)bits >= 0x00800000 ? ((bits << 8) | 0x80000000u) : 0u;   // zero, denormals, negatives -> 0
+    return ((u64)hi << 32) >> sft;
+}
+__device__ __forceinline__ u64 osc_fix_d_pow2(u64 a0, u64 a1, int log2P) {   // (a1 - a0) / P, two's complement
+    return (u64)((long long)(a1 - a0) >> log2P);
+}
 // One workgroup per (tile of 1024 coarse samples, utterance):
 //   Cloc[b][j] = sum of the segment totals of the tile before j   (exclusive)
 //   Ttot[b][tile] = tile total
@@ -614,9 +633,18 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r <= PER; ++r) pv[r] = prow.ld(min(j0 + r, Tp - 1));
     u64 tsum = 0;
+    if (os == 4 && P == 4) {   // (the only configuration osc_fused_kernel serves; the same conversions as there)
+        u64 aq[PER + 1];
 #pragma unroll
-    for (int r = 0; r < PER; ++r)
-        if (j0 + r < Tp - 1) tsum += (u64)P * osc_fix_a(pv[r], scale_a) + osc_fix_d(pv[r], pv[r + 1], scale_d) * tri;
+        for (int r = 0; r <= PER; ++r) aq[r] = osc_fix_a_pow2(pv[r], 2);
+#pragma unroll
+        for (int r = 0; r < PER; ++r)
+            if (j0 + r < Tp - 1) tsum += (aq[r] << 2) + osc_fix_d_pow2(aq[r], aq[r + 1], 2) * (u64)6;
+    } else {
+#pragma unroll
+        for (int r = 0; r < PER; ++r)
+            if (j0 + r < Tp - 1) tsum += (u64)P * osc_fix_a(pv[r], scale_a) + osc_fix_d(pv[r], pv[r + 1], scale_d) * tri;
+    }
     const u64 incl = wave_incl_scan(tsum, tid & 63);
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
@@ -631,9 +659,11 @@ template <int EE, int KS>
 __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout, int XS,
+    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout, int /*XS*/,
     int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
     constexpr int OS = 4, P = 4, NTH = OSCF_THREADS, CPT = OSCF_CPT;
+    constexpr int span = OSCF_TO + 4 * KS;       // coarse samples rendered (index u <-> coarse sample j_lo + u)
+    constexpr int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;   // padded polyphase row (the host sizes the LDS with the same)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u64 wtot[NTH / 64];
     __shared__ u64 base_sh, halo_sh;
@@ -644,7 +674,6 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int o0 = tile * OSCF_TO;
-    constexpr int span = OSCF_TO + 4 * KS;       // coarse samples rendered (index u <-> coarse sample j_lo + u)
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
     // ---- 0. Toeplitz fragments of the taps (laid out by osc_tile_totals_kernel), straight into registers: coalesced
     //         loads issued now, consumed in step 4
@@ -670,54 +699,63 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     }
     const int m_first = max(j_lo, 0) * P;        // first fine sample that exists in this tile
     const int r_first = m_first / hop_t;         // control frame of that sample; rows r_first .. r_first + nrows - 1
-    for (int rr = 0; rr + 1 < nrows; ++rr) {     // pair rr = (row r_first+rr, row r_first+rr+1 - row r_first+rr)
-        const float* t0[2];
-        float pw[2];
+    {   // blended control-frame rows r_first .. r_first + nrows - 1, every column ONCE (a thread keeps its columns' values
+        // of all rows in registers), written as pairs rr = (row rr, row rr+1 - row rr); column L = wrap-around copy of
+        // column 0.  (Round 2 staged pair by pair: every interior row blended twice, the one extra column costing a
+        // whole third pass of the workgroup, clamps on every load -- 30 % of the kernel's instructions.)
+        const float* t0[OSCF_MAXROWS];
+        float pw[OSCF_MAXROWS];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int k = r_first + rr + e;
-            if (k > Fw - 1) k = Fw - 1;          // replicate-padded frames (models/synth.py:141-146)
+        for (int e = 0; e < OSCF_MAXROWS; ++e) {
+            int k = r_first + (e < nrows ? e : nrows - 1);
+            if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
+            // (b, k) is the workgroup's: the row base and the weight are uniform -- say so (the loaded value sits in a VGPR), so
+            // that the row loads below take an SGPR base + one shared lane offset instead of a 64-bit address each
             const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
-            int i0 = (int)idx;
+            int i0 = __builtin_amdgcn_readfirstlane((int)idx);
             i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
             pw[e] = idx - (float)i0;
             t0[e] = table + (size_t)i0 * L;
         }
-        float2* dst = pairs + (size_t)rr * LR;
         constexpr int SU = 2;
-        for (int cb0 = 0; cb0 < L + 1; cb0 += SU * NTH) {   // all loads of a batch before the first blend
-            float va[2][SU], vb[2][SU];
+        for (int cb0 = 0; cb0 < L; cb0 += SU * NTH) {
+            float R[OSCF_MAXROWS][SU];
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int e = 0; e < OSCF_MAXROWS; ++e)
+                if (e < nrows) {                      // uniform
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    int c = cb0 + u * NTH + tid;
-                    c = c > L ? L : c;
-                    c = c == L ? 0 : c;                      // column L = wrap-around copy of column 0
-                    va[e][u] = t0[e][c];
-                    vb[e][u] = t0[e][L + c];
+                    for (int u = 0; u < SU; ++u) {
+                        const int c = cb0 + u * NTH + tid;
+                        const int cc = c < L ? c : 0;
+                        const float va = t0[e][cc], vb = t0[e][L + cc];
+                        R[e][u] = fmaf(vb, pw[e], va * (1.0f - pw[e]));
+                    }
                 }
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int c = cb0 + u * NTH + tid;
-                const float ra = va[0][u] * (1.0f - pw[0]) + vb[0][u] * pw[0];
-                const float rb = va[1][u] * (1.0f - pw[1]) + vb[1][u] * pw[1];
-                if (c <= L) dst[c] = make_float2(ra, rb - ra);
-            }
+            for (int rr = 0; rr + 1 < OSCF_MAXROWS; ++rr)
+                if (rr + 1 < nrows) {
+                    float2* dst = pairs + (size_t)rr * LR;
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int c = cb0 + u * NTH + tid;
+                        const float2 pr = make_float2(R[rr][u], R[rr + 1][u] - R[rr][u]);
+                        if (c < L) dst[c] = pr;
+                        if (c == 0) dst[L] = pr;
+                    }
+                }
         }
     }
     // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
-    const double scale_a = 18446744073709551616.0 / (double)OS;
-    const double scale_d = scale_a / (double)P;
-    u64 av[CPT], dv[CPT], tv[CPT];
+    u64 av[CPT + 1], dv[CPT], tv[CPT];
     u64 tsum = 0;
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[r], 2);   // OS = 4
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
         const int j = j_lo + u0 + r;
-        av[r] = osc_fix_a(pv[r], scale_a);
-        dv[r] = osc_fix_d(pv[r], pv[r + 1], scale_d);
+        dv[r] = osc_fix_d_pow2(av[r], av[r + 1], 2);              // P = 4
         const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-        tv[r] = seg ? (u64)P * av[r] + dv[r] * (u64)6 : 0;
+        tv[r] = seg ? (av[r] << 2) + dv[r] * (u64)6 : 0;
         tsum += tv[r];
     }
     const u64 incl = wave_incl_scan(tsum, lane);
@@ -741,14 +779,21 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     // nrows - 1 control intervals are staged (pairs 0 .. nrows - 2)
     const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
     u64 ph = base_sh - halo_sh + run;
+    // fraction of the table step: the (at most 24) bits of the phase below the column index, as one bit-field extract
+    const int fw = 32 - lshift < 24 ? 32 - lshift : 24, fo = 32 - lshift - fw;
+    const float fscale = __uint_as_float((unsigned)(127 - fw) << 23);   // 2^-fw
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
         const int u = u0 + r;
+        const u64 ph_next = ph + tv[r];
         if (u < span) {
             const int j = j_lo + u;
             const float p0 = pv[r], p1 = pv[r + 1];
-            u64 phk = ph, inc = av[r];
-            const u64 dinc = dv[r];
+            // inclusive phases of the 4 fine samples: ph + (k+1) a + d k(k+1)/2; the last one is the next coarse sample's
+            // start (tv = 4 a + 6 d wherever that fine sample exists) -- four independent 64-bit adds instead of a chain of 8
+            const u64 c2 = (av[r] << 1) + dv[r], c3 = c2 + av[r] + (dv[r] << 1);
+            const unsigned hik[P] = {(unsigned)((ph + av[r]) >> 32), (unsigned)((ph + c2) >> 32),
+                                     (unsigned)((ph + c3) >> 32), (unsigned)(ph_next >> 32)};
             const int m0 = j * P;
             const int rr = (m0 >= bnd1) + (m0 >= bnd2);
             const float2* ra = pairs + (size_t)rr * LR;
@@ -764,29 +809,32 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
                 lin = fabsf(p1 - p0) <= 0.002f * p0;   // second-order term below 1e-6 (3 steps): speech f0 always is
             }
             const bool any_jump = EE && __builtin_amdgcn_ballot_w64(!lin) != 0;
+            float sck[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) sck[k] = fmaf((float)k, ds, s0);
+            if (any_jump) {
+                // f0 jumps (voicing boundaries): exact.  Wave-uniform and behind an opaque statement, so that the four
+                // quarter-rate v_rsq_f32 are not issued at all in the common case (hipcc if-converted the plain branch: it
+                // evaluated both forms for every sample)
+                asm volatile("; exact equal-energy factors" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < P; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
+            }
             float* xp = X + oscf_xaddr(u);
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                phk += inc;
-                inc += dinc;
-                const unsigned hi = (unsigned)(phk >> 32);
+                const unsigned hi = hik[k];
                 const int c0 = (int)(hi >> (32 - lshift));
-                const float cf = (float)((hi << lshift) >> 8) * (1.0f / 16777216.0f);
+                const float cf = (float)__builtin_amdgcn_ubfe(hi, (unsigned)fo, (unsigned)fw) * fscale;
                 const float2 e0 = ra[c0], e1 = ra[c0 + 1];
                 const float t0 = fmaf(rf, e0.y, e0.x), t1 = fmaf(rf, e1.y, e1.x);
                 float v = fmaf(cf, t1 - t0, t0);
-                if (EE) {
-                    float sc = fmaf((float)k, ds, s0);
-                    // f0 jumps (voicing boundaries): exact.  Wave-uniform test, so that the transcendental is not
-                    // issued at all in the common case (a per-lane select made hipcc evaluate both forms always)
-                    if (any_jump) sc = lin ? sc : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
-                    v *= sc;
-                }
+                if (EE) v *= sck[k];
                 xp[k * XS] = (k == 0 ? v0 : vk) ? v : 0.f;
                 rf += inv_hop_t;
             }
         }
-        ph += tv[r];
+        ph = ph_next;
     }
     __syncthreads();
     // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
@@ -1304,9 +1352,10 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
         const int nrows = nint_touched + 1;
         const int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;       // padded polyphase row: i + 4 * (i >> 4)
-        const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1));
+        static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
+        const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1)) + lds_pad;
         if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin < span &&
-            ldsf <= 80 * 1024) {
+            ldsf <= 80 * 1024 + lds_pad) {
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
             float* Bf = (float*)((char*)ws + g.off_bf);
@@ -1316,7 +1365,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
 #define GOLF_FUSED(EE, KSV)                                                                                           \
     do {                                                                                                              \
         static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
-            (const void*)osc_fused_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);           \
+            (const void*)osc_fused_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);           \
         if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
             return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
                         hipGetErrorString(lds_attr));                                                                 \

@@ -31,3 +31,23 @@ def rel_err(x, ref):
     den_max = max(np.abs(ref).max(), 1e-300)
     den_l2 = max(np.linalg.norm(ref), 1e-300)
     return np.abs(x - ref).max() / den_max, np.linalg.norm(x - ref) / den_l2
+
+
+@pytest.fixture(autouse=True)
+def poisoned_workspaces(request, monkeypatch):
+    """Every `-m gpu` test runs with the kernels' workspaces pre-filled with NaN bit patterns (0xFF bytes): a kernel that
+    reads a word nobody wrote (round 3: padding columns of the chunk maps, tests/test_gpu_lpc_ss.py::test_poisoned_workspace)
+    fails its parity check here instead of depending on what the allocator handed out.  GOLF_TEST_NO_POISON=1 turns it off."""
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("GOLF_TEST_NO_POISON"):
+        yield
+        return
+    import torch
+    from golf_amd import functional as GF
+
+    def poisoned(nbytes, device):
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        t.fill_(0xFF)
+        return t
+
+    monkeypatch.setattr(GF, "_workspace", poisoned)
+    yield
