@@ -66,9 +66,9 @@ __device__ __forceinline__ u64 osc_fix_d(float p0, float p1, double scale_d) {  
 // The same two numbers by exponent arithmetic when os and P are powers of two (the fused kernels: os = P = 4).  A float
 // is m 2^(e-150): p 2^(64 - log2 os) is a shift of the mantissa -- exact, and equal to osc_fix_a's rounded double product
 // whenever that product is an integer (p >= 2^-39 cycles per sample; below that this truncates where that rounds to
-// nearest, 2^-64 of a cycle; denormal increments count as 0).  Round 2 spent ~8 double-precision instructions per
-// conversion (v_ldexp_f64, v_floor_f64, v_rndne_f64, two v_cvt_u32_f64 ...), a quarter of osc_fused_kernel's issue cycles;
-// this is 8 integer ones.
+// nearest, 2^-64 of a cycle; denormal increments count as 0).  8 integer instructions where the double-precision route
+// takes ~8 fp64 ones (v_ldexp_f64, v_floor_f64, v_rndne_f64, two v_cvt_u32_f64 ...); measured: fewer instructions, the
+// same kernel time -- osc_fused_kernel is bound by workgroup latency x occupancy, DESIGN.md 4.3 "Round 3".
 __device__ __forceinline__ u64 osc_fix_a_pow2(float p, int log2os) {
     // mantissa (hidden bit included) at the top of a 64-bit word, shifted down by what the exponent says:
     // p = 1.m 2^(e-127)  ->  p 2^(64 - log2os) = (1.m 2^63) >> (126 + log2os - e)
