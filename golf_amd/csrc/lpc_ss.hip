@@ -113,7 +113,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
     p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
-    p->off_tier = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);     // conditioning tier + hot-chunk count per utterance
+    p->off_tier = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 2), 256);   // conditioning tier + hot-chunk count per utterance; [2B] scan kind of the forward, [2B+1] backward mismatch
     p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
     p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);   // fix-up units completed / claimed per utterance
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
@@ -180,6 +180,16 @@ static bool no_fixup() {
     return v;
 }
 constexpr unsigned kTierHot = 2u, kTierPrecise = 3u;
+// Which boundary scan the forward ran is recorded behind the tier words ([2B]); the backward's first kernel compares it with
+// its own and raises [2B + 1], which golf_ltv_allpole_status_u32 reports: a C caller that hands the backward other scan
+// flags than the forward (or a workspace some other forward filled) would otherwise read composites nobody wrote.
+constexpr unsigned kScanTwoLevel = 0x2C0DE001u, kScanFlat = 0x2C0DE002u;
+__device__ __forceinline__ void record_scan_kind(const unsigned* tier, int B, unsigned kind) {
+    if (tier) { unsigned* w = const_cast<unsigned*>(tier); w[2 * B] = kind; w[2 * B + 1] = 0u; }
+}
+__device__ __forceinline__ void check_scan_kind(const unsigned* tier, int B, unsigned kind) {
+    if (tier && tier[2 * B] != kind) const_cast<unsigned*>(tier)[2 * B + 1] = 1u;
+}
 // tier words: tier[2 b] = 0 / 2 / 3, tier[2 b + 1] = number of hot chunks (wave-uniform reads: b is)
 __device__ __forceinline__ bool tier3(const unsigned* __restrict__ tier, int b) {
     return tier != nullptr && __builtin_amdgcn_readfirstlane((int)tier[2 * b]) == (int)kTierPrecise;
@@ -1729,6 +1739,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
     __shared__ float st[(kGroup + 1) * 32];
     __shared__ float dl[MODE == 3 ? kGroup * 32 : 1];
     if constexpr (MODE == 3) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) record_scan_kind(tier, B, kScanTwoLevel);
         if ((int)blockIdx.y >= B) {   // fp64 boundary scan of a tier-3 utterance (x = the zero-state responses z)
             const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
             if (bp < B && tier3(tier, bp))
@@ -1828,6 +1839,7 @@ __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict
                                                          const unsigned* __restrict__ tier,
                                                          const double* __restrict__ Phi64) {
     const int i = threadIdx.x;
+    if (!ACC && blockIdx.x == 0 && i == 0) record_scan_kind(tier, B, kScanFlat);
     if ((int)blockIdx.x >= B) {
         const int bp = (int)blockIdx.x - B;
         if (tier3(tier, bp))
@@ -2029,6 +2041,7 @@ __global__ __launch_bounds__(64) void lpc_adjq_kernel(const float* __restrict__ 
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
+    if (MODE == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) check_scan_kind(tier, (int)gridDim.y, kScanFlat);
     if (MODE == 2 && tier3(tier, blockIdx.y)) return;   // tier-3 utterances take no refinement sweep
     adjq_body<W, NT, MODE>(gy, gy_stride, a, lamEnd, out, g_stride, T, F, M, hop, L, NC, NC, xt, yt, blockIdx.y, blockIdx.x,
                            threadIdx.x);
@@ -2134,6 +2147,9 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
     __shared__ float st[(kGroup + 1) * 32];
     __shared__ float dl[kGroup * 32];
+    if constexpr (MODE == 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) check_scan_kind(tier, B, kScanTwoLevel);
+    }
     if constexpr (MODE == 3) {
         if ((int)blockIdx.y >= B) {   // fp64 adjoint boundary scan of a tier-3 utterance (x = zadj) -> L1 rows c+1
             const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
@@ -2554,7 +2570,12 @@ __global__ __launch_bounds__(256) void lpc_status_kernel(const unsigned* __restr
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = status[0]; out[3] = sh[2][0]; }
+    if (threadIdx.x == 0) {
+        out[0] = sh[0][0]; out[1] = sh[1][0]; out[3] = sh[2][0];
+        // bit 0: a non-finite sample left the filter, bit 1: a wait for the fix-up timed out, bit 2: a backward ran on this
+        // workspace with another boundary scan than the forward that filled it
+        out[2] = (status[0] ? 1u : 0u) | (status[1] ? 2u : 0u) | (tier[2 * B + 1] ? 4u : 0u);
+    }
 }
 __global__ void lpc_status_zero_kernel(unsigned* __restrict__ out) { if (threadIdx.x < 4) out[threadIdx.x] = 0u; }
 
@@ -2879,7 +2900,7 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
     }
     if (!done) {   // flat adjoint scan, with the same refinement sweep in delta form
         hipLaunchKernelGGL((lpc_adjq_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, (const float*)nullptr,
-                           zadj, (int64_t)0, T, F, M, hop, p.L, p.NC, (const unsigned*)nullptr);
+                           zadj, (int64_t)0, T, F, M, hop, p.L, p.NC, tier);
         GOLF_LAUNCH_CHECK();
         hipLaunchKernelGGL((lpc_adj_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, Phi, (const float*)zadj, lam,
                            p.NC, p.NP, B, tier, Phi64);

@@ -23,36 +23,48 @@ __global__ __launch_bounds__(NB_THREADS) void noise_band_fwd_kernel(const float*
                                                                     const int* __restrict__ offs,
                                                                     const float* __restrict__ log_gain, int F, int hop,
                                                                     float* __restrict__ out, int64_t out_stride, int T,
-                                                                    int K, int nrows) {
+                                                                    int K, int nrows, int KC) {
+    // The bands are walked KC at a time (KC = K when the block's gain rows fit the LDS budget -- the GOLF configurations;
+    // short gain hops, down to sample-rate gains, stage (256 / hop + 3) rows and take several passes: the reference's
+    // NoiseBand works at any hop, models/noise.py:114-124)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* rows = sm;                                       // [nrows][K] exp(log_gain)
-    int* off = reinterpret_cast<int*>(sm + (size_t)nrows * K);  // [K]
+    float* rows = sm;                                        // [nrows][KC] exp(log_gain) of bands k0 .. k0 + KC - 1
+    int* off = reinterpret_cast<int*>(sm + (size_t)nrows * KC);  // [KC]
     const int tid = threadIdx.x, b = blockIdx.y;
     const int t_lo = blockIdx.x * NB_THREADS;
     const int row_lo = F >= 2 ? min(t_lo / hop, F - 2) : 0;
     const int nr = min(nrows, F - row_lo);
     const float* lg = log_gain + ((size_t)b * F + row_lo) * K;
-    for (int e = tid; e < nr * K; e += NB_THREADS) rows[e] = __expf(lg[e]);
-    for (int k = tid; k < K; k += NB_THREADS) off[k] = offs[(size_t)b * K + k];
-    __syncthreads();
     const int t = t_lo + tid;
-    if (t >= T) return;
     int f = 0;
     float w = 0.f;
-    if (F >= 2) { f = min(t / hop, F - 2); w = (float)(t - f * hop) / (float)hop; }
-    const float* r0 = rows + (size_t)(f - row_lo) * K;
-    const float* r1 = F >= 2 ? r0 + K : r0;
+    if (F >= 2) { f = min(min(t, T - 1) / hop, F - 2); w = (float)(t - f * hop) / (float)hop; }
     const unsigned mask = (unsigned)Lb - 1u;
     float acc0 = 0.f, acc1 = 0.f;
-    for (int k = 0; k < K; k += 2) {
-        const float g0 = fmaf(w, r1[k] - r0[k], r0[k]);
-        acc0 = fmaf(bands[(size_t)k * Lb + (((unsigned)t + (unsigned)off[k]) & mask)], g0, acc0);
-        if (k + 1 < K) {
-            const float g1 = fmaf(w, r1[k + 1] - r0[k + 1], r0[k + 1]);
-            acc1 = fmaf(bands[(size_t)(k + 1) * Lb + (((unsigned)t + (unsigned)off[k + 1]) & mask)], g1, acc1);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kc = min(KC, K - k0);
+        if (k0) __syncthreads();                             // the previous pass's rows are still being read
+        for (int e = tid; e < nr * kc; e += NB_THREADS) {
+            const int r = e / kc, k = e - r * kc;
+            rows[(size_t)r * KC + k] = __expf(lg[(size_t)r * K + k0 + k]);
+        }
+        for (int k = tid; k < kc; k += NB_THREADS) off[k] = offs[(size_t)b * K + k0 + k];
+        __syncthreads();
+        if (t < T) {
+            const float* r0 = rows + (size_t)(f - row_lo) * KC;
+            const float* r1 = F >= 2 ? r0 + KC : r0;
+            const float* bk = bands + (size_t)k0 * Lb;
+            for (int k = 0; k < kc; k += 2) {
+                const float g0 = fmaf(w, r1[k] - r0[k], r0[k]);
+                acc0 = fmaf(bk[(size_t)k * Lb + (((unsigned)t + (unsigned)off[k]) & mask)], g0, acc0);
+                if (k + 1 < kc) {
+                    const float g1 = fmaf(w, r1[k + 1] - r0[k + 1], r0[k + 1]);
+                    acc1 = fmaf(bk[(size_t)(k + 1) * Lb + (((unsigned)t + (unsigned)off[k + 1]) & mask)], g1, acc1);
+                }
+            }
         }
     }
-    out[(size_t)b * out_stride + t] = acc0 + acc1;
+    if (t < T) out[(size_t)b * out_stride + t] = acc0 + acc1;
 }
 
 // part[b][sg][2][K]: segment sg = samples [sg*hop, (sg+1)*hop) (the last also owns the clamped tail), weight (1-w) -> row
@@ -136,11 +148,12 @@ extern "C" int golf_noise_band_fwd_f32(const float* noise_bands, int Lb, const i
     if (int rc = nb_check("noise_band_fwd", noise_bands, offsets, log_gain, B, T, F, K, Lb, hop)) return rc;
     if (!out || out_stride < T) return fail(GOLF_EINVAL, "noise_band_fwd: bad output / stride");
     const int nrows = NB_THREADS / hop + 3;
-    const size_t lds = sizeof(float) * ((size_t)nrows * K + K);
-    if (lds > 64 * 1024)
-        return fail(GOLF_EUNSUPPORTED, "noise_band_fwd: %d bands at gain hop %d exceed the LDS staging", K, hop);
+    // bands per pass: all of them if their gain rows fit 60 KB of LDS, else as many (an even number) as do
+    int KC = K;
+    if (sizeof(float) * ((size_t)nrows + 1) * K > 60 * 1024) KC = std::max(2, (int)(60 * 1024 / sizeof(float) / (nrows + 1)) & ~1);
+    const size_t lds = sizeof(float) * ((size_t)nrows + 1) * KC;
     hipLaunchKernelGGL(noise_band_fwd_kernel, dim3((unsigned)ceil_div(T, NB_THREADS), B), dim3(NB_THREADS), lds,
-                       (hipStream_t)stream, noise_bands, Lb, offsets, log_gain, F, hop, out, out_stride, T, K, nrows);
+                       (hipStream_t)stream, noise_bands, Lb, offsets, log_gain, F, hop, out, out_stride, T, K, nrows, KC);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

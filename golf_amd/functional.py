@@ -206,7 +206,8 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
 def ss_status(status: torch.Tensor) -> dict:
     """Decode the 4 status words of ltv_allpole_ss(..., status=t) (synchronises: reads the device tensor)."""
     w = status.detach().to("cpu").view(torch.int32)[:4]
-    return {"hot_utterances": int(w[0]), "tier3_utterances": int(w[1]), "nonfinite": bool(int(w[2]) != 0),
+    return {"hot_utterances": int(w[0]), "tier3_utterances": int(w[1]), "nonfinite": bool(int(w[2]) & 1),
+            "fixup_timeout": bool(int(w[2]) & 2), "scan_mismatch": bool(int(w[2]) & 4),
             "max_phi": float(w[3:4].view(torch.float32)[0])}
 
 

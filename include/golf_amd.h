@@ -117,7 +117,12 @@ int golf_ltv_allpole_fwd_f32(const float* ex, int64_t ex_stride, const float* ga
  * output is finite -- asynchronously, on `stream`, into 4 caller-owned DEVICE words the host reads when it likes:
  *   out[0]  utterances with at least one chunk whose matrix was recomputed from fp64 trajectories
  *   out[1]  utterances whose boundary states came from the fp64 scan (tier 3)
- *   out[2]  1 if a non-finite sample was written to y (an unstable filter is surfaced, not hidden)
+ *   out[2]  bit 0: a non-finite sample was written to y (an unstable filter is surfaced, not hidden);
+ *           bit 1: a wait inside the pre-pass launch for the recomputed matrices ran into its bound (never observed; the
+ *           result is then the fp32 matrices' -- less accurate, not undefined);
+ *           bit 2: golf_ltv_allpole_bwd_f32 ran on this workspace with another boundary scan than the forward that filled
+ *           it (GOLF_SS_FLAT_SCAN / _CHUNKED bits that differ between the two calls): its gradients are void.  Call this
+ *           function after the backward to see it.
  *   out[3]  the largest |entry| over all transition matrices of the batch, as the bits of an fp32
  * (B,T,F,M,hop,flags) as given to the forward.  The serial / generic algorithms form no matrices: all four words 0. */
 int golf_ltv_allpole_status_u32(const void* ws, size_t ws_bytes, int B, int T, int F, int M, int hop, int flags,

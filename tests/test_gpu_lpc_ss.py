@@ -769,3 +769,33 @@ def test_poisoned_workspace(B, F, M, hop, T, poison, monkeypatch):
         check(res[1][:, : r_ex.shape[1]], r_ex, f"{mode} g_ex")
         check(res[2], r_gain, f"{mode} g_gain")
         check(res[3], r_a, f"{mode} g_a")
+
+
+def test_backward_on_another_scan_is_reported():
+    """the backward decides between the two-level and the flat adjoint scan from ITS flags; a C caller that hands
+    it other scan bits than the forward gave would read composites nobody wrote.  The forward records its scan kind in the
+    workspace, the backward's first kernel compares, golf_ltv_allpole_status_u32 reports (bit 2 of word 2)."""
+    from golf_amd import functional as GF, _lib
+
+    B, F, M, hop = 2, 200, 22, 240
+    ex, gain, a = smooth_case(B, F, M, hop, seed=77)
+    lib = _lib.load()
+
+    def status_after_backward(fwd_mode, bwd_mode):
+        t = [dev(v).requires_grad_(True) for v in (ex, gain, a)]
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, mode=fwd_mode)
+        ws = y.grad_fn.saved_tensors[4]
+        y.grad_fn.mode = GF.SS_MODES[bwd_mode]          # what a C caller with inconsistent flags would do
+        y.sum().backward()
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        flags = GF.SS_MODES[fwd_mode] | GF.FAST_TRANSITIONS | GF.TRAINING
+        rc = lib.golf_ltv_allpole_status_u32(ws.data_ptr(), ws.numel(), B, y.shape[1], F, M, hop, flags, st.data_ptr(),
+                                             _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return GF.ss_status(st)
+
+    assert not status_after_backward(None, None)["scan_mismatch"]
+    assert not status_after_backward("flat-scan", "flat-scan")["scan_mismatch"]
+    assert status_after_backward(None, "flat-scan")["scan_mismatch"]
+    assert status_after_backward("flat-scan", None)["scan_mismatch"]

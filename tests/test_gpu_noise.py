@@ -68,7 +68,10 @@ def test_noise_band_golden_g24(golden):
 
 
 @pytest.mark.parametrize("B,T,F,hop,K,L", [(3, 4801, 21, 240, 64, 2048), (2, 1000, 9, 128, 37, 512),
-                                           (4, 48000, 201, 240, 256, 8192)])
+                                           (4, 48000, 201, 240, 256, 8192),
+                                           # short gain hops, down to sample-rate gains: the block's gain rows exceed the LDS
+                                           # budget and the bands are walked in several passes (round 2 returned EUNSUPPORTED)
+                                           (2, 600, 600, 1, 128, 512), (2, 2000, 501, 4, 1024, 1024), (1, 900, 301, 3, 75, 256)])
 def test_noise_band_vs_oracle(B, T, F, hop, K, L):
     from golf_amd import functional as GF
     from oracle import golf_oracle as O
