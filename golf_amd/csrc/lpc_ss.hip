@@ -2629,13 +2629,20 @@ static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, 
 }
 // fix-up workgroups (4 waves of 16 units) per utterance: KF1 lead the grid (the guarantee), KF2 trail it (the speed);
 // together at most one pass over all units of an utterance
-static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2) {
+static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2, bool own_launch = false) {
     static const int e1 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF1"); return e ? atoi(e) : 0; }();   // dev knobs
     static const int e2 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF2"); return e ? atoi(e) : -1; }();
     const int64_t all = ceil_div((int64_t)p.NP * NT, 64);   // workgroups that cover every unit in one pass
     int k1 = e1 > 0 ? e1 : 6;
     if (k1 > all) k1 = (int)(all < 1 ? 1 : all);
-    int64_t k2 = e2 >= 0 ? e2 : 42;
+    // Every fix-up workgroup that finds nothing to do is dispatch cost, and with several batches in flight that is what
+    // counts.  Measured, (KF1, KF2) -> us/step pipelined: B = 256, launch of its own (18 hot utterances + one tier 3 in the
+    // four slots; kernel alone in brackets): (6, 10) 452 [77], (6, 26) 461 [52], (6, 42) 470 [61], (6, 90) 483 [67];
+    // B = 32, merged into the pre-pass (headline / driver's 20 steps / recipe_stream): (6, 10) 74.3 / 82.9 / 77.9,
+    // (6, 26) 74.9 / 83.5 / 78.4, (6, 42) 75.8 / 86.4 / 80.9.  16 workgroups = 1024 units per pass: one pass for up to 46 hot
+    // chunks of an utterance (typical: 5 - 20); a tier-3 utterance (all 199) takes five.
+    (void)own_launch;
+    int64_t k2 = e2 >= 0 ? e2 : 10;
     if (k1 + k2 > all) k2 = all - k1 > 0 ? all - k1 : 0;
     *kf1 = k1;
     *kf2 = (int)k2;
@@ -2647,7 +2654,7 @@ static int launch_fixup(const SsPlan& p, const float* a, int B, int F, int M, in
                         int training, hipStream_t st) {
     if (p.NP <= 0 || no_fixup()) return GOLF_OK;
     int k1, k2;
-    fixup_kf(p, NT, &k1, &k2);
+    fixup_kf(p, NT, &k1, &k2, true);
     FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate, training);
     fa.B = B;
     hipLaunchKernelGGL((lpc_fixup_kernel<W, NT>), dim3((unsigned)(k1 + k2), B), dim3(256), 0, st, fa);
