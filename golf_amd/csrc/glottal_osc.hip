@@ -836,6 +836,13 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
         }
         ph = ph_next;
     }
+    // the fused addend of this wave's outputs: loads issued before the barrier, consumed after the MFMA chain
+    // D rows 4*lk + r, column li  ->  output o0 + 256*wv + 16*(4*lk + r) + li
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+    const int ob = o0 + 256 * wv + 64 * lk + li;
+    float ad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
     __syncthreads();
     // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
     //         D[m][n] (output 256*wv + 16*m + n) = sum_ph sum_k' X_ph[256*wv + 16*m + k'] * B_ph[k'][n]
@@ -855,13 +862,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
             }
         }
     }
-    // D rows 4*lk + r, column li  ->  output o0 + 256*wv + 16*(4*lk + r) + li
-    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
     const BufRow orow(out + (size_t)b * out_stride, Tout);
-    const int ob = o0 + 256 * wv + 64 * lk + li;
-    float ad[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
 #pragma unroll
     for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
 }
