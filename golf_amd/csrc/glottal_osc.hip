@@ -600,23 +600,31 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 //      without bank conflicts.  132 VALU multiply-adds per output become 12 LDS reads.
 // About 125 VALU lane-instructions per output instead of 433.  Same exact phases as the three-kernel path; the values
 // agree to 1e-6 (tests/test_gpu_osc.py).
+#ifndef OSCF_TO               // (tile geometry as build parameters: occupancy experiments)
 #define OSCF_TO 2048
+#endif
 #define OSCF_THREADS 512
+#ifndef OSCF_CPT
 #define OSCF_CPT 5            // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + 4 * KS
+#endif
+#ifndef OSCF_MIN_WAVES
+#define OSCF_MIN_WAVES 1      // launch bound: waves per SIMD the register allocation must allow
+#endif
 #define OSCF_MAXROWS 4
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
 //  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
-__global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
+#define OSCT_THREADS 512
+__global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
                                                               float* __restrict__ Bf) {
-    __shared__ u64 wsum[4];
+    __shared__ u64 wsum[OSCT_THREADS / 64];
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tile == 0 && b == 0) {
         const int half = (K - 1) / 2;
-        for (int e = tid; e < 4 * KS * 64; e += 256) {
+        for (int e = tid; e < 4 * KS * 64; e += OSCT_THREADS) {
             const int lane = e & 63, kk = (e >> 6) % KS, ph = (e >> 6) / KS;
             const int q = 4 * kk + (lane >> 4) - (lane & 15);
             const int k = half + 4 * (dmin + q) + ph;
@@ -627,28 +635,40 @@ __global__ __launch_bounds__(256) void osc_tile_totals_kernel(const float* __res
     const double scale_a = 18446744073709551616.0 / (double)os;
     const double scale_d = scale_a / (double)P;
     const u64 tri = (u64)P * (u64)(P - 1) / 2;
-    constexpr int PER = OSCF_TO / 256;
-    const int j0 = tile * OSCF_TO + tid * PER;
-    float pv[PER + 1];
+    // A pure reduction: any assignment of samples to threads will do, so consecutive lanes take consecutive samples
+    // (coalesced; the successor p_{j+1} is a second, cached, coalesced load).  Round 2 gave each thread 8 consecutive
+    // samples (lane stride 32 B: every load instruction touched all the wave's cache lines) on 256 threads: 1.47 ms at
+    // B = 16 384 where 512 threads x 4 consecutive samples already took 0.83 ms (tile-geometry experiment).
+    constexpr int PER = OSCF_TO / OSCT_THREADS;
+    static_assert(OSCF_TO % OSCT_THREADS == 0, "tile = whole passes of the workgroup");
+    const int j0 = tile * OSCF_TO + tid;
+    float p0[PER], p1[PER];
 #pragma unroll
-    for (int r = 0; r <= PER; ++r) pv[r] = prow.ld(min(j0 + r, Tp - 1));
+    for (int r = 0; r < PER; ++r) {
+        const int j = j0 + r * OSCT_THREADS;
+        p0[r] = prow.ld(min(j, Tp - 1));
+        p1[r] = prow.ld(min(j + 1, Tp - 1));
+    }
     u64 tsum = 0;
-    if (os == 4 && P == 4) {   // (the only configuration osc_fused_kernel serves; the same conversions as there)
-        u64 aq[PER + 1];
 #pragma unroll
-        for (int r = 0; r <= PER; ++r) aq[r] = osc_fix_a_pow2(pv[r], 2);
-#pragma unroll
-        for (int r = 0; r < PER; ++r)
-            if (j0 + r < Tp - 1) tsum += (aq[r] << 2) + osc_fix_d_pow2(aq[r], aq[r + 1], 2) * (u64)6;
-    } else {
-#pragma unroll
-        for (int r = 0; r < PER; ++r)
-            if (j0 + r < Tp - 1) tsum += (u64)P * osc_fix_a(pv[r], scale_a) + osc_fix_d(pv[r], pv[r + 1], scale_d) * tri;
+    for (int r = 0; r < PER; ++r) {
+        if (j0 + r * OSCT_THREADS >= Tp - 1) continue;   // segments 0 .. Tp-2 advance the phase
+        if (os == 4 && P == 4) {   // (the only configuration osc_fused_kernel serves; the same conversions as there)
+            const u64 a0 = osc_fix_a_pow2(p0[r], 2), a1 = osc_fix_a_pow2(p1[r], 2);
+            tsum += (a0 << 2) + osc_fix_d_pow2(a0, a1, 2) * (u64)6;
+        } else {
+            tsum += (u64)P * osc_fix_a(p0[r], scale_a) + osc_fix_d(p0[r], p1[r], scale_d) * tri;
+        }
     }
     const u64 incl = wave_incl_scan(tsum, tid & 63);
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
-    if (tid == 0) Ttot[(size_t)b * ntile + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) {
+        u64 tot = 0;
+#pragma unroll
+        for (int w = 0; w < OSCT_THREADS / 64; ++w) tot += wsum[w];
+        Ttot[(size_t)b * ntile + tile] = tot;
+    }
 }
 
 // signal tile: polyphase branch ph, coarse index i  ->  X[ph * XS + i + 4 * (i >> 4)]
@@ -656,7 +676,7 @@ __device__ __forceinline__ int oscf_xaddr(int i) { return i + 4 * (i >> 4); }
 
 // KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
 template <int EE, int KS>
-__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
+__global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
     int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout, int /*XS*/,
@@ -703,11 +723,14 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
         // of all rows in registers), written as pairs rr = (row rr, row rr+1 - row rr); column L = wrap-around copy of
         // column 0.  (Round 2 staged pair by pair: every interior row blended twice, the one extra column costing a
         // whole third pass of the workgroup, clamps on every load -- 30 % of the kernel's instructions.)
+        // rows this tile's samples really touch (the launch sizes the LDS for the worst alignment: nrows)
+        const int m_last = min(j_lo + span - 1, Tp - 1) * P + (P - 1);
+        const int nrw = min(nrows, m_last / hop_t - r_first + 2);
         const float* t0[OSCF_MAXROWS];
         float pw[OSCF_MAXROWS];
 #pragma unroll
         for (int e = 0; e < OSCF_MAXROWS; ++e) {
-            int k = r_first + (e < nrows ? e : nrows - 1);
+            int k = r_first + (e < nrw ? e : nrw - 1);
             if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
             // (b, k) is the workgroup's: the row base and the weight are uniform -- say so (the loaded value sits in a VGPR), so
             // that the row loads below take an SGPR base + one shared lane offset instead of a 64-bit address each
@@ -722,7 +745,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
             float R[OSCF_MAXROWS][SU];
 #pragma unroll
             for (int e = 0; e < OSCF_MAXROWS; ++e)
-                if (e < nrows) {                      // uniform
+                if (e < nrw) {                        // uniform
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const int c = cb0 + u * NTH + tid;
@@ -733,7 +756,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
                 }
 #pragma unroll
             for (int rr = 0; rr + 1 < OSCF_MAXROWS; ++rr)
-                if (rr + 1 < nrows) {
+                if (rr + 1 < nrw) {
                     float2* dst = pairs + (size_t)rr * LR;
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
@@ -846,6 +869,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_kernel(
     __syncthreads();
     // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
     //         D[m][n] (output 256*wv + 16*m + n) = sum_ph sum_k' X_ph[256*wv + 16*m + k'] * B_ph[k'][n]
+    if (256 * wv >= OSCF_TO) return;   // (tiles shorter than 8 x 256 outputs: build-parameter experiments)
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     {
         // A[m = li][k' = 4*kk + lk]: element 256*wv + 16*li + 4*kk + lk  ->  address + 4 * (16*wv + li + (kk >> 2))
@@ -1351,7 +1375,8 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int KS = nq + 15 <= 48 ? 12 : 16;                     // K-steps of the 16-window Toeplitz product
         const int span = OSCF_TO + 4 * KS;
         const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
-        const int nrows = nint_touched + 1;
+        static const int nrows_force = [] { const char* e = getenv("GOLF_OSCF_NROWS"); return e ? atoi(e) : 0; }();   // dev knob: timing proxies only (wrong results)
+        const int nrows = nrows_force > 0 ? nrows_force : nint_touched + 1;
         const int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;       // padded polyphase row: i + 4 * (i >> 4)
         static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
         const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1)) + lds_pad;
@@ -1360,7 +1385,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
             float* Bf = (float*)((char*)ws + g.off_bf);
-            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(256), 0, st, phase, phase_stride, Ttot, Tp,
+            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
                                g.P, os, ntile2, taps, K, dmin, KS, Bf);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
