@@ -732,13 +732,19 @@ constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 #ifndef P1F_CHAINS
 #define P1F_CHAINS 2
 #endif
+#ifndef P1F_TILE_BYTES
+#define P1F_TILE_BYTES 16384   // LDS per wave for the copy-out transposition.  A build parameter for one A/B: with 64 KB per
+// workgroup only two of them (or one + one oscillator workgroup) fit a CU while four batches are in flight; 8 KB / 4 KB per
+// wave left the pipelined rate where it was (74.1 / 76.3 vs 74.3 us/step) and made the kernel itself slower (41.3 / 44.9
+// vs 40.4 us: more copy-out passes) -- LDS capacity is not what the batches in flight compete for.
+#endif
 template <int W, int NT>
 struct P1fGeom {
     static constexpr int KT = 4;
     static constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
     static constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
     static constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
-    static constexpr int CPP0 = (16384 / 4) / (NT * LDT);  // chunks staged per copy-out pass: <= 16 KB per wave
+    static constexpr int CPP0 = (P1F_TILE_BYTES / 4) / (NT * LDT);  // chunks staged per copy-out pass: <= P1F_TILE_BYTES per wave
     static constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
     static constexpr int TILE_FLOATS = P1F_WPB * CPP * NT * LDT;
 };
