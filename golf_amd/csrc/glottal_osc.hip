@@ -619,7 +619,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
-                                                              float* __restrict__ Bf) {
+                                                              float* __restrict__ Bf, int reversed = 0, int dmax = 0) {
     __shared__ u64 wsum[OSCT_THREADS / 64];
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tile == 0 && b == 0) {
@@ -627,8 +627,10 @@ __global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const flo
         for (int e = tid; e < 4 * KS * 64; e += OSCT_THREADS) {
             const int lane = e & 63, kk = (e >> 6) % KS, ph = (e >> 6) / KS;
             const int q = 4 * kk + (lane >> 4) - (lane & 15);
-            const int k = half + 4 * (dmin + q) + ph;
-            Bf[e] = (q >= 0 && k >= 0 && k < K) ? taps[k] : 0.f;
+            // forward: tap of branch ph at d = dmin + q; backward (transposed FIR, osc_fused_bwd_kernel): at d = dmax - q
+            const int d = reversed ? dmax - q : dmin + q;
+            const int k = half + 4 * d + ph;
+            Bf[e] = (q >= 0 && d >= dmin && d <= (reversed ? dmax : 0x3fffffff) && k >= 0 && k < K) ? taps[k] : 0.f;
         }
     }
     const BufRow prow(phase + (size_t)b * phase_stride, Tp);
@@ -889,6 +891,250 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     const BufRow orow(out + (size_t)b * out_stride, Tout);
 #pragma unroll
     for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
+}
+
+// ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
+// One workgroup owns OSCF_TO coarse samples (no halo on the sample side: every fine sample is counted once) of one
+// utterance:
+//   1. the gradient tile Y[v] = g_out[o0 - dmax + v] (+ the FIR's reach on both sides) -> LDS, the table DIFFERENCE rows
+//      D_k = T[i0_k + 1] - T[i0_k] of the control frames the tile touches -> LDS, the phase scan as in the forward;
+//   2. the transposed polyphase FIR on the matrix pipe: g_pre[4j + ph] = sum_q' Y[j - o0 + q'] h_ph[dmax - q'] -- the same
+//      16-window Toeplitz product as the forward's with reversed taps, one accumulator per branch -> LDS, laid out so that
+//      the thread that owns coarse samples 4t .. 4t+3 finds its 16 values in one row of 20 words (four 16-byte reads);
+//   3. every thread walks the 4 fine samples of its 4 coarse samples: d pre / d p of frame k is (1 - rf) D_k(phase), of
+//      frame k + 1 it is rf D_{k+1}(phase), times the equal-energy factor; sums per staged row, block reduction ->
+//      part[b][tile][row].  osc_wsel_reduce_tiles_kernel adds the tiles' rows into g_wsel.
+// Replaces osc_phase_tile + osc_decimate_T4 + osc_render<1> (46 us and a 12 MB prefix + a 24 MB oversampled gradient on a
+// round trip through HBM at B = 32) for the GOLF configuration; everything else keeps the three-kernel path.
+#define OSCB_CPT (OSCF_TO / OSCF_THREADS)
+template <int EE, int KS>
+__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_bwd_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
+    int hop_t, const float* __restrict__ Bf, const float* __restrict__ g_out, int64_t g_out_stride, int Tout, int dmax,
+    int nrows, float* __restrict__ part) {
+    constexpr int P = 4, NTH = OSCF_THREADS, CPT = OSCB_CPT;
+    static_assert(OSCF_TO == 2048 && OSCF_THREADS == 512, "4 consecutive coarse samples per thread, 8 waves x 256 outputs");
+    constexpr int spanY = OSCF_TO + 4 * KS;                     // gradient samples the windows reach
+    constexpr int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;  // padded like the forward's signal tile
+    constexpr int GR = 20;                                       // words per thread row of the fine-gradient tile: 16 + 4, so
+    // that a thread reads its row as four 16-byte words and 16 consecutive lanes cover all 64 banks exactly once
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ u64 wtot[NTH / 64];
+    __shared__ u64 base_sh;
+    __shared__ float red[OSCF_MAXROWS][NTH / 64];
+    // layout: Y [YS] | G [NTH][17] | difference rows [nrows][L + 1]
+    float* Y = smem;
+    float* G = smem + YS;
+    float* rows = G + NTH * GR;
+    const int LR = L + 1;
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int o0 = tile * OSCF_TO;
+    // ---- 0. reversed Toeplitz fragments (osc_tile_totals_kernel, reversed = 1)
+    float bfrag[4][KS];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
+    // ---- 1. base phase, own phase samples, gradient tile, difference rows
+    if (wv == 0) {
+        u64 acc = 0;
+        for (int i = lane; i < tile; i += 64) acc += Ttot[(size_t)b * ntile + i];
+        acc = wave_incl_scan(acc, lane);
+        if (lane == 63) base_sh = acc;
+    }
+    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
+    const int u0 = tid * CPT;
+    float pv[CPT + 1];
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) {
+        const int j = o0 + u0 + r;
+        pv[r] = prow.ld(j > Tp - 1 ? Tp - 1 : j);
+    }
+    {
+        const BufRow grow(g_out + (size_t)b * g_out_stride, Tout);
+        for (int v = tid; v < spanY; v += NTH) {
+            const int o = o0 - dmax + v;
+            const float x = grow.ld(o < 0 ? 0 : o);             // (past the end: dropped by the descriptor -> 0)
+            Y[oscf_xaddr(v)] = o >= 0 ? x : 0.f;
+        }
+    }
+    const int m_first = o0 * P;
+    const int r_first = m_first / hop_t;
+    {
+        const int m_last = min(o0 + OSCF_TO - 1, Tp - 1) * P + (P - 1);
+        const int nrw = min(nrows, m_last / hop_t - r_first + 2);
+        const float* t0[OSCF_MAXROWS];
+#pragma unroll
+        for (int e = 0; e < OSCF_MAXROWS; ++e) {
+            int k = r_first + (e < nrw ? e : nrw - 1);
+            if (k > Fw - 1) k = Fw - 1;                          // replicate-padded frames
+            const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+            int i0 = __builtin_amdgcn_readfirstlane((int)idx);
+            i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+            t0[e] = table + (size_t)i0 * L;
+        }
+        constexpr int SU = 4;                                    // all loads of a batch in flight before the first store
+        for (int cb0 = 0; cb0 < L; cb0 += SU * NTH) {
+            float dvv[OSCF_MAXROWS][SU];
+#pragma unroll
+            for (int e = 0; e < OSCF_MAXROWS; ++e)
+                if (e < nrw) {                                   // uniform
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int c = cb0 + u * NTH + tid;
+                        const int cc = c < L ? c : 0;
+                        dvv[e][u] = t0[e][L + cc] - t0[e][cc];
+                    }
+                }
+#pragma unroll
+            for (int e = 0; e < OSCF_MAXROWS; ++e)
+                if (e < nrw) {
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int c = cb0 + u * NTH + tid;
+                        if (c < L) rows[(size_t)e * LR + c] = dvv[e][u];
+                        if (c == 0) rows[(size_t)e * LR + L] = dvv[e][u];   // column L = wrap-around copy of column 0
+                    }
+                }
+        }
+    }
+    // ---- 2. phase scan: thread owns coarse samples u0 .. u0 + 3
+    u64 av[CPT + 1], dv[CPT], tv[CPT];
+    u64 tsum = 0;
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[r], 2);
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int j = o0 + u0 + r;
+        dv[r] = osc_fix_d_pow2(av[r], av[r + 1], 2);
+        tv[r] = j < Tp - 1 ? (av[r] << 2) + dv[r] * (u64)6 : 0;
+        tsum += tv[r];
+    }
+    const u64 incl = wave_incl_scan(tsum, lane);
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();                                             // Y, rows, base_sh, wtot
+    u64 ph = base_sh + incl - tsum;
+    for (int w = 0; w < wv; ++w) ph += wtot[w];
+    // ---- 3. transposed FIR: wave wv owns coarse samples 256 wv .. +255 as a 16 x 16 tile per polyphase branch
+    {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int phs = 0; phs < 4; ++phs) acc[phs] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const float* ap = Y + 320 * wv + 20 * li + lk;           // A[m = li][k' = 4 kk + lk]: see the forward
+        float a[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[kk] = ap[4 * kk + 4 * (kk >> 2)];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int phs = 0; phs < 4; ++phs)
+                acc[phs] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc[phs], 0, 0, 0);
+        // D rows 4 lk + r, column li -> coarse sample i = 256 wv + 16 (4 lk + r) + li -> owner thread i >> 2, slot 4 (i & 3) + ph
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 256 * wv + 16 * (4 * lk + r) + li;
+            float* gp = G + (size_t)(i >> 2) * GR + 4 * (i & 3);
+#pragma unroll
+            for (int phs = 0; phs < 4; ++phs) gp[phs] = acc[phs][r];
+        }
+    }
+    __syncthreads();
+    // ---- 4. per fine sample: (1 - rf) D_rr(phase) and rf D_rr+1(phase), weighted by the incoming gradient
+    const float inv_hop_t = 1.0f / (float)hop_t;
+    const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
+    const int fw = 32 - lshift < 24 ? 32 - lshift : 24, fo = 32 - lshift - fw;
+    const float fscale = __uint_as_float((unsigned)(127 - fw) << 23);
+    float racc[OSCF_MAXROWS] = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t gq[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) gq[r] = *reinterpret_cast<const f32x4_t*>(G + (size_t)tid * GR + 4 * r);
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int j = o0 + u0 + r;
+        const u64 ph_next = ph + tv[r];
+        const float p0 = pv[r], p1 = pv[r + 1];
+        const u64 c2 = (av[r] << 1) + dv[r], c3 = c2 + av[r] + (dv[r] << 1);
+        const unsigned hik[P] = {(unsigned)((ph + av[r]) >> 32), (unsigned)((ph + c2) >> 32),
+                                 (unsigned)((ph + c3) >> 32), (unsigned)(ph_next >> 32)};
+        const int m0 = j * P;
+        const int rr = (m0 >= bnd1) + (m0 >= bnd2);
+        const float* ra = rows + (size_t)rr * LR;
+        float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
+        const bool v0 = j <= Tp - 1, vk = j < Tp - 1;            // the last coarse sample has only k = 0
+        const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;
+        float sck[P] = {1.f, 1.f, 1.f, 1.f};
+        if (EE) {   // the forward's equal-energy factors: linear over the 4 fine samples unless f0 jumps (wave-uniform branch)
+            const float s0 = __builtin_amdgcn_rsqf(q0), ds = -0.5f * s0 * s0 * s0 * dq;
+            const bool lin = fabsf(p1 - p0) <= 0.002f * p0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) sck[k] = fmaf((float)k, ds, s0);
+            if (__builtin_amdgcn_ballot_w64(!lin) != 0) {
+                asm volatile("; exact equal-energy factors" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < P; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
+            }
+        }
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const unsigned hi = hik[k];
+            const int c0 = (int)(hi >> (32 - lshift));
+            const float cf = (float)__builtin_amdgcn_ubfe(hi, (unsigned)fo, (unsigned)fw) * fscale;
+            const float d00 = ra[c0], d01 = ra[c0 + 1], d10 = ra[LR + c0], d11 = ra[LR + c0 + 1];
+            const float top = fmaf(cf, d01 - d00, d00), bot = fmaf(cf, d11 - d10, d10);
+            const float g = gq[r][k] * sck[k];
+            // fine samples past the end of the signal: a select on the PRODUCT (their rows may not be staged: 0 x garbage)
+            const bool ok = k == 0 ? v0 : vk;
+            const float t0_ = g * (1.0f - rf) * top, t1_ = g * rf * bot;
+            a0 += ok ? t0_ : 0.f;
+            a1 += ok ? t1_ : 0.f;
+            rf += inv_hop_t;
+        }
+#pragma unroll
+        for (int e = 0; e < OSCF_MAXROWS; ++e) racc[e] += (rr == e ? a0 : 0.f) + (rr + 1 == e ? a1 : 0.f);
+        ph = ph_next;
+    }
+    // ---- 5. block reduction per staged row
+#pragma unroll
+    for (int e = 0; e < OSCF_MAXROWS; ++e) {
+        float v = racc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[e][wv] = v;
+    }
+    __syncthreads();
+    if (tid < OSCF_MAXROWS) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NTH / 64; ++w) v += red[tid][w];
+        part[((size_t)b * ntile + tile) * OSCF_MAXROWS + tid] = v;
+    }
+}
+
+// partials of the fused backward -> g_wsel: staged row e of tile t is control frame min(r_first(t) + e, Fw - 1)
+__global__ void osc_wsel_reduce_tiles_kernel(const float* __restrict__ part, float* __restrict__ g_wsel, int B, int Fw,
+                                             int ntile, int n_tab, int hop_t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Fw) return;
+    const int b = idx / Fw, k = idx - b * Fw;
+    float acc = 0.f;
+    // only the tiles whose staged rows can be frame k: r_first(t) in [k - 3, k] (the last frame also collects the clamped rows)
+    const int fine = OSCF_TO * 4;
+    int t_lo = (int)(((int64_t)(k - (OSCF_MAXROWS - 1)) * hop_t) / fine) - 1;
+    int t_hi = k >= Fw - 1 ? ntile - 1 : (int)(((int64_t)(k + 1) * hop_t) / fine) + 1;
+    t_lo = t_lo < 0 ? 0 : t_lo;
+    t_hi = t_hi > ntile - 1 ? ntile - 1 : t_hi;
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int r_first = (t * fine) / hop_t;
+#pragma unroll
+        for (int e = 0; e < OSCF_MAXROWS; ++e) {
+            const int row = r_first + e > Fw - 1 ? Fw - 1 : r_first + e;
+            if (row == k) acc += part[((size_t)b * ntile + t) * OSCF_MAXROWS + e];
+        }
+    }
+    g_wsel[idx] = acc * (float)(n_tab - 1);
 }
 
 // ---- decimator launches (shared by the oscillator entry points and golf_decimate_fir_*) -----------------------------
@@ -1451,8 +1697,52 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         return fail(GOLF_EWORKSPACE, "glottal_osc_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
-    // recomputed: the fused forward leaves no per-sample prefix behind, and the backward must not depend on which
-    // forward variant ran or on the caller keeping the workspace untouched in between
+    // ---- fused path (the GOLF configuration, as in the forward): tile totals + osc_fused_bwd_kernel + a reduction
+    static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
+    if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !unfused_env) {
+        const int half = (K - 1) / 2;
+        const int dmin = -((half + os - 1) / os);
+        const int dmax = half / os;
+        const int nq = dmax - dmin + 1;
+        const int KS = nq + 15 <= 48 ? 12 : 16;
+        const int nint_touched = (OSCF_TO * 4 - 2) / g.hop_t + 2;
+        const int nrows = nint_touched + 1;
+        const int spanY = OSCF_TO + 4 * KS;
+        const int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;
+        const size_t ldsb = sizeof(float) * ((size_t)YS + (size_t)OSCF_THREADS * 20 + (size_t)nrows * (L + 1));
+        const int ntile2 = (int)ceil_div(Tp, OSCF_TO);            // tiles of COARSE SAMPLES here (Tp = Tout at hop 1)
+        if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && ldsb <= 80 * 1024 && ntile2 <= g.ntile &&
+            sizeof(float) * (size_t)B * ntile2 * OSCF_MAXROWS <= sizeof(float) * (size_t)B * g.pre_stride) {
+            const int lshift = 31 - __builtin_clz((unsigned)L);
+            u64* Ttot = (u64*)((char*)ws + g.off_ttot);
+            float* Bf = (float*)((char*)ws + g.off_bf);
+            float* part2 = (float*)((char*)ws + g.off_pre);      // the oversampled-gradient buffer is not needed here
+            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
+                               g.P, os, ntile2, taps, K, dmin, KS, Bf, 1, dmax);
+            GOLF_LAUNCH_CHECK();
+#define GOLF_FUSED_BWD(EE, KSV)                                                                                       \
+    do {                                                                                                              \
+        static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
+            (const void*)osc_fused_bwd_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);       \
+        if (lds_attr != hipSuccess)                                                                                   \
+            return fail((int)lds_attr, "glottal_osc_bwd: cannot raise the dynamic LDS limit: %s",                     \
+                        hipGetErrorString(lds_attr));                                                                 \
+        hipLaunchKernelGGL((osc_fused_bwd_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsb, st, phase,     \
+                           phase_stride, (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t,    \
+                           (const float*)Bf, g_out, g_out_stride, Tout, dmax, nrows, part2);                          \
+    } while (0)
+            if (KS == 12) { if (equal_energy) GOLF_FUSED_BWD(1, 12); else GOLF_FUSED_BWD(0, 12); }
+            else          { if (equal_energy) GOLF_FUSED_BWD(1, 16); else GOLF_FUSED_BWD(0, 16); }
+#undef GOLF_FUSED_BWD
+            GOLF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(osc_wsel_reduce_tiles_kernel, dim3((unsigned)ceil_div(B * Fw, 256)), dim3(256), 0, st,
+                               (const float*)part2, g_wsel, B, Fw, ntile2, n_tab, g.hop_t);
+            GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
+        }
+    }
+    // three-kernel path; the phase prefix is recomputed: the fused forward leaves no per-sample prefix behind, and the
+    // backward must not depend on which forward variant ran or on the caller keeping the workspace untouched in between
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, (u64*)((char*)ws + g.off_ttot), Tp, g.P, os, g.ntile, B,
                                     (hipStream_t)stream))

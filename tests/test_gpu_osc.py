@@ -345,3 +345,32 @@ def test_fused_kernel_other_tap_counts():
         out = GF.glottal_osc(dev(phase), dev(w), m.table.cuda(), taps.cuda(), 1, w_hop, 4, True).cpu().numpy()
         ref = O.indexed_glottal_forward(phase, 1, w, w_hop, m.table.numpy(), 4, True, decim_taps=taps.numpy())["out"]
         check(out, ref, f"fused osc, {taps.numel()} taps")
+
+
+@pytest.mark.parametrize("Tp,w_hop,eq", [(10000, 2400, True), (6145, 2400, False), (47761, 2400, True), (2049, 960, True),
+                                         (4000, 4800, True)])
+def test_fused_backward_wsel_vs_oracle(Tp, w_hop, eq):
+    """The fused backward w.r.t. table_select_weight (round 3: gradient tile -> transposed polyphase FIR on the matrix pipe
+    -> table-difference lookups -> per-row sums; osc_fused_bwd_kernel) on the GOLF configuration -- ragged lengths, tiles that
+    touch one, two and three control frames, f0 jumps, replicate-padded frames -- against the float64 closed-form adjoint."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(Tp)
+    B = 3
+    t = np.arange(Tp) / 24000
+    f0 = 120 + 60 * np.sin(2 * np.pi * (0.7 + 0.3 * np.arange(B))[:, None] * t[None])
+    f0[:, Tp // 3: Tp // 3 + 5] *= 1.5                            # an f0 jump (voicing boundary)
+    phase = (f0 / 24000).astype(np.float32)
+    Fw = (Tp - 1) // w_hop + 1                                      # one frame short of full coverage: padding is used
+    w = rng.uniform(0.02, 0.98, (B, Fw)).astype(np.float32)
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=eq)
+    table, taps = m.table.numpy(), m.decimater.taps.numpy()
+    wt = dev(w).requires_grad_(True)
+    out = GF.glottal_osc(dev(phase), wt, dev(table), dev(taps), 1, w_hop, 4, eq)
+    gy = rng.normal(0, 1, tuple(out.shape)).astype(np.float32)
+    (out * dev(gy)).sum().backward()
+    torch.cuda.synchronize()
+    ref = O.indexed_glottal_backward(gy, phase, 1, w, w_hop, table, 4, eq, decim_taps=taps)["g_weight"]
+    check(wt.grad.cpu().numpy(), ref, f"fused g_wsel Tp{Tp} w_hop{w_hop} eq{eq}", 2e-4)
