@@ -175,12 +175,6 @@ static float phi_guard3() {
 // rows of 16 utterances are addressed through one 32-bit buffer descriptor (serial kernels)
 static bool serial_strides_ok(int64_t s0, int64_t s1) { return s0 < (1 << 24) && s1 < (1 << 24); }
 // diagnostic A/B switch (bench): no fix-up launch at all, every utterance is treated as tier 1 (status words are then void)
-// dev knob (A/B): GOLF_P1_MFMA=1 computes the fp32 transition maps on the matrix pipe (p1m_body: built, measured, NOT
-// adopted -- 64.8 us against the packed-FMA kernel's 40.2 us at B = 32, see the comment above p1m_body and DESIGN.md 4.1)
-static bool p1_valu() {
-    static const bool v = [] { const char* e = getenv("GOLF_P1_MFMA"); return !(e && atoi(e) != 0); }();
-    return v;
-}
 static bool no_fixup() {
     static const bool v = [] { const char* e = getenv("GOLF_SS_NO_FIXUP"); return e && atoi(e) != 0; }();
     return v;
@@ -934,226 +928,23 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// fp32 transition maps on the MATRIX pipe (round 3, verdict r2 #4: "cut the transition kernel's work").
-// p1f_body above is bound by the packed-FMA issue rate of lone waves (637 waves x 240 steps x 55 v_pk_fma_f32, a fifth of
-// them coefficient interpolation repeated in every lane).  The same arithmetic as 16 independent 4x4 outer products per
-// instruction (v_mfma_f32_4x4x1_16b_f32):  a QUAD of lanes owns 4 trajectories of one chunk and advances them 4 samples
-// per block step,
-//       D[r][j] = sum_{h=1..NT} cf_{h+r-1}[n+r] * y_j[n-h]        (r = 0..3: the part that only needs samples before n)
-// -- NT instructions with A = this lane's coefficient for row r = lane & 3 (so a lane interpolates the coefficients of ONE
-// of the four samples: 4 x fewer interpolations), B = this lane's own trajectory history (a statically indexed register ring),
-// D = four samples of this lane's own trajectory -- followed by the 4 x 4 triangular part in 6 VALU FMAs
-//       y[n+r] = u[n+r] - D[r] - sum_{m<r} cf_{r-1-m}[n+r] y[n+m].
-// Every product is one fp32 FMA as before (K = 1 per instruction), only the order of the tap sum differs.  The MFMAs of the
-// taps h >= 5 do not depend on the previous block step's result, so a wave's matrix pipe runs ahead of its triangular
-// solves; on paper 44 matrix-pipe cycles per sample per 64 trajectories against ~88 VALU-issue cycles, on 2 388 waves
-// instead of 637 (B = 32), with the VALU left to the batches in flight beside it.
-// MEASURED (tools/ubench/mfma_4x4x1_probe.hip, MI355X): the 2-pass instruction sustains one issue per ~11.4 cycles, not 8,
-// and -- what decides it -- VALU instructions of OTHER waves on the SIMD do not issue beside it: 22 MFMAs + 38 VALU
-// instructions per block step cost 400-420 SIMD cycles at 1..4 waves per SIMD (250 for the MFMAs alone), i.e. the sum, against
-// 375 for the packed-FMA kernel's same work.  The kernel: 64.8 us (p1fz: 40.2), step 159 us alone / 87.9 pipelined
-// (136 / 74.4).  Parity identical (all lpc_ss tests pass on it).  Not adopted; opt-in via GOLF_P1_MFMA=1 for the record.
-// A chunk has 4 NQ >= NT trajectories; when 4 NQ > M the first spare one carries the chunk's ZERO-STATE response (the
-// excitation staged in LDS, u = ex * gain added in the triangular step), which is the whole of the P1z pass: no zero-state
-// waves, no second read of `a` (ZF).  Workgroups of 3 waves = 48 quads = whole chunks (8 for NT = 22).
-constexpr int P1M_WPB = 3;
-typedef float f32x4m __attribute__((ext_vector_type(4)));
-template <int W, int NT>
-struct P1mGeom {
-    static constexpr int NQ = (NT + 3) / 4;             // quads (of trajectories) per chunk
-    static constexpr int QPB = P1M_WPB * 16;            // quads per workgroup
-    static constexpr int CPB = QPB / NQ;                // whole chunks per workgroup
-    static constexpr int LDT = W + 4;                   // LDS row stride of the copy-out tile (floats)
-    static constexpr int LDU = 256 + 4;                 // ... of the staged excitation (L <= 256)
-    static constexpr int TILE_FLOATS = CPB * NT * LDT;
-    static constexpr int U_FLOATS = CPB * LDU;
-    static constexpr int LDS_FLOATS = TILE_FLOATS > U_FLOATS ? TILE_FLOATS : U_FLOATS;
-};
-template <int W, int NT, bool ZF>
-__device__ __forceinline__ void p1m_body(const float* __restrict__ ex, int64_t ex_stride, const float* __restrict__ gain,
-                                         const float* __restrict__ a, float* __restrict__ z, float* __restrict__ PhiT,
-                                         int F, int M, int hop, int L, int NP, int nq, float* __restrict__ lds, int blk_id,
-                                         float* __restrict__ pmax, unsigned* __restrict__ fixcnt, int B,
-                                         float* __restrict__ Phi) {
-    using G = P1mGeom<W, NT>;
-    constexpr int NQ = G::NQ, CPB = G::CPB, LDT = G::LDT, LDU = G::LDU;
-    constexpr int NP2 = NT / 2;
-    static_assert(W % 4 == 0 && NT % 2 == 0 && W >= NT, "block steps of 4 samples, tap pairs");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = wv * 16 + (lane >> 2), t = lane & 3;
-    const int cl = ql / NQ, grp = ql - cl * NQ;
-    const int q0 = blk_id * CPB;
-    const int q = q0 + cl;
-    const bool live = cl < CPB && q < nq;
-    const int j = 4 * grp + t;                // this lane's trajectory
-    const int qq = live ? q : (nq - 1);
-    const int b = qq / NP, c = qq - b * NP;
-    const float inv_hop = 1.0f / (float)hop;
-    if (fixcnt && blk_id == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = tid; e < 2 * B; e += 64 * P1M_WPB) fixcnt[e] = 0u;
-    if constexpr (ZF) {   // u = ex * gain of the workgroup's chunks -> LDS (coalesced; chunks of one utterance are contiguous)
-        for (int e = tid; e < CPB * L; e += 64 * P1M_WPB) {
-            const int ccl = e / L, s = e - ccl * L;
-            const int qe = q0 + ccl;
-            float u = 0.f;
-            if (qe < nq) {
-                const int be = qe / NP, ce = qe - be * NP;
-                const int te = ce * L + s;
-                int f = te / hop;
-                if (f > F - 2) f = F - 2;
-                const float g0 = gain[(size_t)be * F + f];
-                const float dg = (gain[(size_t)be * F + f + 1] - g0) * inv_hop;
-                u = ex[(size_t)be * ex_stride + te] * fmaf((float)(te - f * hop), dg, g0);
-            }
-            lds[ccl * LDU + s] = u;
-        }
-        __syncthreads();
-    }
-    const bool zl = ZF && j == M;             // the lane that carries the zero-state response
-    const float* urow = lds + (cl < CPB ? cl : 0) * LDU;
-    float hy[W];                               // slot k = sample k (mod W) of this lane's trajectory
-#pragma unroll
-    for (int k = 0; k < W; ++k) hy[k] = (W - 1 - k == j && j < M) ? 1.f : 0.f;
-    f32x2 a0s[NP2], dds[NP2];                  // taps i = h - 1 + t, h = 1..NT (this lane's row of the block)
-    float ta0[3], tdd[3];                      // taps 0..2 (triangular part; the same in every lane of a chunk)
-    int fcur = -1;
-    const int nblk = L / W;
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int t0 = c * L + blk * W;
-        int f = t0 / hop;
-        if (f > F - 2) f = F - 2;
-        if (f != fcur) {
-            fcur = f;
-            const float* pa0 = a + ((size_t)b * F + f) * M;
-            const float* pa1 = pa0 + M;
-#pragma unroll
-            for (int pp = 0; pp < NP2; ++pp) {
-                const int i0 = 2 * pp + t, i1 = 2 * pp + 1 + t;
-                const float u0 = i0 < M ? pa0[i0] : 0.f, u1 = i1 < M ? pa0[i1] : 0.f;
-                const float v0 = i0 < M ? pa1[i0] : 0.f, v1 = i1 < M ? pa1[i1] : 0.f;
-                a0s[pp] = f32x2{u0, u1};
-                dds[pp] = f32x2{(v0 - u0) * inv_hop, (v1 - u1) * inv_hop};
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float u0 = i < M ? pa0[i] : 0.f, v0 = i < M ? pa1[i] : 0.f;
-                ta0[i] = u0;
-                tdd[i] = (v0 - u0) * inv_hop;
-            }
-        }
-        const int n0 = t0 - f * hop;
-#pragma unroll
-        for (int m = 0; m < W / 4; ++m) {
-            const float nb = (float)(n0 + 4 * m);
-            const float nf = nb + (float)t;
-            const f32x2 n2 = f32x2{nf, nf};
-            f32x2 cfp[NP2];
-#pragma unroll
-            for (int pp = 0; pp < NP2; ++pp) cfp[pp] = __builtin_elementwise_fma(n2, dds[pp], a0s[pp]);
-            f32x4m d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int h = NT; h >= 1; --h) {   // oldest samples first: only h <= 4 waits for the previous block step
-                const float cf = ((h - 1) & 1) ? cfp[(h - 1) / 2].y : cfp[(h - 1) / 2].x;
-                d = __builtin_amdgcn_mfma_f32_4x4x1f32(cf, hy[(4 * m - h + 2 * W) % W], d, 0, 0, 0);
-            }
-            float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
-            if constexpr (ZF) {
-                const float4 u4 = *reinterpret_cast<const float4*>(urow + blk * W + 4 * m);
-                u0 = zl ? u4.x : 0.f; u1 = zl ? u4.y : 0.f; u2 = zl ? u4.z : 0.f; u3 = zl ? u4.w : 0.f;
-            }
-            const float n1 = nb + 1.f, n2s = nb + 2.f, n3 = nb + 3.f;
-            const float c01 = fmaf(n1, tdd[0], ta0[0]);
-            const float c02 = fmaf(n2s, tdd[0], ta0[0]), c12 = fmaf(n2s, tdd[1], ta0[1]);
-            const float c03 = fmaf(n3, tdd[0], ta0[0]), c13 = fmaf(n3, tdd[1], ta0[1]), c23 = fmaf(n3, tdd[2], ta0[2]);
-            const float y0 = u0 - d[0];
-            const float y1 = fmaf(-c01, y0, u1 - d[1]);
-            const float y2 = fmaf(-c02, y1, fmaf(-c12, y0, u2 - d[2]));
-            const float y3 = fmaf(-c03, y2, fmaf(-c13, y1, fmaf(-c23, y0, u3 - d[3])));
-            hy[4 * m] = y0; hy[4 * m + 1] = y1; hy[4 * m + 2] = y2; hy[4 * m + 3] = y3;
-        }
-    }
-    // ---- outputs.  Row i of a map = state component i = sample L-1-i = slot W-1-i.
-    __syncthreads();   // (ZF) every wave is done with the staged excitation: the LDS becomes the copy-out tile
-    unsigned* red = reinterpret_cast<unsigned*>(lds);
-    if (pmax) {   // largest |entry| of the chunk's map, compared as bit patterns (a NaN ranks above +inf)
-        unsigned mx = 0u;
-        if (j < M) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) mx = max(mx, __float_as_uint(fabsf(hy[k])));
-        }
-        red[ql * 4 + t] = mx;
-        __syncthreads();
-        if (live && grp == 0 && t == 0) {
-            for (int u = 1; u < 4 * NQ; ++u) mx = max(mx, red[cl * 4 * NQ + u]);
-            pmax[q] = __uint_as_float(mx);
-        }
-        __syncthreads();
-    }
-    if (ZF && zl && live) {   // z[q][i]: end state of the zero-state response
-        float* zp = z + (size_t)q * W;
-#pragma unroll
-        for (int i4 = 0; i4 < W / 4; ++i4) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (4 * i4 + e) < M ? hy[W - 1 - (4 * i4 + e)] : 0.f;
-            reinterpret_cast<float4*>(zp)[i4] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-    // training (GOLF_SS_TRAINING): Phi[q][j][i], the adjoint scan's orientation -- a lane owns a row of W floats
-    if (Phi && live && j < NT) {
-        float4* o = reinterpret_cast<float4*>(Phi + ((size_t)q * NT + j) * W);
-#pragma unroll
-        for (int i4 = 0; i4 < W / 4; ++i4) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((4 * i4 + e) < M && j < M) ? hy[W - 1 - (4 * i4 + e)] : 0.f;
-            o[i4] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-    // PhiT[q][i][j] = d s_end[i] / d s_start[j]: transposition through the workgroup's LDS tile, then CPB chunks x NT rows
-    // x W floats leave as one contiguous run
-    if constexpr (4 * NQ < W) {   // columns no trajectory covers: zeros (the group composites read whole rows)
-        for (int e = tid; e < G::TILE_FLOATS; e += 64 * P1M_WPB) lds[e] = 0.f;
-        __syncthreads();
-    }
-    if (cl < CPB && j < W) {
-        float* tcol = lds + (size_t)cl * NT * LDT + j;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) tcol[(size_t)i * LDT] = (i < M && j < M) ? hy[W - 1 - i] : 0.f;
-    }
-    __syncthreads();
-    constexpr int RW4 = W / 4;
-    int nch = nq - q0;
-    nch = nch < 0 ? 0 : (nch > CPB ? CPB : nch);
-    float4* dst = reinterpret_cast<float4*>(PhiT + (size_t)q0 * NT * W);
-    for (int e = tid; e < nch * NT * RW4; e += 64 * P1M_WPB) {
-        const int rowi = e / RW4, c4 = e - rowi * RW4;
-        dst[e] = *reinterpret_cast<const float4*>(lds + (size_t)rowi * LDT + c4 * 4);
-    }
-}
-
-// Transition maps alone (transitions prepared ahead of the excitation) ...
-template <int W, int NT>
-__global__ __launch_bounds__(64 * P1M_WPB) void lpc_p1m_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
-                                                               int F, int M, int hop, int L, int NP, int nq,
-                                                               float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
-                                                               int B, float* __restrict__ Phi) {
-    __shared__ __attribute__((aligned(16))) float lds[P1mGeom<W, NT>::LDS_FLOATS];
-    p1m_body<W, NT, false>(nullptr, 0, nullptr, a, nullptr, PhiT, F, M, hop, L, NP, nq, lds, blockIdx.x, pmax, fixcnt, B, Phi);
-}
-// ... and with the zero-state response riding in the spare trajectory (the inference / training forward: one launch opens it)
-template <int W, int NT>
-__global__ __launch_bounds__(64 * P1M_WPB) void lpc_p1mz_kernel(const float* __restrict__ ex, int64_t ex_stride,
-                                                                const float* __restrict__ gain,
-                                                                const float* __restrict__ a, float* __restrict__ z,
-                                                                float* __restrict__ PhiT, int F, int M, int hop, int L,
-                                                                int NP, int nq, int B, float* __restrict__ pmax,
-                                                                unsigned* __restrict__ fixcnt, float* __restrict__ Phi) {
-    __shared__ __attribute__((aligned(16))) float lds[P1mGeom<W, NT>::LDS_FLOATS];
-    p1m_body<W, NT, true>(ex, ex_stride, gain, a, z, PhiT, F, M, hop, L, NP, nq, lds, blockIdx.x, pmax, fixcnt, B, Phi);
-}
-
+// Tried and NOT adopted (round 3, verdict r2 #4; the kernel is in git history: commit f49862c, `p1m_body`): the fp32 maps on
+// the MATRIX pipe -- v_mfma_f32_4x4x1_16b_f32 = 16 independent 4x4 outer products per instruction; a quad of lanes owns 4
+// trajectories of a chunk and advances them 4 samples per block step: D[r][j] = sum_h cf_{h+r-1}[n+r] y_j[n-h] in NT
+// instructions (A = the lane's coefficient for row r = lane & 3: 4 x fewer interpolations; B = the lane's own history ring),
+// then the 4 x 4 triangular part in 6 VALU FMAs; the zero-state response rode in the chunk's spare 23rd trajectory (no P1z
+// waves).  On paper 44 matrix-pipe cycles per sample per 64 trajectories against ~88 VALU-issue cycles.  MEASURED
+// (tools/ubench/mfma_4x4x1_probe.hip): the 2-pass instruction sustains one issue per ~11.4 cycles, not 8, and VALU
+// instructions of OTHER waves on the SIMD do not issue beside it -- 22 MFMAs + 38 VALU instructions per block step cost
+// 400-420 SIMD cycles at 1..4 waves per SIMD (250 for the MFMAs alone), the SUM, against 375 for p1f_body's same work.  The
+// kernel: 64.8 us (p1fz: 40.2), step 159 us alone / 87.9 pipelined (136 / 74.4); parity identical (every lpc_ss test passed).
+// Also tried and NOT adopted: the zero-state response in the spare trajectory of p1f_body itself (M = 22 of 24: the .x half
+// of group 5's hB ring; u = ex * gain staged per wave in the copy-out tile, one v_sub_f32 per sample) -- the 416 P1z waves
+// and a tenth of the step's VALU instructions gone, parity green -- but the kernel took 46.9 us instead of 39.9 (staging
+// prologue + 24 more live registers in waves that are the critical path; the P1z waves had been running on CUs the
+// transition waves leave idle), the step 141.7 us alone instead of 134.6 and 74.2 us pipelined either way: the pipelined
+// rate is NOT bound by the amount of VALU work (a finding that redirects the search: DESIGN.md 4.1).
+// ------------------------------------------------------------------------------------------
 // `upw` zero-state units (16 chunks of one utterance each) per wave, one after the other: the host picks upw so that the
 // fused grid has no more workgroups than the device has CUs -- an extra workgroup would share the SIMDs of a CU whose
 // transition waves are issue-bound.
@@ -2926,14 +2717,7 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    if (fast && !p1_valu()) {  // fp32 trajectories on the matrix pipe (the forward then runs one refinement sweep)
-        hipLaunchKernelGGL((lpc_p1m_kernel<W, NT>), dim3((unsigned)ceil_div(nq, P1mGeom<W, NT>::CPB)), dim3(64 * P1M_WPB), 0,
-                           st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
-                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
-        GOLF_LAUNCH_CHECK();
-        return launch_composites<W, NT>(p, a, B, F, M, hop, ws, 0, flags, st);
-    }
-    if (fast) {  // (dev knob GOLF_P1_VALU=1: the packed-FMA kernel, 4 trajectories per lane as float2 pairs)
+    if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
         constexpr int CPW = 64 / ((NT + 3) / 4);
         hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
                            st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
@@ -3011,14 +2795,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                 const int nq = B * p.NP, ncg = (int)ceil_div(p.NP, 16);
                 const int64_t nunit = (int64_t)ncg * B;
                 const int n_cu = device_cu_count();
-                if (fast && !p1_valu() && M < 4 * P1mGeom<W, NT>::NQ && p.L <= 256) {
-                    // matrix-pipe transition maps, the zero-state response in the chunk's spare trajectory
-                    hipLaunchKernelGGL((lpc_p1mz_kernel<W, NT>), dim3((unsigned)ceil_div(nq, P1mGeom<W, NT>::CPB)),
-                                       dim3(64 * P1M_WPB), 0, st, ex, ex_stride, gain, a, z, PhiT, F, M, hop, p.L, p.NP,
-                                       nq, B, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
-                                       training ? (float*)(ws + p.off_phi) : (float*)nullptr);
-                    GOLF_LAUNCH_CHECK();
-                } else if (fast) {
+                if (fast) {
                     const int nblk_f = (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
                     int upw = 1;
                     while (upw < 4 && nblk_f + ceil_div(nunit, 4 * upw) > n_cu) ++upw;
