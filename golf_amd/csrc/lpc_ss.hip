@@ -732,6 +732,9 @@ constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 #ifndef P1F_CHAINS
 #define P1F_CHAINS 2
 #endif
+#ifndef P1F_DIRECT
+#define P1F_DIRECT 1   // 1: the maps leave the transition kernel by direct 16-byte stores; 0: through a 16 KB LDS tile per wave
+#endif
 #ifndef P1F_TILE_BYTES
 #define P1F_TILE_BYTES 16384   // LDS per wave for the copy-out transposition.  A build parameter for one A/B: with 64 KB per
 // workgroup only two of them (or one + one oscillator workgroup) fit a CU while four batches are in flight; 8 KB / 4 KB per
@@ -746,7 +749,12 @@ struct P1fGeom {
     static constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
     static constexpr int CPP0 = (P1F_TILE_BYTES / 4) / (NT * LDT);  // chunks staged per copy-out pass: <= P1F_TILE_BYTES per wave
     static constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
-    static constexpr int TILE_FLOATS = P1F_WPB * CPP * NT * LDT;
+#if P1F_DIRECT
+    static constexpr int WAVE_TILE = 64;                // only the 64-word scratch of the per-chunk maximum
+#else
+    static constexpr int WAVE_TILE = CPP * NT * LDT;
+#endif
+    static constexpr int TILE_FLOATS = P1F_WPB * WAVE_TILE;
 };
 template <int W, int NT>
 __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
@@ -762,7 +770,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* tile = tile_all + wv * (CPP * NT * LDT);
+    float* tile = tile_all + wv * G::WAVE_TILE;
     const int cl = lane / NG, grp = lane - cl * NG;
     const int q0 = (blk_id * P1F_WPB + wv) * CPW;
     if (fixcnt && blk_id == 0 && wv == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
@@ -879,6 +887,33 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
         }
     }
     // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
+#if P1F_DIRECT
+    // Straight from the registers: 16 bytes per lane and row, the NG lanes of a chunk cover the row's W floats, NT store
+    // instructions.  No LDS tile: the workgroup's footprint drops from 64 KB to the zero-state units' 7 KB, so that it fits
+    // a CU beside TWO oscillator workgroups (2 x 73 KB of the 160 KB) while other batches are in flight -- see P1F_DIRECT.
+    if (live) {
+        float* prow = PhiT + (size_t)q * NT * W + jb;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bool ok = i < M;
+            const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
+            float4 v;
+            v.x = (ok && jb < M) ? va.x : 0.f;
+            v.y = (ok && jb + 1 < M) ? va.y : 0.f;
+            v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
+            v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
+            if (jb + 3 < W) *reinterpret_cast<float4*>(prow + (size_t)i * W) = v;
+            if constexpr (4 * NG < W) {   // columns no trajectory group covers: zeros (the group composites read whole rows)
+                if (grp == NG - 1) {
+#pragma unroll
+                    for (int cc = 4 * NG; cc < W; cc += 4)
+                        *reinterpret_cast<float4*>(prow - jb + cc + (size_t)i * W) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    }
+    return;
+#endif
     // Copy-out through the wave's LDS tile, CPP chunks per pass: CPP chunks x NT rows x W floats are contiguous in PhiT.
     constexpr int RW4 = W / 4;
     for (int c0 = 0; c0 < CPW; c0 += CPP) {
@@ -1135,7 +1170,8 @@ struct FixArgs {
 // any number of waves can share the work in any order: the workgroups that lead the grid guarantee that it gets done
 // (they are resident or finished before any wave that waits for them starts), the ones that trail the grid only make it
 // faster when there is room for them.  `hotlist`: the wave's own LDS scratch for the compact list of hot chunks.
-constexpr int kHotListMax = 1024;   // chunks per utterance the compact list holds (ushort); longer utterances enumerate all chunks
+constexpr int kHotListMax = 512;    // chunks per utterance the compact list holds (ushort); longer utterances enumerate all chunks
+                                    // (4 lists x 1 KB + the composites' 8 KB = 12 KB: the pre-pass fits a CU beside two oscillator workgroups)
 template <int W, int NT>
 __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes_tier, unsigned short* __restrict__ hotlist) {
     constexpr int TPL = quad_tpl(W, NT);
