@@ -5,6 +5,8 @@ Every function raises if the tensors are not fp32 ROCm-device tensors — no CPU
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 from . import _lib
@@ -978,16 +980,30 @@ class _HarmonicOsc(torch.autograd.Function):
     def backward(ctx, g_out):
         phase, tscale, hscale, amp, phase_offset, initial_phase = ctx.saved_tensors
         H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = ctx.geom
-        if ctx.needs_input_grad[10]:
-            raise NotImplementedError("golf_amd: no gradient w.r.t. the harmonic oscillator's initial_phase (a constant in "
-                                      "every reference call site, models/synth.py:411)")
         if ctx.needs_input_grad[3]:
             raise NotImplementedError("golf_amd: the per-harmonic scale of the harmonic oscillator is a constant "
                                       "(SawToothOscillator's 1/h buffer)")
         lib = _lib.load()
         g_out = _rows(g_out.float())
         B, Tp = phase.shape
-        g_phase = g_amp = g_ts = g_po = None
+        g_phase = g_amp = g_ts = g_po = g_ip = None
+        if ctx.needs_input_grad[10]:
+            # d out / d initial_phase[b,h] = 2 pi sum_t g[t] A_h[t] cos(2 pi theta_h[t]), A = the (masked, scaled) amplitude
+            # track.  cos(x) = sin(x + 1/4 cycle) and A_h[t] = sum_f hat_f(t) amp[b,f,h]: the amplitude-gradient kernel run
+            # with initial_phase + 1/4 returns G[b,f,h] = sum_t hat_f(t) g[t] cos(.) (scales and Nyquist mask included), and
+            # g_ip = 2 pi sum_f amp[b,f,h] G[b,f,h].  Without an amplitude track (A = 1): two frames one whole signal apart,
+            # whose hat functions sum to one.  (reference: autograd through models/synth.py:434-440)
+            Fq, hq = (Fa, amp_hop) if has_amp else (2, max(Tout - 1, 1))
+            G = torch.empty(B, Fq, H, dtype=torch.float32, device=phase.device)
+            ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fq, H), phase.device)
+            shifted = (initial_phase + 0.25).contiguous()
+            rc = lib.golf_harmonic_osc_bwd_amp_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(),
+                                                   phase.stride(0), Tp, phase_hop, Fq, hq, _lib.ptr(tscale), Fs,
+                                                   ts_hop, _lib.ptr(hscale), H, G.data_ptr(), B, Tout,
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr(), _lib.ptr(phase_offset),
+                                                   ctx.po[0], ctx.po[1], shifted.data_ptr())
+            _lib.check(rc, "golf_harmonic_osc_bwd_amp_f32")
+            g_ip = (2.0 * math.pi) * ((G * amp).sum(1) if has_amp else G.sum(1))
         if has_amp and ctx.needs_input_grad[1]:
             g_amp = torch.empty(B, Fa, H, dtype=torch.float32, device=phase.device)
             ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fa, H), phase.device)
@@ -1014,7 +1030,7 @@ class _HarmonicOsc(torch.autograd.Function):
             S = _HarmonicOsc._run(lib, "golf_harmonic_osc_fwd_f32", phase, amp if has_amp else None, None, hscale, geom,
                                   phase_offset, ctx.po, initial_phase)
             g_ts = upsample_adjoint(g_out[:, :Tout] * S, ts_hop, Fs)
-        return g_phase, g_amp, g_ts, None, None, None, None, None, g_po, None, None
+        return g_phase, g_amp, g_ts, None, None, None, None, None, g_po, None, g_ip
 
 
 def upsample_adjoint(v: torch.Tensor, hop: int, F: int) -> torch.Tensor:
@@ -1036,7 +1052,7 @@ def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, 
                  hscale=None, phase_offset=None, po_hop: int = 1, initial_phase=None) -> torch.Tensor:
     """out[t] = sum_h [h p(t) < 0.5] * up(amp)[t,h] * up(tscale)[t] * hscale[h]
                       * sin(2 pi (h (cumsum(p)[t] + up(phase_offset)[t]) + initial_phase[b,h])),   p = up(phase);
-    differentiable w.r.t. ``amp``, ``phase``, ``tscale`` and ``phase_offset`` (reference models/synth.py:403-446)."""
+    differentiable w.r.t. ``amp``, ``phase``, ``tscale``, ``phase_offset`` and ``initial_phase`` (reference models/synth.py:403-446)."""
     return _HarmonicOsc.apply(phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop, phase_offset, int(po_hop),
                               initial_phase)
 

@@ -986,6 +986,20 @@ def harmonic_oscillator_backward_offset(gy, phase, phase_hop: int, amplitudes, a
     return _upsample_adjoint(gy * d, po_hop, np.asarray(phase_offset).shape[1])
 
 
+def harmonic_oscillator_backward_initial_phase(gy, phase, phase_hop: int, amplitudes, amp_hop: int, phase_offset=None,
+                                               po_hop: int = 1, initial_phase=None) -> np.ndarray:
+    """d/d initial_phase[b,h] of harmonic_oscillator_forward (autograd through models/synth.py:434-446):
+    sum_t gy[t] * amp[t,h] * mask * 2 pi cos(2 pi phase_h[t])."""
+    amplitudes = np.asarray(amplitudes, dtype=np.float64)
+    gy = np.asarray(gy, dtype=np.float64)
+    n_out = gy.shape[1]
+    H = amplitudes.shape[-1]
+    A = linear_upsample(amplitudes, amp_hop, axis=1)[:, :n_out]
+    dcos, mask = _harmonic_terms(phase, phase_hop, H, n_out, phase_offset, po_hop, initial_phase, deriv=True)
+    dcos = dcos / np.arange(1, H + 1, dtype=np.float64)          # d / d initial_phase: no factor h
+    return np.einsum("bt,bth->bh", gy, dcos * mask * A)
+
+
 def harmonic_oscillator_backward_amp(gy, phase, phase_hop: int, amplitudes_shape, amp_hop: int) -> np.ndarray:
     """d/d amplitudes of harmonic_oscillator_forward (the phase is data)."""
     gy = np.asarray(gy, dtype=np.float64)

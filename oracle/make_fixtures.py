@@ -800,7 +800,7 @@ for tag, (B, F, K, hop, W, T) in (("a", (2, 9, 3, 8, 32, 64)), ("b", (1, 6, 5, 1
 save("g26_biquad_cascade_grads", **d)
 # ----------------------------------------------------------------------------- g27 harmonic oscillator with phase terms (a-11)
 # HarmonicOscillator.forward with initial_phase (B,H) and phase_offset (hop-rate AudioTensor), models/synth.py:429-435:
-# values and the reference's autograd gradients w.r.t. the amplitudes and the phase offset.  Own generator.
+# values and the reference's autograd gradients w.r.t. the amplitudes, the phase offset and the initial phase.  Own generator.
 rng27 = np.random.default_rng(27)
 d = {}
 H = 6
@@ -818,12 +818,12 @@ for tag, (B, Tp, ph, Fa, ah, Fo, oh) in (("t", (2, 97, 1, 7, 16, 13, 8)), ("r", 
     phase = dyadic((B, Tp), 10, 0.01, 0.12)
     amp = torch.from_numpy(rng27.uniform(0, 1, (B, Fa, H)).astype(np.float32)).requires_grad_(True)
     off = torch.from_numpy(rng27.uniform(-1.5, 1.5, (B, Fo)).astype(np.float32)).requires_grad_(True)
-    ip = torch.from_numpy(rng27.uniform(-1, 1, (B, H)).astype(np.float32))
+    ip = torch.from_numpy(rng27.uniform(-1, 1, (B, H)).astype(np.float32)).requires_grad_(True)
     y = rs.HarmonicOscillator()(AT(phase, ph), AT(amp, ah), initial_phase=ip, phase_offset=ATu(off, oh)).as_tensor()
     gy = torch.from_numpy(rng27.normal(0, 1, tuple(y.shape)).astype(np.float32))
     (y * gy).sum().backward()
     d.update({f"{tag}_phase": phase, f"{tag}_phase_hop": ph, f"{tag}_amp": amp, f"{tag}_amp_hop": ah, f"{tag}_offset": off,
               f"{tag}_offset_hop": oh, f"{tag}_initial_phase": ip, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_g_amp": amp.grad,
-              f"{tag}_g_offset": off.grad})
+              f"{tag}_g_offset": off.grad, f"{tag}_g_initial_phase": ip.grad})
 save("g27_harmonic_phase_terms", **d)
 print("done")

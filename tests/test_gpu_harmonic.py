@@ -189,7 +189,7 @@ def test_additive_synth_trains_through_f0():
 def test_harmonic_phase_terms_golden_g27(golden, tag):
     """initial_phase (B,H) and phase_offset (an AudioTensor at its own hop) of HarmonicOscillator.forward,
     models/synth.py:429-435: the drop-in module against the reference's values and its autograd gradients w.r.t. the
-    amplitudes and the offset."""
+    amplitudes, the offset and the initial phase."""
     from golf_amd.audiotensor import AudioTensor
     from golf_amd.synth import HarmonicOscillator
 
@@ -197,18 +197,45 @@ def test_harmonic_phase_terms_golden_g27(golden, tag):
     dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
     amp = dev(g[f"{tag}_amp"]).requires_grad_(True)
     off = dev(g[f"{tag}_offset"]).requires_grad_(True)
+    ip = dev(g[f"{tag}_initial_phase"]).requires_grad_(True)
     osc = HarmonicOscillator().cuda()
     y = osc(AudioTensor(dev(g[f"{tag}_phase"]), int(g[f"{tag}_phase_hop"])), AudioTensor(amp, int(g[f"{tag}_amp_hop"])),
-            initial_phase=dev(g[f"{tag}_initial_phase"]),
-            phase_offset=AudioTensor(off, int(g[f"{tag}_offset_hop"]))).as_tensor()
+            initial_phase=ip, phase_offset=AudioTensor(off, int(g[f"{tag}_offset_hop"]))).as_tensor()
     (y * dev(g[f"{tag}_gy"])).sum().backward()
     torch.cuda.synchronize()
     for name, got, want in (("y", y.detach(), g[f"{tag}_y"]), ("g_amp", amp.grad, g[f"{tag}_g_amp"]),
-                            ("g_offset", off.grad, g[f"{tag}_g_offset"])):
+                            ("g_offset", off.grad, g[f"{tag}_g_offset"]),
+                            ("g_initial_phase", ip.grad, g[f"{tag}_g_initial_phase"])):
         got = got.cpu().numpy()
         err = np.abs(got - want).max() / np.abs(want).max()
         print(f"g27{tag} {name}: rel-max {err:.2e}")
         assert got.shape == want.shape and err <= 1e-4, (name, err)
+
+
+def test_initial_phase_gradient_without_amplitude_track():
+    """SawToothOscillator (constant 1/h scale, no amplitude track) with a trainable initial_phase: the gradient comes from the
+    amplitude-gradient kernel run a quarter cycle ahead over two frames whose hat functions sum to one; checked against the
+    float64 oracle's closed form with amplitudes = 1/h at every frame."""
+    from golf_amd import functional as GF
+    from oracle import golf_oracle as O
+
+    rng = np.random.default_rng(31)
+    B, T, H = 2, 1201, 12
+    dev = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).cuda()
+    phase = (rng.uniform(150, 500, (B, 1)) * (1 + 0.05 * np.sin(np.arange(T) / 90.0)) / 24000).astype(np.float32)
+    hs = (1.0 / np.arange(1, H + 1)).astype(np.float32)
+    ip = dev(rng.uniform(-1, 1, (B, H))).requires_grad_(True)
+    gy = rng.normal(0, 1, (B, T)).astype(np.float32)
+    y = GF.harmonic_osc(dev(phase), H, 1, hscale=dev(hs), initial_phase=ip)
+    (y * dev(gy)).sum().backward()
+    amp = np.broadcast_to(hs, (B, 2, H)).astype(np.float64)
+    ipn = ip.detach().cpu().numpy()
+    ref_y = O.harmonic_oscillator_forward(phase, 1, amp, T - 1, None, 1, ipn)
+    ref_g = O.harmonic_oscillator_backward_initial_phase(gy, phase, 1, amp, T - 1, None, 1, ipn)
+    ey = np.abs(y.detach().cpu().numpy() - ref_y).max() / np.abs(ref_y).max()
+    eg = np.abs(ip.grad.cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
+    print(f"saw-tooth bank with initial_phase: y {ey:.2e}, g_initial_phase {eg:.2e}")
+    assert ey <= 1e-4 and eg <= 1e-4, (ey, eg)
 
 
 def test_harmonic_phase_terms_full_size():
