@@ -423,15 +423,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)   # before the communicator exists: RCCL's first collective binds to the current device
+    device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.dist_backend)  # "nccl" is RCCL on ROCm
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
 
     if args.fork_transitions:
         import golf_amd.functional as _GF

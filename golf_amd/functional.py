@@ -202,6 +202,12 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``status``: optional int32 device tensor of >= 4 elements that receives, asynchronously, the conditioning / health
     words of this call (decode with ss_status): utterances with recomputed chunk maps, utterances on the fp64 boundary
     scan, non-finite output flag, largest transition-matrix entry."""
+    if ex.dim() == 2 and (ex.shape[0] == 0 or ex.shape[1] == 0):
+        # an empty batch / zero samples: what the reference's tensor ops return (an empty result that stays in the graph);
+        # the C ABI itself rejects non-positive sizes
+        _lib.require_device(ex, gain, a)
+        T = ss_output_length(ex.shape[1], a.shape[1], int(hop)) if ex.shape[1] else 0
+        return ex[:, :T] * 1.0 + 0.0 * (gain.sum() + a.sum())
     return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode], status)
 
 
@@ -470,6 +476,11 @@ def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampli
     """Indexed glottal-flow wavetable oscillator (see include/golf_amd.h golf_glottal_osc_fwd_f32).
     ``add`` (B, Tadd), oversampling > 1: fused ``out[:, :Tadd] += add`` (differentiable w.r.t. ``add``); the caller
     truncates to the common length as AudioTensor addition would."""
+    if phase.dim() == 2 and phase.shape[0] == 0:   # an empty batch: empty outputs of the right widths, like the reference's ops
+        _lib.require_device(phase, wsel, table)
+        N, Tout = osc_lengths(phase.shape[1], int(phase_hop), int(oversampling))
+        out = phase.new_zeros(0, Tout) + 0.0 * wsel.sum()
+        return (out, phase.new_zeros(0, N)) if return_pre else out
     if add is not None and oversampling <= 1:   # no decimator to fuse into
         out, pre = _GlottalOsc.apply(phase, wsel, table, taps, int(phase_hop), int(w_hop), int(oversampling),
                                      bool(equal_energy), bool(return_pre))

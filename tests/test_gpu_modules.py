@@ -340,3 +340,26 @@ def test_long_utterance_decoder_vs_oracle():
     emax, el2 = rel_err(y.detach().cpu().numpy(), ref)
     print("12.5 s decoder", y.shape, emax, el2)
     assert emax < 1e-4 and el2 < 1e-4
+
+
+def test_empty_batch_and_zero_samples():
+    """B = 0 / zero excitation samples: the reference's tensor ops return empty results that stay in the autograd graph;
+    the drop-in wrappers do the same (the C ABI itself rejects non-positive sizes with GOLF_EINVAL)."""
+    from golf_amd import functional as GF
+    from golf_amd import _lib
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=2, T=2400, device="cuda")
+    a0 = inp["a"][:0].clone().requires_grad_(True)
+    y = GF.ltv_allpole_ss(inp["noise"][:0], inp["gain"][:0], a0, 240)
+    assert y.shape == (0, 2400) and y.requires_grad
+    y.sum().backward()
+    assert a0.grad.shape == a0.shape
+    y = GF.ltv_allpole_ss(inp["noise"][:, :0], inp["gain"], inp["a"], 240)
+    assert y.shape == (2, 0)
+    osc_args = (inp["wsel"][:0], torch.rand(8, 2048, device="cuda"), torch.ones(129, device="cuda") / 129, 1, inp["w_hop"], 4, True)
+    out = GF.glottal_osc(inp["phase"][:0], *osc_args)
+    assert out.shape == (0, GF.osc_lengths(inp["phase"].shape[1], 1, 4)[1])
+    lib = _lib.load()
+    rc = lib.golf_ltv_allpole_fwd_f32(0, 0, 0, 0, 0, 0, 0, 2400, 11, 22, 240, 0, 0, 0, 0, 0)
+    assert rc != 0   # GOLF_EINVAL, no launch

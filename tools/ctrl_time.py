@@ -1,5 +1,5 @@
-import torch, time, sys
-sys.path.insert(0, '/root/repo')
+import os, torch, time, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from golf_amd.synthetic import make_decoder
 from golf_amd.audiotensor import AudioTensor
 dec = make_decoder().cuda()

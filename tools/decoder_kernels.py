@@ -1,7 +1,7 @@
 """Kernels of one module-level decoder call (golf-precise.yaml) driven from encoder logits: names, counts, device time."""
-import sys
+import os, sys
 import torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py"]
 import bench
 from golf_amd.synthetic import make_inputs
