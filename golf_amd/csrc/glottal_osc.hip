@@ -603,10 +603,16 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 #ifndef OSCF_TO               // (tile geometry as build parameters: occupancy experiments)
 #define OSCF_TO 2048
 #endif
+#ifndef OSCF_THREADS
 #define OSCF_THREADS 512
+#endif
 #ifndef OSCF_CPT
 #define OSCF_CPT 5            // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + 4 * KS
 #endif
+#ifndef OSCF_ROWS
+#define OSCF_ROWS 0           // 1: the blended control-frame rows staged as plain rows (nrows x (L+1) floats) instead of
+#endif                        //    (value, difference) pairs: 24.6 instead of 32.8 KB at 3 rows, two more VALU + one more LDS
+                              //    instruction per lookup (occupancy experiments)
 #ifndef OSCF_MIN_WAVES
 #define OSCF_MIN_WAVES 1      // launch bound: waves per SIMD the register allocation must allow
 #endif
@@ -616,6 +622,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
 //  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
 #define OSCT_THREADS 512
+template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backward's OSCB_TO
 __global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
@@ -641,9 +648,9 @@ __global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const flo
     // (coalesced; the successor p_{j+1} is a second, cached, coalesced load).  Round 2 gave each thread 8 consecutive
     // samples (lane stride 32 B: every load instruction touched all the wave's cache lines) on 256 threads: 1.47 ms at
     // B = 16 384 where 512 threads x 4 consecutive samples already took 0.83 ms (tile-geometry experiment).
-    constexpr int PER = OSCF_TO / OSCT_THREADS;
-    static_assert(OSCF_TO % OSCT_THREADS == 0, "tile = whole passes of the workgroup");
-    const int j0 = tile * OSCF_TO + tid;
+    constexpr int PER = TO / OSCT_THREADS;
+    static_assert(TO % OSCT_THREADS == 0, "tile = whole passes of the workgroup");
+    const int j0 = tile * TO + tid;
     float p0[PER], p1[PER];
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
@@ -692,6 +699,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     // layout: X polyphase signal tile [4][XS] | row pairs [(nrows-1)][L+1] float2
     float* X = smem;
     float2* pairs = reinterpret_cast<float2*>(smem + OS * XS);
+    float* rowsL = smem + OS * XS;               // (OSCF_ROWS) the same region as plain rows [nrows][L+1]
     const int LR = L + 1;
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -756,6 +764,19 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
                         R[e][u] = fmaf(vb, pw[e], va * (1.0f - pw[e]));
                     }
                 }
+#if OSCF_ROWS
+#pragma unroll
+            for (int rr = 0; rr < OSCF_MAXROWS; ++rr)
+                if (rr < nrw) {
+                    float* dst = rowsL + (size_t)rr * LR;
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int c = cb0 + u * NTH + tid;
+                        if (c < L) dst[c] = R[rr][u];
+                        if (c == 0) dst[L] = R[rr][u];
+                    }
+                }
+#else
 #pragma unroll
             for (int rr = 0; rr + 1 < OSCF_MAXROWS; ++rr)
                 if (rr + 1 < nrw) {
@@ -768,6 +789,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
                         if (c == 0) dst[L] = pr;
                     }
                 }
+#endif
         }
     }
     // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
@@ -822,6 +844,8 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
             const int m0 = j * P;
             const int rr = (m0 >= bnd1) + (m0 >= bnd2);
             const float2* ra = pairs + (size_t)rr * LR;
+            const float* rwa = rowsL + (size_t)rr * LR;
+            (void)ra; (void)rwa;
             float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
             const bool v0 = j >= 0 && j <= Tp - 1;     // fine sample k = 0 exists
             const bool vk = j >= 0 && j < Tp - 1;      // k = 1..3 exist (the last coarse sample has only k = 0)
@@ -851,8 +875,13 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
                 const unsigned hi = hik[k];
                 const int c0 = (int)(hi >> (32 - lshift));
                 const float cf = (float)__builtin_amdgcn_ubfe(hi, (unsigned)fo, (unsigned)fw) * fscale;
+#if OSCF_ROWS
+                const float a0 = rwa[c0], a1 = rwa[c0 + 1], b0 = rwa[LR + c0], b1 = rwa[LR + c0 + 1];
+                const float t0 = fmaf(rf, b0 - a0, a0), t1 = fmaf(rf, b1 - a1, a1);
+#else
                 const float2 e0 = ra[c0], e1 = ra[c0 + 1];
                 const float t0 = fmaf(rf, e0.y, e0.x), t1 = fmaf(rf, e1.y, e1.x);
+#endif
                 float v = fmaf(cf, t1 - t0, t0);
                 if (EE) v *= sck[k];
                 xp[k * XS] = (k == 0 ? v0 : vk) ? v : 0.f;
@@ -894,7 +923,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
-// One workgroup owns OSCF_TO coarse samples (no halo on the sample side: every fine sample is counted once) of one
+// One workgroup owns OSCB_TO coarse samples (no halo on the sample side: every fine sample is counted once) of one
 // utterance:
 //   1. the gradient tile Y[v] = g_out[o0 - dmax + v] (+ the FIR's reach on both sides) -> LDS, the table DIFFERENCE rows
 //      D_k = T[i0_k + 1] - T[i0_k] of the control frames the tile touches -> LDS, the phase scan as in the forward;
@@ -906,16 +935,18 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
 //      part[b][tile][row].  osc_wsel_reduce_tiles_kernel adds the tiles' rows into g_wsel.
 // Replaces osc_phase_tile + osc_decimate_T4 + osc_render<1> (46 us and a 12 MB prefix + a 24 MB oversampled gradient on a
 // round trip through HBM at B = 32) for the GOLF configuration; everything else keeps the three-kernel path.
-#define OSCB_CPT (OSCF_TO / OSCF_THREADS)
+#define OSCB_TO 2048          // the backward's own tile geometry (independent of the forward's build parameters)
+#define OSCB_THREADS 512
+#define OSCB_CPT (OSCB_TO / OSCB_THREADS)
 template <int EE, int KS>
-__global__ __launch_bounds__(OSCF_THREADS) void osc_fused_bwd_kernel(
+__global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
     const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
     int hop_t, const float* __restrict__ Bf, const float* __restrict__ g_out, int64_t g_out_stride, int Tout, int dmax,
     int nrows, float* __restrict__ part) {
-    constexpr int P = 4, NTH = OSCF_THREADS, CPT = OSCB_CPT;
-    static_assert(OSCF_TO == 2048 && OSCF_THREADS == 512, "4 consecutive coarse samples per thread, 8 waves x 256 outputs");
-    constexpr int spanY = OSCF_TO + 4 * KS;                     // gradient samples the windows reach
+    constexpr int P = 4, NTH = OSCB_THREADS, CPT = OSCB_CPT;
+    static_assert(OSCB_TO == 2048 && OSCB_THREADS == 512, "4 consecutive coarse samples per thread, 8 waves x 256 outputs");
+    constexpr int spanY = OSCB_TO + 4 * KS;                     // gradient samples the windows reach
     constexpr int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;  // padded like the forward's signal tile
     constexpr int GR = 20;                                       // words per thread row of the fine-gradient tile: 16 + 4, so
     // that a thread reads its row as four 16-byte words and 16 consecutive lanes cover all 64 banks exactly once
@@ -930,7 +961,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_bwd_kernel(
     const int LR = L + 1;
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int o0 = tile * OSCF_TO;
+    const int o0 = tile * OSCB_TO;
     // ---- 0. reversed Toeplitz fragments (osc_tile_totals_kernel, reversed = 1)
     float bfrag[4][KS];
 #pragma unroll
@@ -963,7 +994,7 @@ __global__ __launch_bounds__(OSCF_THREADS) void osc_fused_bwd_kernel(
     const int m_first = o0 * P;
     const int r_first = m_first / hop_t;
     {
-        const int m_last = min(o0 + OSCF_TO - 1, Tp - 1) * P + (P - 1);
+        const int m_last = min(o0 + OSCB_TO - 1, Tp - 1) * P + (P - 1);
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);
         const float* t0[OSCF_MAXROWS];
 #pragma unroll
@@ -1121,7 +1152,7 @@ __global__ void osc_wsel_reduce_tiles_kernel(const float* __restrict__ part, flo
     const int b = idx / Fw, k = idx - b * Fw;
     float acc = 0.f;
     // only the tiles whose staged rows can be frame k: r_first(t) in [k - 3, k] (the last frame also collects the clamped rows)
-    const int fine = OSCF_TO * 4;
+    const int fine = OSCB_TO * 4;
     int t_lo = (int)(((int64_t)(k - (OSCF_MAXROWS - 1)) * hop_t) / fine) - 1;
     int t_hi = k >= Fw - 1 ? ntile - 1 : (int)(((int64_t)(k + 1) * hop_t) / fine) + 1;
     t_lo = t_lo < 0 ? 0 : t_lo;
@@ -1625,13 +1656,17 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         const int nrows = nrows_force > 0 ? nrows_force : nint_touched + 1;
         const int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;       // padded polyphase row: i + 4 * (i >> 4)
         static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
+#if OSCF_ROWS
+        const size_t ldsf = sizeof(float) * ((size_t)os * XS + (size_t)nrows * (L + 1)) + lds_pad;
+#else
         const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1)) + lds_pad;
+#endif
         if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin < span &&
             ldsf <= 80 * 1024 + lds_pad) {
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
             float* Bf = (float*)((char*)ws + g.off_bf);
-            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
+            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
                                g.P, os, ntile2, taps, K, dmin, KS, Bf);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
@@ -1705,19 +1740,19 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         const int dmax = half / os;
         const int nq = dmax - dmin + 1;
         const int KS = nq + 15 <= 48 ? 12 : 16;
-        const int nint_touched = (OSCF_TO * 4 - 2) / g.hop_t + 2;
+        const int nint_touched = (OSCB_TO * 4 - 2) / g.hop_t + 2;
         const int nrows = nint_touched + 1;
-        const int spanY = OSCF_TO + 4 * KS;
+        const int spanY = OSCB_TO + 4 * KS;
         const int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;
-        const size_t ldsb = sizeof(float) * ((size_t)YS + (size_t)OSCF_THREADS * 20 + (size_t)nrows * (L + 1));
-        const int ntile2 = (int)ceil_div(Tp, OSCF_TO);            // tiles of COARSE SAMPLES here (Tp = Tout at hop 1)
+        const size_t ldsb = sizeof(float) * ((size_t)YS + (size_t)OSCB_THREADS * 20 + (size_t)nrows * (L + 1));
+        const int ntile2 = (int)ceil_div(Tp, OSCB_TO);            // tiles of COARSE SAMPLES here (Tp = Tout at hop 1)
         if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && ldsb <= 80 * 1024 && ntile2 <= g.ntile &&
             sizeof(float) * (size_t)B * ntile2 * OSCF_MAXROWS <= sizeof(float) * (size_t)B * g.pre_stride) {
             const int lshift = 31 - __builtin_clz((unsigned)L);
             u64* Ttot = (u64*)((char*)ws + g.off_ttot);
             float* Bf = (float*)((char*)ws + g.off_bf);
             float* part2 = (float*)((char*)ws + g.off_pre);      // the oversampled-gradient buffer is not needed here
-            hipLaunchKernelGGL(osc_tile_totals_kernel, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
+            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
                                g.P, os, ntile2, taps, K, dmin, KS, Bf, 1, dmax);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \
@@ -1727,7 +1762,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         if (lds_attr != hipSuccess)                                                                                   \
             return fail((int)lds_attr, "glottal_osc_bwd: cannot raise the dynamic LDS limit: %s",                     \
                         hipGetErrorString(lds_attr));                                                                 \
-        hipLaunchKernelGGL((osc_fused_bwd_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsb, st, phase,     \
+        hipLaunchKernelGGL((osc_fused_bwd_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCB_THREADS), ldsb, st, phase,     \
                            phase_stride, (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t,    \
                            (const float*)Bf, g_out, g_out_stride, Tout, dmax, nrows, part2);                          \
     } while (0)
