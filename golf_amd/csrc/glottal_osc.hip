@@ -621,7 +621,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
 //  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
+#ifndef OSCT_THREADS
 #define OSCT_THREADS 512
+#endif
 template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backward's OSCB_TO
 __global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
