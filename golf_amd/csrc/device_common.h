@@ -87,11 +87,21 @@ struct Tile {
     }
 };
 
-// Orders the LDS traffic of ONE wave (a wave that owns its LDS region needs no workgroup barrier).
+// Orders the LDS traffic of ONE wave (a wave that owns its LDS region needs no workgroup barrier).  The fences name the
+// LDS address space: a fence over all address spaces also waits for the wave's outstanding GLOBAL stores and prefetch
+// loads (s_waitcnt vmcnt(0)) -- in the kernels that store a tile and then fence, once per block of the recursion, that was
+// a store round trip on the critical path of every block (found in round 3 with the block-recursion frame kernel, where it
+// was 2/3 of the kernel: DESIGN.md 4.2).
 __device__ __forceinline__ void wave_lds_fence() {
+#ifdef GOLF_FENCE_ALL_SPACES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#endif
 }
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {

@@ -223,6 +223,234 @@ __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restr
     y[(size_t)b * y_stride + n] = acc / norm;
 }
 
+// ------------------------------------------------------------------------------------------
+// Block recursion (round 3): 16 samples of a frame per step instead of one.
+// A frame's coefficients are CONSTANT, so the recursion's look-ahead form costs its set-up once per frame:
+//     y[n + r] = sum_{m <= r} h[r - m] x[n + m]  +  sum_j G[r][j] y[n - 1 - j],        r = 0 .. 15,
+// h = the frame's impulse response, G[r] = e_0^T C^(r+1) (C = companion matrix of the frame's coefficients) -- both from one
+// 16-step row recurrence v <- v^T C (v[j] <- v[j+1] - a_j v[0]; h[s] = v_s[0], G[s] = v_(s+1)) that every lane of the frame
+// runs.  16 lanes own one frame, lane r owns row r (16 + NS coefficients in registers): a block is 38 independent FMAs per
+// lane on operands broadcast from LDS (the block's 16 inputs, the last NS outputs), and the serial chain per frame is Wl / 16
+// = 60 blocks instead of 960 samples: ~45 instructions per 16 samples and lane against ~18 per sample for a quad of the
+// direct form (ff_framesq_kernel) -- the same lane-instructions per sample, a quarter of the chain, four times the waves
+// (1 600 at B = 32, where the quads' 400 left 60 % of the SIMDs idle).
+// Arithmetic: not the reference's order of operations (each output is a dot product with impulse-response values instead of
+// a feedback sum with the coefficients), same conditioning (h and G are what the feedback sum builds implicitly); measured
+// against the float64 oracle next to the direct form in tests/test_gpu_lpc_ff.py.
+// Inputs: forward -- the union of the wave's 4 overlapping frames, ex * up(gain), staged once in LDS; adjoint (REV) -- the 4
+// frames' window * g_q products, staged per frame, the recursion walking them backwards.
+//   grid (ceil(nfr / 4), B), 64 threads; needs Wl % 32 == 0, hop % 4 == 0, M <= NT <= 24; dynamic LDS = the staged inputs.
+#ifndef FF_SETUP_T
+#define FF_SETUP_T double
+#endif
+template <int NT, bool REV>
+__global__ __launch_bounds__(64) void ff_framesb_kernel(const float* __restrict__ ex, int64_t ex_stride,
+                                                        const float* __restrict__ gain, const float* __restrict__ a,
+                                                        const float* __restrict__ window, float* __restrict__ wf,
+                                                        int Tx, int F, int M, int hop, int Wl, int nfr, float kappa_max) {
+    constexpr int NS = (NT + 3) & ~3;          // state values a block reads (whole 16-byte words)
+    constexpr int NS4 = NS / 4;
+    static_assert(NS <= 24, "the output ring holds two blocks");
+    __shared__ __attribute__((aligned(16))) double Gs[4][16][NS];
+    __shared__ __attribute__((aligned(16))) float hs[4][32];
+    __shared__ __attribute__((aligned(16))) double yr[4][32];   // the last two blocks' outputs, kept in double: the FEEDBACK
+    // part of a block (G . state) runs in double -- C^16's rows cancel against the state as the coefficients themselves do
+    // in the direct form, only sixteen-fold, and in fp32 that cost 1.5 digits (5e-3 instead of 1e-4 on the order-22 filter
+    // with poles at 0.97); the input part (h . x) has no such cancellation and stays fp32.
+    extern __shared__ __attribute__((aligned(16))) float stage[];   // forward: U[3 hop + Wl]; adjoint: P[4][Wl]
+    const int lane = threadIdx.x, fr = lane >> 4, r = lane & 15;
+    const int b = blockIdx.y, f0 = blockIdx.x * 4;
+    const int f = f0 + fr;
+    const bool mine = f < nfr;
+    const int fc = mine ? f : nfr - 1;
+    const int pad = Wl / 2;
+    const BufRow xrow(ex + (size_t)b * ex_stride, Tx);
+    // ---- inputs -> LDS (coalesced, zero outside [0, Tx): the frames' zero padding)
+    if (!REV) {
+        const float inv_hop = 1.0f / (float)hop;
+        const float* gb = gain + (size_t)b * F;
+        const int nu = 3 * hop + Wl;
+        constexpr int UB = 8;   // loads of UB elements in flight before the first is used (a loop of dependent round trips otherwise)
+        for (int i0 = lane; i0 < nu; i0 += 64 * UB) {
+            float xv_[UB], g0_[UB], g1_[UB], nn_[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + 64 * u;
+                const int d = i - pad;
+                int q = (int)floorf((float)d * inv_hop);
+                int n = d - q * hop;
+                if (n < 0) { n += hop; q -= 1; }
+                if (n >= hop) { n -= hop; q += 1; }
+                int ft = f0 + q;
+                if (ft > F - 2) { n += (ft - (F - 2)) * hop; ft = F - 2; }
+                if (ft < 0) { ft = 0; n = 0; }   // t < 0: the sample is zero padding anyway
+                g0_[u] = gb[ft];
+                g1_[u] = gb[ft + 1];
+                nn_[u] = (float)n;
+                xv_[u] = xrow.ld(f0 * hop - pad + i);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + 64 * u;
+                if (i < nu) stage[i] = xv_[u] * fmaf(nn_[u], (g1_[u] - g0_[u]) * inv_hop, g0_[u]);
+            }
+        }
+    } else {
+        constexpr int UB = 8;
+        const BufRow wrow(window, Wl);
+        for (int k0s = lane; k0s < Wl; k0s += 64 * UB) {   // 4 frames x UB positions per pass
+            float xv_[4][UB], wv_[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int k = k0s + 64 * u;
+                wv_[u] = wrow.ld(k);
+#pragma unroll
+                for (int ff = 0; ff < 4; ++ff) xv_[ff][u] = xrow.ld(k < Wl ? (f0 + ff) * hop - pad + k : -1);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int k = k0s + 64 * u;
+                if (k < Wl) {
+#pragma unroll
+                    for (int ff = 0; ff < 4; ++ff) stage[ff * Wl + k] = xv_[ff][u] * wv_[u];
+                }
+            }
+        }
+    }
+    // ---- set-up: impulse response and look-ahead rows of this lane's frame
+    // (in double: the rows of C^r cancel heavily while they are built; rounded to fp32 once, they carry only their own
+    //  rounding into the main loop -- fp32 set-up: 5e-3 instead of 1e-4 on the order-22 filter with poles at 0.97)
+    FF_SETUP_T av[NT], v[NT];
+    {
+        // (bounds-checked loads: `i < M ? pa[i] : 0` became NT conditional loads, each waited for -- 22 serial round trips,
+        //  two thirds of the kernel's first version)
+        const BufRow arow(a + ((size_t)b * F + fc) * M, M);
+        float af[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) af[i] = arow.ld(i);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            av[i] = (FF_SETUP_T)af[i];
+            v[i] = i == 0 ? (FF_SETUP_T)1 : (FF_SETUP_T)0;
+        }
+    }
+    hs[fr][r] = 0.f;
+    yr[fr][r] = 0.0;
+    yr[fr][16 + r] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (r == 0) hs[fr][16 + s] = (float)v[0];             // h[s] = (C^s)[0][0]
+        const FF_SETUP_T v0 = v[0];
+#pragma unroll
+        for (int j = 0; j + 1 < NT; ++j) v[j] = __builtin_fma(-av[j], v0, v[j + 1]);
+        v[NT - 1] = -av[NT - 1] * v0;
+        if (r == 0) {                                         // row s of G = e_0^T C^(s+1)
+#pragma unroll
+            for (int j2 = 0; j2 < NS / 2; ++j2) {
+                double2 w2;
+                w2.x = 2 * j2 < NT ? v[(2 * j2) < NT ? 2 * j2 : 0] : 0.0;
+                w2.y = 2 * j2 + 1 < NT ? v[(2 * j2 + 1) < NT ? 2 * j2 + 1 : 0] : 0.0;
+                *reinterpret_cast<double2*>(&Gs[fr][s][2 * j2]) = w2;
+            }
+        }
+    }
+    wave_lds_fence();
+    double Grow[NS];
+    float hrow[16];
+#pragma unroll
+    for (int j2 = 0; j2 < NS / 2; ++j2) {
+        const double2 w2 = *reinterpret_cast<const double2*>(&Gs[fr][r][2 * j2]);
+        Grow[2 * j2] = w2.x; Grow[2 * j2 + 1] = w2.y;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) hrow[m] = hs[fr][16 + r - m];   // h[r - m], 0 for m > r
+    // ---- conditioning tier of the wave: kappa = the largest row sum of |G| among its 4 frames.  The feedback part G . state
+    // cancels like the direct form's coefficient sum does, sixteen-fold: in fp32 it is as accurate as the direct form while
+    // kappa stays small and loses up to 1.5 digits on badly conditioned frames, so those waves -- and only
+    // those -- keep the ring, G and the feedback sum in double.
+    float kap = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) kap += fabsf((float)Grow[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) kap = fmaxf(kap, __shfl_xor(kap, o));
+    const bool precise = __builtin_amdgcn_ballot_w64(!(kap <= kappa_max)) != 0ull;   // wave-uniform (NaN -> precise)
+    // ---- main loop: two blocks per iteration (the output ring's phase is then a compile-time constant)
+    const float* xsrc = REV ? stage + (size_t)fr * Wl : stage + (size_t)fr * hop;
+    float* orow = wf + ((size_t)b * nfr + fc) * Wl;
+    const int nblk = Wl / 16;
+    auto xpart = [&](int k0) -> float {
+        float xv[16];
+        const float* xp = REV ? xsrc + (Wl - 16 - k0) : xsrc + k0;
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(xp + 4 * m4);
+            if (REV) { xv[15 - 4 * m4] = w4.x; xv[14 - 4 * m4] = w4.y; xv[13 - 4 * m4] = w4.z; xv[12 - 4 * m4] = w4.w; }
+            else     { xv[4 * m4] = w4.x; xv[4 * m4 + 1] = w4.y; xv[4 * m4 + 2] = w4.z; xv[4 * m4 + 3] = w4.w; }
+        }
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; m += 4) {
+            acc0 = fmaf(hrow[m], xv[m], acc0);
+            acc1 = fmaf(hrow[m + 1], xv[m + 1], acc1);
+            acc2 = fmaf(hrow[m + 2], xv[m + 2], acc2);
+            acc3 = fmaf(hrow[m + 3], xv[m + 3], acc3);
+        }
+        return (acc0 + acc1) + (acc2 + acc3);
+    };
+    // sv[j] = y[k0 - 1 - j] = ring[(k0 - 1 - j) & 31], k0 & 31 = 16 * par: the word at i0 = (16 par - 4 - 4 j4) & 31 holds
+    // j = 4 j4 + 3 .. 4 j4 in ascending memory order
+    if (precise) {
+        for (int blk = 0; blk < nblk; blk += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int k0 = (blk + par) * 16;           // recursion index of the block's first sample
+                double d0 = (double)xpart(k0), d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+                for (int j4 = 0; j4 < NS4; ++j4) {
+                    const int i0 = ((16 * par - 4 - 4 * j4) & 31);
+                    const double2 lo = *reinterpret_cast<const double2*>(&yr[fr][i0]);
+                    const double2 hi = *reinterpret_cast<const double2*>(&yr[fr][i0 + 2]);
+                    d0 = __builtin_fma(Grow[4 * j4], hi.y, d0);
+                    d1 = __builtin_fma(Grow[4 * j4 + 1], hi.x, d1);
+                    d2 = __builtin_fma(Grow[4 * j4 + 2], lo.y, d2);
+                    d3 = __builtin_fma(Grow[4 * j4 + 3], lo.x, d3);
+                }
+                const double yd = (d0 + d1) + (d2 + d3);
+                wave_lds_fence();                          // every lane has read the ring before it is overwritten
+                yr[fr][16 * par + r] = yd;
+                if (mine) orow[REV ? Wl - 1 - k0 - r : k0 + r] = (float)yd;
+                wave_lds_fence();
+            }
+        }
+    } else {
+        float Gf[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) Gf[j] = (float)Grow[j];
+        float* yrf = reinterpret_cast<float*>(&yr[fr][0]);   // the same ring, 32 floats (all zeros so far)
+        for (int blk = 0; blk < nblk; blk += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int k0 = (blk + par) * 16;
+                float a0 = xpart(k0), a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < NS4; ++j4) {
+                    const int i0 = ((16 * par - 4 - 4 * j4) & 31);
+                    const float4 w4 = *reinterpret_cast<const float4*>(yrf + i0);
+                    a0 = fmaf(Gf[4 * j4], w4.w, a0);
+                    a1 = fmaf(Gf[4 * j4 + 1], w4.z, a1);
+                    a2 = fmaf(Gf[4 * j4 + 2], w4.y, a2);
+                    a3 = fmaf(Gf[4 * j4 + 3], w4.x, a3);
+                }
+                const float y = (a0 + a1) + (a2 + a3);
+                wave_lds_fence();
+                yrf[16 * par + r] = y;
+                if (mine) orow[REV ? Wl - 1 - k0 - r : k0 + r] = y;
+                wave_lds_fence();
+            }
+        }
+    }
+}
+
 // ---- cascade of second-order sections ---------------------------------------------------------
 // BatchSecondOrderLPCSynth.forward, models/lpc.py:94-131: every frame runs through K all-pole biquads
 // 1/(a0 + a1 z^-1 + a2 z^-2) one after the other.  A cascade is a pipeline: section k can work on sample m while section
@@ -474,6 +702,17 @@ static FfBwdPlan ff_bwd_plan(int B, int F, int Wl, int nfr, int Ty) {
     return p;
 }
 
+// Row sum of |G| up to which a wave of the block-recursion kernel keeps its feedback part in fp32 (dev knob GOLF_FF_KAPPA)
+static float ff_kappa_max() {
+    static const float v = [] { const char* e = getenv("GOLF_FF_KAPPA"); return e ? (float)atof(e) : 64.f; }();
+    return v;
+}
+// The block-recursion kernel's conditions (dev knob GOLF_FF_QUADS=1: the direct-form quad kernel, A/B)
+static bool ff_block_ok(int Wl, int hop, size_t lds_bytes) {
+    static const bool quads = [] { const char* e = getenv("GOLF_FF_QUADS"); return e && atoi(e) != 0; }();
+    return !quads && Wl % 32 == 0 && hop % 4 == 0 && lds_bytes <= 56 * 1024;
+}
+
 template <int W, int NT>
 static int launch_ff_bwd(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, const float* gain,
                          const float* a, const float* window, float* g_ex, int64_t g_ex_stride, float* g_gain,
@@ -490,9 +729,25 @@ static int launch_ff_bwd(const float* gy, int64_t gy_stride, const float* ex, in
     hipLaunchKernelGGL(ff_gq_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, gy, gy_stride, window, gq, B,
                        Ty, hop, Wl, nfr);
     GOLF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((ff_framesq_kernel<W, NT, true>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64),
-                       sizeof(float) * (size_t)Wl, st, (const float*)gq, (int64_t)Ty, gain, a, window, uf, Ty, F, M,
-                       hop, Wl, nfr);
+    bool blocked = false;
+    if constexpr (NT <= 24) {
+        const size_t ldsb = sizeof(float) * 4 * (size_t)Wl;
+        // the adjoint stages 4 whole frames of window * g_q per wave instead of their union: 56 us against the quads' 45 at
+        // B = 32 -- measured, so the backward keeps the quad kernel unless GOLF_FF_BLOCK_BWD=1 (A/B)
+        static const bool bwd_block = [] { const char* e = getenv("GOLF_FF_BLOCK_BWD"); return e && atoi(e) != 0; }();
+        if (bwd_block && ff_block_ok(Wl, hop, ldsb)) {   // block recursion (ff_framesb_kernel)
+            static const hipError_t attr = hipFuncSetAttribute((const void*)ff_framesb_kernel<NT, true>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (attr != hipSuccess) return fail((int)attr, "lti_frames_bwd: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL((ff_framesb_kernel<NT, true>), dim3((unsigned)ceil_div(nfr, 4), B), dim3(64), ldsb, st,
+                               (const float*)gq, (int64_t)Ty, gain, a, window, uf, Ty, F, M, hop, Wl, nfr, ff_kappa_max());
+            blocked = true;
+        }
+    }
+    if (!blocked)
+        hipLaunchKernelGGL((ff_framesq_kernel<W, NT, true>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64),
+                           sizeof(float) * (size_t)Wl, st, (const float*)gq, (int64_t)Ty, gain, a, window, uf, Ty, F, M,
+                           hop, Wl, nfr);
     GOLF_LAUNCH_CHECK();
     const int nq = B * F;
     const int RS = 2 * Wl + NT + 8;
@@ -513,7 +768,20 @@ static int launch_ff(const float* ex, int64_t ex_stride, const float* gain, cons
                      float* y, int64_t y_stride, int B, int Tx, int F, int M, int hop, int Wl, int Ty, int nfr,
                      float* wf, hipStream_t st) {
     const int nq = B * nfr;
-    if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29) && Wl <= 32768) {
+    bool blocked = false;
+    if constexpr (NT <= 24) {
+        const size_t ldsb = sizeof(float) * (3 * (size_t)hop + (size_t)Wl);
+        if (ff_block_ok(Wl, hop, ldsb)) {   // block recursion (ff_framesb_kernel)
+            static const hipError_t attr = hipFuncSetAttribute((const void*)ff_framesb_kernel<NT, false>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (attr != hipSuccess) return fail((int)attr, "lti_frames_ola: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL((ff_framesb_kernel<NT, false>), dim3((unsigned)ceil_div(nfr, 4), B), dim3(64), ldsb, st, ex,
+                               ex_stride, gain, a, window, wf, Tx, F, M, hop, Wl, nfr, ff_kappa_max());
+            blocked = true;
+        }
+    }
+    if (blocked) {
+    } else if (Wl % W == 0 && (int64_t)nfr * Wl < (1ll << 29) && Wl <= 32768) {
         hipLaunchKernelGGL((ff_framesq_kernel<W, NT, false>), dim3((unsigned)ceil_div(nfr, 16), B), dim3(64), 0, st, ex,
                            ex_stride, gain, a, window, wf, Tx, F, M, hop, Wl, nfr);
     } else {
