@@ -322,15 +322,17 @@ __global__ __launch_bounds__(64) void ff_framesb_kernel(const float* __restrict_
     //  rounding into the main loop -- fp32 set-up: 5e-3 instead of 1e-4 on the order-22 filter with poles at 0.97)
     FF_SETUP_T av[NT], v[NT];
     {
-        // (bounds-checked loads: `i < M ? pa[i] : 0` became NT conditional loads, each waited for -- 22 serial round trips,
-        //  two thirds of the kernel's first version)
-        const BufRow arow(a + ((size_t)b * F + fc) * M, M);
+        // (unconditional loads from a clamped index, the select after the conversion: `i < M ? (double)pa[i] : 0` became NT
+        //  conditional loads, each waited for -- 22 serial round trips.  No buffer descriptor: the four frames of a wave have
+        //  four bases, a descriptor has to be wave-uniform.)
+        const float* pa = a + ((size_t)b * F + fc) * M;
         float af[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) af[i] = arow.ld(i);
+        for (int i = 0; i < NT; ++i) af[i] = pa[i < M ? i : M - 1];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            av[i] = (FF_SETUP_T)af[i];
+            const FF_SETUP_T w = (FF_SETUP_T)af[i];
+            av[i] = i < M ? w : (FF_SETUP_T)0;
             v[i] = i == 0 ? (FF_SETUP_T)1 : (FF_SETUP_T)0;
         }
     }

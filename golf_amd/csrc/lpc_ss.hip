@@ -668,12 +668,20 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
         const int f = t0 / hop;  // <= F-2: chunks with a transition matrix end before (F-1)*hop
         if (f != fcur) {
             fcur = f;
+            // (unconditional loads from a clamped index, the select after the conversion: see fixup_wave)
             const float* pa0 = a + ((size_t)b * F + f) * M;
             const float* pa1 = pa0 + M;
+            float u0[NT], u1[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const R v0 = i < M ? (R)pa0[i] : (R)0;
-                const R v1 = i < M ? (R)pa1[i] : (R)0;
+                const int ic = i < M ? i : M - 1;
+                u0[i] = pa0[ic];
+                u1[i] = pa1[ic];
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const R w0 = (R)u0[i], w1 = (R)u1[i];
+                const R v0 = i < M ? w0 : (R)0, v1 = i < M ? w1 : (R)0;
                 a0[i] = v0;
                 dd[i] = (v1 - v0) * inv_hop;
             }
@@ -1235,13 +1243,24 @@ __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes
             const int f = t0 / hop;  // <= F-2: chunks with a transition matrix end before (F-1)*hop
             if (f != fcur) {
                 fcur = f;
+                // Unconditional loads from a clamped index, the select AFTER the conversion: written as
+                // `i < M ? (double)pa0[i] : 0.0` these were 12 conditional loads each waited for -- twelve serial round trips
+                // per hot chunk (found in round 3's last session, ISA of the pre-pass).  (No buffer descriptors here: the
+                // lanes of a wave work on different chunks, a descriptor has to be wave-uniform.)
                 const float* pa0 = fa.a + ((size_t)b * F + f) * M;
                 const float* pa1 = pa0 + M;
+                float u0[TPL], u1[TPL];
 #pragma unroll
                 for (int kk = 0; kk < TPL; ++kk) {
-                    const int i = r * TPL + kk;
-                    const double v0 = i < M ? (double)pa0[i < M ? i : 0] : 0.0;
-                    const double v1 = i < M ? (double)pa1[i < M ? i : 0] : 0.0;
+                    const int i = r * TPL + kk, ic = i < M ? i : M - 1;
+                    u0[kk] = pa0[ic];
+                    u1[kk] = pa1[ic];
+                }
+#pragma unroll
+                for (int kk = 0; kk < TPL; ++kk) {
+                    const bool in = r * TPL + kk < M;
+                    const double w0 = (double)u0[kk], w1 = (double)u1[kk];
+                    const double v0 = in ? w0 : 0.0, v1 = in ? w1 : 0.0;
                     a0[kk] = -v0;                       // NEGATED coefficients: the tap sum is the new sample itself
                     dd[kk] = (v0 - v1) * inv_hop;
                 }
@@ -1843,9 +1862,24 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
             for (int e = lane; e < (kGroup + 1) * 32; e += 64)
                 st[e] = c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
         } else {
+            // the first-pass states S1 of the group (written by the refinement pass): all loads issued BEFORE the prologue and
+            // added after it.  (As a loop `st[e] += cond ? s1b[..] : 0` this was 9 conditional loads each waited for -- nine
+            // serial round trips in front of the recursion; found in round 3 via the same pattern in the frame kernel.)
+            constexpr int NE = ((kGroup + 1) * 32 + 63) / 64;
+            float s1v[NE];
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = lane + 64 * u;
+                const bool ok = e < (kGroup + 1) * 32 && c0 + e / 32 <= NP;
+                const float v = s1b[(size_t)c0 * 32 + (ok ? e : 0)];
+                s1v[u] = ok ? v : 0.f;
+            }
             group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);   // delta_c (V = defect responses, x = defects)
-            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
-                st[e] += c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = lane + 64 * u;
+                if (e < (kGroup + 1) * 32) st[e] += s1v[u];
+            }
         }
         wave_lds_fence();
     }
@@ -2255,9 +2289,21 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
             for (int e = lane; e < (kGroup + 1) * 32; e += 64)   // rows 0 .. NP of L1 hold L(-1) .. L(NP-1); L(NP) = 0
                 st[e] = c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
         } else {
+            constexpr int NE = ((kGroup + 1) * 32 + 63) / 64;   // (loads ahead of the prologue: see lpc_fwdq2_kernel)
+            float l1v[NE];
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = lane + 64 * u;
+                const bool ok = e < (kGroup + 1) * 32 && c0 + e / 32 <= NP;
+                const float v = l1b[(size_t)c0 * 32 + (ok ? e : 0)];
+                l1v[u] = ok ? v : 0.f;
+            }
             adj_group_prologue<W, NT>(Phi, MTt, Wv, x, NC, false, st, b, g, NP, NG, lane);   // delta (Wv = Wd, x = defects)
-            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
-                st[e] += c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = lane + 64 * u;
+                if (e < (kGroup + 1) * 32) st[e] += l1v[u];
+            }
         }
         wave_lds_fence();
         adjq_body<W, NT, 1, true>(gy, gy_stride, a, nullptr, out, g_stride, T, F, M, hop, L, NC, NC, xt, yt, b, g, lane, st,
