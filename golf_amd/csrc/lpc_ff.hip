@@ -213,12 +213,33 @@ __global__ void ff_ola_kernel(const float* __restrict__ wf, const float* __restr
     int flo = (m - Wl + hop) / hop; // smallest f with m - f*hop <= Wl-1  (ceil((m-Wl+1)/hop))
     if (m - Wl + 1 <= 0) flo = 0;
     float acc = 0.f, norm = 0.f;
-    for (int f = flo; f <= fhi; ++f) {
-        const int k = m - f * hop;
-        if (k < 0 || k >= Wl) continue;
-        const float wk = window[k];
-        acc = fmaf(wk, wf[((size_t)b * nfr + f) * Wl + k], acc);
-        norm += wk;
+    if (Wl <= 4 * hop) {
+        // at most 4 frames overlap a sample (every shipped config: Wl = 4 hop or 2 hop): all loads issued before the first
+        // use -- as a loop with a data-dependent trip count this was up to 4 serial pairs of round trips per sample
+        float wk[4], vf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = flo + u;
+            const int k = m - f * hop;
+            const bool ok = f <= fhi && k >= 0 && k < Wl;
+            const int kc = ok ? k : 0, fc = ok ? f : flo;
+            wk[u] = window[kc];
+            vf[u] = wf[((size_t)b * nfr + fc) * Wl + kc];
+            if (!ok) { wk[u] = 0.f; vf[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(wk[u], vf[u], acc);
+            norm += wk[u];
+        }
+    } else {
+        for (int f = flo; f <= fhi; ++f) {
+            const int k = m - f * hop;
+            if (k < 0 || k >= Wl) continue;
+            const float wk = window[k];
+            acc = fmaf(wk, wf[((size_t)b * nfr + f) * Wl + k], acc);
+            norm += wk;
+        }
     }
     y[(size_t)b * y_stride + n] = acc / norm;
 }
@@ -580,11 +601,24 @@ __global__ void ff_gq_kernel(const float* __restrict__ gy, int64_t gy_stride, co
     int flo = (m - Wl + hop) / hop;
     if (m - Wl + 1 <= 0) flo = 0;
     float norm = 0.f;
-    for (int f = flo; f <= fhi; ++f) {
-        const int k = m - f * hop;
-        if (k >= 0 && k < Wl) norm += window[k];
+    const float gv = gy[(size_t)b * gy_stride + n];
+    if (Wl <= 4 * hop) {   // (loads issued together: see ff_ola_kernel)
+        float wk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = flo + u, k = m - f * hop;
+            const bool ok = f <= fhi && k >= 0 && k < Wl;
+            wk[u] = window[ok ? k : 0];
+            if (!ok) wk[u] = 0.f;
+        }
+        norm = (wk[0] + wk[1]) + (wk[2] + wk[3]);
+    } else {
+        for (int f = flo; f <= fhi; ++f) {
+            const int k = m - f * hop;
+            if (k >= 0 && k < Wl) norm += window[k];
+        }
     }
-    gq[idx] = gy[(size_t)b * gy_stride + n] / norm;
+    gq[idx] = gv / norm;
 }
 
 // B2: g_a[b,f,i] = -sum_k u_f[k] * y_f[k-1-i].  One wave per frame; both rows staged in LDS (y_f behind NT zeros).
@@ -605,9 +639,20 @@ __global__ __launch_bounds__(256) void ff_grad_a_kernel(const float* __restrict_
         float* us = ga_lds + wv * RS;          // Wl floats
         float* ys = us + Wl;                   // NT zeros, then Wl floats
         const size_t base = ((size_t)b * nfr + f) * Wl;
-        for (int k = lane; k < Wl; k += 64) {
-            us[k] = uf[base + k];
-            ys[NT + k] = yf[base + k];
+        constexpr int UB = 8;   // (loads of a batch issued before the first LDS write: 15 serial round trips otherwise)
+        for (int k0 = lane; k0 < Wl; k0 += 64 * UB) {
+            float uv[UB], yv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int k = k0 + 64 * u, kc = k < Wl ? k : 0;
+                uv[u] = uf[base + kc];
+                yv[u] = yf[base + kc];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int k = k0 + 64 * u;
+                if (k < Wl) { us[k] = uv[u]; ys[NT + k] = yv[u]; }
+            }
         }
         if (lane < NT) ys[lane] = 0.f;
         wave_lds_fence();
@@ -655,12 +700,24 @@ __global__ __launch_bounds__(256) void ff_bwd_ola_kernel(const float* __restrict
             if (fhi > nfr - 1) fhi = nfr - 1;
             int flo = (m - Wl + hop) / hop;
             if (m - Wl + 1 <= 0) flo = 0;
-            for (int f = flo; f <= fhi; ++f) {
-                const int k = m - f * hop;
-                if (k >= 0 && k < Wl) gx += uf[((size_t)b * nfr + f) * Wl + k];
+            const float e = ex[(size_t)b * ex_stride + t];
+            if (Wl <= 4 * hop) {   // (loads issued together: see ff_ola_kernel)
+                float uv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = flo + u, k = m - f * hop;
+                    const bool ok = f <= fhi && k >= 0 && k < Wl;
+                    uv[u] = uf[((size_t)b * nfr + (ok ? f : flo)) * Wl + (ok ? k : 0)];
+                    if (!ok) uv[u] = 0.f;
+                }
+                gx = ((uv[0] + uv[1]) + uv[2]) + uv[3];
+            } else {
+                for (int f = flo; f <= fhi; ++f) {
+                    const int k = m - f * hop;
+                    if (k >= 0 && k < Wl) gx += uf[((size_t)b * nfr + f) * Wl + k];
+                }
             }
             const float w = (float)(t - t_lo) * inv_hop;
-            const float e = ex[(size_t)b * ex_stride + t];
             g_ex[(size_t)b * g_ex_stride + t] = gx * fmaf(w, g1 - g0, g0);
             p0 = fmaf((1.0f - w) * gx, e, p0);
             p1 = fmaf(w * gx, e, p1);

@@ -2455,20 +2455,35 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     const float* gb = g + (size_t)b * g_stride;
     const float* yb = y + (size_t)b * y_stride;
     const float* eb = ex + (size_t)b * ex_stride;
-    for (int u = k; u < 256; u += 64) {
-        float gv = 0.f, ev = 0.f;
-        const float n = (float)(nbase + u);
-        if (u < len) {
-            gv = gb[ts + u];
-            ev = eb[ts + u];
-            g_ex[(size_t)b * g_ex_stride + ts + u] = gv * fmaf(n, dg, g0);
+    {   // every load of the staging issued before the first use (as loops with the loads under `if (u < len)` these were
+        // 4 + 5 serial round trips per wave)
+        float gv[4], ev[4], yv[5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = k + 64 * q;
+            const int uc = u < len ? u : 0;
+            gv[q] = gb[ts + uc];
+            ev[q] = eb[ts + uc];
         }
-        gp[u] = f32x2{gv, gv * n};   // zero beyond the segment
-        es[u] = ev;
-    }
-    for (int u = k; u < 256 + 64; u += 64) {  // ys[u] = y[ts - 64 + u]
-        const int t = ts - 64 + u;
-        ys[u] = (t >= 0 && t < T) ? yb[t] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int t = ts - 64 + k + 64 * q;
+            yv[q] = yb[(t >= 0 && t < T) ? t : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = k + 64 * q;
+            const float n = (float)(nbase + u);
+            const float g = u < len ? gv[q] : 0.f;
+            if (u < len) g_ex[(size_t)b * g_ex_stride + ts + u] = g * fmaf(n, dg, g0);
+            gp[u] = f32x2{g, g * n};   // zero beyond the segment
+            es[u] = u < len ? ev[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {  // ys[u] = y[ts - 64 + u]
+            const int u = k + 64 * q, t = ts - 64 + u;
+            ys[u] = (t >= 0 && t < T) ? yv[q] : 0.f;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);  // single wave owns its LDS rows
     __builtin_amdgcn_wave_barrier();
