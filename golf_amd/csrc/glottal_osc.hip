@@ -609,6 +609,10 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 #ifndef OSCF_CPT
 #define OSCF_CPT 5            // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + 4 * KS
 #endif
+#ifndef OSCF_SU
+#define OSCF_SU 4            // 4: the control-frame rows of a tile staged in ONE pass (24 loads in flight per thread, 128 VGPRs: still 4
+                             // waves per SIMD) instead of two: 28.7 -> 27.8 us at B = 32, 8.70 -> 8.45 ms at B = 16 384
+#endif
 #ifndef OSCF_ROWS
 #define OSCF_ROWS 0           // 1: the blended control-frame rows staged as plain rows (nrows x (L+1) floats) instead of
 #endif                        //    (value, difference) pairs: 24.6 instead of 32.8 KB at 3 rows, two more VALU + one more LDS
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
             pw[e] = idx - (float)i0;
             t0[e] = table + (size_t)i0 * L;
         }
-        constexpr int SU = 2;
+        constexpr int SU = OSCF_SU;   // columns per thread and pass of the row staging: L / (SU * threads) passes, each one round trip
         for (int cb0 = 0; cb0 < L; cb0 += SU * NTH) {
             float R[OSCF_MAXROWS][SU];
 #pragma unroll
@@ -987,10 +991,17 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
     }
     {
         const BufRow grow(g_out + (size_t)b * g_out_stride, Tout);
-        for (int v = tid; v < spanY; v += NTH) {
-            const int o = o0 - dmax + v;
-            const float x = grow.ld(o < 0 ? 0 : o);             // (past the end: dropped by the descriptor -> 0)
-            Y[oscf_xaddr(v)] = o >= 0 ? x : 0.f;
+        constexpr int NY = (spanY + NTH - 1) / NTH;          // 5 loads per thread, all issued before the first LDS write (as
+        float xv[NY];                                           // a loop: five serial round trips in front of everything)
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+            const int o = o0 - dmax + tid + q * NTH;
+            xv[q] = grow.ld(o < 0 ? 0 : o);                     // (past the end: dropped by the descriptor -> 0)
+        }
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+            const int v = tid + q * NTH, o = o0 - dmax + v;
+            if (v < spanY) Y[oscf_xaddr(v)] = o >= 0 ? xv[q] : 0.f;
         }
     }
     const int m_first = o0 * P;
