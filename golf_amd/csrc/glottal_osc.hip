@@ -744,13 +744,20 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);
         const float* t0[OSCF_MAXROWS];
         float pw[OSCF_MAXROWS];
+        float wsv[OSCF_MAXROWS];                     // (all four weights in flight before the first readfirstlane waits for one)
+#pragma unroll
+        for (int e = 0; e < OSCF_MAXROWS; ++e) {
+            int k = r_first + (e < nrw ? e : nrw - 1);
+            if (k > Fw - 1) k = Fw - 1;
+            wsv[e] = wsel[(size_t)b * Fw + k];
+        }
 #pragma unroll
         for (int e = 0; e < OSCF_MAXROWS; ++e) {
             int k = r_first + (e < nrw ? e : nrw - 1);
             if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
             // (b, k) is the workgroup's: the row base and the weight are uniform -- say so (the loaded value sits in a VGPR), so
             // that the row loads below take an SGPR base + one shared lane offset instead of a 64-bit address each
-            const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+            const float idx = wsv[e] * (float)(n_tab - 1);
             int i0 = __builtin_amdgcn_readfirstlane((int)idx);
             i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
             pw[e] = idx - (float)i0;
@@ -1010,11 +1017,16 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
         const int m_last = min(o0 + OSCB_TO - 1, Tp - 1) * P + (P - 1);
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);
         const float* t0[OSCF_MAXROWS];
+        float wsv[OSCF_MAXROWS];                                 // (all four weights in flight before the first readfirstlane)
 #pragma unroll
         for (int e = 0; e < OSCF_MAXROWS; ++e) {
             int k = r_first + (e < nrw ? e : nrw - 1);
-            if (k > Fw - 1) k = Fw - 1;                          // replicate-padded frames
-            const float idx = wsel[(size_t)b * Fw + k] * (float)(n_tab - 1);
+            if (k > Fw - 1) k = Fw - 1;
+            wsv[e] = wsel[(size_t)b * Fw + k];
+        }
+#pragma unroll
+        for (int e = 0; e < OSCF_MAXROWS; ++e) {
+            const float idx = wsv[e] * (float)(n_tab - 1);       // (replicate-padded frames: k clamped above)
             int i0 = __builtin_amdgcn_readfirstlane((int)idx);
             i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
             t0[e] = table + (size_t)i0 * L;
