@@ -131,8 +131,15 @@ __global__ __launch_bounds__(64) void ff_framesq_kernel(const float* __restrict_
     const int nblk = Wl / W;
     // window in LDS (REV only: applied to the incoming gradient frame)
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    if (REV) {
-        for (int k = lane; k < Wl; k += 64) wl[k] = window[k];
+    if (REV) {   // (batches of 8 loads in flight: one waited-for round trip per 64 window values otherwise -- 15 of them)
+        for (int k0 = lane; k0 < Wl; k0 += 64 * 8) {
+            float wv_[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv_[u] = window[k0 + 64 * u < Wl ? k0 + 64 * u : 0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + 64 * u < Wl) wl[k0 + 64 * u] = wv_[u];
+        }
     }
     float nx[TL::ITS], ng[TL::ITS];
     // Forward: the interpolated gain G(t) is evaluated per ELEMENT in the coalesced (parallel) fetch phase, one block
