@@ -1833,19 +1833,26 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
     float* s1b = S1 + (size_t)b * (NP + 1) * 32;
     if constexpr (MODE == 3) {
         if (precise) return;
+        // (the successor-fold operands below are fetched HERE, ahead of the prologue they do not depend on: a round trip
+        //  off the critical path)
+        const bool fold_next = c0 + kGroup <= NP;   // wave-uniform; the composite of this group exists (lpc_group_prepass_kernel)
+        float4 mb[W / 4];
+        float vv = 0.f;
+        {
+            const int ii = lane < NT ? lane : 0;
+            const int gc = fold_next ? g : 0;
+            const float4* mrow = reinterpret_cast<const float4*>(MT + (((size_t)b * NG + gc) * NT + ii) * W);
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
+            vv = V[((size_t)b * NG + gc) * 32 + ii];
+        }
         group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);
         // The state the NEXT group starts from is its own fold, M_g S1_{c0} + v_g -- not this wave's scan result st[16]
         // (the two differ by the composite's rounding).  The defect of the group's last chunk has to be taken against the
         // state its successor really runs from, or that difference would never be corrected: recompute the successor's
         // fold step here (same operands, same instruction sequence: bit-identical) and put it in st[16].
-        if (c0 + kGroup <= NP) {   // wave-uniform; the composite of this group exists (lpc_group_prepass_kernel)
+        if (fold_next) {
             const bool act = lane < NT;
-            const int ii = act ? lane : 0;
-            const float4* mrow = reinterpret_cast<const float4*>(MT + (((size_t)b * NG + g) * NT + ii) * W);
-            float4 mb[W / 4];
-#pragma unroll
-            for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
-            const float vv = V[((size_t)b * NG + g) * 32 + ii];
             const float t0 = lane < 32 ? st[lane] : 0.f;
             const float t1 = matvec_step<W, NT>(mb, t0, vv, act);
             if (lane < 32) st[kGroup * 32 + lane] = t1;
@@ -2266,13 +2273,16 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
         if (g >= NG || precise) return;   // a group without chunk maps (it holds only the final partial chunk)
     } else if constexpr (MODE == 3) {
         if (precise) return;
-        adj_group_prologue<W, NT>(Phi, MTt, Wv, x, NC, true, st, b, g, NP, NG, lane);
-        if (g >= 1) {   // the state the group BELOW really starts from: its fold step M_g^T L1(c0+15) + w_g, recomputed here
+        float4 mb[W / 4];   // (operands of the fold step below, fetched ahead of the prologue: see lpc_fwdq2_kernel)
+        float vv;
+        {
             const float4* mrow = reinterpret_cast<const float4*>(MTt + (((size_t)b * NG + g) * NT + ii) * W);
-            float4 mb[W / 4];
 #pragma unroll
             for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
-            const float vv = Wv[((size_t)b * NG + g) * 32 + ii];
+            vv = Wv[((size_t)b * NG + g) * 32 + ii];
+        }
+        adj_group_prologue<W, NT>(Phi, MTt, Wv, x, NC, true, st, b, g, NP, NG, lane);
+        if (g >= 1) {   // the state the group BELOW really starts from: its fold step M_g^T L1(c0+15) + w_g, recomputed here
             const int ktop = (c0 + kGroup - 1 < NP - 1 ? kGroup - 1 : NP - 1 - c0);   // row of the group's top chunk map
             const float tin = lane < 32 ? st[(ktop + 1) * 32 + lane] : 0.f;
             const float t1 = matvec_step<W, NT>(mb, tin, vv, act);
