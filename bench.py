@@ -660,30 +660,56 @@ def main():
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
         step_us = event_time_us(step)                       # one batch alone, eager, one stream
         graph_us = event_time_us(graphs[0].replay) if use_graphs else None   # the same as one hipGraph launch
-        traffic = None
-        try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/prof_pmc.sh), if committed
-            for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-                fn = os.path.join(ROOT, "profiles", name)
-                if not os.path.exists(fn):
-                    continue
+        # HBM bytes per launch and issued VALU instructions per step come from separate rocprofv3 --pmc passes (counters
+        # cannot be read in this run): the committed round-4 summaries only -- no fallback to an older round's file
+        traffic, valu = None, None
+        try:
+            fn = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+            if os.path.exists(fn):
                 tr = json.load(open(fn))
                 for kname, v in tr.get("kernels", {}).items():
                     if kname in dom and tr.get("batch") == B:
                         traffic = v["hbm_bytes_per_launch"]
-                if traffic is not None:
-                    break
+            fn = os.path.join(ROOT, "profiles", "r04_sq_counters_4stream.json")
+            if os.path.exists(fn):
+                sq = json.load(open(fn))
+                if sq.get("batch") == B and sq.get("workload") == args.workload:
+                    valu = sq
         except Exception:
             pass
+        # stage level: the dominant kernel's stage bytes against the SUM of that stage's kernels (charging the
+        # whole stage's bytes to one of its kernels flatters it)
+        stage_key = "osc" if ("osc" in dom or "harm" in dom) else ("lpc" if "lpc_" in dom else None)
+        stage_us = sum(v for k, v in ours.items() if stage_key and (("osc" in k or "harm" in k) if stage_key == "osc"
+                                                                    else "lpc_" in k)) or dom_us
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/ (separate rocprofv3 --pmc passes, not measured in this run)",
+                    "traffic_source": None if traffic is None else "profiles/r04_hbm_traffic.json (separate rocprofv3 --pmc passes, not measured in this run)",
                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "stage_frac": round(alg_bytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "stage_us": round(stage_us, 2),
                     "path_frac": round(PATH_BYTES[args.workload] * samples / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "path_frac_single_stream": round(PATH_BYTES[args.workload] * samples / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "note": f"B={B}: bound by the serial T=47761 recursion (dependency/issue latency), not by HBM; "
                             "frac = the dominant kernel's stage bytes / its duration, path_frac = the whole step's "
                             "algorithmic bytes / the step time (pipelined and single stream); DESIGN.md §5"}
+        if valu is not None:
+            # VALU-issue roofline of the run the headline is quoted on (S batches in flight): wave-instructions issued per
+            # step (SQ_INSTS_VALU summed over the step's kernels, PMC pass over the same command) x 4 cycles / (SIMDs x
+            # clock x the step time measured HERE).  4 cycles per wave-instruction is the convention of the SQ counters
+            # (SQ_ACTIVE_INST_VALU counts one quad-cycle per instruction); a plain wave64 VALU instruction occupies a
+            # SIMD-32 for 2 cycles and a packed one for 4, so the true pipe occupancy is lower: valu_pipe_frac prices every
+            # packed instruction (SQ_INSTS_VALU of the transition waves ~ all v_pk_fma_f32) at 4 and the rest at 2.
+            n_simd, clk = 1024, 2.4e9
+            step_s = elapsed / args.steps
+            insts = float(valu["SQ_INSTS_VALU_per_step"])
+            roofline["valu_issue_frac"] = round(insts * 4.0 / (n_simd * clk * step_s), 4)
+            if "packed_insts_per_step" in valu:
+                pk = float(valu["packed_insts_per_step"])
+                roofline["valu_pipe_frac"] = round((pk * 4.0 + (insts - pk) * 2.0) / (n_simd * clk * step_s), 4)
+            roofline["valu_insts_per_step"] = int(insts)
+            roofline["valu_source"] = "profiles/r04_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
         single_us = graph_us if graph_us is not None else step_us
         result = {

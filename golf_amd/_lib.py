@@ -107,7 +107,7 @@ SIGNATURES = {
     "golf_peer_wait_u32": (_int, [_vp, _int, _int, ctypes.c_uint32, _i64, _vp, _vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lock = threading.Lock()
 _lib = None
 
@@ -128,8 +128,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in srcs:
         o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-c", s,
-               "-o", o] + os.environ.get("GOLF_HIPCC_FLAGS", "").split()      # kernel-tuning A/B builds (-DP1F_CHAINS=2 ...)
+        # -falign-loops=64: the transition kernel's unrolled loop is ~1 300 8-byte packed-FMA encodings; when an unrelated edit
+        # moved its start to 4 mod 8 bytes the kernel went from 38.8 to 43.0 us with an otherwise identical instruction stream
+        # (round 4, tools/ab2.sh ab_place2) -- aligned loop heads take the placement lottery out of every kernel
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-falign-loops=64", "-I" + INCLUDE, "-I" + CSRC,
+               "-c", s, "-o", o] + os.environ.get("GOLF_HIPCC_FLAGS", "").split()   # kernel-tuning A/B builds (-DP1F_CHAINS=2 ...)
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

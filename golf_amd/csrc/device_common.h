@@ -87,34 +87,36 @@ struct Tile {
     }
 };
 
+// Issue priority of the LIGHT waves (round 4).  A SIMD arbitrates VALU issue between its resident waves by priority, then
+// age: with several batches in flight the transition kernel's long-running, issue-bound waves are the oldest on their
+// SIMDs and win every slot they can use, while the short latency-bound waves of the other batches' kernels (oscillator
+// tiles, zero-state pass, pre-pass, chunk passes) queue behind them although they need few slots.  Those kernels raise
+// their priority once at entry; the transition waves stay at 0.  Build parameter for the A/B (0 = no s_setprio at all).
+#ifndef GOLF_PRIO_LIGHT
+#define GOLF_PRIO_LIGHT 1   // measured (tools/ab2.sh ab_prio, B = 32, 4 batches in flight): 0 -> 73.0 - 73.9 us/step, 1 -> 71.1 - 71.4, 3 -> 71.0 - 71.1; one batch alone unchanged
+#endif
+__device__ __forceinline__ void light_wave_priority() {
+#if GOLF_PRIO_LIGHT > 0
+    __builtin_amdgcn_s_setprio(GOLF_PRIO_LIGHT);
+#endif
+}
+
 // Orders the LDS traffic of ONE wave (a wave that owns its LDS region needs no workgroup barrier).  The fences name the
 // LDS address space: a fence over all address spaces also waits for the wave's outstanding GLOBAL stores and prefetch
 // loads (s_waitcnt vmcnt(0)) -- in the kernels that store a tile and then fence, once per block of the recursion, that was
 // a store round trip on the critical path of every block (found in round 3 with the block-recursion frame kernel, where it
 // was 2/3 of the kernel: DESIGN.md 4.2).
 __device__ __forceinline__ void wave_lds_fence() {
-#ifdef GOLF_FENCE_ALL_SPACES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-#endif
 }
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
-// acc += s * v with the broadcast value taken straight from an SGPR (v_readlane result): one instruction.
-// NOT used by the scans: measured SLOWER than what hipcc emits on its own (it SLP-packs pairs into v_pk_fma_f32 at
-// the cost of ~17 v_mov per step): P2 31.2 -> 36.6 us.  Kept for the record.
-__device__ __forceinline__ float fmac_sgpr(float acc, float v, float lane_src, int lane) {
-    const int sj = __builtin_amdgcn_readlane(__builtin_bit_cast(int, lane_src), lane);
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(sj), "v"(v));
-    return acc;
-}
+// (Scalar-operand v_fmac_f32 by inline asm instead of what hipcc emits for the scans' broadcast-FMA chains measured slower,
+// 31.2 -> 36.6 us: it SLP-packs pairs into v_pk_fma_f32.  Round 2; the helper is gone, the finding stays.)
 __device__ __forceinline__ float f4get(const float4& v, int k) {
     return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }

@@ -625,15 +625,16 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
 //  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
-#ifndef OSCT_THREADS
-#define OSCT_THREADS 512
-#endif
+// threads of the totals kernel: whole passes of the workgroup over a tile (2048 -> 512, 1920 -> 384)
+constexpr int osct_threads(int TO) { return TO % 512 == 0 ? 512 : (TO % 384 == 0 ? 384 : 256); }
 template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backward's OSCB_TO
-__global__ __launch_bounds__(OSCT_THREADS) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
+__global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
                                                               float* __restrict__ Bf, int reversed = 0, int dmax = 0) {
+    constexpr int OSCT_THREADS = osct_threads(TO);
     __shared__ u64 wsum[OSCT_THREADS / 64];
+    light_wave_priority();
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tile == 0 && b == 0) {
         const int half = (K - 1) / 2;
@@ -702,6 +703,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u64 wtot[NTH / 64];
     __shared__ u64 base_sh, halo_sh;
+    light_wave_priority();
     // layout: X polyphase signal tile [4][XS] | row pairs [(nrows-1)][L+1] float2
     float* X = smem;
     float2* pairs = reinterpret_cast<float2*>(smem + OS * XS);
@@ -932,7 +934,12 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     }
     const BufRow orow(out + (size_t)b * out_stride, Tout);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
+    for (int r = 0; r < 4; ++r) {
+        // (a tile that is not a whole number of 256-output wave tiles, e.g. 1920: the last wave's rows beyond it belong to the
+        //  next workgroup and were not rendered here -- out-of-range offset = dropped by the buffer descriptor)
+        const int o = ob + 16 * r;
+        orow.st((OSCF_TO % 256 == 0 || o < o0 + OSCF_TO) ? o : -1, acc0[r] + acc1[r] + ad[r]);
+    }
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
@@ -1691,7 +1698,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
             const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
             const int lshift = 31 - __builtin_clz((unsigned)L);
             float* Bf = (float*)((char*)ws + g.off_bf);
-            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
+            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride, Ttot, Tp,
                                g.P, os, ntile2, taps, K, dmin, KS, Bf);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
@@ -1777,7 +1784,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
             u64* Ttot = (u64*)((char*)ws + g.off_ttot);
             float* Bf = (float*)((char*)ws + g.off_bf);
             float* part2 = (float*)((char*)ws + g.off_pre);      // the oversampled-gradient buffer is not needed here
-            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(OSCT_THREADS), 0, st, phase, phase_stride, Ttot, Tp,
+            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
                                g.P, os, ntile2, taps, K, dmin, KS, Bf, 1, dmax);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \
@@ -1892,7 +1899,9 @@ static int harmonic_osc_run(const char* who, const float* phase, int64_t phase_s
                             const float* hscale, int H, float* out, int64_t out_stride, int B, int Tout, void* ws,
                             size_t ws_bytes, void* stream, HarmPhase hp);
 static int harm_phase_check(const char* who, const float* phase_offset, int Fo, int po_hop, int Tout) {
-    if (phase_offset && (Fo < 1 || po_hop < 1 || (Fo >= 2 && (int64_t)(Fo - 1) * po_hop + 1 < Tout) || (Fo == 1 && Tout > 1 && po_hop == 1)))
+    // every frame count, Fo = 1 included: linear upsampling of Fo frames at hop po_hop yields (Fo - 1) po_hop + 1 samples
+    // (a lone frame with a hop > 1 used to pass and was then read as a constant track: ADVICE r3)
+    if (phase_offset && (Fo < 1 || po_hop < 1 || (int64_t)(Fo - 1) * po_hop + 1 < Tout))
         return fail(GOLF_EINVAL, "%s: phase_offset (%d frames at hop %d) does not cover %d samples", who, Fo, po_hop, Tout);
     return GOLF_OK;
 }

@@ -115,7 +115,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
     p->off_tier = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 2), 256);   // conditioning tier + hot-chunk count per utterance; [2B] scan kind of the forward, [2B+1] backward mismatch
     p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
-    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * (size_t)B * 2, 256);   // fix-up units completed / claimed per utterance
+    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 1), 256);   // fix-up units completed / claimed per utterance; [2B]: a wait for the fix-up ran out
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
     // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
@@ -343,6 +343,9 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 if constexpr (MODE == 3) {
                     v -= lst[(row + 1) * 32 + i];
                     ldl[row * 32 + i] = v;
+                }
+                if constexpr (MODE == 0) {   // zero-state pass inside the pre-pass launch: z also stays in LDS for the group scan
+                    if (ldl) ldl[row * 32 + i] = v;
                 }
                 zp[i] = v;
             }
@@ -740,28 +743,13 @@ constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 #ifndef P1F_CHAINS
 #define P1F_CHAINS 2
 #endif
-#ifndef P1F_DIRECT
-#define P1F_DIRECT 1   // 1: the maps leave the transition kernel by direct 16-byte stores; 0: through a 16 KB LDS tile per wave
-#endif
-#ifndef P1F_TILE_BYTES
-#define P1F_TILE_BYTES 16384   // LDS per wave for the copy-out transposition.  A build parameter for one A/B: with 64 KB per
-// workgroup only two of them (or one + one oscillator workgroup) fit a CU while four batches are in flight; 8 KB / 4 KB per
-// wave left the pipelined rate where it was (74.1 / 76.3 vs 74.3 us/step) and made the kernel itself slower (41.3 / 44.9
-// vs 40.4 us: more copy-out passes) -- LDS capacity is not what the batches in flight compete for.
-#endif
 template <int W, int NT>
 struct P1fGeom {
     static constexpr int KT = 4;
     static constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
     static constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
-    static constexpr int LDT = W + 4;               // LDS row stride (floats), 16-byte aligned rows
-    static constexpr int CPP0 = (P1F_TILE_BYTES / 4) / (NT * LDT);  // chunks staged per copy-out pass: <= P1F_TILE_BYTES per wave
-    static constexpr int CPP = CPP0 < 1 ? 1 : (CPP0 > CPW ? CPW : CPP0);
-#if P1F_DIRECT
-    static constexpr int WAVE_TILE = 64;                // only the 64-word scratch of the per-chunk maximum
-#else
-    static constexpr int WAVE_TILE = CPP * NT * LDT;
-#endif
+    static constexpr int WAVE_TILE = 64;            // LDS per wave: the 64-word scratch of the per-chunk maximum (the maps leave
+                                                    // by direct stores; a 16 KB transposition tile per wave was round 3's losing arm)
     static constexpr int TILE_FLOATS = P1F_WPB * WAVE_TILE;
 };
 template <int W, int NT>
@@ -774,7 +762,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
     // puts one wave on each SIMD of its CU.
     using G = P1fGeom<W, NT>;
-    constexpr int KT = G::KT, NG = G::NG, CPW = G::CPW, LDT = G::LDT, CPP = G::CPP;
+    constexpr int KT = G::KT, NG = G::NG, CPW = G::CPW;
     constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -782,7 +770,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     const int cl = lane / NG, grp = lane - cl * NG;
     const int q0 = (blk_id * P1F_WPB + wv) * CPW;
     if (fixcnt && blk_id == 0 && wv == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = lane; e < 2 * B; e += 64) fixcnt[e] = 0u;
+        for (int e = lane; e < 2 * B + 1; e += 64) fixcnt[e] = 0u;
     if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
@@ -895,10 +883,9 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
         }
     }
     // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
-#if P1F_DIRECT
     // Straight from the registers: 16 bytes per lane and row, the NG lanes of a chunk cover the row's W floats, NT store
     // instructions.  No LDS tile: the workgroup's footprint drops from 64 KB to the zero-state units' 7 KB, so that it fits
-    // a CU beside TWO oscillator workgroups (2 x 73 KB of the 160 KB) while other batches are in flight -- see P1F_DIRECT.
+    // a CU beside TWO oscillator workgroups (2 x 73 KB of the 160 KB) while other batches are in flight.
     if (live) {
         float* prow = PhiT + (size_t)q * NT * W + jb;
 #pragma unroll
@@ -920,54 +907,163 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
             }
         }
     }
-    return;
-#endif
-    // Copy-out through the wave's LDS tile, CPP chunks per pass: CPP chunks x NT rows x W floats are contiguous in PhiT.
-    constexpr int RW4 = W / 4;
-    for (int c0 = 0; c0 < CPW; c0 += CPP) {
-        wave_lds_fence();
-        if (cl >= c0 && cl < c0 + CPP && cl < CPW) {
-            float* trow = tile + (size_t)(cl - c0) * NT * LDT + jb;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same trajectories with TWO per lane (round 4): one float2 ring, NT / 2 lanes per chunk (no padding trajectories: 22 of
+// 22 instead of 22 of 24), thread = chunk_in_workgroup * (NT / 2) + pair, 23 whole chunks per 256-thread workgroup.
+// Per step 22 + 11 packed FMAs instead of 44 + 11: a wave is 0.61 x as long, there are 1.75 x as many (1 116 instead of 637
+// at B = 32 -- all 1 024 SIMDs busy instead of 637), and the kernel needs ~120 VGPRs instead of 205, so four of its waves --
+// or one and an oscillator workgroup -- share a SIMD's register file where the four-trajectory kernel allowed two.  The
+// coefficient interpolation is amortised over half as many FMAs (+6 % instructions in total).  Selected by p1f_kt().
+// ------------------------------------------------------------------------------------------
+template <int W, int NT>
+struct P1f2Geom {
+    static_assert(NT % 2 == 0, "trajectory pairs");
+    static constexpr int NG = NT / 2;                       // trajectory pairs (= lanes) per chunk
+    static constexpr int CPB = (64 * P1F_WPB) / NG;         // whole chunks per workgroup
+};
+template <int W, int NT>
+__device__ __forceinline__ void p1f2_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
+                                          int L, int NP, int nq, float* __restrict__ tile_all, int blk_id,
+                                          float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0,
+                                          float* __restrict__ Phi = nullptr) {
+    using G = P1f2Geom<W, NT>;
+    constexpr int NG = G::NG, CPB = G::CPB, NP2 = NT / 2;
+    const int t = threadIdx.x;
+    if (fixcnt && blk_id == 0 && t < 64)   // counters of the fix-up that follows in the next launch (see fixup_wave)
+        for (int e = t; e < 2 * B + 1; e += 64) fixcnt[e] = 0u;
+    const int cl = t / NG, grp = t - cl * NG;
+    const int q = blk_id * CPB + cl;
+    const bool live = cl < CPB && q < nq;     // (idle lanes shadow the last chunk: every wave reaches the barrier below)
+    const int jb = 2 * grp;
+    const int qq = live ? q : (nq - 1);
+    const int b = qq / NP, c = qq - b * NP;
+    f32x2 h[W];   // trajectories (jb, jb + 1)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const bool ok = i < M;
-                const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
-                float4 v;
-                v.x = (ok && jb < M) ? va.x : 0.f;
-                v.y = (ok && jb + 1 < M) ? va.y : 0.f;
-                v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
-                v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
-                if (jb + 3 < W) *reinterpret_cast<float4*>(trow + (size_t)i * LDT) = v;
-                // columns no trajectory group covers (4 NG .. W-1, e.g. W = 8 with NT <= 4, W = 24 with NT = 20): zeros, not
-                // whatever the tile held -- the group composites read whole rows, and garbage x 0 is NaN when the garbage is
-                if constexpr (4 * NG < W) {
-                    if (grp == NG - 1) {
+    for (int k = 0; k < W; ++k) {
+        const int j = W - 1 - k;
+        h[k] = f32x2{(j == jb && jb < M) ? 1.f : 0.f, (j == jb + 1 && jb + 1 < M) ? 1.f : 0.f};
+    }
+    f32x2 a0p[NP2], ddp[NP2];
+    const float inv_hop = 1.0f / (float)hop;
+    int fcur = -1;
+    const int nblk = L / W;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int t0 = c * L + blk * W;
+        const int f = t0 / hop;
+        if (f != fcur) {
+            fcur = f;
+            const float* pa0 = a + ((size_t)b * F + f) * M;
+            const float* pa1 = pa0 + M;
 #pragma unroll
-                        for (int cc = 4 * NG; cc < W; cc += 4)
-                            *reinterpret_cast<float4*>(trow - jb + cc + (size_t)i * LDT) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
+            for (int pp = 0; pp < NP2; ++pp) {
+                const int i0 = 2 * pp, i1 = 2 * pp + 1;
+                const float u0 = i0 < M ? pa0[i0] : 0.f, u1 = i1 < M ? pa0[i1] : 0.f;
+                const float v0 = i0 < M ? pa1[i0] : 0.f, v1 = i1 < M ? pa1[i1] : 0.f;
+                a0p[pp] = f32x2{u0, u1};
+                ddp[pp] = f32x2{(v0 - u0) * inv_hop, (v1 - u1) * inv_hop};
             }
         }
-        wave_lds_fence();
-        int nch = nq - (q0 + c0);
-        nch = nch < 0 ? 0 : (nch > CPP ? CPP : nch);
-        nch = nch > CPW - c0 ? CPW - c0 : nch;
-        float4* dst = reinterpret_cast<float4*>(PhiT + (size_t)(q0 + c0) * NT * W);
-        for (int e = lane; e < nch * NT * RW4; e += 64) {
-            const int rowi = e / RW4, c4 = e - rowi * RW4;
-            dst[e] = *reinterpret_cast<const float4*>(tile + (size_t)rowi * LDT + c4 * 4);
+        const float n0 = (float)(t0 - f * hop);
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            const float n = n0 + (float)s;
+            const f32x2 n2 = f32x2{n, n};
+            // the coefficient pair of taps (2 pp, 2 pp + 1) is interpolated one pair ahead of its use (22 live registers
+            // less than interpolating all pairs first; the 128-register budget is the point of this variant)
+            f32x2 r0 = f32x2{0.f, 0.f}, r1 = f32x2{0.f, 0.f};
+            f32x2 cq = __builtin_elementwise_fma(n2, ddp[NP2 - 1], a0p[NP2 - 1]);
+            float cf0 = 0.f;
+#pragma unroll
+            for (int pp = NP2 - 1; pp >= 0; --pp) {
+                f32x2 cn = cq;
+                if (pp > 0) cn = __builtin_elementwise_fma(n2, ddp[pp - 1], a0p[pp - 1]);
+                {
+                    const int i = 2 * pp + 1;
+                    const f32x2 c2 = f32x2{cq.y, cq.y};
+                    r1 = __builtin_elementwise_fma(c2, h[(s - 1 - i + 2 * W) % W], r1);
+                }
+                if (pp > 0) {
+                    const int i = 2 * pp;
+                    const f32x2 c2 = f32x2{cq.x, cq.x};
+                    r0 = __builtin_elementwise_fma(c2, h[(s - 1 - i + 2 * W) % W], r0);
+                } else {
+                    cf0 = cq.x;
+                }
+                cq = cn;
+            }
+            const f32x2 c0 = f32x2{-cf0, -cf0};
+            h[s] = __builtin_elementwise_fma(c0, h[(s - 1 + W) % W], -(r0 + r1));
+        }
+    }
+    // largest |entry| of the chunk's matrix -> pmax[q] (bit patterns: a NaN ranks above +inf), through the workgroup's LDS
+    if (pmax) {
+        unsigned mx = 0u;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            mx = max(mx, __float_as_uint(fabsf(h[k].x)));
+            mx = max(mx, __float_as_uint(fabsf(h[k].y)));
+        }
+        reinterpret_cast<unsigned*>(tile_all)[t] = mx;
+        __syncthreads();
+        if (live && grp == 0) {
+#pragma unroll
+            for (int u = 1; u < NG; ++u) mx = max(mx, reinterpret_cast<const unsigned*>(tile_all)[t + u]);
+            pmax[q] = __uint_as_float(mx);
+        }
+    }
+    if (!live) return;
+    // Training (GOLF_SS_TRAINING): the adjoint orientation Phi[q][j][i], rows j = this lane's two trajectories
+    if (Phi) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = jb + u;
+            float4* o = reinterpret_cast<float4*>(Phi + ((size_t)q * NT + j) * W);
+#pragma unroll
+            for (int i4 = 0; i4 < W / 4; ++i4) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e;
+                    const f32x2 hv = h[(W - 1 - i + W) % W];
+                    v[e] = (i < M && j < M) ? (u == 0 ? hv.x : hv.y) : 0.f;
+                }
+                o[i4] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    // PhiT[q][i][j]: this lane owns columns jb, jb + 1 of every row i -- 8 bytes per lane and row, straight from the registers
+    float* prow = PhiT + (size_t)q * NT * W + jb;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const bool ok = i < M;
+        const f32x2 va = h[W - 1 - i];
+        *reinterpret_cast<float2*>(prow + (size_t)i * W) = make_float2((ok && jb < M) ? va.x : 0.f, (ok && jb + 1 < M) ? va.y : 0.f);
+        if constexpr (2 * NG < W) {   // columns no trajectory covers: zeros (the group composites read whole rows)
+            if (grp == NG - 1) {
+#pragma unroll
+                for (int cc = 2 * NG; cc < W; cc += 2)
+                    *reinterpret_cast<float2*>(prow - jb + cc + (size_t)i * W) = make_float2(0.f, 0.f);
+            }
         }
     }
 }
 
-template <int W, int NT>
+// trajectories per lane of the fp32 transition kernel: 4 (p1f_body) or 2 (p1f2_body); dev knob GOLF_P1F_KT
+static int p1f_kt() {
+    static const int v = [] { const char* e = getenv("GOLF_P1F_KT"); return e ? atoi(e) : 4; }();
+    return v == 2 ? 2 : 4;
+}
+
+template <int W, int NT, int KT = 4>
 __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
                                                                int F, int M, int hop, int L, int NP, int nq,
                                                                float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
                                                                int B, float* __restrict__ Phi) {
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
-    p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+    if constexpr (KT == 2) p1f2_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+    else                   p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -997,6 +1093,7 @@ __device__ __forceinline__ void p1z_units(const float* __restrict__ ex, int64_t 
                                           float* __restrict__ z, int T, int F, int M, int hop, int L, int NP, int ncg,
                                           int B, int upw, int zblk, float (*xt)[Tile<W, 16>::SIZE]) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    light_wave_priority();
     for (int u = 0; u < upw; ++u) {
         const int unit = (zblk * 4 + wv) * upw + u;
         if (unit >= ncg * B) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
@@ -1011,7 +1108,7 @@ __device__ __forceinline__ void p1z_units(const float* __restrict__ ex, int64_t 
 // (416 light waves).  Workgroups [0, nblk_f) run p1f_body, the rest run four P1z units as four independent waves, so
 // P1z uses the CUs the transition kernel leaves idle instead of a launch of its own after it.  (Forking P1z onto a
 // second stream instead costs more in event record/wait than it hides: DESIGN.md.)
-template <int W, int NT>
+template <int W, int NT, int KT = 4>
 __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                                 const float* __restrict__ gain,
                                                                 const float* __restrict__ a, float* __restrict__ z,
@@ -1023,7 +1120,8 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
     __shared__ float xt[P1F_WPB][TL::SIZE];
     if ((int)blockIdx.x < nblk_f) {
-        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+        if constexpr (KT == 2) p1f2_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+        else                   p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
     } else {
         p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_f, xt);
     }
@@ -1059,7 +1157,7 @@ __global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restr
     __shared__ float t[4][NT * (W + 1)];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (fixcnt && blockIdx.x == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = threadIdx.x; e < 2 * B; e += 256) fixcnt[e] = 0u;
+        for (int e = threadIdx.x; e < 2 * B + 1; e += 256) fixcnt[e] = 0u;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
     const float* src = Phi + (size_t)q * NT * W;
@@ -1167,8 +1265,9 @@ struct FixArgs {
     double* Phi64;       // maps as doubles [b][c][j][i] (tier 3 only)
     const float* pmax;   // largest |entry| per chunk, from the transition kernel
     unsigned* tier;      // [b][2]: tier, hot chunks
-    unsigned* status;    // [0] non-finite output, [1] a wait for the fix-up timed out
-    unsigned* fixcnt;    // [b]: fix-up units completed, [B + b]: units claimed (zeroed by the transition kernel)
+    unsigned* status;    // [0] non-finite output of the forward (reset by its first boundary-scan kernel)
+    unsigned* fixcnt;    // [b]: fix-up units completed, [B + b]: units claimed, [2 B]: a wait for the fix-up ran out (all zeroed by
+                         // the transition kernel, i.e. once per set of maps: a handle reused for several forwards keeps reporting it)
     int F, M, hop, L, NP, B;
     float g1, g2, g3;
     int accurate;
@@ -1191,7 +1290,6 @@ __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes
     if (writes_tier && lane == 0) {
         fa.tier[2 * b] = d.t3 ? kTierPrecise : (d.t2 ? kTierHot : 0u);
         fa.tier[2 * b + 1] = d.nhot;
-        if (b == 0) { fa.status[0] = 0u; fa.status[1] = 0u; }   // the final pass ORs 1 into [0] when a non-finite sample leaves
     }
     if (d.nhot == 0u) return;   // wave-uniform: the common case ends here
     const bool listed = NP <= kHotListMax;
@@ -1317,15 +1415,17 @@ __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes
 }
 
 // Waves of the SAME launch that read an utterance's maps after its fix-up (the composite and zero-state workgroups of
-// lpc_group_prepass_kernel): wait until all units have reported.  The leading fix-up workgroups precede every waiter in
-// the grid, so they are resident or done when a waiter starts: no deadlock; a bounded spin, so no hang either way.
+// lpc_group_prepass_kernel): wait until all units have reported.  A waiter first runs fixup_wave itself (the claim loop), so
+// when it gets here every unit is finished or claimed by a wave that is resident and computing: forward progress does not
+// depend on the order in which workgroups were dispatched.  The spin is bounded all the same (a hang is never acceptable);
+// running out is reported in fixcnt[2 B] -> bit 1 of status word 2, which the Python binding raises on.
 __device__ __forceinline__ void wait_for_fixup(const FixArgs& fa, int b, unsigned nhot, int NT) {
     const unsigned expected = (fa.NP <= kHotListMax ? nhot : (unsigned)fa.NP) * (unsigned)NT;
     unsigned it = 0u;
     while (__hip_atomic_load(fa.fixcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
         __builtin_amdgcn_s_sleep(8);
         if (++it > (1u << 16)) {
-            if ((threadIdx.x & 63) == 0) atomicOr(fa.status + 1, 1u);
+            if ((threadIdx.x & 63) == 0) atomicOr(fa.fixcnt + 2 * fa.B, 1u);
             break;
         }
     }
@@ -1660,30 +1760,85 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
     if (i < 32) V[((size_t)b * NG + g) * 32 + i] = s;
 }
 
+// Group-local scan from a zero state with the inputs in LDS (x[k][32], k = chunk of the group): v = the response of the
+// group's chunk maps -> V[b][g].  Epilogue of the refinement pass (inputs = its defects) and of the zero-state units that
+// run inside the pre-pass launch (inputs = their z).
+template <int W, int NT>
+__device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, const float* __restrict__ xl,
+                                               float* __restrict__ Vout, int b, int g, int NP, int NG, int lane) {
+    const bool act = lane < NT;
+    const int ii = act ? lane : 0;
+    const int c0 = g * kGroup;
+    const size_t cstride4 = (size_t)NT * W / 4;
+    const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+    const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+    constexpr int D = 4;
+    float4 pb[D][W / 4];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+    }
+    float s = 0.f;
+    for (int cb = c0; cb < c1; cb += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (cb + u < c1) {   // wave-uniform
+                s = matvec_step<W, NT>(pb[u], s, xl[(cb + u - c0) * 32 + ii], act);
+                const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
+#pragma unroll
+                for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cn * cstride4 + k];
+            }
+        }
+    }
+    if (lane < 32) Vout[((size_t)b * NG + g) * 32 + lane] = s;
+}
+
 // Both pre-passes of the two-level scan AND the fix-up of hot chunk maps in ONE launch (they depend only on the transition
-// kernel's outputs).  Workgroup ranges, in grid order (`parts` bit 0: fix-up + composites, bit 1: zero-state scans):
+// kernel's outputs) -- and, round 4, the zero-state pass itself (`parts` bit 2): the wave that scans group g's zero-state
+// responses first COMPUTES them (fwdq_body MODE 0 on the group's 16 chunks; z stays in its LDS tile, a copy goes to HBM for the
+// refinement pass) and then scans them through the group's maps.  The transition kernel is then a launch of its own that
+// needs only the coefficients -- the form in which it can run beside the oscillator (golf_source_transitions_f32).
+// Workgroup ranges, in grid order (`parts` bit 0: fix-up + composites, bit 1: zero-state scans, bit 2: ... preceded by the
+// zero-state pass):
 //   B*KF1               leading fix-up workgroups (fixup_wave; 4 independent waves each): every wave derives its utterance's
-//                       tier and returns at once unless the utterance has hot chunks.  Few (KF1 per utterance): they are
-//                       what GUARANTEES the fix-up (a waiter never starts before them), not what makes it fast;
+//                       tier and returns at once unless the utterance has hot chunks.  A head start for hot utterances, not a
+//                       guarantee the launch depends on (waiters help, see wait_for_fixup);
 //   ceil(NG*B / 4)      the groups' zero-state responses (one wave per group, four independent waves per workgroup);
 //   NG*B                group composites (4 waves cooperating on one group);
 //   B*KF2               trailing fix-up workgroups: the same waves again, claiming units from the same counters -- they make
 //                       a hot utterance's fix-up ~one 13 us pass, and cost a cold batch nothing (they start after everything
 //                       else has been dispatched and return after one load).
 // A composite / zero-state wave looks at its OWN group's 16 chunk maxima first: nothing beyond G2 there (the common case)
-// -> its maps are final, go ahead.  Otherwise it derives the utterance's tier like the fix-up waves do: tier 2 waits until
-// the utterance's units have all reported (wait_for_fixup), tier 3 steps aside (its states come from the fp64 scan wave in
-// the refinement launch).  So a batch without hot chunks pays neither a launch nor a wait for the conditioning machinery
-// (as a launch of its own the fix-up cost 4 us of latency and 6 us/step of the pipelined rate; with all its workgroups
-// leading this grid, 7 us), and a hot one pays about one fix-up pass inside this launch.
+// -> its maps are final, go ahead.  Otherwise it derives the utterance's tier like the fix-up waves do: tier 2 helps with the
+// fix-up and then waits until the utterance's units have all reported (wait_for_fixup), tier 3 steps aside (its states
+// come from the fp64 scan wave in the refinement launch).  So a batch without hot chunks pays neither a launch nor a wait
+// for the conditioning machinery (as a launch of its own the fix-up cost 4 us of latency and 6 us/step of the pipelined
+// rate; with all its workgroups leading this grid, 7 us), and a hot one pays about one fix-up pass inside this launch.
+struct ZPassArgs {            // the zero-state pass of `parts` bit 2 (fwdq_body MODE 0)
+    const float* ex; int64_t ex_stride; const float* gain; int T;
+};
+template <int W, int NT>
+struct PrepassLds {           // one workgroup is a fix-up, a zero-state or a composite workgroup: the regions overlap
+    using TL = Tile<W, 16>;
+    static constexpr int HOT = 4 * kHotListMax * 2;                                   // bytes: the fix-up waves' lists
+    static constexpr int COMP = 32 * 32 * 8;                                          // the composites' P_B (doubles)
+    static constexpr int ZP = 4 * (TL::SIZE + kGroup * 32) * 4;                       // per wave: input tile + z[16][32]
+    static constexpr int BYTES = HOT + (COMP > ZP ? COMP : ZP);
+};
 template <int W, int NT>
 __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __restrict__ PhiT,
-                                                                const float* __restrict__ z, float* __restrict__ MT,
+                                                                float* __restrict__ z, float* __restrict__ MT,
                                                                 float* __restrict__ V, int NP, int NG, int B,
                                                                 int parts, FixArgs fa, int KF1, int KF2,
-                                                                float* __restrict__ MTt) {
-    __shared__ __attribute__((aligned(32))) double pb_lds[32 * 32];
-    __shared__ unsigned short hot_lds[4][kHotListMax];   // the fix-up waves' lists (an array of its own: no type punning)
+                                                                float* __restrict__ MTt, ZPassArgs zp) {
+    using PL = PrepassLds<W, NT>;
+    using TL = Tile<W, 16>;
+    __shared__ __attribute__((aligned(32))) unsigned char lds_raw[PL::BYTES];
+    unsigned short (*hot_lds)[kHotListMax] = reinterpret_cast<unsigned short (*)[kHotListMax]>(lds_raw);
+    double* pb_lds = reinterpret_cast<double*>(lds_raw + PL::HOT);
+    light_wave_priority();
     const bool fix = fa.pmax != nullptr && (parts & 1);   // (no fix-up at all: diagnostic switch GOLF_SS_NO_FIXUP)
     const int nu = NG * B;
     const int nf1 = fix ? B * KF1 : 0, nz = (parts & 2) ? (nu + 3) / 4 : 0, nc = (parts & 1) ? nu : 0;
@@ -1701,6 +1856,7 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
     }
     const bool comp = blk >= nz;
     int b, g;
+    float* zl = nullptr;
     if (comp) {
         blk -= nz;
         // the fold of group g runs over the groups BEFORE it: the last composite is needed only when the final partial
@@ -1712,6 +1868,13 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
         const int u2 = blk * 4 + wv;
         if (u2 >= nu) return;
         b = u2 / NG; g = u2 % NG;
+        if (parts & 4) {   // the zero-state pass of this group's 16 chunks: needs the excitation, not the maps
+            float* xt = reinterpret_cast<float*>(lds_raw + PL::HOT) + wv * (TL::SIZE + kGroup * 32);
+            zl = xt + TL::SIZE;
+            fwdq_body<W, NT, 0>(zp.ex, zp.ex_stride, zp.gain, fa.a, nullptr, z, 0, zp.T, fa.F, fa.M, fa.hop, fa.L, NP, NP,
+                                nullptr, xt, nullptr, b, g, lane, nullptr, zl);
+            wave_lds_fence();
+        }
     }
     if (fa.pmax) {
         const int c = g * kGroup + (lane & 15);
@@ -1719,11 +1882,19 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
         if (__builtin_amdgcn_ballot_w64(!(v <= fa.g2)) != 0ull) {   // a chunk of this group may have been recomputed
             const UttTier d = utterance_tier(fa.pmax + (size_t)b * NP, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
             if (d.t3) return;
-            if (d.nhot > 0u && !fa.accurate) wait_for_fixup(fa, b, d.nhot, NT);
+            if (d.nhot > 0u && !fa.accurate) {
+                // Help before waiting: the units are claimed from a counter, so this wave takes whatever nobody has claimed
+                // yet.  When it returns every unit is done or in the hands of a RESIDENT wave (claiming is what a wave does
+                // right before computing), so the wait below ends whatever order the workgroups were dispatched in -- the
+                // leading fix-up workgroups are a head start, not a progress guarantee the launch depends on.
+                fixup_wave<W, NT>(fa, b, false, hot_lds[wv]);
+                wait_for_fixup(fa, b, d.nhot, NT);
+            }
         }
     }
-    if (comp) group_composite_wg<W, NT>(PhiT, MT, NP, NG, b, g, pb_lds, MTt);
-    else      group_zscan_body<W, NT>(PhiT, z, V, NP, NG, b, g, lane);
+    if (comp)    group_composite_wg<W, NT>(PhiT, MT, NP, NG, b, g, pb_lds, MTt);
+    else if (zl) group_scan_lds<W, NT>(PhiT, zl, V, b, g, NP, NG, lane);
+    else         group_zscan_body<W, NT>(PhiT, z, V, NP, NG, b, g, lane);
 }
 
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
@@ -1800,8 +1971,11 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 //   Tier-3 utterances (see phi_guard) skip the refinement pass: rows blockIdx.y >= B of ITS grid hold one wave per utterance
 //     that returns at once unless the utterance is tier 3 and then scans its boundary states in fp64 -> S1 (this launch has
 //     the registers and lasts 26 us anyway); the final pass takes those as they are.
+#ifndef GOLF_FWDQ2_WAVES
+#define GOLF_FWDQ2_WAVES 1   // waves per SIMD the chunk kernels' register allocation must allow (build parameter: A/B of residency)
+#endif
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__ ex, int64_t ex_stride,
+__global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                        const float* __restrict__ gain, const float* __restrict__ a,
                                                        float* __restrict__ out, int64_t y_stride, int T, int F, int M,
                                                        int hop, int L, int NCQ, const float* __restrict__ PhiT,
@@ -1812,13 +1986,17 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
                                                        unsigned* __restrict__ nonfinite, int B,
                                                        const double* __restrict__ Phi64) {
     static_assert(MODE == 1 || MODE == 3, "final pass or refinement pass");
+    light_wave_priority();
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
     __shared__ float yt[MODE == 1 ? TL::SIZE : 1];
     __shared__ float st[(kGroup + 1) * 32];
     __shared__ float dl[MODE == 3 ? kGroup * 32 : 1];
     if constexpr (MODE == 3) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) record_scan_kind(tier, B, kScanTwoLevel);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            record_scan_kind(tier, B, kScanTwoLevel);
+            if (nonfinite) nonfinite[0] = 0u;   // per forward: the final pass (next launch) ORs 1 in when a non-finite sample leaves
+        }
         if ((int)blockIdx.y >= B) {   // fp64 boundary scan of a tier-3 utterance (x = the zero-state responses z)
             const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
             if (bp < B && tier3(tier, bp))
@@ -1894,32 +2072,7 @@ __global__ __launch_bounds__(64) void lpc_fwdq2_kernel(const float* __restrict__
                                  b, g, lane, st, dl, nonfinite);
     if (MODE == 3) {   // epilogue: the group's response to its own defects, for the final pass's fold
         wave_lds_fence();
-        const bool act = lane < NT;
-        const int ii = act ? lane : 0;
-        const size_t cstride4 = (size_t)NT * W / 4;
-        const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
-        const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
-        constexpr int D = 4;
-        float4 pb[D][W / 4];
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
-#pragma unroll
-            for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
-        }
-        float s = 0.f;
-        for (int cb = c0; cb < c1; cb += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                if (cb + u < c1) {   // wave-uniform
-                    s = matvec_step<W, NT>(pb[u], s, dl[(cb + u - c0) * 32 + ii], act);
-                    const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
-#pragma unroll
-                    for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cn * cstride4 + k];
-                }
-            }
-        }
-        if (lane < 32) V2out[((size_t)b * NG + g) * 32 + lane] = s;
+        group_scan_lds<W, NT>(PhiT, dl, V2out, b, g, NP, NG, lane);
     }
 }
 
@@ -1938,9 +2091,13 @@ template <int W, int NT, int D, bool ACC>
 __global__ __launch_bounds__(64) void lpc_p2_scan_kernel(const float* __restrict__ PhiT, const float* __restrict__ z,
                                                          float* __restrict__ S, int NC, int NP, int B,
                                                          const unsigned* __restrict__ tier,
-                                                         const double* __restrict__ Phi64) {
+                                                         const double* __restrict__ Phi64,
+                                                         unsigned* __restrict__ nonfinite = nullptr) {
     const int i = threadIdx.x;
-    if (!ACC && blockIdx.x == 0 && i == 0) record_scan_kind(tier, B, kScanFlat);
+    if (!ACC && blockIdx.x == 0 && i == 0) {
+        record_scan_kind(tier, B, kScanFlat);
+        if (nonfinite) nonfinite[0] = 0u;   // per forward (see lpc_fwdq2_kernel)
+    }
     if ((int)blockIdx.x >= B) {
         const int bp = (int)blockIdx.x - B;
         if (tier3(tier, bp))
@@ -2682,6 +2839,7 @@ __global__ __launch_bounds__(64) void lpc_inverse_bwd_a_kernel(const float* __re
 // Conditioning / health status of the forward that last used a workspace (golf_ltv_allpole_status_u32): one workgroup.
 __global__ __launch_bounds__(256) void lpc_status_kernel(const unsigned* __restrict__ tier,
                                                          const unsigned* __restrict__ status,
+                                                         const unsigned* __restrict__ fixcnt,
                                                          const float* __restrict__ pmax, int B, int NP,
                                                          unsigned* __restrict__ out) {
     __shared__ unsigned sh[3][256];
@@ -2705,7 +2863,7 @@ __global__ __launch_bounds__(256) void lpc_status_kernel(const unsigned* __restr
         out[0] = sh[0][0]; out[1] = sh[1][0]; out[3] = sh[2][0];
         // bit 0: a non-finite sample left the filter, bit 1: a wait for the fix-up timed out, bit 2: a backward ran on this
         // workspace with another boundary scan than the forward that filled it
-        out[2] = (status[0] ? 1u : 0u) | (status[1] ? 2u : 0u) | (tier[2 * B + 1] ? 4u : 0u);
+        out[2] = (status[0] ? 1u : 0u) | (fixcnt[2 * B] ? 2u : 0u) | (tier[2 * B + 1] ? 4u : 0u);
     }
 }
 __global__ void lpc_status_zero_kernel(unsigned* __restrict__ out) { if (threadIdx.x < 4) out[threadIdx.x] = 0u; }
@@ -2807,14 +2965,41 @@ static int launch_composites(const SsPlan& p, const float* a, int B, int F, int 
             fixup_kf(p, NT, &k1, &k2);
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B;
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)(nf + nu)), dim3(256), 0, st,
-                               (const float*)(ws + p.off_phiT), (const float*)nullptr, (float*)(ws + p.off_mt),
+                               (const float*)(ws + p.off_phiT), (float*)nullptr, (float*)(ws + p.off_mt),
                                (float*)nullptr, p.NP, p.NG, B, 1, fa, k1, k2,
-                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr);
+                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr, ZPassArgs{nullptr, 0, nullptr, 0});
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }
     }
     return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, training, st);
+}
+
+// The zero-state pass inside the pre-pass launch (round 4; dev knob GOLF_SS_ZPASS_IN_PREPASS=0/1 for the A/B against the
+// transition kernel that carries it, lpc_p1fz_kernel).
+static bool zpass_in_prepass() {
+    static const bool v = [] { const char* e = getenv("GOLF_SS_ZPASS_IN_PREPASS"); return e ? atoi(e) != 0 : false; }();
+    return v;
+}
+
+// The fp32 transition matrices alone (+ their per-chunk maxima): needs only the coefficients.
+template <int W, int NT>
+static int launch_maps(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int flags, hipStream_t st) {
+    if (p.NP <= 0) return GOLF_OK;
+    float* Phi = (float*)(ws + p.off_phi);
+    float* PhiT = (float*)(ws + p.off_phiT);
+    const int nq = B * p.NP;
+    constexpr int CPW = 64 / ((NT + 3) / 4);
+    if (p1f_kt() == 2)
+        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT, 2>), dim3((unsigned)ceil_div(nq, P1f2Geom<W, NT>::CPB)),
+                           dim3(64 * P1F_WPB), 0, st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
+                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
+    else
+        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT, 4>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB),
+                           0, st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
+                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
 }
 
 template <int W, int NT>
@@ -2824,12 +3009,9 @@ static int launch_transitions(const SsPlan& p, const float* a, int B, int T, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    if (fast) {  // fp32 trajectories, 4 per lane as float2 pairs (the forward then runs one refinement sweep)
-        constexpr int CPW = 64 / ((NT + 3) / 4);
-        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB), 0,
-                           st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
-                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
-        GOLF_LAUNCH_CHECK();
+    if (fast) {  // fp32 trajectories as float2 pairs (the forward then runs one refinement sweep)
+        if (int rc = launch_maps<W, NT>(p, a, B, F, M, hop, ws, flags, st)) return rc;
+        if (flags & GOLF_SS_MAPS_ONLY) return GOLF_OK;   // the forward runs the fix-up and the composites itself
         return launch_composites<W, NT>(p, a, B, F, M, hop, ws, 0, flags, st);
     }
     static const int kt_env = [] { const char* e = getenv("GOLF_P1H_KT"); return e ? atoi(e) : 0; }();  // dev knob
@@ -2890,7 +3072,15 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     const int fast = (flags & GOLF_SS_FAST_TRANSITIONS) ? 1 : 0;
     const int training = (!fast || (flags & GOLF_SS_TRAINING)) ? 1 : 0;   // the backward follows: keep what it needs
     ForkJoin fork, join;
-    bool fused_p1 = false;
+    bool fused_p1 = false;     // the fix-up of hot maps and the group composites are still to be run by this call
+    bool z_done = false;       // the zero-state pass ran inside the transition launch (lpc_p1fz / lpc_p1hz)
+    // Round 4: the zero-state pass inside the pre-pass launch (lpc_group_prepass_kernel `parts` bit 2) -- the transition
+    // kernel then needs only the coefficients and is a launch of its own (or part of the oscillator's: MAPS_ONLY).
+    bool two_level = false;
+    if constexpr (NT <= 24) two_level = use_two_level_scan(p, B, flags);
+    const bool maps_only = (flags & GOLF_SS_HAVE_TRANSITIONS) && (flags & GOLF_SS_MAPS_ONLY);
+    const bool zin = two_level && fast && !side && !(flags & GOLF_SS_SPLIT_P1) && p.NP > 0 &&
+                     (zpass_in_prepass() || maps_only);
     if (p.NP > 0) {
         if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
             hipStream_t s1 = st;
@@ -2898,19 +3088,30 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                 if (fork.record_and_wait(st, side)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream fork failed");
                 s1 = side;
             }
-            if (!side && !(flags & GOLF_SS_SPLIT_P1)) {   // transitions + zero-state pass in one launch
+            if (zin) {   // the matrices alone; fix-up, composites and the zero-state pass follow in the pre-pass launch
+                if (int rc = launch_maps<W, NT>(p, a, B, F, M, hop, ws, flags, st)) return rc;
+                fused_p1 = true;
+            } else if (!side && !(flags & GOLF_SS_SPLIT_P1)) {   // transitions + zero-state pass in one launch
                 const int nq = B * p.NP, ncg = (int)ceil_div(p.NP, 16);
                 const int64_t nunit = (int64_t)ncg * B;
                 const int n_cu = device_cu_count();
                 if (fast) {
-                    const int nblk_f = (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
+                    const int kt = p1f_kt();
+                    const int nblk_f = kt == 2 ? (int)ceil_div(nq, P1f2Geom<W, NT>::CPB)
+                                               : (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
                     int upw = 1;
                     while (upw < 4 && nblk_f + ceil_div(nunit, 4 * upw) > n_cu) ++upw;
                     const int nblk_z = (int)ceil_div(nunit, 4 * upw);
-                    hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
-                                       0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
-                                       B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
-                                       training ? (float*)(ws + p.off_phi) : (float*)nullptr);
+                    if (kt == 2)
+                        hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT, 2>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
+                                           0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
+                                           B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
+                                           training ? (float*)(ws + p.off_phi) : (float*)nullptr);
+                    else
+                        hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT, 4>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
+                                           0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
+                                           B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
+                                           training ? (float*)(ws + p.off_phi) : (float*)nullptr);
                     GOLF_LAUNCH_CHECK();
                 } else {
                     constexpr int KT = 3, NG = (NT + KT - 1) / KT;
@@ -2928,12 +3129,15 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                                        (unsigned*)(ws + p.off_fixcnt), B);
                     GOLF_LAUNCH_CHECK();
                 }
-                fused_p1 = true;
+                fused_p1 = z_done = true;
             } else if (int rc = launch_transitions<W, NT>(p, a, B, T, F, M, hop, ws, fast, flags, s1)) {
                 return rc;
             }
+        } else if (maps_only) {
+            fused_p1 = true;   // the caller's transitions call left the matrices only
         }
-        if (!fused_p1) {
+        if (!zin && !z_done) {
+            // the zero-state pass as a launch of its own (prepared transitions, side stream, SPLIT_P1)
             hipLaunchKernelGGL((lpc_fwdq_kernel<W, NT, 0>), dim3((unsigned)ceil_div(p.NP, 16), B), dim3(64), 0, st, ex,
                                ex_stride, gain, a, (const float*)nullptr, z, (int64_t)0, T, F, M, hop, p.L, p.NP, p.NP,
                                (const float*)nullptr, (const unsigned*)nullptr);
@@ -2942,7 +3146,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
         if (side && join.record_and_wait(side, st)) return fail((int)hipErrorUnknown, "ltv_allpole_fwd: stream join failed");
     }
     if constexpr (NT <= 24) {
-        if (use_two_level_scan(p, B, flags)) {   // two-level boundary scan (see the kernels above)
+        if (two_level) {   // two-level boundary scan (see the kernels above)
             float* MT = (float*)(ws + p.off_mt);
             float* Vz = (float*)(ws + p.off_gv);                    // [b][NG][32] zero-state group responses
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
@@ -2955,17 +3159,17 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             int k1, k2;
             fixup_kf(p, NT, &k1, &k2);
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B, nz = (int)ceil_div(nu, 4);
-            const int parts = fused_p1 ? 3 : 2, count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
+            const int parts = (fused_p1 ? 3 : 2) | (zin ? 4 : 0), count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
-                               (const float*)PhiT, (const float*)z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2,
-                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr);
+                               (const float*)PhiT, z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2,
+                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr, ZPassArgs{ex, ex_stride, gain, T});
             GOLF_LAUNCH_CHECK();
             // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
             const int gx3 = (int)ceil_div(p.NP, kGroup);
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0, st,
                                ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
                                (const float*)MT, (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier,
-                               (unsigned*)nullptr, B, Phi64);
+                               nonfinite, B, Phi64);
             GOLF_LAUNCH_CHECK();
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride, gain,
                                a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,
@@ -2978,7 +3182,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     if (fused_p1)   // (otherwise launch_transitions / the caller's transitions call ran it)
         if (int rc = launch_fixup<W, NT>(p, a, B, F, M, hop, ws, fast ? 0 : 1, training, st)) return rc;
     hipLaunchKernelGGL((lpc_p2_scan_kernel<W, NT, D, false>), dim3(2 * B), dim3(64), 0, st, (const float*)PhiT,
-                       (const float*)z, S, p.NC, p.NP, B, tier, Phi64);
+                       (const float*)z, S, p.NC, p.NP, B, tier, Phi64, nonfinite);
     GOLF_LAUNCH_CHECK();
     if (p.NP > 0) {  // one refinement sweep in delta form (see fwdq_body, MODE 2): defects, their scan added to S
         float* dfc = (float*)(ws + p.off_z2);
@@ -3098,6 +3302,13 @@ static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride
 
 // (W, NT) instantiation table — must list exactly kTable.
 #define GOLF_SS_CASE(FN, w, nt, ...) case (w) * 100 + (nt): return FN<w, nt>(__VA_ARGS__);
+#ifdef GOLF_SS_ONLY_24_22   // dev builds (tools/build_variant.sh): only the benchmark's instantiation, a 10x shorter compile
+#define GOLF_SS_DISPATCH(FN, ...)               \
+    switch (p.W * 100 + p.NT) {                 \
+        GOLF_SS_CASE(FN, 24, 22, __VA_ARGS__)   \
+        default: break;                         \
+    }
+#else
 #define GOLF_SS_DISPATCH(FN, ...)               \
     switch (p.W * 100 + p.NT) {                 \
         GOLF_SS_CASE(FN, 8, 2, __VA_ARGS__)     \
@@ -3121,6 +3332,7 @@ static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride
         GOLF_SS_CASE(FN, 40, 38, __VA_ARGS__)   \
         default: break;                         \
     }
+#endif
 
 static int ss_mode(int flags) {
     return (flags & GOLF_SS_SERIAL) ? GOLF_SS_SERIAL : ((flags & GOLF_SS_CHUNKED) ? GOLF_SS_CHUNKED : 0);
@@ -3189,7 +3401,8 @@ extern "C" int golf_ltv_allpole_status_u32(const void* ws, size_t ws_bytes, int 
                     ws_bytes);
     const char* w = (const char*)ws;
     hipLaunchKernelGGL(lpc_status_kernel, dim3(1), dim3(256), 0, st, (const unsigned*)(w + p.off_tier),
-                       (const unsigned*)(w + p.off_status), (const float*)(w + p.off_pmax), B, p.NP, (unsigned*)out);
+                       (const unsigned*)(w + p.off_status), (const unsigned*)(w + p.off_fixcnt),
+                       (const float*)(w + p.off_pmax), B, p.NP, (unsigned*)out);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

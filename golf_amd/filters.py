@@ -99,10 +99,46 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
         self._prepared = GF.ltv_allpole_prepare(a.as_tensor(), hop, T, overlap=overlap, fast=True,
                                                 training=torch.is_grad_enabled())
 
+    # Health monitor (not in the reference).  The filter reports, per forward, how many utterances needed their
+    # chunk maps recomputed, whether a non-finite sample left it and whether a bounded device-side wait ran out
+    # (include/golf_amd.h golf_ltv_allpole_status_u32).  With ``health_check = True`` every eager forward queues those four
+    # words for an asynchronous copy to pinned host memory and the NEXT forward (or ``health()``) looks at the ones that have
+    # arrived: no synchronisation, one tiny kernel + 16 bytes per call.  Off while a hipGraph is being captured.
+    health_check = False
+
+    def health(self, wait: bool = False) -> dict:
+        """Status words of the most recent monitored forward that has reached the host (``wait=True``: synchronise on it).
+        Warns once per occurrence of a fix-up timeout, a scan mismatch or non-finite output."""
+        import warnings
+
+        pend = getattr(self, "_health_pending", None)
+        if pend is not None:
+            host, ev = pend
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                self._health_pending = None
+                self._health_last = w = GF.ss_status(host)
+                bad = [k for k in ("fixup_timeout", "scan_mismatch", "nonfinite") if w[k]]
+                if bad:
+                    warnings.warn(f"golf_amd: sample-wise LPC filter reported {', '.join(bad)} (status {w})", RuntimeWarning)
+        return getattr(self, "_health_last", None)
+
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
         hop = _check_filter_inputs(ex, gain, a)
         prepared, self._prepared = getattr(self, "_prepared", None), None
-        y = GF.ltv_allpole_ss(ex.as_tensor(), gain.as_tensor(), a.as_tensor(), hop, prepared)
+        x = ex.as_tensor()
+        st = None
+        if self.health_check and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.health()
+            st = torch.zeros(4, dtype=torch.int32, device=x.device)
+        y = GF.ltv_allpole_ss(x, gain.as_tensor(), a.as_tensor(), hop, prepared, status=st)
+        if st is not None:
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(st, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(x.device))
+            self._health_pending = (host, ev)
         return AudioTensor(y)
 
     def reverse(self, ex: AudioTensor, y: AudioTensor, gain: AudioTensor, a: AudioTensor

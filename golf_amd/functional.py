@@ -20,9 +20,16 @@ __all__ = ["ltv_allpole_ss", "ltv_allpole_prepare", "ltv_inverse", "lti_frames_o
 HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
 TRAINING = 64            # GOLF_SS_TRAINING
+MAPS_ONLY = 128          # GOLF_SS_MAPS_ONLY (ABI 4)
 FORK_TRANSITIONS = False
 SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
+
+# Mixed-precision entry (reference intent: models/synth.py:250-251 pins the phase cumsum to fp32 so that the decoder survives
+# `precision: 16-mixed`).  The kernels are fp32: under torch.autocast every Function casts its floating-point inputs to fp32
+# and runs with autocast off; the backward runs in the same mode.  Outside autocast a non-fp32 tensor is still an error.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -40,12 +47,14 @@ class PreparedTransitions:
     """Handle returned by ltv_allpole_prepare: the workspace with the transition matrices in flight on the side
     stream, plus the shape key they are valid for."""
 
-    def __init__(self, ws, key, stream, a, fast=False, training=False):
+    def __init__(self, ws, key, stream, a, fast=False, training=False, maps_only=False):
         self.ws, self.key, self.stream, self.a, self.fast, self.training = ws, key, stream, a, fast, training
+        self.maps_only = maps_only   # the matrices alone: the forward still runs their fix-up and the group composites
 
 
 def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False,
-                        fast: bool = False, mode=None, training: bool = False) -> PreparedTransitions:
+                        fast: bool = False, mode=None, training: bool = False,
+                        maps_only: bool = False) -> PreparedTransitions:
     """Compute the transition matrices for coefficients ``a`` (B,F,M) and output length ``T`` ahead of the
     excitation; pass the handle to ltv_allpole_ss(..., prepared=handle) (e.g. to filter several signals with the
     same coefficients, or to start the most expensive, excitation-independent phase early).
@@ -56,12 +65,16 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
     on one stream; training 370 vs 283) -- and with several batches in flight the chip is full either way.  It pays when
     much more work precedes the filter on the main stream than the join costs (a long encoder).
     ``fast=True`` computes the fp32 matrices of the inference path; ``training=True`` (implied by ``fast=False``) also keeps
-    what the backward reads, so the handle serves a forward whose gradients are needed."""
+    what the backward reads, so the handle serves a forward whose gradients are needed.
+    ``maps_only=True`` (with ``fast``): only the transition matrices; the forward then runs what the boundary scan still
+    needs from them (fix-up of ill-conditioned matrices, group composites) in the launch of its zero-state pass."""
     _lib.require_device(a)
     lib = _lib.load()
     a = a.detach().contiguous()
     B, F, M = a.shape
-    flags = SS_MODES[mode] | (FAST_TRANSITIONS if fast else 0) | (TRAINING if (fast and training) else 0)
+    maps_only = bool(maps_only and fast)
+    flags = (SS_MODES[mode] | (FAST_TRANSITIONS if fast else 0) | (TRAINING if (fast and training) else 0)
+             | (MAPS_ONLY if maps_only else 0))
     ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, flags), a.device)
     cur = torch.cuda.current_stream(a.device)
     side = None
@@ -74,7 +87,7 @@ def ltv_allpole_prepare(a: torch.Tensor, hop: int, T: int, overlap: bool = False
                                               flags, (side or cur).cuda_stream)
     _lib.check(rc, "golf_ltv_allpole_transitions_f32")
     return PreparedTransitions(ws, (B, T, F, M, hop, a.data_ptr(), a._version, SS_MODES[mode]), side, a, fast,
-                               training or not fast)
+                               training or not fast, maps_only)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -110,6 +123,7 @@ def ss_is_trainable(M: int, hop: int, F: int = 2) -> bool:
 # ------------------------------------------------------------------------------------------------
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0, status=None):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
@@ -133,7 +147,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
                 and not (prepared.fast and needs_grad and not prepared.training)):
             ws, flags, side = prepared.ws, HAVE_TRANSITIONS | mode, prepared.stream
             if prepared.fast:
-                flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0)
+                flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0) | (MAPS_ONLY if prepared.maps_only else 0)
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
             flags = mode
@@ -155,7 +169,8 @@ class _LTVAllPoleSS(torch.autograd.Function):
         if status is not None:
             # conditioning / health words of this forward (include/golf_amd.h golf_ltv_allpole_status_u32): written
             # asynchronously on the stream into the caller's 4-word device tensor, read by the host when it likes
-            assert status.is_cuda and status.numel() >= 4 and status.element_size() == 4 and status.is_contiguous()
+            if not (status.is_cuda and status.numel() >= 4 and status.element_size() == 4 and status.is_contiguous()):
+                raise _lib.GolfError("ltv_allpole_ss: `status` must be a contiguous device tensor of >= 4 32-bit words")
             rc = lib.golf_ltv_allpole_status_u32(ws.data_ptr(), ws.numel(), B, T, F, M, hop, flags, status.data_ptr(),
                                                  _lib.stream_ptr())
             _lib.check(rc, "golf_ltv_allpole_status_u32")
@@ -164,6 +179,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         ex, gain, a, y, ws = ctx.saved_tensors
         lib = _lib.load()
@@ -172,9 +188,13 @@ class _LTVAllPoleSS(torch.autograd.Function):
         F, M = a.shape[1], a.shape[2]
         T = y.shape[1]
         gy = _rows(gy.float())
-        g_ex = torch.zeros_like(ex) if Tx > T else torch.empty_like(ex)
+        # the kernels write columns [0, T); only the excitation's tail beyond the output length needs zeros (a full-size fill
+        # was a 6 MB memset in front of every backward: 5.8 us of the B = 32 training step)
+        g_ex = torch.empty_like(ex)
         if g_ex.stride(1) != 1:
-            g_ex = torch.zeros(B, Tx, dtype=torch.float32, device=ex.device)
+            g_ex = torch.empty(B, Tx, dtype=torch.float32, device=ex.device)
+        if Tx > T:
+            g_ex[:, T:].zero_()
         g_gain = torch.empty_like(gain)
         g_a = torch.empty_like(a)
         rc = lib.golf_ltv_allpole_bwd_f32(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), ex.data_ptr(),
@@ -214,6 +234,11 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
 def ss_status(status: torch.Tensor) -> dict:
     """Decode the 4 status words of ltv_allpole_ss(..., status=t) (synchronises: reads the device tensor)."""
     w = status.detach().to("cpu").view(torch.int32)[:4]
+    if int(w[2]) & 2:   # never observed; a wait that ran out means the maps of a hot utterance may be half-updated
+        import warnings
+
+        warnings.warn("golf_amd: a device-side wait for the chunk-map fix-up ran out (golf_ltv_allpole_status_u32 bit 1): "
+                      "the output of hot utterances of this forward is not trustworthy", RuntimeWarning)
     return {"hot_utterances": int(w[0]), "tier3_utterances": int(w[1]), "nonfinite": bool(int(w[2]) & 1),
             "fixup_timeout": bool(int(w[2]) & 2), "scan_mismatch": bool(int(w[2]) & 4),
             "max_phi": float(w[3:4].view(torch.float32)[0])}
@@ -221,6 +246,7 @@ def ss_status(status: torch.Tensor) -> dict:
 
 class _LTVInverse(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, y, a, hop):
         _lib.require_device(y, a)
         lib = _lib.load()
@@ -238,6 +264,7 @@ class _LTVInverse(torch.autograd.Function):
         return e
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_e):
         y, a = ctx.saved_tensors
         hop, T = ctx.geom
@@ -272,6 +299,7 @@ def ff_output_length(Tx: int, F: int, hop: int, W: int):
 
 class _LTIFramesOLA(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, ex, gain, a, window, hop):
         _lib.require_device(ex, gain, a, window)
         lib = _lib.load()
@@ -296,6 +324,7 @@ class _LTIFramesOLA(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         ex, gain, a, window, ws_fwd = ctx.saved_tensors
         hop, Tx, Ty = ctx.geom
@@ -326,6 +355,7 @@ def lti_frames_ola(ex, gain, a, window, hop: int) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 class _RC2LPC(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, logits, max_abs, apply_tanh):
         _lib.require_device(logits)
         lib = _lib.load()
@@ -340,6 +370,7 @@ class _RC2LPC(torch.autograd.Function):
         return a
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_a):
         (x,) = ctx.saved_tensors
         max_abs, apply_tanh = ctx.cfg
@@ -367,6 +398,7 @@ _SOS_REP = {"coef": 0, "conj": 1, "real": 2}
 
 class _SOS2LPC(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, logits, max_abs_pole, rep):
         _lib.require_device(logits)
         lib = _lib.load()
@@ -382,6 +414,7 @@ class _SOS2LPC(torch.autograd.Function):
         return a
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_a):
         (x,) = ctx.saved_tensors
         rho, rep = ctx.cfg
@@ -411,6 +444,7 @@ def osc_lengths(Tp: int, phase_hop: int, os: int):
 
 class _GlottalOsc(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, phase, wsel, table, taps, phase_hop, w_hop, os, equal_energy, want_pre, add=None):
         _lib.require_device(phase, wsel, table, taps)
         if add is not None:
@@ -449,6 +483,7 @@ class _GlottalOsc(torch.autograd.Function):
         return (out, pre) if pre is not None else (out, None)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out, _g_pre):
         phase, wsel, table, taps, ws = ctx.saved_tensors
         phase_hop, w_hop, os, eq = ctx.cfg
@@ -500,6 +535,7 @@ class _WavetableLookup(torch.autograd.Function):
     out[b,n] = bilerp(tables[b], row n/hop_t, column wrapped[b,n]*L); differentiable w.r.t. both inputs."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, wrapped, tables, hop_t):
         _lib.require_device(wrapped, tables)
         lib = _lib.load()
@@ -517,6 +553,7 @@ class _WavetableLookup(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out):
         wrapped, tables = ctx.saved_tensors
         lib = _lib.load()
@@ -542,6 +579,7 @@ class _DecimateFIR(torch.autograd.Function):
     """The oscillator's decimator on its own (golf_decimate_fir_f32 / its adjoint)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, taps, os):
         _lib.require_device(x, taps)
         lib = _lib.load()
@@ -558,6 +596,7 @@ class _DecimateFIR(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out):
         (taps,) = ctx.saved_tensors
         N, os = ctx.cfg
@@ -589,15 +628,20 @@ class _PhaseAccumulate(torch.autograd.Function):
     g_offset = g -- what autograd does through cumsum and F.interpolate in the reference (models/synth.py:239-255)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, phase, phase_offset, phase_hop, os):
+        # float64 / half phases are accepted like the tensor-op version did (the reference forces .float() here,
+        # models/synth.py:251): cast first, then the fp32 / device contract applies
+        off_meta = None if phase_offset is None else (phase_offset.shape, phase_offset.dtype)
+        phase = _rows(phase.float())
+        if phase_offset is not None:
+            phase_offset = _rows(phase_offset.float().reshape(phase.shape[0], -1))
         _lib.require_device(phase, phase_offset)
         lib = _lib.load()
-        phase = _rows(phase.float())
         B, Tp = phase.shape
         P = phase_hop * os
         N = (Tp - 1) * P + 1 if P > 1 else Tp
         if phase_offset is not None:   # AudioTensor addition truncates to the shorter operand (utils.py:230-232)
-            phase_offset = _rows(phase_offset.float())
             N = min(N, phase_offset.shape[1])
         out = torch.empty(B, N, dtype=torch.float32, device=phase.device)
         ws = _workspace(lib.golf_phase_accumulate_workspace_bytes(B, Tp), phase.device)
@@ -606,9 +650,11 @@ class _PhaseAccumulate(torch.autograd.Function):
                                            out.stride(0), B, N, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_phase_accumulate_f32")
         ctx.geom = (Tp, P, os, N, phase_offset is not None and phase_offset.shape[1])
+        ctx.off_meta = off_meta
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         Tp, P, os, N, off_len = ctx.geom
         g_phase = g_off = None
@@ -618,6 +664,7 @@ class _PhaseAccumulate(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g_off = g.new_zeros(g.shape[0], off_len)
             g_off[:, :N] = g
+            g_off = g_off.reshape(ctx.off_meta[0]).to(ctx.off_meta[1])   # the caller's shape and dtype
         return g_phase, g_off, None, None
 
 
@@ -664,6 +711,7 @@ def blend_tables(table: torch.Tensor, wsel: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 class _NoiseBand(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, log_gain, bands, offsets, hop, T):
         _lib.require_device(log_gain, bands)
         lib = _lib.load()
@@ -681,6 +729,7 @@ class _NoiseBand(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out):
         log_gain, bands, offsets = ctx.saved_tensors
         lib = _lib.load()
@@ -755,6 +804,7 @@ class _ZPKernels(torch.autograd.Function):
     """(B,F,n_mag) log magnitudes -> (B*F, row_stride) windowed zero-phase FIR rows (cosine transform on the MFMAs)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, log_mag, window):
         _lib.require_device(log_mag, window)
         lib = _lib.load()
@@ -769,6 +819,7 @@ class _ZPKernels(torch.autograd.Function):
         return kern
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_kern):
         log_mag, window, basis = ctx.saved_tensors
         lib = _lib.load()
@@ -786,6 +837,7 @@ class _FIRFrames(torch.autograd.Function):
     """Per-frame FIR with kernel rows kern (B*F, row_stride): output frame f uses row f + frame0."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, ex, kern, F, N, hop, frame0):
         _lib.require_device(ex, kern)
         lib = _lib.load()
@@ -805,6 +857,7 @@ class _FIRFrames(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         ex, kern = ctx.saved_tensors
         F, N, hop, frame0 = ctx.geom
@@ -880,6 +933,7 @@ def ltv_fir_frames(ex: torch.Tensor, kernels: torch.Tensor, hop: int) -> torch.T
 # ------------------------------------------------------------------------------------------------
 class _LTIFIR(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, ex, taps, lead):
         _lib.require_device(ex, taps)
         lib = _lib.load()
@@ -894,6 +948,7 @@ class _LTIFIR(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         ex, taps = ctx.saved_tensors
         lib = _lib.load()
@@ -932,6 +987,7 @@ def _up_len(n: int, hop: int) -> int:
 
 class _HarmonicOsc(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, phase, amp, tscale, hscale, H, phase_hop, amp_hop, ts_hop, phase_offset=None, po_hop=1,
                 initial_phase=None):
         _lib.require_device(phase, amp, tscale, hscale, phase_offset, initial_phase)
@@ -988,6 +1044,7 @@ class _HarmonicOsc(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out):
         phase, tscale, hscale, amp, phase_offset, initial_phase = ctx.saved_tensors
         H, phase_hop, amp_hop, ts_hop, Fa, Fs, Tout, has_amp = ctx.geom
@@ -1002,9 +1059,15 @@ class _HarmonicOsc(torch.autograd.Function):
             # d out / d initial_phase[b,h] = 2 pi sum_t g[t] A_h[t] cos(2 pi theta_h[t]), A = the (masked, scaled) amplitude
             # track.  cos(x) = sin(x + 1/4 cycle) and A_h[t] = sum_f hat_f(t) amp[b,f,h]: the amplitude-gradient kernel run
             # with initial_phase + 1/4 returns G[b,f,h] = sum_t hat_f(t) g[t] cos(.) (scales and Nyquist mask included), and
-            # g_ip = 2 pi sum_f amp[b,f,h] G[b,f,h].  Without an amplitude track (A = 1): two frames one whole signal apart,
-            # whose hat functions sum to one.  (reference: autograd through models/synth.py:434-440)
-            Fq, hq = (Fa, amp_hop) if has_amp else (2, max(Tout - 1, 1))
+            # g_ip = 2 pi sum_f amp[b,f,h] G[b,f,h].  Without an amplitude track (A = 1): pseudo-frames 256 samples apart, whose
+            # hat functions sum to one over the signal -- G summed over them is the plain sum over t.  (Two frames one whole
+            # signal apart gave the kernel ONE segment: a single wave per utterance walking Tout x H sincos chains, milliseconds
+            # per call -- ADVICE r3.)  (reference: autograd through models/synth.py:434-440)
+            if has_amp:
+                Fq, hq = Fa, amp_hop
+            else:
+                hq = 256 if Tout > 257 else max(Tout - 1, 1)
+                Fq = -(-(Tout - 1) // hq) + 1 if Tout > 1 else 2
             G = torch.empty(B, Fq, H, dtype=torch.float32, device=phase.device)
             ws = _workspace(lib.golf_harmonic_osc_workspace_bytes(B, Tp, phase_hop, Fq, H), phase.device)
             shifted = (initial_phase + 0.25).contiguous()
@@ -1073,6 +1136,7 @@ def harmonic_osc(phase, H: int, phase_hop: int = 1, amp=None, amp_hop: int = 1, 
 # ------------------------------------------------------------------------------------------------
 class _BiquadFramesOLA(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, ex, gain, biquads, window, hop, pad, frame_gain):
         _lib.require_device(ex, gain, biquads, window)
         lib = _lib.load()
@@ -1097,6 +1161,7 @@ class _BiquadFramesOLA(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         ex, gain, biquads, window = ctx.saved_tensors
         hop, pad, frame_gain, Tx, nfr, Ty = ctx.geom

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GOLF_ABI_VERSION 3
+#define GOLF_ABI_VERSION 4
 
 enum {
     GOLF_OK = 0,
@@ -101,6 +101,12 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                fp32 transition matrices of the inference path (hot chunks recomputed from fp64 trajectories, one refinement
  *                sweep in the forward AND in the backward): same accuracy class, ~28 us less per B = 32 step (ABI 3). */
 #define GOLF_SS_TRAINING 64
+/*          GOLF_SS_MAPS_ONLY  (ABI 4, with GOLF_SS_FAST_TRANSITIONS) golf_ltv_allpole_transitions_f32 computes the transition
+ *                matrices and nothing else; the forward, given HAVE_TRANSITIONS | MAPS_ONLY, runs what is still missing (the
+ *                fix-up of ill-conditioned matrices, the group composites) in the launch that holds its zero-state pass.
+ *                The matrices need only `a`: this is the part of the filter that golf_source_transitions_f32 runs in the
+ *                oscillator's launch. */
+#define GOLF_SS_MAPS_ONLY 128
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);

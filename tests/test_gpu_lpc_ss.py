@@ -550,12 +550,31 @@ def test_conditioning_tiers_harsh_tracks(sigma, seed):
         good = ok & (e_ser < 0.05)          # beyond that the sequential recursion itself has lost the signal
         assert np.all(e[good] <= 3 * e_ser[good] + 1e-4), (fast, mode, np.nonzero(good & (e > 3 * e_ser + 1e-4))[0],
                                                             e[good].max())
-    # gradients: finite wherever the forward is, and no worse than the sequential adjoint by more than the known factor
+    # gradients: finite wherever the forward is, and on the rows where the sequential recursion has a signal left within
+    # 3 x the sequential adjoint's error + 2e-4 of the float64 oracle's closed-form backward -- the forward's bar
+    # (this test only asserted finiteness)
+    from oracle import golf_oracle as O
+
     gy = (np.random.default_rng(2).normal(0, 1, ref.shape) / scale[:, None]).astype(np.float32)
     gy[~ok] = 0
     res = run_mode(ex, gain, a, hop, None, gy)
+    ser = run_mode(ex, gain, a, hop, "serial", gy)
     for g, name in zip(res[1:], ("g_ex", "g_gain", "g_a")):
         assert np.isfinite(g[ok]).all(), name
+    good = ok & (e_ser < 0.05)
+    assert good.sum() >= B // 3
+    want = O.ltv_allpole_ss_backward(gy[good], ex[good], gain[good], a[good], hop)
+    n = int(good.sum())
+
+    def gerr(r, ref_g):
+        ref_g = ref_g.reshape(n, -1)
+        r = r[good].reshape(n, -1)[:, : ref_g.shape[1]]
+        return np.abs(r - ref_g).max(1) / (np.abs(ref_g).max(1) + 1e-30)
+
+    for got, sq, w, name in zip(res[1:], ser[1:], want, ("g_ex", "g_gain", "g_a")):
+        e_c, e_s = gerr(got, w), gerr(sq, w)
+        print(f"sigma {sigma} {name}: chunked {e_c.max():.2e} sequential {e_s.max():.2e} worst ratio {(e_c / (e_s + 1e-7)).max():.2f}")
+        assert np.all(e_c <= 3 * e_s + 2e-4), (name, np.nonzero(e_c > 3 * e_s + 2e-4)[0], e_c.max(), e_s.max())
 
 
 def test_two_level_switch_point_by_batch():
@@ -735,7 +754,7 @@ def test_conditioning_tiers_random_shapes(B, F, M, hop, T, sigma):
             return np.abs(r - ref_g).max(1) / (np.abs(ref_g).max(1) + 1e-30)
         for got, sq, want, name in zip(res[1:], ser[1:], (r_ex, r_gain, r_a), ("g_ex", "g_gain", "g_a")):
             e_c, e_s = gerr(got, want), gerr(sq, want)
-            assert np.all(e_c <= 4 * e_s + 3e-4), (name, e_c.max(), e_s.max())
+            assert np.all(e_c <= 3 * e_s + 2e-4), (name, e_c.max(), e_s.max())   # the forward's bar (was 4 x + 3e-4)
 
 
 @pytest.mark.parametrize("B,F,M,hop,T", [(3, 249, 2, 80, 19630), (2, 277, 20, 120, 32849), (3, 585, 4, 32, 18674),
@@ -799,3 +818,61 @@ def test_backward_on_another_scan_is_reported():
     assert not status_after_backward("flat-scan", "flat-scan")["scan_mismatch"]
     assert status_after_backward(None, "flat-scan")["scan_mismatch"]
     assert status_after_backward("flat-scan", None)["scan_mismatch"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,train", [(2434, False), (2435, False), (2435, True)])
+def test_maps_only_handle_is_bit_identical(seed, train):
+    """ABI 4: golf_ltv_allpole_transitions_f32 with GOLF_SS_MAPS_ONLY leaves the transition matrices alone; the forward then
+    runs the zero-state pass, the fix-up of hot matrices and the group composites in ONE launch (lpc_group_prepass_kernel,
+    `parts` = 7).  Same arithmetic in another launch structure: the output -- and the gradients, when the handle was prepared
+    for training -- equal the default path's bit for bit, on a cold batch and on one with a hot utterance (seed 2435:
+    largest transition entry 60)."""
+    from golf_amd import functional as GF
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=32, seed=seed)
+    ex, gain, a, hop = inp["noise"].cuda(), inp["gain"].cuda(), inp["a"].cuda(), inp["hop"]
+    T = GF.ss_output_length(ex.shape[1], a.shape[1], hop)
+
+    def run(prepared):
+        t = [v.clone().requires_grad_(train) for v in (ex, gain, a)]
+        prep = GF.ltv_allpole_prepare(t[2], hop, T, fast=True, training=train, maps_only=True) if prepared else None
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, prepared=prep, status=st)
+        grads = ()
+        if train:
+            y.backward(torch.ones_like(y) / y.shape[1])
+            grads = tuple(v.grad for v in t)
+        return y.detach(), grads, GF.ss_status(st)
+
+    y0, g0, s0 = run(False)
+    y1, g1, s1 = run(True)
+    assert s0 == s1 and not s0["nonfinite"] and not s0["fixup_timeout"], (s0, s1)
+    if seed == 2435:
+        assert s0["hot_utterances"] >= 1, s0
+    assert torch.equal(y0, y1)
+    for u, v in zip(g0, g1):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_status_words_are_per_forward():
+    """the non-finite flag of one forward must not be reported for later forwards on the same workspace (a
+    PreparedTransitions handle is reused for several signals: one prepare, many forwards)."""
+    from golf_amd import functional as GF
+
+    B, F, M, hop = 2, 200, 22, 240
+    ex, gain, a = smooth_case(B, F, M, hop, seed=5)
+    exd, gd, ad = dev(ex), dev(gain), dev(a)
+    T = GF.ss_output_length(exd.shape[1], F, hop)
+    bad = exd.clone()
+    bad[0, 1000] = float("inf")
+    for kw in (dict(), dict(mode="flat-scan")):
+        prep = GF.ltv_allpole_prepare(ad, hop, T, fast=True, **kw)
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        GF.ltv_allpole_ss(bad, gd, ad, hop, prepared=prep, status=st, **kw)
+        assert GF.ss_status(st)["nonfinite"]
+        prep2 = GF.PreparedTransitions(prep.ws, prep.key, prep.stream, prep.a, prep.fast, prep.training, prep.maps_only)
+        y = GF.ltv_allpole_ss(exd, gd, ad, hop, prepared=prep2, status=st, **kw)
+        assert torch.isfinite(y).all() and not GF.ss_status(st)["nonfinite"], kw

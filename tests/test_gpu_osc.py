@@ -133,6 +133,38 @@ def test_osc_full_length_closer_to_f64_than_reference_fp32_order():
     assert e_hip_ref[0] <= 1.1 * (e_ref[0] + e_hip[0])
 
 
+def test_b256_source_every_utterance():
+    """BASELINE configs[3]: 256 utterances of the benchmark recipe, 32 per rank.  Round 3 checked every row of that batch
+    through the FILTER only (tests/test_gpu_lpc_ss.py::test_b256_benchmark_inputs_every_utterance); this is the oscillator
+    on the same 256 utterances -- the whole batch in one call (the shape a single rank would see at B = 256) and as the
+    eight 32-utterance shards the ranks really run -- every row against the float64 oracle (VERDICT r3 #6)."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=256, seed=2434)
+    m = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True,
+                                           lf_v2=True, points=2048)
+    ph, ws = inp["phase"].numpy(), inp["wsel"].numpy()
+    ref = np.concatenate([O.indexed_glottal_forward(ph[lo:lo + 32], 1, ws[lo:lo + 32], inp["w_hop"], m.table.numpy(), 4,
+                                                    True, decim_taps=m.decimater.taps.numpy())["out"]
+                          for lo in range(0, 256, 32)])
+    table, taps = m.table.cuda(), m.decimater.taps.cuda()
+    whole = GF.glottal_osc(inp["phase"].cuda(), inp["wsel"].cuda(), table, taps, 1, inp["w_hop"], 4, True).cpu().numpy()
+    assert whole.shape == ref.shape == (256, 48000)
+    scale = np.abs(ref).max(1)
+    e = np.abs(whole - ref).max(1) / scale
+    print("B=256 oscillator: worst row", int(e.argmax()), float(e.max()))
+    assert np.all(e <= TOL), (np.nonzero(e > TOL)[0], e.max())
+    for lo in range(0, 256, 32):
+        sh = GF.glottal_osc(inp["phase"][lo:lo + 32].cuda(), inp["wsel"][lo:lo + 32].cuda(), table, taps, 1, inp["w_hop"], 4,
+                            True).cpu().numpy()
+        esh = np.abs(sh - ref[lo:lo + 32]).max(1) / scale[lo:lo + 32]
+        assert np.all(esh <= TOL), (lo, np.nonzero(esh > TOL)[0], esh.max())
+        assert np.array_equal(sh, whole[lo:lo + 32]), lo   # a shard's rows do not depend on the batch they are launched in
+
+
 @pytest.mark.parametrize("os_,eq", [(1, False), (4, True)])
 def test_osc_backward_wsel(os_, eq):
     """d out / d table_select_weight against central differences of the float64 oracle
