@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--workload", default="golf-ss-synth",
                     choices=["golf-ss-synth", "golf-ss-train", "golf-ff-synth", "golf-ff-train", "lpc-ss-fwd",
-                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step", "osc-only", "lpc-ss-fast", "golf-ss-decoder-logits"],
+                             "golf-ss-decoder", "golf-ss-decoder-train", "ddsp-decoder", "golf-ss-train-step", "osc-only", "lpc-ss-fast", "golf-ss-decoder-logits", "golf-ss-synth-have-maps"],
                     help="golf-ss-synth (default, BASELINE metric): oscillator + noise + LPC-ss filter; "
                          "golf-ss-decoder: the whole golf-precise.yaml decoder (adds the zero-phase FIR noise filter "
                          "and the room filter); golf-ss-train-step (BASELINE config 5, use --batch 64): one optimisation "
@@ -84,6 +84,10 @@ def parse():
                          "clocks: instantiation is setup, not a step)")
     ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "flat-scan"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
+    ap.add_argument("--lpc-chain", default="auto", choices=["auto", "latency", "throughput"],
+                    help="launch structure of the sample-wise filter (GOLF_SS_THROUGHPUT, include/golf_amd.h): 'throughput' "
+                         "costs the least chip time with several batches in flight, 'latency' finishes a lone batch soonest; "
+                         "auto = throughput when --streams > 1.  Bit-identical outputs.  single_stream reports both.")
     ap.add_argument("--recipe-stream", type=int, default=-1,
                     help="also time a stream of this many consecutive recipe batches (seeds 2434, 2435, ...: benign and hot "
                          "ones alike, each its own captured graph) through the same S streams; -1: 64 for the default "
@@ -126,6 +130,11 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
             # --overlap-transitions: the filter's excitation-independent phase (transition matrices + group composites)
             # on a second stream beside the oscillator -- shortens a lone batch's latency, not the pipelined rate
             prep = GF.ltv_allpole_prepare(a, hop, t_ss, overlap=True, fast=fast, mode=mode) if overlap else None
+            return GF.ltv_allpole_ss(source(), gain, a, hop, prepared=prep, fast_inference=fast, mode=mode)
+    elif workload == "golf-ss-synth-have-maps":   # diagnostic: the step WITHOUT its transition kernel and pre-pass composites
+        prep = GF.ltv_allpole_prepare(a, hop, t_ss, fast=fast, mode=mode)   # (prepared once, outside every timed region)
+
+        def step():
             return GF.ltv_allpole_ss(source(), gain, a, hop, prepared=prep, fast_inference=fast, mode=mode)
     elif workload == "lpc-ss-fwd":
         def step():
@@ -381,7 +390,7 @@ def cpu_baseline(B, hop, M, budget_s=15.0):
 # LPC filter (8.38 = ex 4 + y 4 + (22 + 1) * 4 / 240 frame parameters); derived the same way for the
 # zero-phase FIR noise filter (noise 4 + log_mag 256 * 4 / 240 in, 4 out = 12.27) and the room filter (4 in, 4 out).
 STAGE_BYTES = {"osc": 8.0, "lpc": 8.38, "noise_fir": 12.27, "room": 8.0}
-PATH_BYTES = {"golf-ss-synth": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0,
+PATH_BYTES = {"golf-ss-synth": 16.4, "golf-ss-synth-have-maps": 16.4, "golf-ff-synth": 16.4, "lpc-ss-fwd": 8.38, "lpc-ss-fast": 8.38, "osc-only": 8.0,
               "golf-ss-train": 16.4 + 16.8, "golf-ss-decoder": 16.4 + 12.27 + 8.0,
               "golf-ss-decoder-logits": 16.4 + 12.27 + 8.0, "golf-ss-decoder-train": 2 * (16.4 + 12.27 + 8.0),
               "golf-ff-train": 16.4 + 16.8, "golf-ss-train-step": 2 * (16.4 + 12.27 + 8.0),
@@ -452,6 +461,10 @@ def main():
         assert world == 1, f"{args.workload} is a single-GPU side benchmark"
     S = max(1, args.streams)
     osc, ss, ff = build_modules(device)
+    import golf_amd.functional as _GFm
+
+    throughput_chain = args.lpc_chain == "throughput" or (args.lpc_chain == "auto" and S > 1)
+    _GFm.THROUGHPUT_MODE = throughput_chain   # read when a step is issued or captured: the headline's graphs carry it
 
     # ---- every in-flight slot owns its inputs (seed 2434 + slot; slot 0 = the SURVEY §8d tensors) and its output
     def slot_inputs(slot):
@@ -493,6 +506,7 @@ def main():
     # (8 kernels + allocator traffic -> one launch).  Every step does the full work and writes its own output.
     use_graphs = not args.no_graphs  # training steps (forward + custom backward) are captured whole, like inference
     graphs, outs = [], []
+    g_lat = None
     if use_graphs:
         for i in range(S):
             warm = torch.cuda.Stream(device=device)
@@ -514,6 +528,25 @@ def main():
             assert torch.equal(outs[i], ref), f"hipGraph replay of slot {i} differs from eager execution"
         if S > 1 and not args.shared_inputs:
             assert not torch.equal(outs[0], outs[1]), "slots were expected to hold different batches"
+        # the latency view in the chain a caller WITHOUT batches in flight would ask for (GOLF_SS_THROUGHPUT off): its own
+        # graph of slot 0, captured and warmed like the others, checked against the headline's output (the two chains are
+        # bit-identical by construction)
+        if throughput_chain and "ss" in args.workload:
+            _GFm.THROUGHPUT_MODE = False
+            warm = torch.cuda.Stream(device=device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(2):
+                    steps_fn[0]()
+            torch.cuda.current_stream().wait_stream(warm)
+            g_lat = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_lat):
+                y_lat = steps_fn[0]()
+            g_lat.replay()
+            graphs[0].replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_lat, outs[0]), "latency and throughput chains differ"
+            _GFm.THROUGHPUT_MODE = throughput_chain
     # replay streams are created after capture: ROCm maps streams round-robin onto a few hardware queues, and
     # streams that alias one queue serialise (measured: 131 vs 105 us/step at S=4 depending on creation order)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
@@ -522,6 +555,9 @@ def main():
             for i in range(S):
                 with torch.cuda.stream(streams[i]):
                     graphs[i].replay()
+            if g_lat is not None:
+                with torch.cuda.stream(streams[0]):
+                    g_lat.replay()
         torch.cuda.synchronize()
 
     step_no = [0]
@@ -658,8 +694,14 @@ def main():
         bytes_per_sample = stage_bytes_per_sample(dom)
         alg_bytes = bytes_per_sample * samples
         achieved = alg_bytes / (dom_us * 1e-6) / 1e9
-        step_us = event_time_us(step)                       # one batch alone, eager, one stream
+        step_us = event_time_us(step)                       # one batch alone, eager, one stream (the headline's chain)
         graph_us = event_time_us(graphs[0].replay) if use_graphs else None   # the same as one hipGraph launch
+        lat_graph_us, lat_step_us = graph_us, step_us
+        if g_lat is not None:
+            lat_graph_us = event_time_us(g_lat.replay)
+            _GFm.THROUGHPUT_MODE = False
+            lat_step_us = event_time_us(step)
+            _GFm.THROUGHPUT_MODE = throughput_chain
         # HBM bytes per launch and issued VALU instructions per step come from separate rocprofv3 --pmc passes (counters
         # cannot be read in this run): the committed round-4 summaries only -- no fallback to an older round's file
         traffic, valu = None, None
@@ -711,7 +753,7 @@ def main():
             roofline["valu_insts_per_step"] = int(insts)
             roofline["valu_source"] = "profiles/r04_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
-        single_us = graph_us if graph_us is not None else step_us
+        single_us = lat_graph_us if lat_graph_us is not None else lat_step_us
         result = {
             "metric": ("audio samples/sec (24 kHz) GOLF-ss synth, batch=32x2 s" if args.workload == "golf-ss-synth" and B == 32
                        else f"audio samples/sec (24 kHz) {args.workload}, batch={B}x2 s")
@@ -723,7 +765,8 @@ def main():
                        "lpc_order": 22, "hop": 240, "frames": 200, "table": "100x2048 LF-v2", "oversampling": 4,
                        "samples_out_per_utterance": t_out,
                        "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode}, every {GE} step(s))" if do_gather else ""),
-                       "lpc_mode": args.lpc_mode, "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
+                       "lpc_mode": args.lpc_mode, "lpc_chain": "throughput" if throughput_chain else "latency",
+                       "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
                        "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),
             "timing": {"regions": len(regions), "statistic": "median region wall time (max over ranks per region)",
@@ -732,9 +775,14 @@ def main():
                        "prereplay_per_graph": args.prereplay if use_graphs else 0},
             # one batch at a time on ONE stream (no batches in flight): the latency view of the same step
             "single_stream": {"value": samples / (single_us * 1e-6), "unit": "audio samples/s",
-                              "us_per_step_graph": None if graph_us is None else round(graph_us, 2),
-                              "us_per_step_eager": round(step_us, 2)},
-            "single_batch_latency_us": round(step_us, 2),  # one batch alone, eager, HIP events on the launch stream
+                              "us_per_step_graph": None if lat_graph_us is None else round(lat_graph_us, 2),
+                              "us_per_step_eager": round(lat_step_us, 2),
+                              "lpc_chain": "latency",
+                              # the headline's own graph of slot 0 replayed alone (same launch structure as the headline)
+                              "headline_chain": "throughput" if throughput_chain else "latency",
+                              "us_per_step_graph_headline_chain": None if graph_us is None else round(graph_us, 2),
+                              "us_per_step_eager_headline_chain": round(step_us, 2)},
+            "single_batch_latency_us": round(lat_step_us, 2),  # one batch alone, eager, latency chain, HIP events on the launch stream
             "roofline": roofline,
             "stages_us": stages,
         }

@@ -690,6 +690,19 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
 // signal tile: polyphase branch ph, coarse index i  ->  X[ph * XS + i + 4 * (i >> 4)]
 __device__ __forceinline__ int oscf_xaddr(int i) { return i + 4 * (i >> 4); }
 
+#ifdef OSCF_TIMING   // dev build (tools/osc_phases.py): s_memtime stamps of the workgroup's phases, thread 0 of every workgroup
+__device__ unsigned long long g_oscf_stamps[8 * 4096];
+#define OSCF_STAMP(i) do { if (threadIdx.x == 0) g_oscf_stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_oscf_stamps), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define OSCF_STAMP(i) do { } while (0)
+#endif
+#ifndef OSCF_LATE_BF
+#define OSCF_LATE_BF 1        // 1: the Toeplitz fragments are loaded after the scans (48 registers less through staging + scan:
+                              //    128 -> 111 VGPRs, pipelined headline 70.3 -> 68.1 us/step, one batch alone unchanged; tools/ab2.sh r12_ab)
+#endif
 // KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
 template <int EE, int KS>
 __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel(
@@ -704,6 +717,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     __shared__ u64 wtot[NTH / 64];
     __shared__ u64 base_sh, halo_sh;
     light_wave_priority();
+    OSCF_STAMP(0);
     // layout: X polyphase signal tile [4][XS] | row pairs [(nrows-1)][L+1] float2
     float* X = smem;
     float2* pairs = reinterpret_cast<float2*>(smem + OS * XS);
@@ -716,10 +730,12 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     // ---- 0. Toeplitz fragments of the taps (laid out by osc_tile_totals_kernel), straight into registers: coalesced
     //         loads issued now, consumed in step 4
     float bfrag[OS][KS];
+#if !OSCF_LATE_BF
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
+#endif
     // ---- 1. base phase: the tiles before this one (wave 0); the thread's own coarse phase samples; the row pairs
     if (wv == 0) {
         u64 acc = 0;
@@ -807,22 +823,28 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
 #endif
         }
     }
+    OSCF_STAMP(1);
     // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
-    u64 av[CPT + 1], dv[CPT], tv[CPT];
+    // (only the converted increments av[] stay in registers through the render: the second differences d and the segment
+    //  totals 4 a + 6 d are a shift and two adds away and are recomputed where they are used -- 20 VGPRs that round 4 found
+    //  to matter more than the ~15 integer instructions per coarse sample: the oscillator's register footprint is what the
+    //  other batches' waves have to fit beside)
+    u64 av[CPT + 1];
     u64 tsum = 0;
 #pragma unroll
     for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[r], 2);   // OS = 4
-#pragma unroll
-    for (int r = 0; r < CPT; ++r) {
+    auto seg_total = [&](int r) -> u64 {
         const int j = j_lo + u0 + r;
-        dv[r] = osc_fix_d_pow2(av[r], av[r + 1], 2);              // P = 4
+        const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);       // P = 4
         const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-        tv[r] = seg ? (av[r] << 2) + dv[r] * (u64)6 : 0;
-        tsum += tv[r];
-    }
+        return seg ? (av[r] << 2) + d * (u64)6 : 0;
+    };
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) tsum += seg_total(r);
     const u64 incl = wave_incl_scan(tsum, lane);
     if (lane == 63) wtot[wv] = incl;
     __syncthreads();                             // also: row pairs and base_sh are in place
+    OSCF_STAMP(2);
     u64 run = incl - tsum;                       // exclusive prefix relative to coarse sample j_lo
     for (int w = 0; w < wv; ++w) run += wtot[w];
     {   // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
@@ -831,10 +853,17 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
             if (u0 + r == -dmin) halo_sh = r2;
-            r2 += tv[r];
+            r2 += seg_total(r);
         }
     }
     __syncthreads();
+    OSCF_STAMP(3);
+#if OSCF_LATE_BF
+#pragma unroll
+    for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
+#endif
     // ---- 3. render the 4 fine samples of every owned coarse sample (they lie in ONE control interval: hop_t is a
     //         multiple of 4) into the polyphase tile
     const float inv_hop_t = 1.0f / (float)hop_t;
@@ -847,13 +876,14 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
         const int u = u0 + r;
-        const u64 ph_next = ph + tv[r];
+        const u64 dvr = osc_fix_d_pow2(av[r], av[r + 1], 2);
+        const u64 ph_next = ph + seg_total(r);
         if (u < span) {
             const int j = j_lo + u;
             const float p0 = pv[r], p1 = pv[r + 1];
             // inclusive phases of the 4 fine samples: ph + (k+1) a + d k(k+1)/2; the last one is the next coarse sample's
             // start (tv = 4 a + 6 d wherever that fine sample exists) -- four independent 64-bit adds instead of a chain of 8
-            const u64 c2 = (av[r] << 1) + dv[r], c3 = c2 + av[r] + (dv[r] << 1);
+            const u64 c2 = (av[r] << 1) + dvr, c3 = c2 + av[r] + (dvr << 1);
             const unsigned hik[P] = {(unsigned)((ph + av[r]) >> 32), (unsigned)((ph + c2) >> 32),
                                      (unsigned)((ph + c3) >> 32), (unsigned)(ph_next >> 32)};
             const int m0 = j * P;
@@ -912,7 +942,9 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     float ad[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
+    OSCF_STAMP(4);
     __syncthreads();
+    OSCF_STAMP(5);
     // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
     //         D[m][n] (output 256*wv + 16*m + n) = sum_ph sum_k' X_ph[256*wv + 16*m + k'] * B_ph[k'][n]
     if (256 * wv >= OSCF_TO) return;   // (tiles shorter than 8 x 256 outputs: build-parameter experiments)
@@ -932,6 +964,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
             }
         }
     }
+    OSCF_STAMP(6);
     const BufRow orow(out + (size_t)b * out_stride, Tout);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -940,6 +973,7 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
         const int o = ob + 16 * r;
         orow.st((OSCF_TO % 256 == 0 || o < o0 + OSCF_TO) ? o : -1, acc0[r] + acc1[r] + ad[r]);
     }
+    OSCF_STAMP(7);
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------

@@ -1056,8 +1056,14 @@ static int p1f_kt() {
     return v == 2 ? 2 : 4;
 }
 
+// Register allocation of the transition kernel, measured with 4 batches in flight (tools/ab2.sh r14_ab / r15_ab): 172 VGPRs (what
+// hipcc takes: two such waves fit a SIMD) 69.1 - 69.4 us/step; capped at 168 (three fit) 71.1 - 71.5 -- transition waves of
+// different batches stacked three deep are worse than queued; padded to 264 (one per SIMD) 68.9 - 69.1: no gain.  Left alone.
+#ifndef GOLF_P1F_WAVES
+#define GOLF_P1F_WAVES 1
+#endif
 template <int W, int NT, int KT = 4>
-__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
+__global__ __launch_bounds__(64 * P1F_WPB, GOLF_P1F_WAVES) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
                                                                int F, int M, int hop, int L, int NP, int nq,
                                                                float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
                                                                int B, float* __restrict__ Phi) {
@@ -1763,7 +1769,7 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
 // Group-local scan from a zero state with the inputs in LDS (x[k][32], k = chunk of the group): v = the response of the
 // group's chunk maps -> V[b][g].  Epilogue of the refinement pass (inputs = its defects) and of the zero-state units that
 // run inside the pre-pass launch (inputs = their z).
-template <int W, int NT>
+template <int W, int NT, int D = 4>
 __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, const float* __restrict__ xl,
                                                float* __restrict__ Vout, int b, int g, int NP, int NG, int lane) {
     const bool act = lane < NT;
@@ -1772,8 +1778,7 @@ __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, c
     const size_t cstride4 = (size_t)NT * W / 4;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
-    constexpr int D = 4;
-    float4 pb[D][W / 4];
+    float4 pb[D][W / 4];   // D maps ahead
 #pragma unroll
     for (int u = 0; u < D; ++u) {
         const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
@@ -1900,7 +1905,7 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
 //   t = fold of (M_g', v_g') over the groups before g, then the wave's own chunk maps with inputs x
 //   (first pass: v = zero-state group responses, x = z; correction pass: v = the groups' responses to the defects, x = defects).
-template <int W, int NT>
+template <int W, int NT, bool THIN = false>
 __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, const float* __restrict__ MT,
                                                const float* __restrict__ V, const float* __restrict__ x,
                                                float* __restrict__ st, int b, int g, int NP, int NG, int lane) {
@@ -1909,7 +1914,9 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     const size_t cstride4 = (size_t)NT * W / 4;
     float t = 0.f;
     // the wave's own chunk maps: first fetches issued before the fold below, so they are in flight during it
-    constexpr int DC = GOLF_GP_DC;
+    // THIN (GOLF_SS_THROUGHPUT): 4 + 2 maps ahead instead of 6 + 4 -- 196 / 246 VGPRs instead of 290 / 269, so that two chunk-pass
+    // waves (or one and a transition wave) share a SIMD's registers; costs a lone batch ~1.3 us per pass (tools/ab2.sh ab_regs)
+    constexpr int DC = THIN ? 4 : GOLF_GP_DC;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NP * W + ii;
     const int c0 = g * kGroup;
@@ -1924,7 +1931,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 #pragma unroll
     for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
     {   // (a) the groups before this one
-        constexpr int D = GOLF_GP_D;
+        constexpr int D = THIN ? 2 : GOLF_GP_D;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
         const float* vb = V + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
@@ -1974,7 +1981,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 #ifndef GOLF_FWDQ2_WAVES
 #define GOLF_FWDQ2_WAVES 1   // waves per SIMD the chunk kernels' register allocation must allow (build parameter: A/B of residency)
 #endif
-template <int W, int NT, int MODE>
+template <int W, int NT, int MODE, bool THIN = false>
 __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                        const float* __restrict__ gain, const float* __restrict__ a,
                                                        float* __restrict__ out, int64_t y_stride, int T, int F, int M,
@@ -2024,7 +2031,7 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
             for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
             vv = V[((size_t)b * NG + gc) * 32 + ii];
         }
-        group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);
+        group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane);
         // The state the NEXT group starts from is its own fold, M_g S1_{c0} + v_g -- not this wave's scan result st[16]
         // (the two differ by the composite's rounding).  The defect of the group's last chunk has to be taken against the
         // state its successor really runs from, or that difference would never be corrected: recompute the successor's
@@ -2059,7 +2066,7 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
                 const float v = s1b[(size_t)c0 * 32 + (ok ? e : 0)];
                 s1v[u] = ok ? v : 0.f;
             }
-            group_prologue<W, NT>(PhiT, MT, V, x, st, b, g, NP, NG, lane);   // delta_c (V = defect responses, x = defects)
+            group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane);   // delta_c (V = defect responses, x = defects)
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
                 const int e = lane + 64 * u;
@@ -2975,8 +2982,8 @@ static int launch_composites(const SsPlan& p, const float* a, int B, int F, int 
     return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, training, st);
 }
 
-// The zero-state pass inside the pre-pass launch (round 4; dev knob GOLF_SS_ZPASS_IN_PREPASS=0/1 for the A/B against the
-// transition kernel that carries it, lpc_p1fz_kernel).
+// The zero-state pass inside the pre-pass launch (round 4): what GOLF_SS_THROUGHPUT and GOLF_SS_MAPS_ONLY select; the dev
+// knob GOLF_SS_ZPASS_IN_PREPASS=1 forces it for every call (A/B against lpc_p1fz_kernel, which carries the pass otherwise).
 static bool zpass_in_prepass() {
     static const bool v = [] { const char* e = getenv("GOLF_SS_ZPASS_IN_PREPASS"); return e ? atoi(e) != 0 : false; }();
     return v;
@@ -3080,7 +3087,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     if constexpr (NT <= 24) two_level = use_two_level_scan(p, B, flags);
     const bool maps_only = (flags & GOLF_SS_HAVE_TRANSITIONS) && (flags & GOLF_SS_MAPS_ONLY);
     const bool zin = two_level && fast && !side && !(flags & GOLF_SS_SPLIT_P1) && p.NP > 0 &&
-                     (zpass_in_prepass() || maps_only);
+                     (zpass_in_prepass() || maps_only || (flags & GOLF_SS_THROUGHPUT));
     if (p.NP > 0) {
         if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
             hipStream_t s1 = st;
@@ -3166,15 +3173,19 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             GOLF_LAUNCH_CHECK();
             // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
             const int gx3 = (int)ceil_div(p.NP, kGroup);
-            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0, st,
-                               ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,
-                               (const float*)MT, (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier,
-                               nonfinite, B, Phi64);
-            GOLF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride, gain,
-                               a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,
-                               (const float*)Vd, (float*)nullptr, (const float*)dfc, p.NP, p.NG, S1, tier, nonfinite, B,
+            const bool thin = (flags & GOLF_SS_THROUGHPUT) != 0;
+#define GOLF_FWDQ2_LAUNCH(THINV)                                                                                              \
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3, THINV>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0,  \
+                               st, ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,        \
+                               (const float*)MT, (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier, nonfinite, B,  \
+                               Phi64);                                                                                         \
+            GOLF_LAUNCH_CHECK();                                                                                               \
+            hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1, THINV>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride,    \
+                               gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,            \
+                               (const float*)Vd, (float*)nullptr, (const float*)dfc, p.NP, p.NG, S1, tier, nonfinite, B,       \
                                Phi64);
+            if (thin) { GOLF_FWDQ2_LAUNCH(true) } else { GOLF_FWDQ2_LAUNCH(false) }
+#undef GOLF_FWDQ2_LAUNCH
             GOLF_LAUNCH_CHECK();
             return GOLF_OK;
         }

@@ -48,11 +48,15 @@ __global__ void peer_signal_kernel(PeerPtrs flags, int n, unsigned seq) {
 }
 
 // lane i spins until flags[i * stride] has reached seq (sequence numbers only grow; wrap-around is compared signed),
-// at most `timeout_ticks` of the 100 MHz wall clock: a peer that never arrives must not hang the GPU
+// at most `timeout_ticks` of the device's constant-rate wall clock (wall_clock64; rate from hipDeviceAttributeWallClockRate):
+// a peer that never arrives must not hang the GPU
 __global__ void peer_wait_kernel(const unsigned* __restrict__ flags, int n, int stride, unsigned seq,
                                  unsigned long long timeout_ticks, int* __restrict__ status) {
     const int i = threadIdx.x;
     if (i >= n) return;
+    // latched: once a wait of this exchange has run out, later waits return at once instead of each spending the full
+    // timeout again (a dead peer costs one timeout, not one per queued step) -- ADVICE r2
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const unsigned long long t_end = wall_clock64() + timeout_ticks;
     for (;;) {
         const unsigned v = __hip_atomic_load(flags + (size_t)i * stride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -149,7 +153,11 @@ extern "C" int golf_peer_wait_u32(const uint32_t* flags, int n, int stride, uint
     if (!flags || !status || n < 0 || n > 64 || stride < 1)
         return fail(GOLF_EINVAL, "peer_wait: n=%d stride=%d (at most 64 flags)", n, stride);
     if (n == 0) return GOLF_OK;
-    const unsigned long long ticks = (unsigned long long)(timeout_us < 0 ? 0 : timeout_us) * 100ull;   // 100 MHz
+    // ticks of wall_clock64(): the rate is a device attribute (kHz; 100 MHz on gfx950 today -- asked for, not assumed)
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000;
+    const unsigned long long ticks = (unsigned long long)(timeout_us < 0 ? 0 : timeout_us) * (unsigned long long)khz / 1000ull;
     hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flags, n, stride,
                        (unsigned)seq, ticks, status);
     GOLF_LAUNCH_CHECK();

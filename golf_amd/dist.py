@@ -312,6 +312,22 @@ class PeerStoreGather:
             raise RuntimeError(f"PeerStoreGather: rank {self.rank} timed out waiting for rank {st - 1} "
                                f"(pushed {self.pushed}, consumed {self.consumed})")
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        # leaving by an exception: the peers may be gone, do not add a barrier they will never join -- free what is local
+        if exc_type is None:
+            self.close()
+        else:
+            torch.cuda.synchronize(self.device)
+            for p in self._opened:
+                self.lib.golf_peer_close(p)
+            for p in self._local:
+                self.lib.golf_peer_free(p)
+            self._opened, self._local, self.recv = [], [], None
+        return False
+
     def close(self) -> None:
         """Unmap the peers' buffers and free the local ones (all ranks, after a barrier: nobody stores any more)."""
         import torch.distributed as dist

@@ -21,6 +21,7 @@ HAVE_TRANSITIONS = 1
 FAST_TRANSITIONS = 2
 TRAINING = 64            # GOLF_SS_TRAINING
 MAPS_ONLY = 128          # GOLF_SS_MAPS_ONLY (ABI 4)
+THROUGHPUT = 256         # GOLF_SS_THROUGHPUT (ABI 4)
 FORK_TRANSITIONS = False
 SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
@@ -150,7 +151,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
                 flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0) | (MAPS_ONLY if prepared.maps_only else 0)
         else:
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
-            flags = mode
+            flags = mode | (THROUGHPUT if THROUGHPUT_MODE else 0)
             if fast_inference:
                 # fp32 transition matrices (hot chunks recomputed from fp64 trajectories) + one refinement sweep; with a
                 # gradient pending the forward also keeps the adjoint-orientation maps for the backward's own sweep
@@ -206,6 +207,10 @@ class _LTVAllPoleSS(torch.autograd.Function):
 
 
 SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _FLAT_SCAN
+# Set by a caller that keeps several batches in flight (bench.py's pipelined loop, a serving loop): GOLF_SS_THROUGHPUT
+# is added to every sample-wise filter call.  Bit-identical results; a lone batch takes ~10 us longer, four in flight
+# finish ~2 % more per second (include/golf_amd.h).
+THROUGHPUT_MODE = False
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,

@@ -148,7 +148,12 @@ def get_transformed_lf(R_d: float = 0.3, T_0: float = 5.0, n_iter_eps: int = 5, 
 
 
 def get_transformed_lf_v2(Rd: Tensor, points: int = 1024) -> Tensor:
-    """Closed-form LF derivative pulses for a vector of R_d values -> (len(Rd), points)."""
+    """Closed-form LF derivative pulses for a vector of R_d values -> (len(Rd), points).
+
+    A RESTATEMENT, not a redesign (reference models/utils.py:363-400): the table this produces is a checkpoint-visible
+    buffer, pinned bit for bit by tests/golden/g3 (sha256 of the full post-processed table), so the closed form is evaluated
+    with the reference's operations in the reference's order -- only the names differ.  SURVEY a-7 keeps it in host PyTorch:
+    it runs once, at module construction."""
     Rd = torch.as_tensor(Rd).view(-1, 1)
     Ra = 0.048 * Rd - 0.01
     Rk = 0.118 * Rd + 0.224

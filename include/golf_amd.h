@@ -107,6 +107,13 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                The matrices need only `a`: this is the part of the filter that golf_source_transitions_f32 runs in the
  *                oscillator's launch. */
 #define GOLF_SS_MAPS_ONLY 128
+/*          GOLF_SS_THROUGHPUT  (ABI 4) the caller keeps SEVERAL batches in flight on the device (a serving loop on a few HIP
+ *                streams): prefer the launch structure that costs the least chip time over the one that finishes a lone
+ *                batch soonest.  Today: the zero-state pass runs inside the pre-pass launch instead of inside the transition
+ *                kernel's -- one batch alone 130 -> 140 us, four in flight 71 -> 69.5 us/step (20-step regions 81 -> 78.5),
+ *                MI355X, B = 32 x 2 s.  Results are bit-identical either way.  The library cannot see how many batches its
+ *                caller keeps in flight, hence a flag (cf. GOLF_SS_SERIAL). */
+#define GOLF_SS_THROUGHPUT 256
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);

@@ -876,3 +876,33 @@ def test_status_words_are_per_forward():
         prep2 = GF.PreparedTransitions(prep.ws, prep.key, prep.stream, prep.a, prep.fast, prep.training, prep.maps_only)
         y = GF.ltv_allpole_ss(exd, gd, ad, hop, prepared=prep2, status=st, **kw)
         assert torch.isfinite(y).all() and not GF.ss_status(st)["nonfinite"], kw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,train", [(2434, False), (2435, False), (2435, True)])
+def test_throughput_chain_is_bit_identical(seed, train, monkeypatch):
+    """GOLF_SS_THROUGHPUT (ABI 4) changes the launch structure only -- transition kernel alone, zero-state pass + fix-up +
+    composites in one launch, chunk passes with shallower prefetch rings -- not one bit of the output or the gradients."""
+    from golf_amd import functional as GF
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=32, seed=seed)
+    ex, gain, a, hop = inp["noise"].cuda(), inp["gain"].cuda(), inp["a"].cuda(), inp["hop"]
+
+    def run(throughput):
+        monkeypatch.setattr(GF, "THROUGHPUT_MODE", throughput)
+        t = [v.clone().requires_grad_(train) for v in (ex, gain, a)]
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, status=st)
+        grads = ()
+        if train:
+            y.backward(torch.ones_like(y) / y.shape[1])
+            grads = tuple(v.grad for v in t)
+        return y.detach(), grads, GF.ss_status(st)
+
+    y0, g0, s0 = run(False)
+    y1, g1, s1 = run(True)
+    assert s0 == s1 and not s0["nonfinite"] and not s0["fixup_timeout"], (s0, s1)
+    assert torch.equal(y0, y1)
+    for u, v in zip(g0, g1):
+        assert torch.equal(u, v)

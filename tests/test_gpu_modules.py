@@ -417,6 +417,6 @@ def test_decoder_under_bf16_autocast_matches_fp32():
     # (that is what autocast means for the encoder side), so the audio is compared loosely; the point is that the fp32-only
     # kernels are reached with fp32 tensors and nothing raises
     y_ref = run(h16.float())
-    emax, el2 = rel_err(y_amp.cpu().numpy(), y_ref.detach().cpu().numpy())
+    emax, el2 = rel_err(y_amp.detach().cpu().numpy(), y_ref.detach().cpu().numpy())
     print("bf16 autocast vs fp32", emax, el2)
     assert el2 < 5e-2

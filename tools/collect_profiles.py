@@ -3,7 +3,7 @@ usage: python tools/collect_profiles.py [r02]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -68,4 +68,23 @@ if sq:
                "4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); wave_wait_frac = SQ_WAIT_INST_ANY / "
                "SQ_WAVE_CYCLES; lds_busy_frac = SQ_LDS_IDX_ACTIVE / (cycles * 256 CUs)",
                "kernels": dict(sq)}, open(os.path.join(DST, RND + "_sq_counters.json"), "w"), indent=1)
+# ---- the headline run (4 batches in flight): issued VALU wave-instructions per step, for bench.py's roofline.valu_issue_frac
+sq4 = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(SRC, "sq4_synth", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "golf::" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            sq4[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq4:
+    kern4 = {k: {c: round(sum(v) / len(v)) for c, v in d.items()} for k, d in sq4.items()}
+    for k, d in sq4.items():
+        kern4[k]["launches"] = len(next(iter(d.values())))
+    # every kernel of the step is launched once per step: the per-launch averages add up to the step
+    per_step = sum(d.get("SQ_INSTS_VALU", 0) for d in kern4.values())
+    json.dump({"batch": 32, "workload": "golf-ss-synth", "streams": 4,
+               "method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES over "
+                         "`bench.py --steps 20 --warmup 5` (4 batches in flight, hipGraph replay; tools/refresh_profiles.sh); "
+                         "per-launch averages per kernel, summed over the kernels of one step",
+               "SQ_INSTS_VALU_per_step": int(per_step), "kernels": kern4},
+              open(os.path.join(DST, RND + "_sq_counters_4stream.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): every bench line, rocprofv3 kernel traces and the
 # separate HBM-counter passes that profiles/ is built from (tools/collect_profiles.py turns the output into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RND=${ROUND_TAG:-r03}
+RND=${ROUND_TAG:-r04}
 O=$R/gpurun_out/$RND
 rm -rf $O; mkdir -p $O
 cd $R
@@ -49,6 +49,13 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VA
   bash tools/prof_pmc.sh $O/sq_${i}_decoder $set -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/sq_${i}_decoder.log 2>&1
   bash tools/prof_pmc.sh $O/sq_${i}_train $set -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train --streams 1 --no-graphs > $O/sq_${i}_train.log 2>&1
 done
+# the headline run itself (4 batches in flight, hipGraph replay): issued VALU wave-instructions per kernel launch, for
+# roofline.valu_issue_frac (VERDICT r3 #1b); same command as the driver's, counters only (no timing is read from this pass)
+bash tools/prof_pmc.sh $O/sq4_synth SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES -- python $R/bench.py --no-cpu-baseline --recipe-stream 0 --steps 20 --warmup 5 > $O/sq4_synth.log 2>&1
+b --lpc-chain latency --no-cpu-baseline --recipe-stream 0 > $O/bench_golf_ss_synth_latency_chain.json
+b --workload golf-ss-synth-have-maps --no-cpu-baseline --recipe-stream 0 > $O/bench_synth_have_maps.json
+b --workload osc-only --no-cpu-baseline > $O/bench_osc_only.json
+b --workload lpc-ss-fast --no-cpu-baseline > $O/bench_lpc_only.json
 # keep the merge-back small: summarise the rocpd databases here, drop them and the per-dispatch traces of the counter passes
 for d in $O/trace_*; do
   [ -d "$d" ] || continue
