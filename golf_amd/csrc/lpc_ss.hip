@@ -1458,8 +1458,8 @@ __device__ __forceinline__ double lane_bcast_d(double v, int lane) {
 // element i of every row j, so the wave's accesses are contiguous), one wave per utterance; states leave rounded to fp32
 // into rows of `sstride` floats (32: S1 of the two-level path, 64: S of the flat one).
 template <int W, int NT>
-__device__ __forceinline__ void precise_fwd_scan(const double* __restrict__ P64, const float* __restrict__ zb,
-                                                 float* __restrict__ Sb, int sstride, int NP, int lane) {
+__device__ __forceinline__ void precise_fwd_scan_w1(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                    float* __restrict__ Sb, int sstride, int NP, int lane) {
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
     constexpr int D = 4;
@@ -1501,8 +1501,8 @@ __device__ __forceinline__ void precise_fwd_scan(const double* __restrict__ P64,
 // Tier-3 adjoint boundary states (backward): lam_start(c) = Phi_c^T lam_end(c) + zadj_c in fp64; lane j reads row j of
 // the doubles (contiguous).  Mirrors lpc_adj_scan_kernel: lamEnd[c][:] = adjoint state at the END of chunk c.
 template <int W, int NT>
-__device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64, const float* __restrict__ zb,
-                                                 float* __restrict__ Lb, int lstride, int NP, int lane) {
+__device__ __forceinline__ void precise_adj_scan_w1(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                    float* __restrict__ Lb, int lstride, int NP, int lane) {
     const bool act = lane < NT;
     const int jj = act ? lane : 0;
     if (lane < lstride) Lb[(size_t)NP * lstride + lane] = 0.f;
@@ -1535,6 +1535,134 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
                 }
                 lam = act ? acc0 + acc1 : 0.0;
                 fetch(u, c - D);
+            }
+        }
+    }
+}
+
+// The same scans with the matvec split over the two halves of the wave (round 4; orders up to 32).  Lane (i, h = lane / 32)
+// owns row i and the columns of half h: half as many doubles to fetch per step (a ring twice as deep in the same registers),
+// half as long a dependent FMA chain, and the state reaches a lane by ds_bpermute (per-lane source: readlane's scalar
+// result cannot differ between the halves) -- ~36 instead of ~70 issued instructions per step, and the fetch latency that
+// bounded the one-lane-per-row version (400 ns per step: 80 us for the 199 steps of a 2 s utterance) is covered.
+__device__ __forceinline__ double lane_perm_d(double v, int src_lane) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)x);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)(x >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+template <int W, int NT>
+__device__ __forceinline__ void precise_fwd_scan(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                 float* __restrict__ Sb, int sstride, int NP, int lane) {
+    if constexpr (NT > 32) {
+        precise_fwd_scan_w1<W, NT>(P64, zb, Sb, sstride, NP, lane);
+    } else {
+        constexpr int NH = (NT + 1) / 2;          // columns per half
+        const int h = lane >> 5, i = lane & 31;
+        const bool act = i < NT;
+        const int ii = act ? i : 0, j0 = h * NH;
+        constexpr int D = 4;   // (a deeper ring raises the register count of the whole refinement kernel these waves ride in)
+        double buf[D][NH];
+        float zc[D];
+        auto fetch = [&](int u, int c) {
+            const int cl = c < NP ? c : NP - 1;
+            const double* mp = P64 + (size_t)cl * NT * W + ii;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {   // raw loads from a clamped row: the mask of a padding column (odd orders) is applied
+                const int j = j0 + k;        // to the STATE value at use -- a select here makes hipcc wait for every load at once
+                buf[u][k] = mp[(size_t)(j < NT ? j : NT - 1) * W];
+            }
+            zc[u] = zb[(size_t)cl * W + ii];
+        };
+        double s = 0.0;                            // component i, the same value in both halves
+        if (NP > 0) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) fetch(u, u);
+            for (int c0 = 0; c0 < NP; c0 += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    const int c = c0 + u;
+                    if (c < NP) {   // wave-uniform
+                        if (lane < sstride) Sb[(size_t)c * sstride + lane] = h == 0 ? (float)s : 0.f;
+                        // all permutes of a step in flight at once, ONE wait: left to itself hipcc reuses one register pair
+                        // for the permuted value and waits for every ds_bpermute before the FMA that consumes it -- twelve
+                        // LDS round trips per step, 1.3 us (measured: a tier-3 batch 243 -> 413 us with that schedule)
+                        double sj[NH];
+#pragma unroll
+                        for (int k = 0; k < NH; ++k) {
+                            const double v = lane_perm_d(s, j0 + k < NT ? j0 + k : 0);
+                            sj[k] = (2 * NH == NT || j0 + k < NT) ? v : 0.0;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NH; ++k) {
+                            if (k & 1) acc1 = __builtin_elementwise_fma(buf[u][k], sj[k], acc1);
+                            else       acc0 = __builtin_elementwise_fma(buf[u][k], sj[k], acc0);
+                        }
+                        const double part = acc0 + acc1;
+                        const double tot = part + lane_perm_d(part, lane ^ 32);   // commutative: both halves get the same bits
+                        s = act ? tot + (double)zc[u] : 0.0;
+                        fetch(u, c + D);
+                    }
+                }
+            }
+        }
+        if (lane < sstride) Sb[(size_t)(NP > 0 ? NP : 0) * sstride + lane] = h == 0 ? (float)s : 0.f;
+    }
+}
+template <int W, int NT>
+__device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64, const float* __restrict__ zb,
+                                                 float* __restrict__ Lb, int lstride, int NP, int lane) {
+    if constexpr (NT > 32) {
+        precise_adj_scan_w1<W, NT>(P64, zb, Lb, lstride, NP, lane);
+    } else {
+        constexpr int NH = (NT + 1) / 2;          // rows i of the map per half (lam'_j = sum_i Phi[i][j] lam_i)
+        const int h = lane >> 5, j = lane & 31;
+        const bool act = j < NT;
+        const int jj = act ? j : 0, i0 = h * NH;
+        if (lane < lstride) Lb[(size_t)NP * lstride + lane] = 0.f;
+        double lam = act ? (double)zb[(size_t)NP * W + jj] : 0.0;
+        constexpr int D = 4;   // (a deeper ring raises the register count of the whole refinement kernel these waves ride in)
+        double buf[D][NH];
+        float zc[D];
+        auto fetch = [&](int u, int c) {
+            const int cl = c > 0 ? c : 0;
+            const double* mp = P64 + ((size_t)cl * NT + jj) * W;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {   // (raw loads; padding masked at use: see precise_fwd_scan)
+                const int i = i0 + k;
+                buf[u][k] = mp[i < NT ? i : NT - 1];
+            }
+            zc[u] = zb[(size_t)cl * W + jj];
+        };
+        if (NP <= 0) return;
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, NP - 1 - u);
+        for (int u0 = 0; u0 < NP; u0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = NP - 1 - (u0 + u);
+                if (c >= 0) {   // wave-uniform
+                    if (lane < lstride) Lb[(size_t)c * lstride + lane] = h == 0 ? (float)lam : 0.f;
+                    double li[NH];   // (all permutes of the step in flight at once: see precise_fwd_scan)
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        const double v = lane_perm_d(lam, i0 + k < NT ? i0 + k : 0);
+                        li[k] = (2 * NH == NT || i0 + k < NT) ? v : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        if (k & 1) acc1 = __builtin_elementwise_fma(buf[u][k], li[k], acc1);
+                        else       acc0 = __builtin_elementwise_fma(buf[u][k], li[k], acc0);
+                    }
+                    const double part = acc0 + acc1;
+                    const double tot = part + lane_perm_d(part, lane ^ 32);
+                    lam = act ? tot + (double)zc[u] : 0.0;
+                    fetch(u, c - D);
+                }
             }
         }
     }
@@ -1886,7 +2014,14 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
         const float v = c < NP ? fabsf(fa.pmax[(size_t)b * NP + c]) : 0.f;
         if (__builtin_amdgcn_ballot_w64(!(v <= fa.g2)) != 0ull) {   // a chunk of this group may have been recomputed
             const UttTier d = utterance_tier(fa.pmax + (size_t)b * NP, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
-            if (d.t3) return;
+            if (d.t3) {
+                // a tier-3 utterance needs none of this wave's products (its states come from the fp64 scan), but ALL its
+                // 199 x 22 map units recomputed as doubles -- 4.3 passes of the 64 fix-up waves an utterance owns.  The
+                // utterance's 13 x 5 composite / z-scan waves have nothing else to do: they take units too (round 4:
+                // the fix-up of a tier-3 utterance ~2 passes instead of ~4.3)
+                if (fix) fixup_wave<W, NT>(fa, b, false, hot_lds[wv]);
+                return;
+            }
             if (d.nhot > 0u && !fa.accurate) {
                 // Help before waiting: the units are claimed from a counter, so this wave takes whatever nobody has claimed
                 // yet.  When it returns every unit is done or in the hands of a RESIDENT wave (claiming is what a wave does

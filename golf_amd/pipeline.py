@@ -48,6 +48,20 @@ class ReplayPipeline:
                  use_graphs: bool = True):
         self.fn, self.use_graphs = fn, use_graphs
         self.slots: List[Slot] = [Slot(make_inputs()) for _ in range(max(1, n_slots))]
+        # several batches in flight: ask the sample-wise filter for the launch chain that costs the least chip time
+        # (GOLF_SS_THROUGHPUT, include/golf_amd.h; bit-identical results).  The flag is read when a step is issued or
+        # captured, so it is set around the capture / the eager submits of THIS pipeline only.
+        self.throughput = len(self.slots) > 1
+        from . import functional as _GF
+
+        prev_mode, _GF.THROUGHPUT_MODE = _GF.THROUGHPUT_MODE, self.throughput
+        try:
+            self._capture(fn, check)
+        finally:
+            _GF.THROUGHPUT_MODE = prev_mode
+
+    def _capture(self, fn, check: bool) -> None:
+        use_graphs = self.use_graphs
         self._next = 0
         device = next(t for t in self.slots[0].inputs.values() if isinstance(t, torch.Tensor)).device
         if use_graphs:
@@ -79,7 +93,13 @@ class ReplayPipeline:
             if self.use_graphs:
                 slot.graph.replay()
             else:
-                slot.output = self.fn(slot.inputs)
+                from . import functional as _GF
+
+                prev_mode, _GF.THROUGHPUT_MODE = _GF.THROUGHPUT_MODE, self.throughput
+                try:
+                    slot.output = self.fn(slot.inputs)
+                finally:
+                    _GF.THROUGHPUT_MODE = prev_mode
         return slot
 
     def synchronize(self) -> None:
