@@ -88,6 +88,8 @@ def parse():
                     help="launch structure of the sample-wise filter (GOLF_SS_THROUGHPUT, include/golf_amd.h): 'throughput' "
                          "costs the least chip time with several batches in flight, 'latency' finishes a lone batch soonest; "
                          "auto = throughput when --streams > 1.  Bit-identical outputs.  single_stream reports both.")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="counter passes: run nothing but the headline's own launch chain (no latency-chain graph of slot 0)")
     ap.add_argument("--recipe-stream", type=int, default=-1,
                     help="also time a stream of this many consecutive recipe batches (seeds 2434, 2435, ...: benign and hot "
                          "ones alike, each its own captured graph) through the same S streams; -1: 64 for the default "
@@ -531,7 +533,7 @@ def main():
         # the latency view in the chain a caller WITHOUT batches in flight would ask for (GOLF_SS_THROUGHPUT off): its own
         # graph of slot 0, captured and warmed like the others, checked against the headline's output (the two chains are
         # bit-identical by construction)
-        if throughput_chain and "ss" in args.workload:
+        if throughput_chain and "ss" in args.workload and not args.headline_only:
             _GFm.THROUGHPUT_MODE = False
             warm = torch.cuda.Stream(device=device)
             warm.wait_stream(torch.cuda.current_stream())

@@ -35,13 +35,19 @@ def counters(tag):
     return dict(out)
 
 kern = counters("synth")
+kern.update({k: v for k, v in counters("synthtp").items() if k not in kern})   # the throughput chain's own kernels
 kern.update({k: v for k, v in counters("decoder").items() if k not in kern})
 kern.update({k: v for k, v in counters("train").items() if k not in kern})
 json.dump({"batch": 32, "workload": "golf-ss-synth (headline), golf-ss-decoder (inference) + golf-ss-decoder-train kernels",
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_pmc.sh), "
                      "per-launch averages; hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH doubled per "
                      "MI355X_MICROARCH.md gfx950 note: exact for wide coalesced reads, an upper bound for narrow ones)",
-           "kernels": kern}, open(os.path.join(DST, RND + "_hbm_traffic.json"), "w"), indent=1)
+           "kernels": kern,
+           # one step = one launch of each of its kernels: the two launch chains of the sample-wise filter, summed
+           "step_total_bytes": {
+               "latency_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synth").items()),
+               "throughput_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synthtp").items())}},
+          open(os.path.join(DST, RND + "_hbm_traffic.json"), "w"), indent=1)
 
 # ---- SQ counters -> per-kernel utilisation figures
 sq = collections.defaultdict(dict)

@@ -39,6 +39,8 @@ prof trace_decoder_train --workload golf-ss-decoder-train
 prof trace_ff_train --workload golf-ff-train
 for c in FETCH_SIZE WRITE_SIZE; do
   bash tools/prof_pmc.sh $O/pmc_${c}_synth $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-synth --streams 1 --no-graphs > $O/pmc_${c}_synth.log 2>&1
+  # ... and of the throughput chain the headline runs (GOLF_SS_THROUGHPUT), eager on one stream like the pass above
+  bash tools/prof_pmc.sh $O/pmc_${c}_synthtp $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-synth --streams 1 --no-graphs --lpc-chain throughput > $O/pmc_${c}_synthtp.log 2>&1
   bash tools/prof_pmc.sh $O/pmc_${c}_decoder $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder --streams 1 --no-graphs > $O/pmc_${c}_decoder.log 2>&1
   bash tools/prof_pmc.sh $O/pmc_${c}_train $c -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --workload golf-ss-decoder-train > $O/pmc_${c}_train.log 2>&1
 done
@@ -51,7 +53,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VA
 done
 # the headline run itself (4 batches in flight, hipGraph replay): issued VALU wave-instructions per kernel launch, for
 # roofline.valu_issue_frac (VERDICT r3 #1b); same command as the driver's, counters only (no timing is read from this pass)
-bash tools/prof_pmc.sh $O/sq4_synth SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES -- python $R/bench.py --no-cpu-baseline --recipe-stream 0 --steps 20 --warmup 5 > $O/sq4_synth.log 2>&1
+bash tools/prof_pmc.sh $O/sq4_synth SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES -- python $R/bench.py --no-cpu-baseline --recipe-stream 0 --steps 20 --warmup 5 --headline-only > $O/sq4_synth.log 2>&1
 b --lpc-chain latency --no-cpu-baseline --recipe-stream 0 > $O/bench_golf_ss_synth_latency_chain.json
 b --workload golf-ss-synth-have-maps --no-cpu-baseline --recipe-stream 0 > $O/bench_synth_have_maps.json
 b --workload osc-only --no-cpu-baseline > $O/bench_osc_only.json
