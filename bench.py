@@ -79,9 +79,12 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (EXACTLY --steps steps, barrier + synchronize on both sides) is run this many "
                          "times; ms_per_step / value are the MEDIAN region, every region is listed under 'timing'")
-    ap.add_argument("--prereplay", type=int, default=16,
+    ap.add_argument("--prereplay", type=int, default=64,
                     help="setup: replays of every captured hipGraph before the warm-up steps (graph upload, code objects, "
-                         "clocks: instantiation is setup, not a step)")
+                         "clocks: instantiation is setup, not a step).  64 x 4 graphs = ~18 ms of device work: a 20-step "
+                         "timed region lasts 1.6 ms, and regions measured back to back on a device that has only just left "
+                         "idle fall from 81 to 73 us/step over the first 15 (round 4, DESIGN.md 6) -- with 16 replays "
+                         "(rounds 2-3) the five timed regions sat on that ramp.  Reported in timing.prereplay_per_graph.")
     ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "flat-scan"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
     ap.add_argument("--lpc-chain", default="auto", choices=["auto", "latency", "throughput"],
