@@ -699,10 +699,6 @@ extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
 #else
 #define OSCF_STAMP(i) do { } while (0)
 #endif
-#ifndef OSCF_LATE_BF
-#define OSCF_LATE_BF 1        // 1: the Toeplitz fragments are loaded after the scans (48 registers less through staging + scan:
-                              //    128 -> 111 VGPRs, pipelined headline 70.3 -> 68.1 us/step, one batch alone unchanged; tools/ab2.sh r12_ab)
-#endif
 // KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
 template <int EE, int KS>
 __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel(
@@ -729,13 +725,8 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     const int j_lo = o0 + dmin;                  // may be negative for the first tile
     // ---- 0. Toeplitz fragments of the taps (laid out by osc_tile_totals_kernel), straight into registers: coalesced
     //         loads issued now, consumed in step 4
-    float bfrag[OS][KS];
-#if !OSCF_LATE_BF
-#pragma unroll
-    for (int ph = 0; ph < OS; ++ph)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
-#endif
+    float bfrag[OS][KS];   // (loaded after the scans, in flight during the render: 48 registers that need not be live through the
+                           //  staging and the scans -- 128 -> 111 VGPRs, pipelined headline 70.3 -> 68.1 us/step, tools/ab2.sh r12_ab)
     // ---- 1. base phase: the tiles before this one (wave 0); the thread's own coarse phase samples; the row pairs
     if (wv == 0) {
         u64 acc = 0;
@@ -858,12 +849,10 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
     }
     __syncthreads();
     OSCF_STAMP(3);
-#if OSCF_LATE_BF
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
-#endif
     // ---- 3. render the 4 fine samples of every owned coarse sample (they lie in ONE control interval: hop_t is a
     //         multiple of 4) into the polyphase tile
     const float inv_hop_t = 1.0f / (float)hop_t;

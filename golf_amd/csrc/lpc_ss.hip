@@ -743,16 +743,21 @@ constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
 #ifndef P1F_CHAINS
 #define P1F_CHAINS 2
 #endif
-template <int W, int NT>
+template <int W, int NT, int NR = 2>
 struct P1fGeom {
-    static constexpr int KT = 4;
+    static constexpr int KT = 2 * NR;               // trajectories per lane: NR float2 rings
     static constexpr int NG = (NT + KT - 1) / KT;   // trajectory groups per chunk
     static constexpr int CPW = 64 / NG;             // whole chunks per wave: lane = cl*NG + grp
     static constexpr int WAVE_TILE = 64;            // LDS per wave: the 64-word scratch of the per-chunk maximum (the maps leave
                                                     // by direct stores; a 16 KB transposition tile per wave was round 3's losing arm)
     static constexpr int TILE_FLOATS = P1F_WPB * WAVE_TILE;
 };
-template <int W, int NT>
+// NR = 2 (four trajectories per lane) is what runs: 637 waves at B = 32, one per SIMD of 160 CUs, 36 - 38 us.
+// NR = 3 (six per lane: the 11 coefficient interpolations of a step amortised over 66 instead of 44 dot-product FMAs, all 64
+//   lanes of a wave used, -13 % packed FMAs on 398 waves) was measured in round 4 for the throughput chain: 232 VGPRs, 55 us
+//   alone, and 71.5 instead of 69.0 us/step with four batches in flight -- with four streams the step rate is four chains per
+//   (contended) chain time, and a longer kernel lengthens the chain more than its smaller instruction count shortens it.
+template <int W, int NT, int NR = 2>
 __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
                                          int L, int NP, int nq, float* __restrict__ tile_all, int blk_id,
                                          float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0,
@@ -761,7 +766,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     // FMA-issue bound, so two waves sharing a SIMD double the kernel.  With single-wave workgroups the dispatcher's
     // SIMD choice depended on what ran before (measured: the same launch took 42 us or 63 us); a 4-wave workgroup
     // puts one wave on each SIMD of its CU.
-    using G = P1fGeom<W, NT>;
+    using G = P1fGeom<W, NT, NR>;
     constexpr int KT = G::KT, NG = G::NG, CPW = G::CPW;
     constexpr int NP2 = NT / 2;              // tap pairs (NT is even)
     const int lane = threadIdx.x & 63;
@@ -777,13 +782,14 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     const int jb = KT * grp;
     const int qq = live ? q : (nq - 1);
     const int b = qq / NP, c = qq - b * NP;
-    f32x2 hA[W], hB[W];  // hA = trajectories (jb, jb+1), hB = (jb+2, jb+3)
+    f32x2 h[NR][W];  // ring r = trajectories (jb + 2 r, jb + 2 r + 1)
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
-        const int j = W - 1 - k;
-        hA[k] = f32x2{(j == jb && jb < M) ? 1.f : 0.f, (j == jb + 1 && jb + 1 < M) ? 1.f : 0.f};
-        hB[k] = f32x2{(j == jb + 2 && jb + 2 < M) ? 1.f : 0.f, (j == jb + 3 && jb + 3 < M) ? 1.f : 0.f};
-    }
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int j = W - 1 - k, j0 = jb + 2 * r;
+            h[r][k] = f32x2{(j == j0 && j0 < M) ? 1.f : 0.f, (j == j0 + 1 && j0 + 1 < M) ? 1.f : 0.f};
+        }
     f32x2 a0p[NP2], ddp[NP2];
     const float inv_hop = 1.0f / (float)hop;
     int fcur = -1;
@@ -812,30 +818,34 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
             f32x2 cfp[NP2];
 #pragma unroll
             for (int pp = 0; pp < NP2; ++pp) cfp[pp] = __builtin_elementwise_fma(n2, ddp[pp], a0p[pp]);
-            // NCH independent accumulation chains per ring (2 x NCH in flight).  Measured: 2 and 4 chains per ring run
+            // NCH independent accumulation chains per ring (NR x NCH in flight).  Measured: 2 and 4 chains per ring run
             // the same 41.5 us -- the loop is bound by v_pk_fma_f32 issue (~6.4 cycles each for a lone wave), not by the
             // dependent-result latency
             constexpr int NCH = P1F_CHAINS;
-            f32x2 rA[NCH], rB[NCH];
+            f32x2 acc[NR][NCH];
 #pragma unroll
-            for (int u = 0; u < NCH; ++u) rA[u] = rB[u] = f32x2{0.f, 0.f};
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) acc[r][u] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = NT - 1; i >= 1; --i) {
                 const float cf = (i & 1) ? cfp[i / 2].y : cfp[i / 2].x;
                 const f32x2 c2 = f32x2{cf, cf};
                 const int slot = (s - 1 - i + 2 * W) % W;
-                rA[i % NCH] = __builtin_elementwise_fma(c2, hA[slot], rA[i % NCH]);
-                rB[i % NCH] = __builtin_elementwise_fma(c2, hB[slot], rB[i % NCH]);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r][i % NCH] = __builtin_elementwise_fma(c2, h[r][slot], acc[r][i % NCH]);
             }
 #pragma unroll
             for (int st = NCH / 2; st >= 1; st /= 2)
 #pragma unroll
-                for (int u = 0; u < st; ++u) { rA[u] += rA[u + st]; rB[u] += rB[u + st]; }
+                for (int u = 0; u < st; ++u)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) acc[r][u] += acc[r][u + st];
             const float cf0 = cfp[0].x;
             const f32x2 c0 = f32x2{-cf0, -cf0};
             const int sp = (s - 1 + W) % W;
-            hA[s] = __builtin_elementwise_fma(c0, hA[sp], -rA[0]);
-            hB[s] = __builtin_elementwise_fma(c0, hB[sp], -rB[0]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) h[r][s] = __builtin_elementwise_fma(c0, h[r][sp], -acc[r][0]);
         }
     }
     // largest |entry| of the chunk's matrix -> pmax[q] (the conditioning guard of the chunked algorithm, see
@@ -843,12 +853,12 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     if (pmax) {
         unsigned mx = 0u;
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            mx = max(mx, __float_as_uint(fabsf(hA[k].x)));
-            mx = max(mx, __float_as_uint(fabsf(hA[k].y)));
-            mx = max(mx, __float_as_uint(fabsf(hB[k].x)));
-            mx = max(mx, __float_as_uint(fabsf(hB[k].y)));
-        }
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                mx = max(mx, __float_as_uint(fabsf(h[r][k].x)));
+                mx = max(mx, __float_as_uint(fabsf(h[r][k].y)));
+            }
         wave_lds_fence();
         reinterpret_cast<unsigned*>(tile)[lane] = mx;
         wave_lds_fence();
@@ -859,217 +869,67 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
         }
         wave_lds_fence();
     }
+    // element (row i, trajectory jb + u) of the chunk's map: d s_end[i] / d s_start[jb + u]
+    auto entry = [&](int i, int u) -> float {
+        const f32x2 v = h[u / 2][(W - 1 - i + W) % W];
+        return (i < M && jb + u < M) ? ((u & 1) ? v.y : v.x) : 0.f;
+    };
     // Training (GOLF_SS_TRAINING): the backward's adjoint scan reads the maps in the other orientation, Phi[q][j][i] -- rows
-    // j = this lane's four trajectories, W contiguous floats each: direct float4 stores.
+    // j = this lane's trajectories, W contiguous floats each: direct float4 stores.
     if (Phi && live) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KT; ++u) {
             const int j = jb + u;
             if (j < NT) {
                 float4* o = reinterpret_cast<float4*>(Phi + ((size_t)q * NT + j) * W);
 #pragma unroll
-                for (int i4 = 0; i4 < W / 4; ++i4) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * i4 + e;
-                        const f32x2 ha = hA[(W - 1 - i + W) % W], hb = hB[(W - 1 - i + W) % W];
-                        const float x = u == 0 ? ha.x : (u == 1 ? ha.y : (u == 2 ? hb.x : hb.y));
-                        v[e] = (i < M && j < M) ? x : 0.f;
-                    }
-                    o[i4] = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                for (int i4 = 0; i4 < W / 4; ++i4)
+                    o[i4] = make_float4(entry(4 * i4, u), entry(4 * i4 + 1, u), entry(4 * i4 + 2, u), entry(4 * i4 + 3, u));
             }
         }
     }
-    // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+3 of every row i of its chunk.
-    // Straight from the registers: 16 bytes per lane and row, the NG lanes of a chunk cover the row's W floats, NT store
-    // instructions.  No LDS tile: the workgroup's footprint drops from 64 KB to the zero-state units' 7 KB, so that it fits
-    // a CU beside TWO oscillator workgroups (2 x 73 KB of the 160 KB) while other batches are in flight.
+    // PhiT[q][i][j] = d s_end[i] / d s_start[j]: this lane owns columns jb..jb+KT-1 of every row i of its chunk.
+    // Straight from the registers: 4 KT bytes per lane and row (16-byte stores with four trajectories per lane, 8-byte ones with
+    // six: 24 grp bytes is only 8-byte aligned), the NG lanes of a chunk cover the row, NT rows.  No LDS tile: the workgroup's
+    // footprint is the zero-state units' 7 KB, so that it fits a CU beside TWO oscillator workgroups.
     if (live) {
         float* prow = PhiT + (size_t)q * NT * W + jb;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const bool ok = i < M;
-            const f32x2 va = hA[W - 1 - i], vb = hB[W - 1 - i];
-            float4 v;
-            v.x = (ok && jb < M) ? va.x : 0.f;
-            v.y = (ok && jb + 1 < M) ? va.y : 0.f;
-            v.z = (ok && jb + 2 < M) ? vb.x : 0.f;
-            v.w = (ok && jb + 3 < M) ? vb.y : 0.f;
-            if (jb + 3 < W) *reinterpret_cast<float4*>(prow + (size_t)i * W) = v;
-            if constexpr (4 * NG < W) {   // columns no trajectory group covers: zeros (the group composites read whole rows)
+            if constexpr (KT == 4) {
+                if (jb + 3 < W)
+                    *reinterpret_cast<float4*>(prow + (size_t)i * W) = make_float4(entry(i, 0), entry(i, 1), entry(i, 2), entry(i, 3));
+            } else {
+#pragma unroll
+                for (int u = 0; u < KT; u += 2)
+                    if (jb + u + 1 < W)
+                        *reinterpret_cast<float2*>(prow + u + (size_t)i * W) = make_float2(entry(i, u), entry(i, u + 1));
+            }
+            if constexpr (KT * NG < W) {   // columns no trajectory group covers: zeros (the group composites read whole rows)
                 if (grp == NG - 1) {
 #pragma unroll
-                    for (int cc = 4 * NG; cc < W; cc += 4)
-                        *reinterpret_cast<float4*>(prow - jb + cc + (size_t)i * W) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int cc = KT * NG; cc < W; cc += 2)
+                        *reinterpret_cast<float2*>(prow - jb + cc + (size_t)i * W) = make_float2(0.f, 0.f);
                 }
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// The same trajectories with TWO per lane (round 4): one float2 ring, NT / 2 lanes per chunk (no padding trajectories: 22 of
-// 22 instead of 22 of 24), thread = chunk_in_workgroup * (NT / 2) + pair, 23 whole chunks per 256-thread workgroup.
-// Per step 22 + 11 packed FMAs instead of 44 + 11: a wave is 0.61 x as long, there are 1.75 x as many (1 116 instead of 637
-// at B = 32 -- all 1 024 SIMDs busy instead of 637), and the kernel needs ~120 VGPRs instead of 205, so four of its waves --
-// or one and an oscillator workgroup -- share a SIMD's register file where the four-trajectory kernel allowed two.  The
-// coefficient interpolation is amortised over half as many FMAs (+6 % instructions in total).  Selected by p1f_kt().
-// ------------------------------------------------------------------------------------------
-template <int W, int NT>
-struct P1f2Geom {
-    static_assert(NT % 2 == 0, "trajectory pairs");
-    static constexpr int NG = NT / 2;                       // trajectory pairs (= lanes) per chunk
-    static constexpr int CPB = (64 * P1F_WPB) / NG;         // whole chunks per workgroup
-};
-template <int W, int NT>
-__device__ __forceinline__ void p1f2_body(const float* __restrict__ a, float* __restrict__ PhiT, int F, int M, int hop,
-                                          int L, int NP, int nq, float* __restrict__ tile_all, int blk_id,
-                                          float* __restrict__ pmax, unsigned* __restrict__ fixcnt = nullptr, int B = 0,
-                                          float* __restrict__ Phi = nullptr) {
-    using G = P1f2Geom<W, NT>;
-    constexpr int NG = G::NG, CPB = G::CPB, NP2 = NT / 2;
-    const int t = threadIdx.x;
-    if (fixcnt && blk_id == 0 && t < 64)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = t; e < 2 * B + 1; e += 64) fixcnt[e] = 0u;
-    const int cl = t / NG, grp = t - cl * NG;
-    const int q = blk_id * CPB + cl;
-    const bool live = cl < CPB && q < nq;     // (idle lanes shadow the last chunk: every wave reaches the barrier below)
-    const int jb = 2 * grp;
-    const int qq = live ? q : (nq - 1);
-    const int b = qq / NP, c = qq - b * NP;
-    f32x2 h[W];   // trajectories (jb, jb + 1)
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        const int j = W - 1 - k;
-        h[k] = f32x2{(j == jb && jb < M) ? 1.f : 0.f, (j == jb + 1 && jb + 1 < M) ? 1.f : 0.f};
-    }
-    f32x2 a0p[NP2], ddp[NP2];
-    const float inv_hop = 1.0f / (float)hop;
-    int fcur = -1;
-    const int nblk = L / W;
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int t0 = c * L + blk * W;
-        const int f = t0 / hop;
-        if (f != fcur) {
-            fcur = f;
-            const float* pa0 = a + ((size_t)b * F + f) * M;
-            const float* pa1 = pa0 + M;
-#pragma unroll
-            for (int pp = 0; pp < NP2; ++pp) {
-                const int i0 = 2 * pp, i1 = 2 * pp + 1;
-                const float u0 = i0 < M ? pa0[i0] : 0.f, u1 = i1 < M ? pa0[i1] : 0.f;
-                const float v0 = i0 < M ? pa1[i0] : 0.f, v1 = i1 < M ? pa1[i1] : 0.f;
-                a0p[pp] = f32x2{u0, u1};
-                ddp[pp] = f32x2{(v0 - u0) * inv_hop, (v1 - u1) * inv_hop};
-            }
-        }
-        const float n0 = (float)(t0 - f * hop);
-#pragma unroll
-        for (int s = 0; s < W; ++s) {
-            const float n = n0 + (float)s;
-            const f32x2 n2 = f32x2{n, n};
-            // the coefficient pair of taps (2 pp, 2 pp + 1) is interpolated one pair ahead of its use (22 live registers
-            // less than interpolating all pairs first; the 128-register budget is the point of this variant)
-            f32x2 r0 = f32x2{0.f, 0.f}, r1 = f32x2{0.f, 0.f};
-            f32x2 cq = __builtin_elementwise_fma(n2, ddp[NP2 - 1], a0p[NP2 - 1]);
-            float cf0 = 0.f;
-#pragma unroll
-            for (int pp = NP2 - 1; pp >= 0; --pp) {
-                f32x2 cn = cq;
-                if (pp > 0) cn = __builtin_elementwise_fma(n2, ddp[pp - 1], a0p[pp - 1]);
-                {
-                    const int i = 2 * pp + 1;
-                    const f32x2 c2 = f32x2{cq.y, cq.y};
-                    r1 = __builtin_elementwise_fma(c2, h[(s - 1 - i + 2 * W) % W], r1);
-                }
-                if (pp > 0) {
-                    const int i = 2 * pp;
-                    const f32x2 c2 = f32x2{cq.x, cq.x};
-                    r0 = __builtin_elementwise_fma(c2, h[(s - 1 - i + 2 * W) % W], r0);
-                } else {
-                    cf0 = cq.x;
-                }
-                cq = cn;
-            }
-            const f32x2 c0 = f32x2{-cf0, -cf0};
-            h[s] = __builtin_elementwise_fma(c0, h[(s - 1 + W) % W], -(r0 + r1));
-        }
-    }
-    // largest |entry| of the chunk's matrix -> pmax[q] (bit patterns: a NaN ranks above +inf), through the workgroup's LDS
-    if (pmax) {
-        unsigned mx = 0u;
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            mx = max(mx, __float_as_uint(fabsf(h[k].x)));
-            mx = max(mx, __float_as_uint(fabsf(h[k].y)));
-        }
-        reinterpret_cast<unsigned*>(tile_all)[t] = mx;
-        __syncthreads();
-        if (live && grp == 0) {
-#pragma unroll
-            for (int u = 1; u < NG; ++u) mx = max(mx, reinterpret_cast<const unsigned*>(tile_all)[t + u]);
-            pmax[q] = __uint_as_float(mx);
-        }
-    }
-    if (!live) return;
-    // Training (GOLF_SS_TRAINING): the adjoint orientation Phi[q][j][i], rows j = this lane's two trajectories
-    if (Phi) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = jb + u;
-            float4* o = reinterpret_cast<float4*>(Phi + ((size_t)q * NT + j) * W);
-#pragma unroll
-            for (int i4 = 0; i4 < W / 4; ++i4) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * i4 + e;
-                    const f32x2 hv = h[(W - 1 - i + W) % W];
-                    v[e] = (i < M && j < M) ? (u == 0 ? hv.x : hv.y) : 0.f;
-                }
-                o[i4] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
-    // PhiT[q][i][j]: this lane owns columns jb, jb + 1 of every row i -- 8 bytes per lane and row, straight from the registers
-    float* prow = PhiT + (size_t)q * NT * W + jb;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const bool ok = i < M;
-        const f32x2 va = h[W - 1 - i];
-        *reinterpret_cast<float2*>(prow + (size_t)i * W) = make_float2((ok && jb < M) ? va.x : 0.f, (ok && jb + 1 < M) ? va.y : 0.f);
-        if constexpr (2 * NG < W) {   // columns no trajectory covers: zeros (the group composites read whole rows)
-            if (grp == NG - 1) {
-#pragma unroll
-                for (int cc = 2 * NG; cc < W; cc += 2)
-                    *reinterpret_cast<float2*>(prow - jb + cc + (size_t)i * W) = make_float2(0.f, 0.f);
-            }
-        }
-    }
-}
-
-// trajectories per lane of the fp32 transition kernel: 4 (p1f_body) or 2 (p1f2_body); dev knob GOLF_P1F_KT
-static int p1f_kt() {
-    static const int v = [] { const char* e = getenv("GOLF_P1F_KT"); return e ? atoi(e) : 4; }();
-    return v == 2 ? 2 : 4;
-}
-
+// (Round 4 built the same trajectories with TWO per lane -- one float2 ring, 11 lanes per chunk and no padding trajectories, 114
+// VGPRs, 1 116 waves -- and measured it: alone in its launch 43.8 us against 37.7 (279 workgroups on 256 CUs: the doubled CUs
+// are the tail, and 1 100 lane-sets can never be <= 1 024 waves), four batches in flight 71.3 against 69.2 us/step.  Removed;
+// commit 37966e3 has it.)
 // Register allocation of the transition kernel, measured with 4 batches in flight (tools/ab2.sh r14_ab / r15_ab): 172 VGPRs (what
 // hipcc takes: two such waves fit a SIMD) 69.1 - 69.4 us/step; capped at 168 (three fit) 71.1 - 71.5 -- transition waves of
 // different batches stacked three deep are worse than queued; padded to 264 (one per SIMD) 68.9 - 69.1: no gain.  Left alone.
-#ifndef GOLF_P1F_WAVES
-#define GOLF_P1F_WAVES 1
-#endif
-template <int W, int NT, int KT = 4>
-__global__ __launch_bounds__(64 * P1F_WPB, GOLF_P1F_WAVES) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
+template <int W, int NT, int NR = 2>
+__global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1f_kernel(const float* __restrict__ a, float* __restrict__ PhiT,
                                                                int F, int M, int hop, int L, int NP, int nq,
                                                                float* __restrict__ pmax, unsigned* __restrict__ fixcnt,
                                                                int B, float* __restrict__ Phi) {
-    __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
-    if constexpr (KT == 2) p1f2_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
-    else                   p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+    __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT, NR>::TILE_FLOATS];
+    p1f_body<W, NT, NR>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1114,7 +974,7 @@ __device__ __forceinline__ void p1z_units(const float* __restrict__ ex, int64_t 
 // (416 light waves).  Workgroups [0, nblk_f) run p1f_body, the rest run four P1z units as four independent waves, so
 // P1z uses the CUs the transition kernel leaves idle instead of a launch of its own after it.  (Forking P1z onto a
 // second stream instead costs more in event record/wait than it hides: DESIGN.md.)
-template <int W, int NT, int KT = 4>
+template <int W, int NT>
 __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                                 const float* __restrict__ gain,
                                                                 const float* __restrict__ a, float* __restrict__ z,
@@ -1126,8 +986,7 @@ __global__ __launch_bounds__(64 * P1F_WPB) void lpc_p1fz_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float tile_all[P1fGeom<W, NT>::TILE_FLOATS];
     __shared__ float xt[P1F_WPB][TL::SIZE];
     if ((int)blockIdx.x < nblk_f) {
-        if constexpr (KT == 2) p1f2_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
-        else                   p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
+        p1f_body<W, NT>(a, PhiT, F, M, hop, L, NP, nq, tile_all, blockIdx.x, pmax, fixcnt, B, Phi);
     } else {
         p1z_units<W, NT>(ex, ex_stride, gain, a, z, T, F, M, hop, L, NP, ncg, B, upw, (int)blockIdx.x - nblk_f, xt);
     }
@@ -3117,13 +2976,6 @@ static int launch_composites(const SsPlan& p, const float* a, int B, int F, int 
     return launch_fixup<W, NT>(p, a, B, F, M, hop, ws, accurate, training, st);
 }
 
-// The zero-state pass inside the pre-pass launch (round 4): what GOLF_SS_THROUGHPUT and GOLF_SS_MAPS_ONLY select; the dev
-// knob GOLF_SS_ZPASS_IN_PREPASS=1 forces it for every call (A/B against lpc_p1fz_kernel, which carries the pass otherwise).
-static bool zpass_in_prepass() {
-    static const bool v = [] { const char* e = getenv("GOLF_SS_ZPASS_IN_PREPASS"); return e ? atoi(e) != 0 : false; }();
-    return v;
-}
-
 // The fp32 transition matrices alone (+ their per-chunk maxima): needs only the coefficients.
 template <int W, int NT>
 static int launch_maps(const SsPlan& p, const float* a, int B, int F, int M, int hop, char* ws, int flags, hipStream_t st) {
@@ -3131,15 +2983,10 @@ static int launch_maps(const SsPlan& p, const float* a, int B, int F, int M, int
     float* Phi = (float*)(ws + p.off_phi);
     float* PhiT = (float*)(ws + p.off_phiT);
     const int nq = B * p.NP;
-    constexpr int CPW = 64 / ((NT + 3) / 4);
-    if (p1f_kt() == 2)
-        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT, 2>), dim3((unsigned)ceil_div(nq, P1f2Geom<W, NT>::CPB)),
-                           dim3(64 * P1F_WPB), 0, st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
-                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
-    else
-        hipLaunchKernelGGL((lpc_p1f_kernel<W, NT, 4>), dim3((unsigned)ceil_div(nq, CPW * P1F_WPB)), dim3(64 * P1F_WPB),
-                           0, st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
-                           (unsigned*)(ws + p.off_fixcnt), B, (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr);
+    float* phi_out = (flags & GOLF_SS_TRAINING) ? Phi : (float*)nullptr;
+    hipLaunchKernelGGL((lpc_p1f_kernel<W, NT, 2>), dim3((unsigned)ceil_div(nq, P1fGeom<W, NT, 2>::CPW * P1F_WPB)),
+                       dim3(64 * P1F_WPB), 0, st, a, PhiT, F, M, hop, p.L, p.NP, nq, (float*)(ws + p.off_pmax),
+                       (unsigned*)(ws + p.off_fixcnt), B, phi_out);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
@@ -3222,7 +3069,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
     if constexpr (NT <= 24) two_level = use_two_level_scan(p, B, flags);
     const bool maps_only = (flags & GOLF_SS_HAVE_TRANSITIONS) && (flags & GOLF_SS_MAPS_ONLY);
     const bool zin = two_level && fast && !side && !(flags & GOLF_SS_SPLIT_P1) && p.NP > 0 &&
-                     (zpass_in_prepass() || maps_only || (flags & GOLF_SS_THROUGHPUT));
+                     (maps_only || (flags & GOLF_SS_THROUGHPUT));
     if (p.NP > 0) {
         if (!(flags & GOLF_SS_HAVE_TRANSITIONS)) {
             hipStream_t s1 = st;
@@ -3238,22 +3085,14 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
                 const int64_t nunit = (int64_t)ncg * B;
                 const int n_cu = device_cu_count();
                 if (fast) {
-                    const int kt = p1f_kt();
-                    const int nblk_f = kt == 2 ? (int)ceil_div(nq, P1f2Geom<W, NT>::CPB)
-                                               : (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
+                    const int nblk_f = (int)ceil_div(nq, P1fGeom<W, NT>::CPW * P1F_WPB);
                     int upw = 1;
                     while (upw < 4 && nblk_f + ceil_div(nunit, 4 * upw) > n_cu) ++upw;
                     const int nblk_z = (int)ceil_div(nunit, 4 * upw);
-                    if (kt == 2)
-                        hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT, 2>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
-                                           0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
-                                           B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
-                                           training ? (float*)(ws + p.off_phi) : (float*)nullptr);
-                    else
-                        hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT, 4>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
-                                           0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
-                                           B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
-                                           training ? (float*)(ws + p.off_phi) : (float*)nullptr);
+                    hipLaunchKernelGGL((lpc_p1fz_kernel<W, NT>), dim3((unsigned)(nblk_f + nblk_z)), dim3(64 * P1F_WPB),
+                                       0, st, ex, ex_stride, gain, a, z, PhiT, T, F, M, hop, p.L, p.NP, nq, nblk_f, ncg,
+                                       B, upw, (float*)(ws + p.off_pmax), (unsigned*)(ws + p.off_fixcnt),
+                                       training ? (float*)(ws + p.off_phi) : (float*)nullptr);
                     GOLF_LAUNCH_CHECK();
                 } else {
                     constexpr int KT = 3, NG = (NT + KT - 1) / KT;
