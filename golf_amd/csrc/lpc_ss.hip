@@ -83,6 +83,10 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     } else {
         L = hop * (target / hop);
     }
+    // (Shorter chunks were tried in round 4 with an env override here: L = 120 at hop 240 halves the chunk recursion -- flat-scan
+    //  chunk passes 13 / 10 us instead of ~20 -- but the two-level passes stay at 26 / 21 us because their prologues grow with the
+    //  group count (25 groups: 24 fold steps), the pre-pass goes 16 -> 30 us and the maps double: one batch alone 143 vs 129 us,
+    //  four in flight 87.9 vs 69.3.)
     p->L = L;
     p->NC = (int)ceil_div(T, L);
     p->NP = p->NC - 1;
@@ -1560,6 +1564,24 @@ constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the ch
 // s' = rows . s + add with the state broadcast by v_readlane (lane i = component i, `rw` = row i of the matrix)
 template <int W, int NT>
 __device__ __forceinline__ float matvec_step(const float4* rw, float s, float add, bool act) {
+#ifndef GOLF_MATVEC_SCALAR
+    // Four partial sums (columns j mod 4), written as two packed accumulators over the (x, y) / (z, w) halves of the row's
+    // float4s: the pairs are the registers the loads filled, so each v_pk_fma_f32 takes them as they are.  (Left to hipcc, the
+    // scalar form below is SLP-packed too, but across the accumulators -- columns (3, 5), (7, 9) ... -- and every pair costs two
+    // v_mov to assemble: ~70 instructions per step instead of ~38 for the same 22 FMAs, on the critical path of every scan.)
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    static_assert(NT % 2 == 0, "column pairs");
+    pk2 accA = {add, 0.f}, accB = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NT / 2; ++k) {
+        const float4& q = rw[k / 2];
+        const pk2 pj = (k & 1) ? pk2{q.z, q.w} : pk2{q.x, q.y};
+        const pk2 sj = {lane_bcast(s, 2 * k), lane_bcast(s, 2 * k + 1)};
+        if (k & 1) accB = __builtin_elementwise_fma(pj, sj, accB);
+        else       accA = __builtin_elementwise_fma(pj, sj, accA);
+    }
+    return act ? (accA.x + accA.y) + (accB.x + accB.y) : 0.f;
+#else
     float acc0 = add, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -1571,6 +1593,7 @@ __device__ __forceinline__ float matvec_step(const float4* rw, float s, float ad
         else acc3 = fmaf(pj, sj, acc3);
     }
     return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
+#endif
 }
 
 // Composite map of a group, M_g = Phi_{c1-1} ... Phi_{c0}, accumulated in DOUBLE precision on the matrix pipe.
@@ -1896,13 +1919,24 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
     else         group_zscan_body<W, NT>(PhiT, z, V, NP, NG, b, g, lane);
 }
 
+#ifdef FWDQ2_TIMING   // dev build (tools/fwdq2_phases.py): s_memtime stamps of the chunk-pass waves' phases, lane 0
+__device__ unsigned long long g_fq_stamps[2 * 64 * 64 * 8];
+#define FQ_STAMP(p, i) do { if ((p) && threadIdx.x == 0) (p)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int golf_debug_fwdq2_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fq_stamps), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define FQ_STAMP(p, i) do { } while (0)
+#endif
+
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
 //   t = fold of (M_g', v_g') over the groups before g, then the wave's own chunk maps with inputs x
 //   (first pass: v = zero-state group responses, x = z; correction pass: v = the groups' responses to the defects, x = defects).
 template <int W, int NT, bool THIN = false>
 __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, const float* __restrict__ MT,
                                                const float* __restrict__ V, const float* __restrict__ x,
-                                               float* __restrict__ st, int b, int g, int NP, int NG, int lane) {
+                                               float* __restrict__ st, int b, int g, int NP, int NG, int lane,
+                                               unsigned long long* fqs = nullptr) {
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
     const size_t cstride4 = (size_t)NT * W / 4;
@@ -1949,6 +1983,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
             }
         }
     }
+    FQ_STAMP(fqs, 1);
     {   // (b) the wave's own chunk maps (kGroup = 16 is not a multiple of DC: the slot index runs modulo DC)
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
@@ -2010,6 +2045,12 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
     const int c0 = g * kGroup;
     const bool precise = tier3(tier, b);   // wave-uniform
     float* s1b = S1 + (size_t)b * (NP + 1) * 32;
+#ifdef FWDQ2_TIMING
+    unsigned long long* fqs = (b < 64 && g < 64) ? g_fq_stamps + ((size_t)((MODE == 3 ? 0 : 1) * 64 + b) * 64 + g) * 8 : nullptr;
+#else
+    unsigned long long* fqs = nullptr;
+#endif
+    FQ_STAMP(fqs, 0);
     if constexpr (MODE == 3) {
         if (precise) return;
         // (the successor-fold operands below are fetched HERE, ahead of the prologue they do not depend on: a round trip
@@ -2025,7 +2066,8 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
             for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
             vv = V[((size_t)b * NG + gc) * 32 + ii];
         }
-        group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane);
+        group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane, fqs);
+        FQ_STAMP(fqs, 2);
         // The state the NEXT group starts from is its own fold, M_g S1_{c0} + v_g -- not this wave's scan result st[16]
         // (the two differ by the composite's rounding).  The defect of the group's last chunk has to be taken against the
         // state its successor really runs from, or that difference would never be corrected: recompute the successor's
@@ -2060,7 +2102,8 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
                 const float v = s1b[(size_t)c0 * 32 + (ok ? e : 0)];
                 s1v[u] = ok ? v : 0.f;
             }
-            group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane);   // delta_c (V = defect responses, x = defects)
+            group_prologue<W, NT, THIN>(PhiT, MT, V, x, st, b, g, NP, NG, lane, fqs);   // delta_c (V = defect responses, x = defects)
+            FQ_STAMP(fqs, 2);
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
                 const int e = lane + 64 * u;
@@ -2069,12 +2112,15 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
         }
         wave_lds_fence();
     }
+    FQ_STAMP(fqs, 3);
     fwdq_body<W, NT, MODE, true>(ex, ex_stride, gain, a, nullptr, out, y_stride, T, F, M, hop, L, NCQ, 0, nullptr, xt, yt,
                                  b, g, lane, st, dl, nonfinite);
+    FQ_STAMP(fqs, 4);
     if (MODE == 3) {   // epilogue: the group's response to its own defects, for the final pass's fold
         wave_lds_fence();
         group_scan_lds<W, NT>(PhiT, dl, V2out, b, g, NP, NG, lane);
     }
+    FQ_STAMP(fqs, 5);
 }
 
 // ------------------------------------------------------------------------------------------
