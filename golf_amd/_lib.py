@@ -107,7 +107,7 @@ SIGNATURES = {
     "golf_peer_wait_u32": (_int, [_vp, _int, _int, ctypes.c_uint32, _i64, _vp, _vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lock = threading.Lock()
 _lib = None
 

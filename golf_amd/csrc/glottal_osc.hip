@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, off_bf, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -48,6 +48,7 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->off_pre = o;  o = align_up(o + sizeof(float) * (size_t)B * g->pre_stride, 256);
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
     g->off_bf = o;   o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused kernel
+    g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused backward (transposed FIR)
     g->total = o;
 }
 
@@ -631,7 +632,7 @@ template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backw
 __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
-                                                              float* __restrict__ Bf, int reversed = 0, int dmax = 0) {
+                                                              float* __restrict__ Bf, float* __restrict__ Bfr, int dmax) {
     constexpr int OSCT_THREADS = osct_threads(TO);
     __shared__ u64 wsum[OSCT_THREADS / 64];
     light_wave_priority();
@@ -641,10 +642,16 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
         for (int e = tid; e < 4 * KS * 64; e += OSCT_THREADS) {
             const int lane = e & 63, kk = (e >> 6) % KS, ph = (e >> 6) / KS;
             const int q = 4 * kk + (lane >> 4) - (lane & 15);
-            // forward: tap of branch ph at d = dmin + q; backward (transposed FIR, osc_fused_bwd_kernel): at d = dmax - q
-            const int d = reversed ? dmax - q : dmin + q;
-            const int k = half + 4 * d + ph;
-            Bf[e] = (q >= 0 && d >= dmin && d <= (reversed ? dmax : 0x3fffffff) && k >= 0 && k < K) ? taps[k] : 0.f;
+            // forward: tap of branch ph at d = dmin + q; backward (transposed FIR, osc_fused_bwd_kernel): at d = dmax - q.
+            // The forward leaves both behind: a backward handed the untouched workspace needs no totals launch of its own.
+            if (Bf) {
+                const int d = dmin + q, k = half + 4 * d + ph;
+                Bf[e] = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
+            }
+            if (Bfr) {
+                const int d = dmax - q, k = half + 4 * d + ph;
+                Bfr[e] = (q >= 0 && d >= dmin && d <= dmax && k >= 0 && k < K) ? taps[k] : 0.f;
+            }
         }
     }
     const BufRow prow(phase + (size_t)b * phase_stride, Tp);
@@ -1677,6 +1684,37 @@ extern "C" size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop,
     return g.total;
 }
 
+// The fused forward's geometry, and whether it serves this call (the backward asks too: a workspace the fused forward
+// filled still holds the tile totals and both tap-fragment layouts, GOLF_OSC_WS_KEPT).
+struct OscFusedFwd { int dmin, dmax, KS, nrows, XS, ntile2, lshift; size_t ldsf; };
+static int osc_unfused_env() {
+    static const int v = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
+    return v;
+}
+static bool osc_fused_fwd_plan(const OscGeom& g, int L, int os, int K, bool want_pre, int Tout, OscFusedFwd* f) {
+    if (!(os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !want_pre && !osc_unfused_env())) return false;
+    const int half = (K - 1) / 2;
+    f->dmin = -((half + os - 1) / os);
+    f->dmax = half / os;
+    const int nq = f->dmax - f->dmin + 1;                       // taps per polyphase branch
+    f->KS = nq + 15 <= 48 ? 12 : 16;                            // K-steps of the 16-window Toeplitz product
+    const int span = OSCF_TO + 4 * f->KS;
+    const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
+    static const int nrows_force = [] { const char* e = getenv("GOLF_OSCF_NROWS"); return e ? atoi(e) : 0; }();   // dev knob: timing proxies only (wrong results)
+    f->nrows = nrows_force > 0 ? nrows_force : nint_touched + 1;
+    f->XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;              // padded polyphase row: i + 4 * (i >> 4)
+    static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
+#if OSCF_ROWS
+    f->ldsf = sizeof(float) * ((size_t)os * f->XS + (size_t)f->nrows * (L + 1)) + lds_pad;
+#else
+    f->ldsf = sizeof(float) * ((size_t)os * f->XS + 2 * (size_t)(f->nrows - 1) * (L + 1)) + lds_pad;
+#endif
+    f->ntile2 = (int)ceil_div(Tout, OSCF_TO);                   // <= g.ntile: fits the Ttot region of the workspace
+    f->lshift = 31 - __builtin_clz((unsigned)L);
+    return nq + 15 <= 64 && f->nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -f->dmin < span &&
+           f->ldsf <= 80 * 1024 + lds_pad;
+}
+
 extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                         const float* wsel, int Fw, int w_hop, const float* table, int n_tab, int L,
                                         int os, int equal_energy, const float* taps, int K, float* pre, float* out,
@@ -1698,31 +1736,15 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
-    static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
-    if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !pre && !unfused_env) {
-        const int half = (K - 1) / 2;
-        const int dmin = -((half + os - 1) / os);
-        const int dmax = half / os;
-        const int nq = dmax - dmin + 1;                             // taps per polyphase branch
-        const int KS = nq + 15 <= 48 ? 12 : 16;                     // K-steps of the 16-window Toeplitz product
-        const int span = OSCF_TO + 4 * KS;
-        const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
-        static const int nrows_force = [] { const char* e = getenv("GOLF_OSCF_NROWS"); return e ? atoi(e) : 0; }();   // dev knob: timing proxies only (wrong results)
-        const int nrows = nrows_force > 0 ? nrows_force : nint_touched + 1;
-        const int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;       // padded polyphase row: i + 4 * (i >> 4)
-        static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
-#if OSCF_ROWS
-        const size_t ldsf = sizeof(float) * ((size_t)os * XS + (size_t)nrows * (L + 1)) + lds_pad;
-#else
-        const size_t ldsf = sizeof(float) * ((size_t)os * XS + 2 * (size_t)(nrows - 1) * (L + 1)) + lds_pad;
-#endif
-        if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -dmin < span &&
-            ldsf <= 80 * 1024 + lds_pad) {
-            const int ntile2 = (int)ceil_div(Tout, OSCF_TO);        // <= g.ntile: fits the Ttot region of the workspace
-            const int lshift = 31 - __builtin_clz((unsigned)L);
+    OscFusedFwd ff;
+    if (osc_fused_fwd_plan(g, L, os, K, pre != nullptr, Tout, &ff)) {
+        {
+            const int dmin = ff.dmin, dmax = ff.dmax, KS = ff.KS, nrows = ff.nrows, XS = ff.XS, ntile2 = ff.ntile2, lshift = ff.lshift;
+            const size_t ldsf = ff.ldsf;
             float* Bf = (float*)((char*)ws + g.off_bf);
+            float* Bfr = (float*)((char*)ws + g.off_bfr);
             hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2, taps, K, dmin, KS, Bf);
+                               g.P, os, ntile2, taps, K, dmin, KS, Bf, Bfr, dmax);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
     do {                                                                                                              \
@@ -1787,9 +1809,11 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         return fail(GOLF_EWORKSPACE, "glottal_osc_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", g.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
+    // GOLF_OSC_WS_KEPT: the caller vouches that `ws` is as the forward of these same arguments (with pre == NULL) left it
+    const bool ws_kept = (equal_energy & GOLF_OSC_WS_KEPT) != 0;
+    equal_energy &= 1;
     // ---- fused path (the GOLF configuration, as in the forward): tile totals + osc_fused_bwd_kernel + a reduction
-    static const int unfused_env = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
-    if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !unfused_env) {
+    if (os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !osc_unfused_env()) {
         const int half = (K - 1) / 2;
         const int dmin = -((half + os - 1) / os);
         const int dmax = half / os;
@@ -1805,11 +1829,20 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
             sizeof(float) * (size_t)B * ntile2 * OSCF_MAXROWS <= sizeof(float) * (size_t)B * g.pre_stride) {
             const int lshift = 31 - __builtin_clz((unsigned)L);
             u64* Ttot = (u64*)((char*)ws + g.off_ttot);
-            float* Bf = (float*)((char*)ws + g.off_bf);
+            float* Bf = (float*)((char*)ws + g.off_bfr);
             float* part2 = (float*)((char*)ws + g.off_pre);      // the oversampled-gradient buffer is not needed here
-            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2, taps, K, dmin, KS, Bf, 1, dmax);
-            GOLF_LAUNCH_CHECK();
+            // The fused forward computed exactly these totals (same tiles: OSCB_TO == OSCF_TO, Tp == Tout at hop 1) and wrote
+            // the transposed tap fragments next to its own: with its workspace intact the backward is two launches, not three
+            // (5.9 us of the B = 32 training step).  Otherwise -- a caller that does not say, a forward that took the
+            // three-kernel path -- they are recomputed: the backward must not depend on which forward variant ran.
+            OscFusedFwd ff;
+            const bool have_totals = ws_kept && OSCB_TO == OSCF_TO && osc_fused_fwd_plan(g, L, os, K, false, Tout, &ff) &&
+                                     ff.ntile2 == ntile2 && ff.KS == KS && ff.dmax == dmax;
+            if (!have_totals) {
+                hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
+                                   g.P, os, ntile2, taps, K, dmin, KS, (float*)nullptr, Bf, dmax);
+                GOLF_LAUNCH_CHECK();
+            }
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \
     do {                                                                                                              \
         static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \

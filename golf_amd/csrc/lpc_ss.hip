@@ -2646,7 +2646,7 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
                                                             const float* __restrict__ gain, float* __restrict__ g_ex,
                                                             int64_t g_ex_stride, float* __restrict__ pa,
                                                             float* __restrict__ pg, int T, int F, int NT, int W,
-                                                            int hop, int seg, int NSEG) {
+                                                            int hop, int seg, int NSEG, int tail) {
     // per wave: (g, n g) pairs, ex and y (with 64 samples of history) of the segment.  One loop serves every lane: tap
     // lanes correlate the pairs with y[t-1-k], the gain lane with ex[t] -- two packed FMAs per two samples and lane
     // (first version: scalar FMAs, the n-weights formed in the loop and a second, divergent loop for the gain lane:
@@ -2656,6 +2656,8 @@ __global__ __launch_bounds__(256) void lpc_grad_corr_kernel(const float* __restr
     const int wv = threadIdx.x >> 6, k = threadIdx.x & 63;
     const int sg = blockIdx.x * 4 + wv, b = blockIdx.y;
     if (sg >= NSEG) return;  // whole wave
+    if (sg == NSEG - 1)      // GOLF_SS_ZERO_TAIL: the excitation was longer than the output, its gradient there is zero
+        for (int u = k; u < tail; u += 64) g_ex[(size_t)b * g_ex_stride + T + u] = 0.f;
     f32x2* gp = gp_[wv];
     float* es = es_[wv];
     float* ys = ys_[wv];
@@ -3236,7 +3238,7 @@ template <int W, int NT>
 static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                       const float* ex, int64_t ex_stride, const float* gain, const float* a, float* g_ex,
                       int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T, int F, int M, int hop, char* ws,
-                      int flags, hipStream_t st) {
+                      int flags, int tail, hipStream_t st) {
     const float* Phi = (const float*)(ws + p.off_phi);
     float* zadj = (float*)(ws + p.off_zadj);
     float* lam = (float*)(ws + p.off_lam);
@@ -3291,7 +3293,7 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
         GOLF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st, (const float*)gbuf, (int64_t)T, y,
-                       y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG);
+                       y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T, F, NT, W, hop, p.seg, p.NSEG, tail);
     GOLF_LAUNCH_CHECK();
     const int n4 = B * F * (M + 1);
     hipLaunchKernelGGL(lpc_grad_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)pa,
@@ -3313,7 +3315,7 @@ template <int W, int NT>
 static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const float* y, int64_t y_stride,
                              const float* ex, int64_t ex_stride, const float* gain, const float* a, float* g_ex,
                              int64_t g_ex_stride, float* g_gain, float* g_a, int B, int T, int F, int M, int hop,
-                             char* ws, hipStream_t st) {
+                             char* ws, int tail, hipStream_t st) {
     float* gbuf = (float*)(ws + p.off_g);
     float* pa = (float*)(ws + p.off_pa);
     float* pg = (float*)(ws + p.off_pg);
@@ -3322,7 +3324,7 @@ static int launch_serial_bwd(const SsPlan& p, const float* gy, int64_t gy_stride
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(lpc_grad_corr_kernel, dim3((unsigned)ceil_div(p.NSEG, 4), B), dim3(256), 0, st,
                        (const float*)gbuf, (int64_t)T, y, y_stride, ex, ex_stride, gain, g_ex, g_ex_stride, pa, pg, T,
-                       F, NT, W, hop, p.seg, p.NSEG);
+                       F, NT, W, hop, p.seg, p.NSEG, tail);
     GOLF_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)B * F * (M + 1);
     hipLaunchKernelGGL(lpc_grad_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)pa,
@@ -3487,15 +3489,18 @@ extern "C" int golf_ltv_allpole_bwd_f32(const float* gy, int64_t gy_stride, cons
         return fail(GOLF_EWORKSPACE, "ltv_allpole_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", p.total,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
+    const int64_t tail64 = (flags & GOLF_SS_ZERO_TAIL) ? g_ex_stride - (int64_t)T : 0;
+    if (tail64 > 0x7fffffff) return fail(GOLF_EINVAL, "ltv_allpole_bwd: GOLF_SS_ZERO_TAIL with a row stride beyond 2^31");
+    const int tail = (int)tail64;
     if (p.serial && !serial_strides_ok(gy_stride, gy_stride))
         return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: serial path needs row strides < 2^24");
     if (p.serial) {
         GOLF_SS_DISPATCH(launch_serial_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride,
-                         g_gain, g_a, B, T, F, M, hop, (char*)ws, st)
+                         g_gain, g_a, B, T, F, M, hop, (char*)ws, tail, st)
         return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
     }
     GOLF_SS_DISPATCH(launch_bwd, p, gy, gy_stride, y, y_stride, ex, ex_stride, gain, a, g_ex, g_ex_stride, g_gain, g_a,
-                     B, T, F, M, hop, (char*)ws, flags, st)
+                     B, T, F, M, hop, (char*)ws, flags, tail, st)
     return fail(GOLF_EUNSUPPORTED, "ltv_allpole_bwd: no kernel for W=%d NT=%d", p.W, p.NT);
 }
 

@@ -22,6 +22,8 @@ FAST_TRANSITIONS = 2
 TRAINING = 64            # GOLF_SS_TRAINING
 MAPS_ONLY = 128          # GOLF_SS_MAPS_ONLY (ABI 4)
 THROUGHPUT = 256         # GOLF_SS_THROUGHPUT (ABI 4)
+ZERO_TAIL = 512          # GOLF_SS_ZERO_TAIL (ABI 5): the backward zeroes g_ex beyond the output length itself
+OSC_WS_KEPT = 2          # GOLF_OSC_WS_KEPT (ABI 5): the oscillator's backward reuses the totals in the forward's saved workspace
 FORK_TRANSITIONS = False
 SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
 _side_streams = {}
@@ -189,19 +191,17 @@ class _LTVAllPoleSS(torch.autograd.Function):
         F, M = a.shape[1], a.shape[2]
         T = y.shape[1]
         gy = _rows(gy.float())
-        # the kernels write columns [0, T); only the excitation's tail beyond the output length needs zeros (a full-size fill
-        # was a 6 MB memset in front of every backward: 5.8 us of the B = 32 training step)
-        g_ex = torch.empty_like(ex)
-        if g_ex.stride(1) != 1:
-            g_ex = torch.empty(B, Tx, dtype=torch.float32, device=ex.device)
-        if Tx > T:
-            g_ex[:, T:].zero_()
+        # the kernels write columns [0, T); the excitation's tail beyond the output length needs zeros: GOLF_SS_ZERO_TAIL has
+        # the backward write them (a full-size fill was a 6 MB memset in front of every backward, a strided fill of the
+        # tail alone still a launch: ~5 us of the B = 32 training step either way)
+        g_ex = torch.empty(B, Tx, dtype=torch.float32, device=ex.device)
         g_gain = torch.empty_like(gain)
         g_a = torch.empty_like(a)
         rc = lib.golf_ltv_allpole_bwd_f32(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), ex.data_ptr(),
                                           ex.stride(0), gain.data_ptr(), a.data_ptr(), g_ex.data_ptr(),
                                           g_ex.stride(0), g_gain.data_ptr(), g_a.data_ptr(), B, T, F, M, hop,
-                                          ws.data_ptr(), ws.numel(), ctx.mode, _lib.stream_ptr())
+                                          ws.data_ptr(), ws.numel(), ctx.mode | (ZERO_TAIL if Tx > T else 0),
+                                          _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
         return g_ex, g_gain, g_a, None, None, None, None, None
 
@@ -482,6 +482,7 @@ class _GlottalOsc(torch.autograd.Function):
                                           0 if add is None else add.stride(0), 0 if add is None else add.shape[1])
         _lib.check(rc, "golf_glottal_osc_fwd_f32")
         ctx.cfg = (phase_hop, w_hop, os, bool(equal_energy))
+        ctx.ws_kept = pre is None   # the saved workspace is private to this node: the backward may reuse the forward's totals
         ctx.add_len = None if add is None else add.shape[1]
         ctx.save_for_backward(phase, wsel, table, taps if taps is not None else phase.new_empty(0), ws)
         ctx.mark_non_differentiable(*([pre] if pre is not None else []))
@@ -501,7 +502,8 @@ class _GlottalOsc(torch.autograd.Function):
         g_w = torch.empty_like(wsel)
         rc = lib.golf_glottal_osc_bwd_wsel_f32(g_out.data_ptr(), g_out.stride(0), phase.data_ptr(), phase.stride(0), Tp,
                                                phase_hop, wsel.data_ptr(), Fw, w_hop, table.data_ptr(), n_tab, L, os,
-                                               int(eq), _lib.ptr(taps) if K else 0, K, g_w.data_ptr(), B,
+                                               int(eq) | (OSC_WS_KEPT if ctx.ws_kept else 0), _lib.ptr(taps) if K else 0, K,
+                                               g_w.data_ptr(), B,
                                                g_out.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "golf_glottal_osc_bwd_wsel_f32")
         g_add = None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GOLF_ABI_VERSION 4
+#define GOLF_ABI_VERSION 5
 
 enum {
     GOLF_OK = 0,
@@ -114,6 +114,12 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                MI355X, B = 32 x 2 s.  Results are bit-identical either way.  The library cannot see how many batches its
  *                caller keeps in flight, hence a flag (cf. GOLF_SS_SERIAL). */
 #define GOLF_SS_THROUGHPUT 256
+/*          GOLF_SS_ZERO_TAIL  (ABI 5, golf_ltv_allpole_bwd_f32 only) the excitation rows were longer than the output (the
+ *                oscillator renders Tx = 48 000 samples, the filter consumes T = (F-1)*hop + 1 = 47 761): the backward also
+ *                writes the zeros that are the gradient of the unused tail, g_ex[b][T .. g_ex_stride), so that the caller
+ *                needs neither a full-size memset nor a strided fill launch in front of every backward (each ~5 us of a
+ *                ~260 us B = 32 training step).  g_ex must be dense up to its row stride. */
+#define GOLF_SS_ZERO_TAIL 512
 
 int golf_ltv_allpole_transitions_f32(const float* a, int B, int T, int F, int M, int hop,
                                      void* ws, size_t ws_bytes, int flags, void* stream);
@@ -271,7 +277,12 @@ int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, i
                              const float* addend, int64_t addend_stride, int Tadd);
 
 /* Backward w.r.t. table_select_weight only (phase is data in GOLF training: train_with_true_f0,
- * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = the forward's workspace. */
+ * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = a workspace of the forward's size.
+ * equal_energy | GOLF_OSC_WS_KEPT (ABI 5): the caller vouches that `ws` is exactly as golf_glottal_osc_fwd_f32 left it for
+ * these same arguments with pre == NULL (an autograd node that saved it): the backward then reuses the forward's phase tile
+ * totals and tap fragments instead of recomputing them (one launch of three less, ~6 us at B = 32).  Without the flag nothing
+ * is assumed about the workspace's contents. */
+#define GOLF_OSC_WS_KEPT 2
 int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_stride,
                                   const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                   const float* wsel, int Fw, int w_hop,

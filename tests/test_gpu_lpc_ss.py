@@ -906,3 +906,45 @@ def test_throughput_chain_is_bit_identical(seed, train, monkeypatch):
     assert torch.equal(y0, y1)
     for u, v in zip(g0, g1):
         assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,mode", [(3, 0), (3, 8)])
+def test_backward_zeroes_the_excitation_tail_when_asked(B, mode):
+    """ABI 5, GOLF_SS_ZERO_TAIL: the excitation is longer than the output (the oscillator's 48 000 samples against
+    (F-1)*hop + 1); with the flag the backward writes g_ex[:, T:row stride) = 0 itself, without it the tail is the caller's.
+    Chunked and serial path; the gradient proper is the same bit for bit."""
+    from golf_amd import _lib, functional as GF
+
+    F, M, hop = 40, 22, 240
+    ex, gain, a = smooth_case(B, F, M, hop, seed=11)
+    T = (F - 1) * hop + 1
+    Tx = T + 239
+    exd = torch.cat([dev(ex), torch.randn(B, Tx - ex.shape[1], device="cuda")], 1).contiguous()
+    gd, ad = dev(gain), dev(a)
+    lib = _lib.load()
+    ws = torch.empty(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), dtype=torch.uint8, device="cuda")
+    y = torch.empty(B, T, device="cuda")
+    rc = lib.golf_ltv_allpole_fwd_f32(exd.data_ptr(), exd.stride(0), gd.data_ptr(), ad.data_ptr(), y.data_ptr(), y.stride(0),
+                                      B, T, F, M, hop, ws.data_ptr(), ws.numel(), mode, 0, _lib.stream_ptr())
+    assert rc == 0
+    gy = torch.randn(B, T, device="cuda")
+    res = []
+    for flag in (0, GF.ZERO_TAIL):
+        g_ex = torch.full((B, Tx), float("nan"), device="cuda")
+        g_gain, g_a = torch.empty_like(gd), torch.empty_like(ad)
+        rc = lib.golf_ltv_allpole_bwd_f32(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), exd.data_ptr(), exd.stride(0),
+                                          gd.data_ptr(), ad.data_ptr(), g_ex.data_ptr(), g_ex.stride(0), g_gain.data_ptr(),
+                                          g_a.data_ptr(), B, T, F, M, hop, ws.data_ptr(), ws.numel(), mode | flag,
+                                          _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append((g_ex, g_gain, g_a))
+    assert torch.isnan(res[0][0][:, T:]).all() and torch.isfinite(res[0][0][:, :T]).all()
+    assert (res[1][0][:, T:] == 0).all()
+    assert torch.equal(res[0][0][:, :T], res[1][0][:, :T])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # and through autograd: an excitation longer than the output gets exact zeros there
+    t = exd.clone().requires_grad_(True)
+    GF.ltv_allpole_ss(t, gd, ad, hop, mode={0: None, 8: "serial"}[mode], fast_inference=False).backward(gy)
+    assert (t.grad[:, T:] == 0).all() and torch.equal(t.grad[:, :T], res[1][0][:, :T])

@@ -406,3 +406,36 @@ def test_fused_backward_wsel_vs_oracle(Tp, w_hop, eq):
     torch.cuda.synchronize()
     ref = O.indexed_glottal_backward(gy, phase, 1, w, w_hop, table, 4, eq, decim_taps=taps)["g_weight"]
     check(wt.grad.cpu().numpy(), ref, f"fused g_wsel Tp{Tp} w_hop{w_hop} eq{eq}", 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Tp,eq", [(47761, True), (6145, False)])
+def test_backward_reuses_the_forward_totals_only_when_told(Tp, eq):
+    """ABI 5, GOLF_OSC_WS_KEPT: the autograd node hands the backward the workspace its forward filled, and the backward skips
+    its own tile-totals launch.  Without the flag nothing is assumed about the workspace: called on a poisoned one, the C entry
+    recomputes the totals and the tap fragments itself.  Both give the same gradient bit for bit."""
+    from golf_amd import _lib, functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    rng = np.random.default_rng(Tp)
+    B, w_hop = 3, 2400
+    phase = dev((rng.uniform(80, 400, (B, 1)) / 24000 * np.ones((1, Tp))).astype(np.float32))
+    Fw = (Tp - 1) // w_hop + 2
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=eq)
+    table, taps = dev(m.table.numpy()), dev(m.decimater.taps.numpy())
+    wt = dev(rng.uniform(0.02, 0.98, (B, Fw)).astype(np.float32)).requires_grad_(True)
+    out = GF.glottal_osc(phase, wt, table, taps, 1, w_hop, 4, eq)
+    gy = dev(rng.normal(0, 1, tuple(out.shape)).astype(np.float32))
+    (out * gy).sum().backward()
+    lib = _lib.load()
+    n_tab, L = table.shape
+    ws = torch.full((lib.golf_glottal_osc_workspace_bytes(B, Tp, 1, Fw, w_hop, L, 4),), 0xFF, dtype=torch.uint8, device="cuda")
+    g_w = torch.full_like(wt, float("nan")).detach()
+    rc = lib.golf_glottal_osc_bwd_wsel_f32(gy.data_ptr(), gy.stride(0), phase.data_ptr(), phase.stride(0), Tp, 1,
+                                           wt.data_ptr(), Fw, w_hop, table.data_ptr(), n_tab, L, 4, int(eq), taps.data_ptr(),
+                                           taps.numel(), g_w.data_ptr(), B, gy.shape[1], ws.data_ptr(), ws.numel(),
+                                           _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(g_w).all()
+    assert torch.equal(g_w, wt.grad)
