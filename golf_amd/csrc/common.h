@@ -43,6 +43,7 @@ struct SsPlan {
     // scan (the delta-form refinement adds its correction to exactly these), the status words, and -- touched only for the
     // rare tier-3 utterances -- the transition matrices as doubles
     size_t off_tier, off_S1, off_status, off_phi64, off_fixcnt;
+    size_t off_m64, off_v64, off_g64;   // tier 3 on the two-level path: fp64 group composites, group responses, group start states
     size_t off_mtT, off_L1, off_wadj, off_dadj;   // backward: two-level adjoint scan
 };
 bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode = 0);

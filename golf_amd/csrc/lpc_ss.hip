@@ -98,6 +98,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->NG = p->GS = 0;
         p->off_mt = p->off_gv = p->off_pmax = 0;
         p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = p->off_fixcnt = 0;
+        p->off_m64 = p->off_v64 = p->off_g64 = 0;
         p->off_mtT = p->off_L1 = p->off_wadj = p->off_dadj = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
@@ -119,7 +120,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
     p->off_tier = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 2), 256);   // conditioning tier + hot-chunk count per utterance; [2B] scan kind of the forward, [2B+1] backward mismatch
     p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
-    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 1), 256);   // fix-up units completed / claimed per utterance; [2B]: a wait for the fix-up ran out
+    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 3 + 1), 256);   // fix-up units completed / claimed per utterance; [2B]: a wait for the fix-up ran out; [2B+1 .. 3B]: groups of a tier-3 utterance that have their fp64 composite
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
     // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
@@ -141,6 +142,10 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     // transition matrices as doubles, [b][c][j][i] (trajectory-major), written and read only for tier-3 utterances: the
     // allocation is never touched otherwise (27 MB at B = 32 x 2 s)
     p->off_phi64 = o; o = align_up(o + sizeof(double) * (size_t)B * (p->NP > 0 ? p->NP : 1) * p->NT * W, 256);
+    // ... and, on the two-level path, their group composites / group responses / group start states as doubles
+    p->off_m64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG > 0 ? p->NG : 1) * p->NT * W, 256);
+    p->off_v64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG > 0 ? p->NG : 1) * 32, 256);
+    p->off_g64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG + 1) * 32, 256);
     p->total = o;
     return true;
 }
@@ -158,9 +163,11 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
 //           are amplified by the hot neighbours -- over 2048 utterances of the recipe "chunks beyond 30 only" left one at
 //           3.5 x the sequential error, "beyond 10 where some chunk is beyond 30" none above 1.2 x.)
 //   tier 3  an utterance with an entry beyond G3 (256), a non-finite one, or groups of maps whose product could overflow
-//           fp32: all its maps are recomputed and kept as DOUBLES, one wave scans its boundary states in fp64 (riding in
-//           the pre-pass / first scan launch), and its chunks run from those states without a sweep: at or below the
-//           sequential recursion's error for entries up to 7e4 (beyond that both are garbage).
+//           fp32: all its maps are recomputed and kept as DOUBLES, its boundary states are scanned in fp64 (flat path: one
+//           wave, riding in the first scan launch; two-level path: fp64 group composites + fold in the refinement launch's
+//           extra rows, the groups' own maps in the final pass's prologue -- precise_group_job), and its chunks run from
+//           those states without a sweep: at or below the sequential recursion's error for entries up to 7e4 (beyond that
+//           both are garbage).
 // Cost: one light launch (lpc_fixup_kernel: every wave reads its utterance's per-chunk maxima and returns unless it owns a
 // hot chunk); a hot chunk costs its wave one fp64 pass over the chunk (~25 us), a tier-3 utterance additionally a 199-step
 // fp64 scan (~45 us) beside the 15 us pre-pass.  No sequential fallback exists any more (round 2: 2.6 ms).
@@ -779,7 +786,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     const int cl = lane / NG, grp = lane - cl * NG;
     const int q0 = (blk_id * P1F_WPB + wv) * CPW;
     if (fixcnt && blk_id == 0 && wv == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = lane; e < 2 * B + 1; e += 64) fixcnt[e] = 0u;
+        for (int e = lane; e < 3 * B + 1; e += 64) fixcnt[e] = 0u;
     if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
@@ -1026,7 +1033,7 @@ __global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restr
     __shared__ float t[4][NT * (W + 1)];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (fixcnt && blockIdx.x == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = threadIdx.x; e < 2 * B + 1; e += 256) fixcnt[e] = 0u;
+        for (int e = threadIdx.x; e < 3 * B + 1; e += 256) fixcnt[e] = 0u;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
     const float* src = Phi + (size_t)q * NT * W;
@@ -1742,6 +1749,166 @@ __device__ __forceinline__ void group_composite_wg(const float* __restrict__ Phi
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tier 3 on the two-level path (round 4): the boundary states of an utterance whose maps are kept as doubles used to come
+// from ONE wave's fp64 scan over all its chunks (199 dependent steps, ~45 us, riding in the refinement launch, which then
+// lasted that long).  Now in two levels like the fp32 path: per group an fp64 composite (the same v_mfma_f64 product chain
+// as group_composite_wg, one wave, both column tiles, the operands read as doubles) and the group's zero-state response;
+// the wave that completes an utterance's last group folds them into the group start states G (NG steps); the final pass
+// scans each group's own 16 maps from G in its prologue (what its fp32 prologue costs anyway).  16 + NG + 16 dependent
+// steps instead of NP.
+// precise_scan_range: s <- Phi_c s + z_c over n maps stored [c][j][i] as doubles, the split-half layout of precise_fwd_scan;
+// z of type ZT in rows of zstride; the states before every map and after the last go to Sb (rows of sstride, type ST) when
+// Sb is not null; returns the final state (component lane % 32, the same value in both halves).
+template <int W, int NT, typename ZT, typename ST>
+__device__ __forceinline__ double precise_scan_range(const double* __restrict__ P64, const ZT* __restrict__ zb, int zstride,
+                                                     ST* __restrict__ Sb, int sstride, int n, int lane,
+                                                     const double* __restrict__ s0) {
+    static_assert(NT <= 32, "split-half layout");
+    constexpr int NH = (NT + 1) / 2;          // columns per half
+    const int h = lane >> 5, i = lane & 31;
+    const bool act = i < NT;
+    const int ii = act ? i : 0, j0 = h * NH;
+    constexpr int D = 4;
+    double buf[D][NH];
+    ZT zc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c < n ? c : n - 1;
+        const double* mp = P64 + (size_t)cl * NT * W + ii;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {   // raw loads from a clamped row; padding columns are masked on the state value
+            const int j = j0 + k;
+            buf[u][k] = mp[(size_t)(j < NT ? j : NT - 1) * W];
+        }
+        zc[u] = zb[(size_t)cl * zstride + ii];
+    };
+    double s = 0.0;
+    if (s0) { const double v = s0[ii]; s = act ? v : 0.0; }
+    if (n > 0) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, u);
+        for (int c0 = 0; c0 < n; c0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = c0 + u;
+                if (c < n) {   // wave-uniform
+                    if (Sb && lane < sstride) Sb[(size_t)c * sstride + lane] = h == 0 ? (ST)s : (ST)0;
+                    double sj[NH];   // all permutes of a step in flight at once (see precise_fwd_scan)
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        const double v = lane_perm_d(s, j0 + k < NT ? j0 + k : 0);
+                        sj[k] = (2 * NH == NT || j0 + k < NT) ? v : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        if (k & 1) acc1 = __builtin_elementwise_fma(buf[u][k], sj[k], acc1);
+                        else       acc0 = __builtin_elementwise_fma(buf[u][k], sj[k], acc0);
+                    }
+                    const double part = acc0 + acc1;
+                    const double tot = part + lane_perm_d(part, lane ^ 32);
+                    s = act ? tot + (double)zc[u] : 0.0;
+                    fetch(u, c + D);
+                }
+            }
+        }
+    }
+    if (Sb && lane < sstride) Sb[(size_t)(n > 0 ? n : 0) * sstride + lane] = h == 0 ? (ST)s : (ST)0;
+    return s;
+}
+
+// M = Phi_{c1-1} ... Phi_{c0} of maps kept as doubles ([c][j][i]), one wave, written in the same [j][i] layout (so that the
+// fold over the groups is a precise_scan_range over the composites).
+template <int W, int NT>
+__device__ __forceinline__ void precise_group_composite(const double* __restrict__ P64b, int c0, int c1,
+                                                        double* __restrict__ M64, int lane) {
+    static_assert(NT <= 32 && W % 4 == 0, "two 16-wide tiles");
+    constexpr int NTL = CompGeom<W, NT>::NTL;
+    const int m = lane & 15, kq = lane >> 4;
+    const int rm = 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1);       // rho(m), see group_composite_wg
+    const int rq = 2 * kq;
+    // one column tile after the other (the chain is walked NTL times): the refinement kernel these waves ride in must not
+    // need more registers for this rare path than for its own work
+#pragma unroll 1
+    for (int jt = 0; jt < NTL; ++jt) {
+        f64x4 P[NTL];                                                 // P[kt][v] = P(row 16 kt + rho(kq + 4 v), column 16 jt + m)
+#pragma unroll
+        for (int kt = 0; kt < NTL; ++kt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                P[kt][v] = (16 * kt + 8 * (v / 2) + rq + v % 2 == 16 * jt + m && 16 * jt + m < NT) ? 1.0 : 0.0;
+        constexpr int D = 2;
+        f64x4 fr[D][NTL][NTL];
+        auto fetch = [&](int u, int c) {   // A fragments: row 16 it + rho(m), columns 16 kt + rq + {0, 1, 8, 9}; clamped loads, masks after
+            const double* mp = P64b + (size_t)(c < c1 ? c : c1 - 1) * NT * W;
+#pragma unroll
+            for (int it = 0; it < NTL; ++it)
+#pragma unroll
+                for (int kt = 0; kt < NTL; ++kt) {
+                    const int row = 16 * it + rm, col = 16 * kt + rq;
+                    const int rc = row < NT ? row : 0;
+                    double v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = col + (e & 1) + 8 * (e >> 1);
+                        v[e] = mp[(size_t)(cc < NT ? cc : NT - 1) * W + rc];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = col + (e & 1) + 8 * (e >> 1);
+                        fr[u][it][kt][e] = (row < NT && cc < NT) ? v[e] : 0.0;
+                    }
+                }
+        };
+        if (c1 > c0) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) fetch(u, c0 + u);
+            for (int cb = c0; cb < c1; cb += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    if (cb + u < c1) {   // wave-uniform
+                        comp_product<NT, NTL>(fr[u], P);
+                        fetch(u, cb + u + D);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NTL; ++it)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 16 * it + 8 * (v / 2) + rq + v % 2, nn = 16 * jt + m;
+                if (i < W && nn < NT) M64[(size_t)nn * W + i] = i < NT ? P[it][v] : 0.0;
+            }
+    }
+}
+
+// One (utterance, group) job of a tier-3 utterance in the refinement launch's extra rows (see lpc_fwdq2_kernel).
+template <int W, int NT>
+__device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi64, const float* __restrict__ z,
+                                                  double* __restrict__ M64, double* __restrict__ V64,
+                                                  double* __restrict__ G64, unsigned* __restrict__ arrived, int b, int g,
+                                                  int NP, int NG, int lane) {
+    const double* P64b = Phi64 + (size_t)b * NP * NT * W;
+    const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+    double* m64 = M64 + ((size_t)b * NG + g) * NT * W;
+    precise_group_composite<W, NT>(P64b, c0, c1, m64, lane);
+    const double v = precise_scan_range<W, NT, float, float>(P64b + (size_t)c0 * NT * W, z + ((size_t)b * NP + c0) * W, W,
+                                                              (float*)nullptr, 0, c1 - c0, lane, (const double*)nullptr);
+    if (lane < 32) V64[((size_t)b * NG + g) * 32 + lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    unsigned old = 0u;
+    if (lane == 0) old = atomicAdd(arrived + b, 1u);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (old + 1u != (unsigned)NG) return;   // wave-uniform
+    // this wave completed the utterance: every composite and response is visible after the acquire
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) arrived[b] = 0u;         // ready for the next forward on this workspace (all NG arrivals are in)
+    precise_scan_range<W, NT, double, double>(M64 + (size_t)b * NG * NT * W, V64 + (size_t)b * NG * 32, 32,
+                                               G64 + (size_t)b * (NG + 1) * 32, 32, NG, lane, (const double*)nullptr);
+}
+
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
 template <int W, int NT>
 __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT, const float* __restrict__ x,
@@ -2004,9 +2171,10 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 //     the group's response to its own defects -> V2[b][g].
 //   MODE 1, final pass: the SAME prologue run on the defects (composites folded with V2, chunk maps with inputs d) gives the
 //     correction delta_c; chunks run from S1_c + delta_c and write y.  (Delta form: see fwdq_body.)
-//   Tier-3 utterances (see phi_guard) skip the refinement pass: rows blockIdx.y >= B of ITS grid hold one wave per utterance
-//     that returns at once unless the utterance is tier 3 and then scans its boundary states in fp64 -> S1 (this launch has
-//     the registers and lasts 26 us anyway); the final pass takes those as they are.
+//   Tier-3 utterances (see phi_guard) skip the refinement pass: the waves of rows blockIdx.y >= B of ITS grid share the
+//     (tier-3 utterance, group) jobs of the fp64 two-level scan -- composite, group response, and for the wave that
+//     completes an utterance the fold into the group start states G64 (this launch has the registers and lasts 26 us
+//     anyway); the final pass scans each group's own maps from G64 in its prologue.
 #ifndef GOLF_FWDQ2_WAVES
 #define GOLF_FWDQ2_WAVES 1   // waves per SIMD the chunk kernels' register allocation must allow (build parameter: A/B of residency)
 #endif
@@ -2020,7 +2188,9 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
                                                        int NG, float* __restrict__ S1,
                                                        const unsigned* __restrict__ tier,
                                                        unsigned* __restrict__ nonfinite, int B,
-                                                       const double* __restrict__ Phi64) {
+                                                       const double* __restrict__ Phi64, double* __restrict__ M64,
+                                                       double* __restrict__ V64, double* __restrict__ G64,
+                                                       unsigned* __restrict__ arrived, const float* __restrict__ zq) {
     static_assert(MODE == 1 || MODE == 3, "final pass or refinement pass");
     light_wave_priority();
     using TL = Tile<W, 16>;
@@ -2033,11 +2203,16 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
             record_scan_kind(tier, B, kScanTwoLevel);
             if (nonfinite) nonfinite[0] = 0u;   // per forward: the final pass (next launch) ORs 1 in when a non-finite sample leaves
         }
-        if ((int)blockIdx.y >= B) {   // fp64 boundary scan of a tier-3 utterance (x = the zero-state responses z)
-            const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
-            if (bp < B && tier3(tier, bp))
-                precise_fwd_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, x + (size_t)bp * NP * W,
-                                        S1 + (size_t)bp * (NP + 1) * 32, 32, NP, threadIdx.x);
+        if ((int)blockIdx.y >= B) {
+            // fp64 boundary states of tier-3 utterances, two levels (precise_group_job; x = the zero-state responses z): the
+            // extra rows' waves share the (utterance, group) jobs -- one utterance's groups land on different waves
+            const int w = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
+            const int nw = ((int)gridDim.y - B) * (int)gridDim.x;
+            for (int job = w; job < B * NG; job += nw) {
+                const int bp = job / NG;
+                if (tier3(tier, bp))   // wave-uniform
+                    precise_group_job<W, NT>(Phi64, x, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, threadIdx.x);
+            }
             return;
         }
     }
@@ -2087,8 +2262,15 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
         wave_lds_fence();
     } else {
         if (precise) {
-            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
-                st[e] = c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+            // tier 3: the group's start state from the fold of the fp64 composites (refinement launch), then the own chunk
+            // maps as doubles with the zero-state responses -- the states the fp64 recursion over the whole utterance gives
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
+            wave_lds_fence();
+            const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+            const int n = c1 > c0 ? c1 - c0 : 0;
+            const int cs = c0 < NP ? c0 : (NP > 0 ? NP - 1 : 0);
+            precise_scan_range<W, NT, float, float>(Phi64 + ((size_t)b * NP + cs) * NT * W, zq + ((size_t)b * NP + cs) * W, W, st,
+                                                    32, n, lane, G64 + ((size_t)b * (NG + 1) + g) * 32);
         } else {
             // the first-pass states S1 of the group (written by the refinement pass): all loads issued BEFORE the prologue and
             // added after it.  (As a loop `st[e] += cond ? s1b[..] : 0` this was 9 conditional loads each waited for -- nine
@@ -3181,6 +3363,10 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             float* Vd = Vz + (size_t)B * p.NG * 32;                   // ... and the groups' responses to the defects
             float* dfc = (float*)(ws + p.off_z2);                     // defects E_c - S1_{c+1} of the refinement pass
             float* S1 = (float*)(ws + p.off_S1);                      // first-pass chunk start states
+            double* M64 = (double*)(ws + p.off_m64);                  // tier 3: fp64 group composites, responses, start states
+            double* V64 = (double*)(ws + p.off_v64);
+            double* G64 = (double*)(ws + p.off_g64);
+            unsigned* arrived = (unsigned*)(ws + p.off_fixcnt) + 2 * (size_t)B + 1;
             const int gxf = (int)ceil_div(p.NC, kGroup);
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
             FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1, training);
@@ -3200,12 +3386,12 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3, THINV>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0,  \
                                st, ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,        \
                                (const float*)MT, (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier, nonfinite, B,  \
-                               Phi64);                                                                                         \
+                               Phi64, M64, V64, G64, arrived, (const float*)z);                                                \
             GOLF_LAUNCH_CHECK();                                                                                               \
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 1, THINV>), dim3((unsigned)gxf, B), dim3(64), 0, st, ex, ex_stride,    \
                                gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,            \
                                (const float*)Vd, (float*)nullptr, (const float*)dfc, p.NP, p.NG, S1, tier, nonfinite, B,       \
-                               Phi64);
+                               Phi64, M64, V64, G64, arrived, (const float*)z);
             if (thin) { GOLF_FWDQ2_LAUNCH(true) } else { GOLF_FWDQ2_LAUNCH(false) }
 #undef GOLF_FWDQ2_LAUNCH
             GOLF_LAUNCH_CHECK();

@@ -948,3 +948,42 @@ def test_backward_zeroes_the_excitation_tail_when_asked(B, mode):
     t = exd.clone().requires_grad_(True)
     GF.ltv_allpole_ss(t, gd, ad, hop, mode={0: None, 8: "serial"}[mode], fast_inference=False).backward(gy)
     assert (t.grad[:, T:] == 0).all() and torch.equal(t.grad[:, :T], res[1][0][:, :T])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,sigma,seed", [(193, 1.0, 21), (60, 1.0, 22), (200, 1.3, 23)])
+def test_tier3_two_level_fp64_states(F, sigma, seed):
+    """Round 4: the fp64 boundary states of tier-3 utterances on the two-level path come from fp64 group composites, their
+    fold and a per-group scan in the final pass's prologue instead of one wave's scan over every chunk.  Group counts where
+    the last group is full (192 maps), partial (59) and the benchmark's 199, with SEVERAL tier-3 utterances per batch (the
+    jobs of the refinement launch's extra waves go round more than once): within the sequential fp32 recursion's error of
+    the float64 oracle, and as close to it as the flat fp64 scan is."""
+    B, M, hop = 12, 22, 240
+    ex, gain, a = harsh_case(B, F, M, hop, sigma, seed)
+    ref = oracle_rows(ex, gain, a, hop)
+    ok = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e12)
+    scale = np.abs(ref).max(1) + 1e-300
+    e_ser = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    good = ok & (e_ser < 0.05)
+    assert good.sum() >= 3
+    errs = {}
+    for mode in (None, "flat-scan"):
+        y, st = run_status(ex, gain, a, hop, fast=True, mode=mode)
+        assert st["tier3_utterances"] >= 2, st
+        assert st["nonfinite"] == (not np.isfinite(y).all()), st
+        errs[mode] = np.abs(y - ref).max(1) / scale
+        assert np.all(errs[mode][good] <= 3 * e_ser[good] + 1e-4), (mode, st, errs[mode][good].max(), e_ser[good].max())
+    print(f"F {F}: two-level {errs[None][good].max():.2e} flat {errs['flat-scan'][good].max():.2e} sequential {e_ser[good].max():.2e}")
+    # a second forward on the same prepared handle (the arrival counters reset themselves): same result
+    from golf_amd import functional as GF
+
+    exd, gd, ad = dev(ex), dev(gain), dev(a)
+    T = GF.ss_output_length(exd.shape[1], F, hop)
+    prep = GF.ltv_allpole_prepare(ad, hop, T, fast=True)
+    y1 = GF.ltv_allpole_ss(exd, gd, ad, hop, prepared=prep)
+    y2 = GF.ltv_allpole_ss(exd * 0.5, gd, ad, hop, prepared=prep)
+    y3 = GF.ltv_allpole_ss(exd, gd, ad, hop, prepared=prep)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(y1), torch.nan_to_num(y3))
+    fin = torch.isfinite(y1).all(1) & torch.isfinite(y2).all(1)
+    assert torch.allclose(y2[fin] * 2, y1[fin], rtol=1e-4, atol=1e-4 * float(y1[fin].abs().max()))
