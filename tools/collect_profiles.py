@@ -7,6 +7,19 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+# gpurun MERGES a call's outputs into gpurun_out/: counter CSVs of an earlier refresh (other process ids, kernels that have since
+# been renamed) would be summed in beside the new ones.  When the last call was the refresh, drop what it did not bring back.
+try:
+    last = json.load(open(os.path.join(ROOT, "gpurun_out", ".last_call.json")))
+    if any(f.startswith(RND + "/sq4_synth") for f in last.get("pulled_files", [])):
+        pulled = set(last["pulled_files"])
+        for dp, _, fns in os.walk(SRC):
+            for fn in fns:
+                full = os.path.join(dp, fn)
+                if os.path.relpath(full, os.path.join(ROOT, "gpurun_out")) not in pulled:
+                    os.remove(full)
+except (OSError, ValueError, KeyError):
+    pass
 import rocpd_summary
 
 for f in glob.glob(os.path.join(SRC, "bench_*.json")):
