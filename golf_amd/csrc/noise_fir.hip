@@ -399,6 +399,15 @@ __device__ __forceinline__ void zg_commit(const ZgStage<MODE>& st, float* As, in
     }
 }
 
+#ifdef ZPG_TIMING   // dev build (tools/zp_phases.py): s_memtime stamps of thread 0 of every workgroup
+__device__ unsigned long long g_zpg_stamps[8 * 4096];
+#define ZPG_STAMP(i) do { if (threadIdx.x == 0) g_zpg_stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int golf_debug_zpg_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_zpg_stamps), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define ZPG_STAMP(i) do { } while (0)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ src, int src_stride,
                                                       const float* __restrict__ log_mag,
@@ -410,6 +419,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
     const int g0 = blockIdx.x * ZG_ROWS, c0 = blockIdx.y * ZG_COLS;
     const int N = 2 * (n_mag - 1), H = N >> 1;
     const int li = lane & 15, lk = lane >> 4;
+    ZPG_STAMP(0);
 
     f32x4 acc[ZG_RT][2];
 #pragma unroll
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
     zg_fetch<MODE>(st, src, src_stride, window, g0, G, n_mag, 0, tid);
     zg_commit<MODE>(st, Asm, tid);
     __syncthreads();
+    ZPG_STAMP(1);
     const int nchunk = Pd / ZG_KC;
     for (int ch = 0; ch < nchunk; ++ch) {
         float* Acur = Asm + (ch & 1) * (ZG_ROWS * ZG_LDA);
@@ -463,6 +474,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
         if (more) zg_commit<MODE>(st, Anxt, tid);
         __syncthreads();
     }
+    ZPG_STAMP(2);
     float* As = Asm;
     // epilogue through LDS so that global stores run along rows (the last loop iteration ended with a barrier)
     float* Cs = As;
@@ -474,6 +486,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r)
                 Cs[(rt * 16 + lk * 4 + r) * ZG_LDC + w * 32 + ct * 16 + li] = acc[rt][ct][r];
     __syncthreads();
+    ZPG_STAMP(3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int cc = lane + 64 * h, c = c0 + cc;
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
             }
         }
     }
+    ZPG_STAMP(4);
     if (MODE == 0 && blockIdx.y == 0) {  // zero the row padding [N, out_stride)
         for (int rr = 0; rr < ZG_RPW; ++rr) {
             const int g = g0 + w * ZG_RPW + rr;
