@@ -427,6 +427,23 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The epilogue's own operands, fetched HERE: read where they are used (the window taps of the thread's two columns; in
+    // the backward the log-magnitudes of its 2 x 8 outputs) they were dependent loads in front of the stores -- 4.2 k of a
+    // workgroup's 27 k ticks in the forward (tools/zp_phases.py).
+    float ep_wu[2], ep_wd[2], ep_lm[2][ZG_RPW];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = c0 + lane + 64 * h;
+        if (MODE == 0) {
+            ep_wu[h] = window[H + min(c, H - 1)];
+            ep_wd[h] = window[H - min(c, H)];
+        } else {
+            const int ccl = min(c, n_mag - 1);
+#pragma unroll
+            for (int rr = 0; rr < ZG_RPW; ++rr)
+                ep_lm[h][rr] = log_mag[(size_t)min(g0 + w * ZG_RPW + rr, G - 1) * n_mag + ccl];
+        }
+    }
     // B fragments run 8 k-steps ahead across the whole K range (Bm rows are contiguous in k)
     const int ksteps_all = Pd >> 2;  // multiple of 32 (Pd is a multiple of 128)
     const float* bp = Bm + (size_t)lk * Pd + c0 + w * 32 + li;
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
         const int cc = lane + 64 * h, c = c0 + cc;
         if (MODE == 0) {
             const bool up = c < H, dn = c >= 1 && c <= H;
-            const float wu = window[H + min(c, H - 1)], wd = window[H - min(c, H)];
+            const float wu = ep_wu[h], wd = ep_wd[h];
 #pragma unroll 4
             for (int rr = 0; rr < ZG_RPW; ++rr) {
                 const int row = w * ZG_RPW + rr, g = g0 + row;
@@ -502,12 +519,11 @@ __global__ __launch_bounds__(256) void zp_gemm_kernel(const float* __restrict__ 
                 if (g < G && dn) orow[H - c] = u * wd;
             }
         } else {
-            const int ccl = min(c, n_mag - 1);
-#pragma unroll 4
+#pragma unroll
             for (int rr = 0; rr < ZG_RPW; ++rr) {
                 const int row = w * ZG_RPW + rr, g = g0 + row;
                 const float u = Cs[row * ZG_LDC + cc];
-                const float e = __expf(log_mag[(size_t)min(g, G - 1) * n_mag + ccl]);
+                const float e = __expf(ep_lm[h][rr]);
                 if (g < G && c < n_mag) out[(size_t)g * out_stride + c] = u * e;
             }
         }
