@@ -162,15 +162,18 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
         else:
             wsel_g = wsel
             room_taps = torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)])
+        tail = torch.cat([rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)])   # the constant end of the room filter's taps
 
         def step():
             prep = GF.ltv_allpole_prepare(a, hop, 47760, overlap=True, fast=True) if (overlap and not train) else None
             nz = GF.zero_phase_fir_filter(noise, lm, fir_win, hop)
-            src = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True, add=nz)[:, : nz.shape[1]]
-            y = GF.ltv_allpole_ss(src, gain, a, hop, prepared=prep)
+            # source + filtered noise, the common length taken by the filter itself (`length=`): as `src[:, :n]` the slice's
+            # backward was a 6 MB fill + a 6 MB copy in front of the oscillator's backward
+            src = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True, add=nz)
+            y = GF.ltv_allpole_ss(src, gain, a, hop, prepared=prep, length=nz.shape[1])
             if not train:
                 return GF.lti_fir(y, room_taps, K)
-            y = GF.lti_fir(y, torch.cat([rk, rk.new_ones(1), rk.new_zeros((-(K + 1)) % 4)]), K)
+            y = GF.lti_fir(y, torch.cat([rk, tail]), K)
             for t in (gain, a, wsel_g, lm, rk):
                 t.grad = None
             y.backward(gy)

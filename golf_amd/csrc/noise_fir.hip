@@ -156,9 +156,11 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
     if (unit >= B * F * npass) return;
     const int c = unit % npass, fr = (unit / npass) % F, b = unit / (npass * F);
     const int f = fr - frame0;  // output frame that used kernel row fr (rows outside [frame0, frame0+nfr) get zeros)
-    const BufRow gr(g_kern + (size_t)(b * F + fr) * KS, N);
+    const BufRow gr(g_kern + (size_t)(b * F + fr) * KS, KS);
     const int k0 = c * FIR_TILE, o = 4 * lane;
     const int lim = min(FIR_TILE, N - k0);
+    const int limz = min(FIR_TILE, KS - k0);   // the row's padding taps [N, KS) (last pass) get their zero gradient here:
+                                               // the caller used to fill them with a strided torch kernel of its own
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (f >= 0 && f < nfr) {  // wave-uniform
         float* sig = fir_lds + wv * RS;
@@ -172,10 +174,10 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
         fir_accum(A, sig, gy + b * gy_stride + (size_t)f * hop, hop, lane);
         r = fir_finish(A);
     }
-    gr.st(o + 0 < lim ? k0 + o + 0 : -1, r.x);
-    gr.st(o + 1 < lim ? k0 + o + 1 : -1, r.y);
-    gr.st(o + 2 < lim ? k0 + o + 2 : -1, r.z);
-    gr.st(o + 3 < lim ? k0 + o + 3 : -1, r.w);
+    gr.st(o + 0 < limz ? k0 + o + 0 : -1, o + 0 < lim ? r.x : 0.f);
+    gr.st(o + 1 < limz ? k0 + o + 1 : -1, o + 1 < lim ? r.y : 0.f);
+    gr.st(o + 2 < limz ? k0 + o + 2 : -1, o + 2 < lim ? r.z : 0.f);
+    gr.st(o + 3 < limz ? k0 + o + 3 : -1, o + 3 < lim ? r.w : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -262,11 +262,13 @@ class LTIAcousticFilter(FilterInterface):
             raise ValueError(f"Unknown conv_method: {conv_method}")
         self.kernel = torch.nn.Parameter(torch.zeros(length - 1))
         self._padding = length - 1
+        # the constant end of the tap vector (the direct path's 1 + zeros up to a multiple of 4 taps): a buffer, so that
+        # building the taps is one concatenation instead of two fills and a concatenation per call
+        self.register_buffer("_tail", torch.cat([torch.ones(1), torch.zeros((-length) % 4)]), persistent=False)
 
     def forward(self, ex: AudioTensor) -> AudioTensor:
         K = self._padding
-        pad = (-(K + 1)) % 4
-        taps = torch.cat([self.kernel, self.kernel.new_ones(1), self.kernel.new_zeros(pad)])
+        taps = torch.cat([self.kernel, self._tail.to(self.kernel.dtype)])
         return AudioTensor(GF.lti_fir(ex.as_tensor(), taps, K), hop_length=ex.hop_length)
 
     @property

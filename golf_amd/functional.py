@@ -127,7 +127,7 @@ def ss_is_trainable(M: int, hop: int, F: int = 2) -> bool:
 class _LTVAllPoleSS(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0, status=None):
+    def forward(ctx, ex, gain, a, hop, prepared, fast_inference, mode=0, status=None, length=None):
         _lib.require_device(ex, gain, a)
         lib = _lib.load()
         ex = _rows(ex)
@@ -137,6 +137,10 @@ class _LTVAllPoleSS(torch.autograd.Function):
         F, M = a.shape[1], a.shape[2]
         assert gain.shape == (B, F) and a.shape[0] == B
         T = ss_output_length(Tx, F, hop)
+        if length is not None:   # only the first `length` samples of the excitation rows (no slice op on the caller's side)
+            T = min(T, int(length))
+            if T < 1:
+                raise _lib.GolfError(f"ltv_allpole_ss: length={length} leaves nothing to filter")
         y = torch.empty(B, T, dtype=torch.float32, device=ex.device)
         side, flags = None, 0
         needs_grad = any(ctx.needs_input_grad[:3])
@@ -203,7 +207,7 @@ class _LTVAllPoleSS(torch.autograd.Function):
                                           ws.data_ptr(), ws.numel(), ctx.mode | (ZERO_TAIL if Tx > T else 0),
                                           _lib.stream_ptr())
         _lib.check(rc, "golf_ltv_allpole_bwd_f32")
-        return g_ex, g_gain, g_a, None, None, None, None, None
+        return g_ex, g_gain, g_a, None, None, None, None, None, None
 
 
 SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _FLAT_SCAN
@@ -215,7 +219,7 @@ THROUGHPUT_MODE = False
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
                    prepared: "PreparedTransitions" = None, fast_inference: bool = True,
-                   mode: str = None, status: torch.Tensor = None) -> torch.Tensor:
+                   mode: str = None, status: torch.Tensor = None, length: int = None) -> torch.Tensor:
     """y[t] = ex[t]*up(gain)[t] - sum_i up(a)[t,i] y[t-1-i]; ex (B,Tx), gain (B,F), a (B,F,M) at hop.
     Output (B, min(Tx,(F-1)*hop+1)).  Differentiable w.r.t. ex, gain, a (custom HIP backward).
     ``prepared``: handle from ltv_allpole_prepare(a, hop, T) (ignored if it does not match).
@@ -224,6 +228,10 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
     serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one, "flat-scan" is
     the chunked algorithm with the flat boundary scan instead of the two-level one (A/B).
+    ``length``: filter only the first ``length`` samples of ``ex`` (output (B, min(length, natural length))): what
+    ``ltv_allpole_ss(ex[:, :length], ...)`` computes, without the slice -- whose backward would be a full-size fill and a
+    full-size copy in front of the producer's backward (the gradient of the unused tail is written as zeros by the filter's
+    own backward, GOLF_SS_ZERO_TAIL).
     ``status``: optional int32 device tensor of >= 4 elements that receives, asynchronously, the conditioning / health
     words of this call (decode with ss_status): utterances with recomputed chunk maps, utterances on the fp64 boundary
     scan, non-finite output flag, largest transition-matrix entry."""
@@ -232,8 +240,10 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
         # the C ABI itself rejects non-positive sizes
         _lib.require_device(ex, gain, a)
         T = ss_output_length(ex.shape[1], a.shape[1], int(hop)) if ex.shape[1] else 0
+        if length is not None:
+            T = min(T, max(int(length), 0))
         return ex[:, :T] * 1.0 + 0.0 * (gain.sum() + a.sum())
-    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode], status)
+    return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode], status, length)
 
 
 def ss_status(status: torch.Tensor) -> dict:
@@ -881,8 +891,7 @@ class _FIRFrames(torch.autograd.Function):
                                                    g_kern.data_ptr() if need_k else None,
                                                    B, T, F, N, hop, frame0, _lib.stream_ptr()),
                    "golf_ltv_fir_frames_bwd_f32")
-        if need_k:
-            g_kern[:, N:] = 0  # padding taps carry no gradient
+        # (the padding taps [N, row stride) carry no gradient: the kernel writes their zeros itself)
         return g_ex, g_kern, None, None, None, None
 
 

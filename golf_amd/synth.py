@@ -146,7 +146,9 @@ class IndexedGlottalFlowTable(GlottalFlowTable):
                              add=None if add is None else add.as_tensor())
         if add is not None:   # what AudioTensor addition of two hop-1 signals does: truncate to the shorter
             assert add.hop_length == 1 and not return_pre
-            return AudioTensor(res[:, : min(res.shape[1], add.shape[1])])
+            # (no slice when there is nothing to cut: a full-range slice still records a SliceBackward, whose backward is a
+            #  6 MB fill + a 6 MB copy in front of the oscillator's backward)
+            return AudioTensor(res if add.shape[1] >= res.shape[1] else res[:, : add.shape[1]])
         if return_pre:
             return AudioTensor(res[0]), res[1]
         return AudioTensor(res)

@@ -356,7 +356,7 @@ int golf_ltv_fir_frames_length(int T, int F, int N, int hop);
  * frames f and f+1) needs for its second term. */
 int golf_ltv_fir_frames_fwd_f32(const float* ex, int64_t ex_stride, const float* kern, int kern_row_stride, float* y,
                                 int64_t y_stride, int B, int T, int F, int N, int hop, int frame0, void* stream);
-/* gy (B, nfr*hop).  g_ex (B,T) and g_kern (B*F, kern_row_stride; rows of unused frames zeroed) are fully
+/* gy (B, nfr*hop).  g_ex (B,T) and g_kern (B*F, kern_row_stride; rows of unused frames and the padding taps [N, kern_row_stride) zeroed) are fully
  * overwritten; either may be NULL to skip it.  Requires hop % 4 == 0. */
 int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,
                                 const float* kern, int kern_row_stride, float* g_ex, int64_t g_ex_stride,

@@ -987,3 +987,26 @@ def test_tier3_two_level_fp64_states(F, sigma, seed):
     assert torch.equal(torch.nan_to_num(y1), torch.nan_to_num(y3))
     fin = torch.isfinite(y1).all(1) & torch.isfinite(y2).all(1)
     assert torch.allclose(y2[fin] * 2, y1[fin], rtol=1e-4, atol=1e-4 * float(y1[fin].abs().max()))
+
+
+@pytest.mark.gpu
+def test_length_argument_equals_a_slice_of_the_excitation():
+    """ltv_allpole_ss(ex, ..., length=n) is ltv_allpole_ss(ex[:, :n], ...) without the slice (whose backward is a full-size
+    fill + copy in front of the producer's backward): same output and gradients bit for bit, zeros in the unused tail."""
+    from golf_amd import functional as GF
+
+    B, F, M, hop = 3, 40, 22, 240
+    ex, gain, a = smooth_case(B, F, M, hop, seed=17)
+    n = (F - 1) * hop     # one sample short of the natural length, as the decoder's noise branch makes it
+    exd = torch.cat([dev(ex), torch.randn(B, 200, device="cuda")], 1)
+    res = []
+    for use_length in (False, True):
+        t = [v.clone().requires_grad_(True) for v in (exd, dev(gain), dev(a))]
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, length=n) if use_length else GF.ltv_allpole_ss(t[0][:, :n], t[1], t[2], hop)
+        assert y.shape == (B, n)
+        y.backward(torch.ones_like(y) / n)
+        res.append((y.detach(), [v.grad for v in t]))
+    assert torch.equal(res[0][0], res[1][0])
+    for u, v in zip(res[0][1], res[1][1]):
+        assert torch.equal(u, v)
+    assert (res[1][1][0][:, n:] == 0).all()
