@@ -690,9 +690,11 @@ __global__ __launch_bounds__(256) void ff_bwd_ola_kernel(const float* __restrict
                                                          int64_t ex_stride, const float* __restrict__ gain,
                                                          float* __restrict__ g_ex, int64_t g_ex_stride,
                                                          float* __restrict__ part, int Tx, int Tfull, int F, int hop,
-                                                         int Wl, int nfr) {
+                                                         int Wl, int nfr, int g_ex_len) {
     __shared__ float red0[256], red1[256];
     const int sgm = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (sgm == F - 2)   // the excitation beyond the last coefficient frame reaches no output: its gradient is zero (the
+        for (int t = Tfull + tid; t < g_ex_len; t += 256) g_ex[(size_t)b * g_ex_stride + t] = 0.f;   // caller used to fill it)
     const int pad = Wl / 2;
     const float g0 = gain[(size_t)b * F + sgm], g1 = gain[(size_t)b * F + sgm + 1];
     const float inv_hop = 1.0f / (float)hop;
@@ -783,7 +785,7 @@ template <int W, int NT>
 static int launch_ff_bwd(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride, const float* gain,
                          const float* a, const float* window, float* g_ex, int64_t g_ex_stride, float* g_gain,
                          float* g_a, int B, int Tx, int Tfull, int F, int M, int hop, int Wl, int Ty, int nfr,
-                         const float* yf, char* ws, hipStream_t st) {
+                         const float* yf, char* ws, hipStream_t st, int g_ex_len) {
     if (Wl % W != 0 || (int64_t)nfr * Wl >= (1ll << 29) || Wl > 16384)
         return fail(GOLF_EUNSUPPORTED, "lti_frames_bwd: window length %d must be a multiple of the ring width %d "
                     "(and <= 16384)", Wl, W);
@@ -821,7 +823,7 @@ static int launch_ff_bwd(const float* gy, int64_t gy_stride, const float* ex, in
                        (const float*)uf, yf, g_a, F, M, Wl, nfr, nq, RS);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ff_bwd_ola_kernel, dim3((unsigned)(F - 1), B), dim3(256), 0, st, (const float*)uf, ex,
-                       ex_stride, gain, g_ex, g_ex_stride, part, Tx, Tfull, F, hop, Wl, nfr);
+                       ex_stride, gain, g_ex, g_ex_stride, part, Tx, Tfull, F, hop, Wl, nfr, g_ex_len);
     GOLF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ff_gain_reduce_kernel, dim3((unsigned)ceil_div(B * F, 256)), dim3(256), 0, st,
                        (const float*)part, g_gain, B, F);
@@ -940,13 +942,13 @@ extern "C" int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, c
         return fail(GOLF_EWORKSPACE, "lti_frames_bwd: workspace needs %zu bytes, 256-aligned (got %zu)", need,
                     ws_bytes);
     hipStream_t st = (hipStream_t)stream;
-    // g_ex is written for t < min(g_ex_len, (F-1)*hop+1): zeros beyond Tx
+    // g_ex is written on [0, g_ex_len): zeros beyond Tx and beyond the last coefficient frame's sample (F-1)*hop
     int Tfull = (F - 1) * hop + 1;
     if (Tfull > g_ex_len) Tfull = g_ex_len;
 #define GOLF_FF_TRY(w, nt)                                                                                     \
     if (M <= (nt) && (w) <= hop)                                                                               \
         return launch_ff_bwd<w, nt>(gy, gy_stride, ex, ex_stride, gain, a, window, g_ex, g_ex_stride, g_gain, g_a, B, \
-                                    Tx, Tfull, F, M, hop, W, Ty, nfr, (const float*)ws_fwd, (char*)ws, st);
+                                    Tx, Tfull, F, M, hop, W, Ty, nfr, (const float*)ws_fwd, (char*)ws, st, g_ex_len);
     GOLF_FF_TRY(8, 6)
     GOLF_FF_TRY(16, 14)
     GOLF_FF_TRY(24, 22)

@@ -348,8 +348,7 @@ class _LTIFramesOLA(torch.autograd.Function):
         B, Tx0 = ex.shape
         F, M = a.shape[1], a.shape[2]
         W = window.numel()
-        covered = min(Tx0, (F - 1) * hop + 1)
-        g_ex = torch.empty_like(ex) if covered == Tx0 else torch.zeros_like(ex)
+        g_ex = torch.empty(B, Tx0, dtype=torch.float32, device=ex.device)   # written in full by the backward (zeros in the tail)
         g_gain = torch.empty_like(gain)
         g_a = torch.empty_like(a)
         ws = _workspace(lib.golf_lti_frames_bwd_workspace_bytes(B, Tx, F, M, hop, W), ex.device)

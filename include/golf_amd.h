@@ -196,7 +196,7 @@ int golf_lti_frames_ola_fwd_f32(const float* ex, int64_t ex_stride, const float*
  *     g_a[f,i] = -sum_k u_f[k]*y_f[k-1-i];   g_x = overlap-add of the u_f;   g_ex = g_x*G;   g_gain = up^T(g_x*ex).
  *   ws_fwd = the forward's workspace, unmodified (it holds the filtered frames y_f);
  *   ws     = scratch of golf_lti_frames_bwd_workspace_bytes();
- *   g_ex (B, g_ex_len >= Tx) is written for t < min(g_ex_len, (F-1)*hop+1) (zeros past Tx); g_gain (B,F) and
+ *   g_ex (B, g_ex_len >= Tx) is fully written (zeros past Tx and past sample (F-1)*hop: ABI 5); g_gain (B,F) and
  *   g_a (B,F,M) are fully overwritten.  Requires W % ring width == 0 (the fast path of the forward). */
 size_t golf_lti_frames_bwd_workspace_bytes(int B, int Tx, int F, int M, int hop, int W);
 int golf_lti_frames_ola_bwd_f32(const float* gy, int64_t gy_stride, const float* ex, int64_t ex_stride,

@@ -306,3 +306,25 @@ def test_biquad_cascade_grads_config_size(frame_gain):
         t = [dev(v).requires_grad_(True) for v in (ex, gain, bq)]
         (m(*t) * dev(gy)).sum().backward()
         check(t[2].grad.cpu().numpy(), r_bq, "module g_biquads")
+
+
+def test_ff_backward_writes_the_whole_excitation_gradient():
+    """An excitation longer than (F-1)*hop + 1 reaches no output beyond that sample: the backward writes those zeros itself
+    (round 4: the host used to allocate g_ex with torch.zeros, a full-size fill in front of every backward).  The gradient
+    buffer comes from the caching allocator: a NaN-filled block of its size is released right before, three times."""
+    from golf_amd import functional as GF
+    from test_gpu_lpc_ss import smooth_case
+
+    B, F, M, hop, W = 3, 12, 22, 240, 960
+    Tx = (F - 1) * hop + 1 + 239
+    ex, gain, a = smooth_case(B, F, M, hop, Tx=Tx, seed=5)
+    win = torch.hann_window(W, device="cuda")
+    for _ in range(3):
+        x, g, aa = (dev(v).requires_grad_(True) for v in (ex, gain, a))
+        y = GF.lti_frames_ola(x, g, aa, win, hop)
+        poison = torch.full((B, Tx), float("nan"), device="cuda")
+        del poison
+        y.sum().backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(x.grad).all()
+        assert (x.grad[:, (F - 1) * hop + 1:] == 0).all() and x.grad[:, : (F - 1) * hop + 1].abs().sum() > 0
