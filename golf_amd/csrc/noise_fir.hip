@@ -63,6 +63,7 @@ __device__ __forceinline__ void fir_group(FirAcc& A, const f32x4 cur, const f32x
 // the loop needs 44 VGPRs, so all ~6 waves per SIMD of the B=32 problem are resident at once.  A hand-pipelined
 // version (taps and window of the next 32 taps prefetched during the FMAs of the current ones; 152 VGPRs, 3 waves per
 // SIMD) measured no faster (22.2 vs 22.4 us): what cost the time was the staging loop below, not this one.
+template <bool REV = false>   // REV: the taps applied in reverse order (coef[ntaps-1-k] in place of coef[k]: the adjoint of an LTI FIR)
 __device__ __forceinline__ void fir_accum(FirAcc& A, const float* sig, const float* __restrict__ coef, int ntaps,
                                           int lane) {
     const f32x4* sig4 = reinterpret_cast<const f32x4*>(sig);
@@ -70,7 +71,12 @@ __device__ __forceinline__ void fir_accum(FirAcc& A, const float* sig, const flo
     const int nq = ntaps >> 2;
     for (int q = 0; q < nq; ++q) {
         const f32x4 nxt = sig4[lane + q + 1];
-        fir_group(A, cur, (f32x2){nxt.x, nxt.y}, coef[4 * q], coef[4 * q + 1], coef[4 * q + 2], coef[4 * q + 3]);
+        if (REV) {
+            const float* c = coef + ntaps - 4 - 4 * q;
+            fir_group(A, cur, (f32x2){nxt.x, nxt.y}, c[3], c[2], c[1], c[0]);
+        } else {
+            fir_group(A, cur, (f32x2){nxt.x, nxt.y}, coef[4 * q], coef[4 * q + 1], coef[4 * q + 2], coef[4 * q + 3]);
+        }
         cur = nxt;
     }
 }
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_ex_kernel(
 // models/filters.py:426-449):  y[b,t] = sum_{n<ntaps} taps[n] * ex[b, t - lead + n],  zero outside [0,T).
 // unit = (b, tile of FIR_TILE outputs).  The same kernel with flipped taps and lead' = ntaps-1-lead is its adjoint.
 // ------------------------------------------------------------------------------------------------------------
+template <bool REV>
 __global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                                  const float* __restrict__ taps, int ntaps, int lead,
                                                                  float* __restrict__ y, int64_t y_stride, int B, int T,
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void lti_fir_kernel(const float* __
     wave_lds_fence();
     FirAcc A;
     fir_zero(A);
-    fir_accum(A, sig, taps, ntaps, lane);
+    fir_accum<REV>(A, sig, taps, ntaps, lane);
     const f32x4 r = fir_finish(A);
     const BufRow yr(y + b * y_stride, T);
     const int o = 4 * lane;
@@ -673,13 +680,20 @@ static int lti_check(const char* who, int B, int T, int ntaps, int lead) {
 int golf_lti_fir_f32(const float* ex, int64_t ex_stride, const float* taps, int ntaps, int lead, float* y,
                      int64_t y_stride, int B, int T, void* stream) {
     if (!ex || !taps || !y) return fail(GOLF_EINVAL, "lti_fir: null pointer");
+    const bool rev = ntaps < 0;   // ABI 5: a negative tap count applies the |ntaps| taps in reverse order (the adjoint, no flipped copy)
+    if (rev) ntaps = -ntaps;
     if (int rc = lti_check("lti_fir", B, T, ntaps, lead)) return rc;
     const int ntile = (T + FIR_TILE - 1) / FIR_TILE;
     const int RS = fir_region(256 + ntaps + 4);
     const long long units = (long long)B * ntile;
-    hipLaunchKernelGGL(lti_fir_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)), dim3(64 * FIR_WAVES),
-                       FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, taps, ntaps, lead, y,
-                       y_stride, B, T, ntile, RS);
+    if (rev)
+        hipLaunchKernelGGL(lti_fir_kernel<true>, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)), dim3(64 * FIR_WAVES),
+                           FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, taps, ntaps, lead, y,
+                           y_stride, B, T, ntile, RS);
+    else
+        hipLaunchKernelGGL(lti_fir_kernel<false>, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)), dim3(64 * FIR_WAVES),
+                           FIR_WAVES * RS * sizeof(float), (hipStream_t)stream, ex, ex_stride, taps, ntaps, lead, y,
+                           y_stride, B, T, ntile, RS);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }

@@ -973,8 +973,8 @@ class _LTIFIR(torch.autograd.Function):
         g_ex = g_taps = None
         if ctx.needs_input_grad[0]:
             g_ex = torch.empty_like(ex)
-            rev = taps.flip(0).contiguous()
-            _lib.check(lib.golf_lti_fir_f32(gy.data_ptr(), gy.stride(0), rev.data_ptr(), n, n - 1 - ctx.lead,
+            # the adjoint = the same FIR with the taps in reverse order: a negative tap count (ABI 5) instead of taps.flip(0)
+            _lib.check(lib.golf_lti_fir_f32(gy.data_ptr(), gy.stride(0), taps.data_ptr(), -n, n - 1 - ctx.lead,
                                             g_ex.data_ptr(), g_ex.stride(0), B, T, _lib.stream_ptr()),
                        "golf_lti_fir_f32 (adjoint)")
         if ctx.needs_input_grad[1]:

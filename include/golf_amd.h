@@ -368,7 +368,8 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
  *     y[b,t] = sum_{n<ntaps} taps[n] * ex[b, t - lead + n],   ex = 0 outside [0,T)
  *   (the reference's y = ex + conv(pad(ex[:, :-1], (K,0)), kernel) is taps = [kernel, 1], lead = K).
  *   ntaps must be a multiple of 4 (pad with zero taps), 0 <= lead < ntaps.
- *   The adjoint w.r.t. ex is the same call with the taps reversed and lead' = ntaps-1-lead.
+ *   The adjoint w.r.t. ex is the same call with the taps reversed and lead' = ntaps-1-lead; ABI 5: ntaps < 0 applies the
+ *   |ntaps| taps in reverse order, so the adjoint needs no flipped copy of them.
  * golf_lti_fir_taps_grad_f32: g_taps[n] = sum_{b,t} gy[b,t] * ex[b, t - lead + n]  (deterministic two-stage sum).
  * ------------------------------------------------------------------------------------------- */
 int golf_lti_fir_f32(const float* ex, int64_t ex_stride, const float* taps, int ntaps, int lead, float* y,
