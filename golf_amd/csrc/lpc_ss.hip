@@ -1884,6 +1884,94 @@ __device__ __forceinline__ void precise_group_composite(const double* __restrict
     }
 }
 
+// The adjoint of precise_scan_range: lam <- Phi_c^T lam + z_c over the n maps of a range, from the top map down (the split-half
+// layout of precise_adj_scan: lane (j, h) owns component j and half the rows i; maps [c][j][i] give lane j its row contiguous
+// in i).  Row r + 1 of Sb receives the state above map r, row 0 the state below map 0 (when Sb is not null); s0 = the state
+// above the top map (null: zero).  Returns the final state.
+template <int W, int NT, typename ZT, typename ST, typename S0T>
+__device__ __forceinline__ double precise_adj_range(const double* __restrict__ P64, const ZT* __restrict__ zb, int zstride,
+                                                    ST* __restrict__ Sb, int sstride, int n, int lane,
+                                                    const S0T* __restrict__ s0) {
+    static_assert(NT <= 32, "split-half layout");
+    constexpr int NH = (NT + 1) / 2;
+    const int h = lane >> 5, j = lane & 31;
+    const bool act = j < NT;
+    const int jj = act ? j : 0, i0 = h * NH;
+    constexpr int D = 4;
+    double buf[D][NH];
+    ZT zc[D];
+    auto fetch = [&](int u, int c) {
+        const int cl = c > 0 ? c : 0;
+        const double* mp = P64 + ((size_t)cl * NT + jj) * W;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {   // raw loads; padding rows are masked on the state value
+            const int i = i0 + k;
+            buf[u][k] = mp[i < NT ? i : NT - 1];
+        }
+        zc[u] = zb[(size_t)cl * zstride + jj];
+    };
+    double lam = 0.0;
+    if (s0) { const double v = (double)s0[jj]; lam = act ? v : 0.0; }
+    if (n > 0) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, n - 1 - u);
+        for (int u0 = 0; u0 < n; u0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int c = n - 1 - (u0 + u);
+                if (c >= 0) {   // wave-uniform
+                    if (Sb && lane < sstride) Sb[(size_t)(c + 1) * sstride + lane] = h == 0 ? (ST)lam : (ST)0;
+                    double li[NH];   // all permutes of a step in flight at once (see precise_fwd_scan)
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        const double v = lane_perm_d(lam, i0 + k < NT ? i0 + k : 0);
+                        li[k] = (2 * NH == NT || i0 + k < NT) ? v : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        if (k & 1) acc1 = __builtin_elementwise_fma(buf[u][k], li[k], acc1);
+                        else       acc0 = __builtin_elementwise_fma(buf[u][k], li[k], acc0);
+                    }
+                    const double part = acc0 + acc1;
+                    const double tot = part + lane_perm_d(part, lane ^ 32);
+                    lam = act ? tot + (double)zc[u] : 0.0;
+                    fetch(u, c - D);
+                }
+            }
+        }
+    }
+    if (Sb && lane < sstride) Sb[lane] = h == 0 ? (ST)lam : (ST)0;
+    return lam;
+}
+
+// The backward's counterpart of precise_group_job (refinement launch of the adjoint, extra rows): the group's adjoint response
+// to its zadj from a zero state; the wave that completes the utterance folds the groups from the top down with the TRANSPOSED
+// composites -- M64 as the forward's precise_group_job left it in the workspace ([g][j][i] is exactly the layout the adjoint
+// reads) -- into GA[g] = L(c0_g - 1), GA[NG] = L(NP - 1) = zadj[NP].  The final pass scans each group's own maps from GA[g + 1].
+template <int W, int NT>
+__device__ __forceinline__ void precise_adj_group_job(const double* __restrict__ Phi64, const float* __restrict__ zadj,
+                                                      const double* __restrict__ M64, double* __restrict__ W64,
+                                                      double* __restrict__ GA64, unsigned* __restrict__ arrived, int b,
+                                                      int g, int NP, int NC, int NG, int lane) {
+    const double* P64b = Phi64 + (size_t)b * NP * NT * W;
+    const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+    const double w = precise_adj_range<W, NT, float, float, float>(P64b + (size_t)c0 * NT * W, zadj + ((size_t)b * NC + c0) * W,
+                                                                   W, (float*)nullptr, 0, c1 - c0, lane, (const float*)nullptr);
+    if (lane < 32) W64[((size_t)b * NG + g) * 32 + lane] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    unsigned old = 0u;
+    if (lane == 0) old = atomicAdd(arrived + b, 1u);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (old + 1u != (unsigned)NG) return;   // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) arrived[b] = 0u;
+    precise_adj_range<W, NT, double, double, float>(M64 + (size_t)b * NG * NT * W, W64 + (size_t)b * NG * 32, 32,
+                                                    GA64 + (size_t)b * (NG + 1) * 32, 32, NG, lane,
+                                                    zadj + ((size_t)b * NC + NP) * W);
+}
+
 // One (utterance, group) job of a tier-3 utterance in the refinement launch's extra rows (see lpc_fwdq2_kernel).
 template <int W, int NT>
 __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi64, const float* __restrict__ z,
@@ -2627,7 +2715,9 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
                                                        const float* __restrict__ Wv, float* __restrict__ Wout,
                                                        const float* __restrict__ x, int NP, int NG,
                                                        float* __restrict__ L1, const unsigned* __restrict__ tier, int B,
-                                                       const double* __restrict__ Phi64) {
+                                                       const double* __restrict__ Phi64, const double* __restrict__ M64,
+                                                       double* __restrict__ W64, double* __restrict__ GA64,
+                                                       unsigned* __restrict__ arrived, const float* __restrict__ zq) {
     static_assert(MODE == 0 || MODE == 1 || MODE == 3, "local adjoints, final pass or refinement pass");
     using TL = Tile<W, 16>;
     __shared__ float xt[TL::SIZE];
@@ -2638,11 +2728,14 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) check_scan_kind(tier, B, kScanTwoLevel);
     }
     if constexpr (MODE == 3) {
-        if ((int)blockIdx.y >= B) {   // fp64 adjoint boundary scan of a tier-3 utterance (x = zadj) -> L1 rows c+1
-            const int bp = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
-            if (bp < B && tier3(tier, bp))
-                precise_adj_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, x + (size_t)bp * NC * W,
-                                        L1 + (size_t)bp * (NC + 1) * 32 + 32, 32, NP, threadIdx.x);
+        if ((int)blockIdx.y >= B) {   // fp64 adjoint boundary states of tier-3 utterances, two levels (x = zadj): see lpc_fwdq2_kernel
+            const int w = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
+            const int nw = ((int)gridDim.y - B) * (int)gridDim.x;
+            for (int job = w; job < B * NG; job += nw) {
+                const int bp = job / NG;
+                if (tier3(tier, bp))   // wave-uniform
+                    precise_adj_group_job<W, NT>(Phi64, x, M64, W64, GA64, arrived, bp, job - bp * NG, NP, NC, NG, threadIdx.x);
+            }
             return;
         }
     }
@@ -2682,8 +2775,16 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
         adjq_body<W, NT, 3, true>(gy, gy_stride, a, nullptr, out, 0, T, F, M, hop, L, NC, NP, xt, yt, b, g, lane, st, dl);
     } else {
         if (precise) {
-            for (int e = lane; e < (kGroup + 1) * 32; e += 64)   // rows 0 .. NP of L1 hold L(-1) .. L(NP-1); L(NP) = 0
-                st[e] = c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
+            // tier 3: st[k] = L(c0 + k - 1) from the fold of the transposed fp64 composites (refinement launch) and the group's
+            // own maps as doubles with zadj; L(NP) = 0
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
+            wave_lds_fence();
+            const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+            const int n = c1 > c0 ? c1 - c0 : 0;
+            const int cs = c0 < NP ? c0 : (NP > 0 ? NP - 1 : 0);
+            const int gt = g + 1 < NG ? g + 1 : NG;
+            precise_adj_range<W, NT, float, float, double>(Phi64 + ((size_t)b * NP + cs) * NT * W, zq + ((size_t)b * NC + cs) * W,
+                                                           W, st, 32, n, lane, GA64 + ((size_t)b * (NG + 1) + gt) * 32);
         } else {
             constexpr int NE = ((kGroup + 1) * 32 + 63) / 64;   // (loads ahead of the prologue: see lpc_fwdq2_kernel)
             float l1v[NE];
@@ -3443,18 +3544,23 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
             float* Wz = (float*)(ws + p.off_wadj);
             float* Wd = Wz + (size_t)B * p.NG * 32;
             float* L1 = (float*)(ws + p.off_L1);
+            // tier 3: the forward's fp64 composites (read transposed), and its response / start-state regions reused for the adjoint
+            const double* M64 = (const double*)(ws + p.off_m64);
+            double* W64 = (double*)(ws + p.off_v64);
+            double* GA64 = (double*)(ws + p.off_g64);
+            unsigned* arrived = (unsigned*)(ws + p.off_fixcnt) + 2 * (size_t)B + 1;
             hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 0>), gq, dim3(64), 0, st, gy, gy_stride, a, zadj, (int64_t)0, T, F, M,
                                hop, p.L, p.NC, Phi, MTt, (const float*)nullptr, Wz, (const float*)nullptr, p.NP, p.NG, L1,
-                               tier, B, Phi64);
+                               tier, B, Phi64, M64, W64, GA64, arrived, (const float*)zadj);
             GOLF_LAUNCH_CHECK();
             const int gx3 = (int)ceil_div(p.NP, kGroup);
             hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 3>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0, st,
                                gy, gy_stride, a, dadj, (int64_t)0, T, F, M, hop, p.L, p.NC, Phi, MTt, (const float*)Wz, Wd,
-                               (const float*)zadj, p.NP, p.NG, L1, tier, B, Phi64);
+                               (const float*)zadj, p.NP, p.NG, L1, tier, B, Phi64, M64, W64, GA64, arrived, (const float*)zadj);
             GOLF_LAUNCH_CHECK();
             hipLaunchKernelGGL((lpc_adjq2_kernel<W, NT, 1>), gq, dim3(64), 0, st, gy, gy_stride, a, gbuf, (int64_t)T, T, F, M,
                                hop, p.L, p.NC, Phi, MTt, (const float*)Wd, (float*)nullptr, (const float*)dadj, p.NP, p.NG,
-                               L1, tier, B, Phi64);
+                               L1, tier, B, Phi64, M64, W64, GA64, arrived, (const float*)zadj);
             GOLF_LAUNCH_CHECK();
             done = true;
         }

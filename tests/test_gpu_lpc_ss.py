@@ -974,6 +974,27 @@ def test_tier3_two_level_fp64_states(F, sigma, seed):
         errs[mode] = np.abs(y - ref).max(1) / scale
         assert np.all(errs[mode][good] <= 3 * e_ser[good] + 1e-4), (mode, st, errs[mode][good].max(), e_ser[good].max())
     print(f"F {F}: two-level {errs[None][good].max():.2e} flat {errs['flat-scan'][good].max():.2e} sequential {e_ser[good].max():.2e}")
+    # the backward: its fp64 adjoint states take the same two levels (the forward's composites read transposed); against the
+    # float64 oracle's closed-form backward with the harsh-track test's bound, and beside the flat adjoint scan
+    from oracle import golf_oracle as O
+
+    gy = (np.random.default_rng(seed).normal(0, 1, ref.shape) / scale[:, None]).astype(np.float32)
+    gy[~ok] = 0
+    res = {m: run_mode(ex, gain, a, hop, m, gy) for m in (None, "flat-scan", "serial")}
+    want = O.ltv_allpole_ss_backward(gy[good], ex[good], gain[good], a[good], hop)
+    ng = int(good.sum())
+
+    def gerr(r, ref_g):
+        ref_g = ref_g.reshape(ng, -1)
+        r = r[good].reshape(ng, -1)[:, : ref_g.shape[1]]
+        return np.abs(r - ref_g).max(1) / (np.abs(ref_g).max(1) + 1e-30)
+
+    for k, name in ((1, "g_ex"), (2, "g_gain"), (3, "g_a")):
+        e_s = gerr(res["serial"][k], want[k - 1])
+        for m in (None, "flat-scan"):
+            assert np.isfinite(res[m][k][ok]).all(), (name, m)
+            e_c = gerr(res[m][k], want[k - 1])
+            assert np.all(e_c <= 3 * e_s + 2e-4), (name, m, e_c.max(), e_s.max())
     # a second forward on the same prepared handle (the arrival counters reset themselves): same result
     from golf_amd import functional as GF
 
