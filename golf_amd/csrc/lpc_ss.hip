@@ -120,7 +120,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_pmax = o; o = align_up(o + sizeof(float) * (size_t)B * (p->NP > 0 ? p->NP : 1), 256);   // max |Phi_c| per chunk
     p->off_tier = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 2 + 2), 256);   // conditioning tier + hot-chunk count per utterance; [2B] scan kind of the forward, [2B+1] backward mismatch
     p->off_status = o; o = align_up(o + sizeof(unsigned) * 8, 256);              // status words (non-finite output flag)
-    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 3 + 1), 256);   // fix-up units completed / claimed per utterance; [2B]: a wait for the fix-up ran out; [2B+1 .. 3B]: groups of a tier-3 utterance that have their fp64 composite
+    p->off_fixcnt = o; o = align_up(o + sizeof(unsigned) * ((size_t)B * 5 + 1), 256);   // fix-up units completed / claimed per utterance; [2B]: a wait for the fix-up ran out; [2B+1 .. 3B]: groups of a tier-3 utterance that have their fp64 composite; [3B+1 .. 4B]: largest partial product of those composites; [4B+1 .. 5B]: 1 = that utterance's fp64 states come from the flat scan
     // two-level boundary scan (lpc_group_prepass_kernel + lpc_fwdq2_kernel): worth it from ~48 chunk maps on, and the
     // chunk kernels' prologue keeps rows of up to 24 state components in its prefetch rings
     p->NG = 0;
@@ -178,6 +178,16 @@ static float phi_guard() {
 static float phi_guard2() {
     static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD2"); return e ? (float)atof(e) : 16.f; }();
     return v;   // chunks of an utterance that has a chunk beyond G1 are hot from G2 on
+}
+static float group_log2_guard() {
+    // Sum over a group's 16 chunks of log2(max(|map entries|, 1)) beyond which the utterance is tier 3.  Until round 4 this
+    // was 120: a guard against fp32 overflow of the composites only.  tools/fuzz_tiers.py found what it has to guard as well:
+    // an utterance just under G3 (largest entry 203) whose maps stay large over a whole group came out of the two-level path
+    // at 5 % error where the sequential recursion has 0.26 % and the flat scan 0.9 % -- the products cancel from ~2^115 down,
+    // and neither an fp32 composite nor the fp64 chain behind it survives that.  104 sends it to tier 3 (error 2e-4) and moves
+    // 4 of the recipe's 2 048 utterances with it (tier 3: 2 -> 6; at 112: 2, at 96: 8, at 80: 21).
+    static const float v = [] { const char* e = getenv("GOLF_SS_GROUP_LOG2"); return e ? (float)atof(e) : 104.f; }();
+    return v;
 }
 static float phi_guard3() {
     static const float v = [] { const char* e = getenv("GOLF_SS_PHI_GUARD3"); return e ? (float)atof(e) : 256.f; }();
@@ -786,7 +796,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
     const int cl = lane / NG, grp = lane - cl * NG;
     const int q0 = (blk_id * P1F_WPB + wv) * CPW;
     if (fixcnt && blk_id == 0 && wv == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = lane; e < 3 * B + 1; e += 64) fixcnt[e] = 0u;
+        for (int e = lane; e < 5 * B + 1; e += 64) fixcnt[e] = 0u;
     if (q0 >= nq) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
     const int q = q0 + cl;
     const bool live = cl < CPW && q < nq;
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(256) void lpc_transpose_kernel(const float* __restr
     __shared__ float t[4][NT * (W + 1)];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (fixcnt && blockIdx.x == 0)   // counters of the fix-up that follows in the next launch (see fixup_wave)
-        for (int e = threadIdx.x; e < 3 * B + 1; e += 256) fixcnt[e] = 0u;
+        for (int e = threadIdx.x; e < 5 * B + 1; e += 256) fixcnt[e] = 0u;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
     const float* src = Phi + (size_t)q * NT * W;
@@ -1096,7 +1106,7 @@ __global__ __launch_bounds__(256) void lpc_p1h_kernel(const float* __restrict__ 
 struct UttTier { bool t2, t3; unsigned nhot; };
 
 __device__ __forceinline__ UttTier utterance_tier(const float* __restrict__ pm, int NP, int lane, float g1, float g2,
-                                                  float g3, int accurate) {
+                                                  float g3, int accurate, float glog) {
     unsigned umax = 0u;
     bool ovf = false;
     for (int c0 = 0; c0 < NP; c0 += 64) {
@@ -1108,7 +1118,7 @@ __device__ __forceinline__ UttTier utterance_tier(const float* __restrict__ pm, 
         float lg = __log2f(fmaxf(v, 1.f));
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
-        ovf = ovf || lg > 120.f;
+        ovf = ovf || lg > glog;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) umax = max(umax, (unsigned)__shfl_xor((int)umax, off));
@@ -1145,7 +1155,7 @@ struct FixArgs {
     unsigned* fixcnt;    // [b]: fix-up units completed, [B + b]: units claimed, [2 B]: a wait for the fix-up ran out (all zeroed by
                          // the transition kernel, i.e. once per set of maps: a handle reused for several forwards keeps reporting it)
     int F, M, hop, L, NP, B;
-    float g1, g2, g3;
+    float g1, g2, g3, glog;
     int accurate;
 };
 
@@ -1162,7 +1172,7 @@ __device__ __forceinline__ void fixup_wave(const FixArgs& fa, int b, bool writes
     const int row = lane >> 2, r = lane & 3;
     const int NP = fa.NP, M = fa.M, F = fa.F, hop = fa.hop, L = fa.L;
     const float* pm = fa.pmax + (size_t)b * NP;
-    const UttTier d = utterance_tier(pm, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
+    const UttTier d = utterance_tier(pm, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate, fa.glog);
     if (writes_tier && lane == 0) {
         fa.tier[2 * b] = d.t3 ? kTierPrecise : (d.t2 ? kTierHot : 0u);
         fa.tier[2 * b + 1] = d.nhot;
@@ -1821,8 +1831,8 @@ __device__ __forceinline__ double precise_scan_range(const double* __restrict__ 
 // M = Phi_{c1-1} ... Phi_{c0} of maps kept as doubles ([c][j][i]), one wave, written in the same [j][i] layout (so that the
 // fold over the groups is a precise_scan_range over the composites).
 template <int W, int NT>
-__device__ __forceinline__ void precise_group_composite(const double* __restrict__ P64b, int c0, int c1,
-                                                        double* __restrict__ M64, int lane) {
+__device__ __forceinline__ float precise_group_composite(const double* __restrict__ P64b, int c0, int c1,
+                                                         double* __restrict__ M64, int lane) {
     static_assert(NT <= 32 && W % 4 == 0, "two 16-wide tiles");
     constexpr int NTL = CompGeom<W, NT>::NTL;
     const int m = lane & 15, kq = lane >> 4;
@@ -1830,6 +1840,7 @@ __device__ __forceinline__ void precise_group_composite(const double* __restrict
     const int rq = 2 * kq;
     // one column tile after the other (the chain is walked NTL times): the refinement kernel these waves ride in must not
     // need more registers for this rare path than for its own work
+    double pmx = 0.0;   // largest |entry| of any partial product (NaN-propagating: fmax would drop one, the comparison keeps it out of "small")
 #pragma unroll 1
     for (int jt = 0; jt < NTL; ++jt) {
         f64x4 P[NTL];                                                 // P[kt][v] = P(row 16 kt + rho(kq + 4 v), column 16 jt + m)
@@ -1869,6 +1880,13 @@ __device__ __forceinline__ void precise_group_composite(const double* __restrict
                 for (int u = 0; u < D; ++u) {
                     if (cb + u < c1) {   // wave-uniform
                         comp_product<NT, NTL>(fr[u], P);
+#pragma unroll
+                        for (int kt = 0; kt < NTL; ++kt)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const double av = __builtin_fabs(P[kt][v]);
+                                pmx = (av <= pmx) ? pmx : av;   // a NaN entry becomes the maximum
+                            }
                         fetch(u, cb + u + D);
                     }
                 }
@@ -1882,6 +1900,13 @@ __device__ __forceinline__ void precise_group_composite(const double* __restrict
                 if (i < W && nn < NT) M64[(size_t)nn * W + i] = i < NT ? P[it][v] : 0.0;
             }
     }
+    float fm = (float)pmx;   // (overflows to inf beyond fp32: also "too large")
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(fm, off);
+        fm = (o <= fm) ? fm : o;
+    }
+    return fm;
 }
 
 // The adjoint of precise_scan_range: lam <- Phi_c^T lam + z_c over the n maps of a range, from the top map down (the split-half
@@ -1973,15 +1998,22 @@ __device__ __forceinline__ void precise_adj_group_job(const double* __restrict__
 }
 
 // One (utterance, group) job of a tier-3 utterance in the refinement launch's extra rows (see lpc_fwdq2_kernel).
+// Guard of the fp64 composites (found by tools/fuzz_tiers.py: an utterance whose 16-chunk products pass through entries of 1e10+
+// before cancelling came out at 19 x the sequential recursion's error through the fold, 3.5 x through the flat scan, which only
+// ever applies maps to states): when any partial product of any group exceeds kCompositeGuard, the wave that completes the
+// utterance runs the flat fp64 scan instead of the fold and marks the utterance (word B + b of `arrived`' = 1) for the final
+// pass -- and for the backward, whose adjoint then takes the flat scan too.
+constexpr float kCompositeGuard = 1.0e6f;
 template <int W, int NT>
 __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi64, const float* __restrict__ z,
                                                   double* __restrict__ M64, double* __restrict__ V64,
                                                   double* __restrict__ G64, unsigned* __restrict__ arrived, int b, int g,
-                                                  int NP, int NG, int lane) {
+                                                  int NP, int NG, int lane, int B, float* __restrict__ S1) {
     const double* P64b = Phi64 + (size_t)b * NP * NT * W;
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     double* m64 = M64 + ((size_t)b * NG + g) * NT * W;
-    precise_group_composite<W, NT>(P64b, c0, c1, m64, lane);
+    const float pmx = precise_group_composite<W, NT>(P64b, c0, c1, m64, lane);
+    if (lane == 0) atomicMax(arrived + B + b, pmx == pmx ? __float_as_uint(pmx) : 0x7fc00000u);   // non-negative floats order as their bits
     const double v = precise_scan_range<W, NT, float, float>(P64b + (size_t)c0 * NT * W, z + ((size_t)b * NP + c0) * W, W,
                                                               (float*)nullptr, 0, c1 - c0, lane, (const double*)nullptr);
     if (lane < 32) V64[((size_t)b * NG + g) * 32 + lane] = v;
@@ -1992,9 +2024,18 @@ __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi
     if (old + 1u != (unsigned)NG) return;   // wave-uniform
     // this wave completed the utterance: every composite and response is visible after the acquire
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (lane == 0) arrived[b] = 0u;         // ready for the next forward on this workspace (all NG arrivals are in)
-    precise_scan_range<W, NT, double, double>(M64 + (size_t)b * NG * NT * W, V64 + (size_t)b * NG * 32, 32,
-                                               G64 + (size_t)b * (NG + 1) * 32, 32, NG, lane, (const double*)nullptr);
+    const unsigned mxbits = __hip_atomic_load(arrived + B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool flat = !(__uint_as_float(mxbits) <= kCompositeGuard);   // wave-uniform; NaN -> flat
+    if (lane == 0) {   // ready for the next forward on this workspace (all NG arrivals are in)
+        arrived[b] = 0u;
+        arrived[B + b] = 0u;
+        arrived[2 * B + b] = flat ? 1u : 0u;
+    }
+    if (flat)
+        precise_fwd_scan<W, NT>(P64b, z + (size_t)b * NP * W, S1 + (size_t)b * (NP + 1) * 32, 32, NP, lane);
+    else
+        precise_scan_range<W, NT, double, double>(M64 + (size_t)b * NG * NT * W, V64 + (size_t)b * NG * 32, 32,
+                                                   G64 + (size_t)b * (NG + 1) * 32, 32, NG, lane, (const double*)nullptr);
 }
 
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
@@ -2150,7 +2191,7 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
         const int c = g * kGroup + (lane & 15);
         const float v = c < NP ? fabsf(fa.pmax[(size_t)b * NP + c]) : 0.f;
         if (__builtin_amdgcn_ballot_w64(!(v <= fa.g2)) != 0ull) {   // a chunk of this group may have been recomputed
-            const UttTier d = utterance_tier(fa.pmax + (size_t)b * NP, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate);
+            const UttTier d = utterance_tier(fa.pmax + (size_t)b * NP, NP, lane, fa.g1, fa.g2, fa.g3, fa.accurate, fa.glog);
             if (d.t3) {
                 // a tier-3 utterance needs none of this wave's products (its states come from the fp64 scan), but ALL its
                 // 199 x 22 map units recomputed as doubles -- 4.3 passes of the 64 fix-up waves an utterance owns.  The
@@ -2299,7 +2340,7 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
             for (int job = w; job < B * NG; job += nw) {
                 const int bp = job / NG;
                 if (tier3(tier, bp))   // wave-uniform
-                    precise_group_job<W, NT>(Phi64, x, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, threadIdx.x);
+                    precise_group_job<W, NT>(Phi64, x, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, threadIdx.x, B, S1);
             }
             return;
         }
@@ -2349,7 +2390,10 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
         for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
         wave_lds_fence();
     } else {
-        if (precise) {
+        if (precise && arrived[2 * B + b] != 0u) {   // tier 3, composites beyond the guard: S1 from the flat fp64 scan
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] = c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+        } else if (precise) {
             // tier 3: the group's start state from the fold of the fp64 composites (refinement launch), then the own chunk
             // maps as doubles with the zero-state responses -- the states the fp64 recursion over the whole utterance gives
             for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
@@ -2732,9 +2776,15 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
             const int w = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
             const int nw = ((int)gridDim.y - B) * (int)gridDim.x;
             for (int job = w; job < B * NG; job += nw) {
-                const int bp = job / NG;
-                if (tier3(tier, bp))   // wave-uniform
-                    precise_adj_group_job<W, NT>(Phi64, x, M64, W64, GA64, arrived, bp, job - bp * NG, NP, NC, NG, threadIdx.x);
+                const int bp = job / NG, gj = job - bp * NG;
+                if (!tier3(tier, bp)) continue;   // wave-uniform
+                if (arrived[2 * B + bp] != 0u) {   // the forward found this utterance's composites beyond the guard: flat adjoint scan
+                    if (gj == 0)
+                        precise_adj_scan<W, NT>(Phi64 + (size_t)bp * NP * NT * W, x + (size_t)bp * NC * W,
+                                                L1 + (size_t)bp * (NC + 1) * 32 + 32, 32, NP, threadIdx.x);
+                } else {
+                    precise_adj_group_job<W, NT>(Phi64, x, M64, W64, GA64, arrived, bp, gj, NP, NC, NG, threadIdx.x);
+                }
             }
             return;
         }
@@ -2774,7 +2824,10 @@ __global__ __launch_bounds__(64) void lpc_adjq2_kernel(const float* __restrict__
         wave_lds_fence();
         adjq_body<W, NT, 3, true>(gy, gy_stride, a, nullptr, out, 0, T, F, M, hop, L, NC, NP, xt, yt, b, g, lane, st, dl);
     } else {
-        if (precise) {
+        if (precise && arrived[2 * B + b] != 0u) {   // rows 0 .. NP of L1 hold L(-1) .. L(NP-1) from the flat fp64 scan; L(NP) = 0
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] = c0 + e / 32 <= NP ? l1b[(size_t)c0 * 32 + e] : 0.f;
+        } else if (precise) {
             // tier 3: st[k] = L(c0 + k - 1) from the fold of the transposed fp64 composites (refinement launch) and the group's
             // own maps as doubles with zadj; L(NP) = 0
             for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
@@ -3242,7 +3295,7 @@ static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, 
     fa.fixcnt = (unsigned*)(ws + p.off_fixcnt);
     fa.F = F; fa.M = M; fa.hop = hop; fa.L = p.L; fa.NP = p.NP;
     fa.B = 0;   // set by the caller
-    fa.g1 = phi_guard(); fa.g2 = phi_guard2(); fa.g3 = phi_guard3();
+    fa.g1 = phi_guard(); fa.g2 = phi_guard2(); fa.g3 = phi_guard3(); fa.glog = group_log2_guard();
     fa.accurate = accurate;
     static const bool nowait = [] { const char* e = getenv("GOLF_SS_FIXUP_NOWAIT"); return e && atoi(e) != 0; }();   // dev knob (A/B timing only: wrong for hot batches)
     if (nowait) fa.g3 = -12345.f;
