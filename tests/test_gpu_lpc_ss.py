@@ -1031,3 +1031,25 @@ def test_length_argument_equals_a_slice_of_the_excitation():
     for u, v in zip(res[0][1], res[1][1]):
         assert torch.equal(u, v)
     assert (res[1][1][0][:, n:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_sustained_large_maps_under_g3_take_tier3():
+    """Found by tools/fuzz_tiers.py (round 4): utterance 3 of this batch has no map entry beyond G3 = 256 (largest 203) but a
+    whole group of large maps; their products cancel from ~2^115 down, and the two-level path with fp32 composites returned it
+    at 5 % error (sequential fp32 recursion 0.26 %, flat scan 0.9 %).  The group criterion of tier 3 (sum of log2 of a group's
+    chunk maxima > 104) now sends it to the fp64 path: within the usual bound of the float64 oracle on both scan paths."""
+    B, F, M, hop, sigma, seed = 13, 75, 16, 240, 1.3, 791569511
+    ex, gain, a = harsh_case(B, F, M, hop, sigma, seed)
+    ref = oracle_rows(ex, gain, a, hop)
+    ok = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e12)
+    scale = np.abs(ref).max(1) + 1e-300
+    e_ser = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    good = ok & (e_ser < 0.05)
+    assert good[3]
+    for mode in (None, "flat-scan"):
+        y, st = run_status(ex, gain, a, hop, fast=True, mode=mode)
+        e = np.abs(y - ref).max(1) / scale
+        assert st["tier3_utterances"] >= 7, st          # 6 by their largest entry + utterance 3 by its group
+        assert e[3] <= 3 * e_ser[3] + 1e-4, (mode, e[3], e_ser[3])
+        assert np.all(e[good] <= 3 * e_ser[good] + 1e-4), (mode, e[good].max())
