@@ -125,9 +125,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    hdr_time = max(os.path.getmtime(d) for d in deps[len(srcs):])
     for s in srcs:
-        o = os.path.join(LIB_DIR, os.path.basename(s) + ".o")
+        o = os.path.join(LIB_DIR, os.path.basename(s) + (".flags.o" if os.environ.get("GOLF_HIPCC_FLAGS") else ".o"))
         objs.append(o)
+        # only the translation units that changed (lpc_ss.hip alone takes three minutes); GOLF_HIPCC_FLAGS builds are always whole
+        if (not force and not os.environ.get("GOLF_HIPCC_FLAGS") and os.path.exists(o)
+                and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_time)):
+            continue
         # -falign-loops=64: the transition kernel's unrolled loop is ~1 300 8-byte packed-FMA encodings; when an unrelated edit
         # moved its start to 4 mod 8 bytes the kernel went from 38.8 to 43.0 us with an otherwise identical instruction stream
         # (round 4, tools/ab2.sh ab_place2) -- aligned loop heads take the placement lottery out of every kernel

@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, off_bf4, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -49,6 +49,7 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
     g->off_bf = o;   o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused kernel
     g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused backward (transposed FIR)
+    g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and the forward's again, four K-steps per 16-byte word (osc_fused2)
     g->total = o;
 }
 
@@ -632,7 +633,8 @@ template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backw
 __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
-                                                              float* __restrict__ Bf, float* __restrict__ Bfr, int dmax) {
+                                                              float* __restrict__ Bf, float* __restrict__ Bfr, int dmax,
+                                                              float* __restrict__ Bf4 = nullptr) {
     constexpr int OSCT_THREADS = osct_threads(TO);
     __shared__ u64 wsum[OSCT_THREADS / 64];
     light_wave_priority();
@@ -644,9 +646,12 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
             const int q = 4 * kk + (lane >> 4) - (lane & 15);
             // forward: tap of branch ph at d = dmin + q; backward (transposed FIR, osc_fused_bwd_kernel): at d = dmax - q.
             // The forward leaves both behind: a backward handed the untouched workspace needs no totals launch of its own.
-            if (Bf) {
+            if (Bf || Bf4) {
                 const int d = dmin + q, k = half + 4 * d + ph;
-                Bf[e] = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
+                const float v = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
+                if (Bf) Bf[e] = v;
+                // osc_fused2 reads four K-steps of a lane as one 16-byte word: [(ph * KS/4 + kk/4) * 64 + lane][kk % 4]
+                if (Bf4) Bf4[(((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3)] = v;
             }
             if (Bfr) {
                 const int d = dmax - q, k = half + 4 * d + ph;
@@ -699,12 +704,20 @@ __device__ __forceinline__ int oscf_xaddr(int i) { return i + 4 * (i >> 4); }
 
 #ifdef OSCF_TIMING   // dev build (tools/osc_phases.py): s_memtime stamps of the workgroup's phases, thread 0 of every workgroup
 __device__ unsigned long long g_oscf_stamps[8 * 4096];
-#define OSCF_STAMP(i) do { if (threadIdx.x == 0) g_oscf_stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (s_memtime counters are per XCD and not synchronised: the XCC id rides in the top 4 bits of every stamp)
+#define OSCF_STAMP(i) do { if (threadIdx.x == 0) g_oscf_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) & 4095) + (i)] = (__builtin_amdgcn_s_memtime() & 0x0fffffffffffffffull) | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 60); } while (0)
+// ... and the workgroup's entry / exit on the 100 MHz real-time counter, which all XCDs share (s_memtime offsets differ per SE)
+__device__ unsigned long long g_oscf_rt[2 * 4096];
+#define OSCF_RT(i) do { if (threadIdx.x == 0) g_oscf_rt[2 * ((blockIdx.y * gridDim.x + blockIdx.x) & 4095) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int golf_debug_oscf_rt(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_oscf_rt), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_oscf_stamps), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
 }
 #else
 #define OSCF_STAMP(i) do { } while (0)
+#define OSCF_RT(i) do { } while (0)
 #endif
 // KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
 template <int EE, int KS>
@@ -970,6 +983,438 @@ __global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel
         orow.st((OSCF_TO % 256 == 0 || o < o0 + OSCF_TO) ? o : -1, acc0[r] + acc1[r] + ad[r]);
     }
     OSCF_STAMP(7);
+}
+
+// ---- round 5: the fused forward rebuilt (osc_fused2) ----------------------------------------------------------------
+// Same algorithm and the same exact phases as osc_fused_kernel above, reorganised around what round 4's stamps and counters
+// showed it to be bound by -- instruction count (981 VALU instructions per wave), a 5.4 k-cycle global-load prologue, one LDS
+// round trip per table gather, three barriers, and 75 KB of LDS per workgroup (two workgroups per CU, in lock step):
+//   * the tile's NP passes share one staging of the table rows and ONE signal buffer of TO/NP + halo coarse samples: at NP = 2
+//     and 384 threads a workgroup needs 52.6 KB and 3 fit a CU (768 workgroups of the B = 32 configuration = one round);
+//   * table rows arrive as 16-byte loads (6 - 8 per thread instead of 24 - 32 dword loads with a 64-bit address each) and are
+//     written as 16-byte pair stores; the phase samples are loaded first and converted / scanned while the rows are in flight;
+//   * ONE barrier publishes the row pairs, the wave totals of every pass, the tile's base phase and the in-wave prefixes at the
+//     halo and at the pass boundaries; then one barrier after each render and one before the next pass reuses the buffer;
+//   * the render issues the 4 gathers of a coarse sample (as two 8-byte reads each: ds_read_b64 is served 32 lanes per LDS cycle
+//     on 64 banks, ds_read2_b64 16 lanes on 32) before it consumes the first, and the next coarse sample's before it stores;
+//   * interior tiles (every sample exists) run a body without the existence masks; 64-bit phase steps are single
+//     v_lshl_add_u64; the control-frame position is one multiply + v_fract;
+//   * the signal tile is padded 2 words per 16 (ds_read_b32 is served 32 lanes per cycle on 32 banks: 18 li + lk is a
+//     permutation there, the old 20 li + lk was a 2-way conflict).
+#ifndef OSCF2_NTH
+#define OSCF2_NTH 512
+#endif
+#ifndef OSCF2_NP
+#define OSCF2_NP 1
+#endif
+#ifndef OSCF2_SPLIT_GATHER
+#define OSCF2_SPLIT_GATHER 1
+#endif
+#ifndef OSCF2_PERSIST
+#define OSCF2_PERSIST 0       // 1: a grid of resident workgroups, each walking a contiguous run of units with the next unit's HBM loads
+#endif                        //    in flight.  Measured (B = 4096): 2036 us against 2121 for the same code launched one workgroup per
+                              //    unit -- the round trip it hides is 4 % -- and against 1910 for the plain kernel, whose 80 VGPRs the
+                              //    loop's live ranges turn into 128 (+ 100 SGPR spills): not adopted
+#ifndef OSCF2_SKIP
+#define OSCF2_SKIP 0          // dev: timing proxies with parts of the kernel left out (wrong results): 1 MFMA chain, 2 render, 4 row staging, 8 gathers
+#endif
+#ifndef OSCF2_STAGES
+#define OSCF2_STAGES 2        // gathers of the next coarse sample in flight while the current one is blended and stored (1: not)
+#endif
+template <int KS, int NP>
+struct Oscf2Geom {
+    static constexpr int TO = 2048, HALO = 4 * KS, PASS = TO / NP, SPAN = PASS + HALO;
+    static constexpr int XS = (SPAN + 2 * ((SPAN + 15) >> 4) + 3) & ~3;      // padded polyphase row: i + 2 * (i >> 4)
+    static constexpr int SCRATCH = 512;                                      // bytes behind the row pairs: wave totals, bases
+};
+__device__ __forceinline__ int oscf2_xaddr(int i) { return i + 2 * (i >> 4); }
+
+// Toeplitz fragments of the taps as osc_tile_totals_kernel lays them out for 16-byte loads
+template <int KS>
+__device__ __forceinline__ void oscf2_load_frags(const float* __restrict__ Bf4, int lane, float (&bfrag)[4][KS]) {
+#pragma unroll
+    for (int phs = 0; phs < 4; ++phs)
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Bf4 + (((phs * (KS / 4) + q) * 64 + lane) << 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfrag[phs][4 * q + j] = v[j];
+        }
+}
+
+// blended control-frame rows r_first .. r_first + NR - 1 of one utterance -> (value, row difference) pairs in LDS
+template <int NR, int NTH>
+__device__ __forceinline__ void oscf2_stage_rows(const float* __restrict__ wrow, int Fw, const float* __restrict__ table, int n_tab,
+                                                 int L, int r_first, int nrw, float2* pairs, int LRP, int tid) {
+    const float* t0[NR];
+    float pw[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        int k = r_first + (e < nrw ? e : nrw - 1);
+        if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
+        const float idx = wrow[k] * (float)(n_tab - 1);
+        int i0 = __builtin_amdgcn_readfirstlane((int)idx);
+        i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+        pw[e] = idx - (float)i0;
+        t0[e] = table + (size_t)i0 * L;
+    }
+    for (int c4 = tid; 4 * c4 < L; c4 += NTH) {
+        f32x4_t va[NR], vb[NR], R[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            va[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + 4 * c4);
+            vb[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + L + 4 * c4);
+        }
+#pragma unroll
+        for (int e = 0; e < NR; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[e][q] = fmaf(vb[e][q], pw[e], va[e][q] * (1.0f - pw[e]));
+#pragma unroll
+        for (int rr = 0; rr + 1 < NR; ++rr) {
+            f32x4_t* dst = reinterpret_cast<f32x4_t*>(pairs + (size_t)rr * LRP + 4 * c4);
+            const f32x4_t lo = {R[rr][0], R[rr + 1][0] - R[rr][0], R[rr][1], R[rr + 1][1] - R[rr][1]};
+            const f32x4_t hi = {R[rr][2], R[rr + 1][2] - R[rr][2], R[rr][3], R[rr + 1][3] - R[rr][3]};
+            dst[0] = lo;
+            dst[1] = hi;
+            if (c4 == 0) pairs[(size_t)rr * LRP + L] = make_float2(lo[0], lo[1]);   // column L = column 0
+        }
+    }
+}
+
+// What a workgroup fetches from HBM for one unit = (utterance, tile): its threads' coarse phase samples of every pass (clamped at
+// the ends of the utterance), wave 0's share of the earlier tiles' totals, and the fused addend of the wave's output tile of
+// every pass.  A persistent workgroup issues these for its NEXT unit right after the current unit's first barrier, so that they
+// arrive during the render and the matrix phase: only the first unit of a workgroup pays the round trip.
+template <int KS, int NTH, int NP>
+struct Oscf2Pref {
+    static constexpr int CPT = (Oscf2Geom<KS, NP>::SPAN + NTH - 1) / NTH;
+    float pv[NP][CPT + 1];
+    float ad[NP][4];
+    u64 tacc;
+};
+template <int KS, int NTH, int NP>
+__device__ __forceinline__ void oscf2_prefetch(Oscf2Pref<KS, NTH, NP>& pf, const float* __restrict__ phase, int64_t phase_stride,
+                                               const u64* __restrict__ Ttot, int ntile, int Tp, int dmin,
+                                               const float* __restrict__ addend, int64_t addend_stride, int Tadd, int b, int tile) {
+    typedef Oscf2Geom<KS, NP> G;
+    constexpr int CPT = Oscf2Pref<KS, NTH, NP>::CPT, NW = NTH / 64, NT = G::PASS / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int o0 = tile * G::TO, j_lo = o0 + dmin;
+    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r <= CPT; ++r) {
+            const int j = j_lo + p * G::PASS + tid * CPT + r;
+            pf.pv[p][r] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
+        }
+    pf.tacc = 0;
+    if (wv == 0)
+        for (int i = lane; i < tile; i += 64) pf.tacc += Ttot[(size_t)b * ntile + i];
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int shift = NW > NT ? (p * (NW - NT)) % NW : 0;
+        const int tw0 = (wv - shift + NW) % NW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf.ad[p][r] = arow.ld(o0 + p * G::PASS + 256 * tw0 + 64 * lk + li + 16 * r);
+    }
+}
+
+template <int EE, int KS, int NTH, int NP, bool EDGE>
+__device__ __forceinline__ void oscf2_body(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
+    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem,
+    int b, int tile, Oscf2Pref<KS, NTH, NP>& pf, bool has_next, int b_next, int tile_next, bool first_unit) {
+    typedef Oscf2Geom<KS, NP> G;
+    constexpr int TO = G::TO, PASS = G::PASS, SPAN = G::SPAN, XS = G::XS;
+    constexpr int CPT = (SPAN + NTH - 1) / NTH, NW = NTH / 64, NT = PASS / 256;
+    static_assert(NTH % 64 == 0 && PASS % 256 == 0, "whole waves, whole 256-output wave tiles");
+    const int LRP = L + 2;                       // entries per pair row: L columns + the wrap-around copy of column 0, even
+    float* X = smem;
+    float2* pairs = reinterpret_cast<float2*>(smem + 4 * XS);
+    u64* scr = reinterpret_cast<u64*>(pairs + (size_t)(nrows - 1) * LRP);
+    u64* wtot = scr;                             // [NP][NW]
+    u64* passin = scr + NP * NW;                 // [NP]: in-wave prefix at index PASS of each pass
+    u64* base_p = passin + NP;                   // base phase of the tile start
+    u64* halo_p = base_p + 1;                    // prefix at index -dmin of pass 0
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int o0 = tile * TO;
+    const int j_lo = o0 + dmin;
+    if (first_unit) { OSCF_STAMP(0); OSCF_RT(0); }
+    // ---- 1. the unit's phase samples, tile totals and addend are in registers (oscf2_prefetch); table rows
+    const int i0t = tid * CPT;
+    float (&pv)[NP][CPT + 1] = pf.pv;
+    u64 tacc = pf.tacc;
+    const int m_first = max(j_lo, 0) * 4;        // first fine sample that exists in this tile
+    const int r_first = m_first / hop_t;         // its control frame; rows r_first .. r_first + nrows - 1 are staged
+    {
+        const int m_last = min(j_lo + TO + G::HALO - 1, Tp - 1) * 4 + 3;
+        const int nrw = min(nrows, m_last / hop_t - r_first + 2);   // rows this tile's samples really touch
+        // rows beyond nrw repeat row nrw - 1 (their pair rows hold zeros as differences and are never read by a sample that
+        // exists): every load below is unconditional, so all of a thread's 16-byte row loads are in flight together
+        if (OSCF2_SKIP & 4) {}
+        else if (nrows <= 2) oscf2_stage_rows<2, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+        else if (nrows == 3) oscf2_stage_rows<3, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+        else                 oscf2_stage_rows<4, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+    }
+    if (wv == 0) {
+        tacc = wave_incl_scan(tacc, lane);
+        if (lane == 63) *base_p = tacc;
+    }
+    if (first_unit) OSCF_STAMP(1);
+    const float inv_hop_t = 1.0f / (float)hop_t;
+    const int fw = 32 - lshift < 24 ? 32 - lshift : 24, fo = 32 - lshift - fw;
+    const float fscale = __uint_as_float((unsigned)(127 - fw) << 23);   // 2^-fw
+    const int row_bytes = LRP * 8;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const f32x2_t lds_cf2;   // (LDS byte offsets as integers: see the gathers)
+    const unsigned pbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)reinterpret_cast<const char*>(pairs);
+    const BufRow orow(out + (size_t)b * out_stride, Tout);
+    Oscf2Pref<KS, NTH, NP> nx;                    // the next unit's loads: issued after this unit's first barrier
+    u64 phb = 0;                                 // phase at index 0 of the pass (pass 0: known after the first barrier)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        // ---- 2. conversions and the in-wave scan of this pass (pass 0: while the table rows are in flight; later passes:
+        //         before the barrier that frees the signal buffer)
+        u64 av[CPT + 1];
+#pragma unroll
+        for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[p][r], 2);
+        const int jb = j_lo + p * PASS + i0t;
+        auto seg_of = [&](int r) -> u64 {
+            const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);
+            const u64 sg = ((av[r] + d) << 2) + (d << 1);             // 4 a + 6 d
+            if (!EDGE) return sg;
+            const int j = jb + r;
+            return (j >= 0 && j < Tp - 1) ? sg : 0;                   // segments 0 .. Tp-2 advance the phase
+        };
+        u64 excl;
+        {
+            u64 tsum = 0;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) tsum += seg_of(r);
+            const u64 incl = wave_incl_scan(tsum, lane);
+            excl = incl - tsum;
+            if (lane == 63) wtot[p * NW + wv] = incl;
+            // in-wave prefix at index PASS (the next pass starts there) and, in pass 0, at -dmin (the tile's first output)
+            if (p + 1 < NP) {
+                constexpr int TB = PASS / CPT, RB = PASS % CPT;
+                u64 r2 = excl;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) r2 += seg_of(r);
+                if (tid == TB) passin[p] = r2;
+            }
+            if (p == 0) {
+                const int th = (-dmin) / CPT, rh = (-dmin) % CPT;   // (uniform)
+                u64 r2 = excl;
+#pragma unroll
+                for (int r = 0; r + 1 < CPT; ++r) r2 += r < rh ? seg_of(r) : 0;
+                if (tid == th) *halo_p = r2;
+            }
+        }
+        __syncthreads();                         // pass 0: row pairs, bases; every pass: wave totals; later passes: buffer free
+        if (p == 0 && first_unit) OSCF_STAMP(2);
+        if (p == 0) phb = *base_p - *halo_p;
+        if (p == 0 && has_next)
+            oscf2_prefetch<KS, NTH, NP>(nx, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd, b_next, tile_next);
+        u64 ph = phb + excl;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ph += w < wv ? wtot[p * NW + w] : 0;
+        if (p + 1 < NP) {   // the next pass starts at this pass's index PASS
+            constexpr int WB = (PASS / CPT) / 64;
+            u64 nb = phb + passin[p];
+#pragma unroll
+            for (int w = 0; w < WB; ++w) nb += wtot[p * NW + w];
+            phb = nb;
+        }
+        // ---- 3. render the 4 fine samples of every owned coarse sample into the polyphase tile
+        if (i0t < SPAN && !(OSCF2_SKIP & 2)) {
+            // gathers of one coarse sample: (row pair address, column) -> (value, row difference) of columns c0 and c0 + 1
+            f32x2_t e0[2][4], e1[2][4];
+            unsigned hik[2][4];
+            float rf0[2];
+            u64 phn = ph;
+            auto issue = [&](int r) {
+                const int s = r & 1;
+                // (the second difference and the segment total are recomputed from an opaque copy of the increment: kept from the
+                //  scan they are 6 registers per coarse sample, which is what decides the waves per SIMD here)
+                u64 a = av[r];
+                asm volatile("" : "+v"(a));
+                const u64 d = osc_fix_d_pow2(a, av[r + 1], 2), t = a + d;
+                u64 sg = (t << 2) + (d << 1);
+                if (EDGE) {
+                    const int j = jb + r;
+                    sg = (j >= 0 && j < Tp - 1) ? sg : 0;
+                }
+                hik[s][0] = (unsigned)((phn + a) >> 32);
+                hik[s][1] = (unsigned)((phn + ((a << 1) + d)) >> 32);
+                hik[s][2] = (unsigned)((phn + ((t << 1) + t)) >> 32);
+                phn += sg;
+                hik[s][3] = (unsigned)(phn >> 32);
+                // control-frame position of the coarse sample's first fine sample: frames from r_first, integer + fraction
+                const float x = (float)(4 * (jb + r) - r_first * hop_t) * inv_hop_t;
+                const float xi = floorf(x);
+                rf0[s] = x - xi;
+                const unsigned rowaddr = pbase + (int)xi * row_bytes;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned c0 = hik[s][k] >> (32 - lshift);
+                    const unsigned q = rowaddr + c0 * 8;
+                    if (OSCF2_SKIP & 8) { e0[s][k] = (f32x2_t){__uint_as_float(q), 1.f}; e1[s][k] = (f32x2_t){__uint_as_float(q + 8), 2.f}; continue; }
+                    e0[s][k] = *(lds_cf2*)(uintptr_t)q;
+#if OSCF2_SPLIT_GATHER
+                    unsigned q1 = q;
+                    asm volatile("" : "+v"(q1));   // an opaque copy of the address: two ds_read_b64, not one ds_read2_b64
+                    e1[s][k] = *(lds_cf2*)(uintptr_t)(q1 + 8);
+#else
+                    e1[s][k] = *(lds_cf2*)(uintptr_t)(q + 8);
+#endif
+                }
+            };
+            if (OSCF2_STAGES == 2) issue(0);
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                const int s = r & 1;
+                const int i = i0t + r;
+                if (OSCF2_STAGES == 2) { if (r + 1 < CPT) issue(r + 1); } else issue(r);
+                const float p0 = pv[p][r], p1 = pv[p][r + 1];
+                float sck[4] = {1.f, 1.f, 1.f, 1.f};
+                if (EE) {
+                    const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;   // fine increment q0 + k dq (cycles per fine sample)
+                    const float s0 = __builtin_amdgcn_rsqf(q0);              // raw v_rsq_f32: q0 is a normal number
+                    const float ds = -0.5f * s0 * s0 * s0 * dq;              // d/dk rsqrt(q0 + k dq) at k = 0
+                    const bool lin = fabsf(p1 - p0) <= 0.002f * p0;          // second-order term below 1e-6: speech f0 always is
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sck[k] = fmaf((float)k, ds, s0);
+                    if (__builtin_amdgcn_ballot_w64(!lin) != 0) {
+                        // f0 jumps (voicing boundaries): exact, wave-uniform and behind an opaque statement so that the four
+                        // quarter-rate v_rsq_f32 are not issued in the common case
+                        asm volatile("; exact equal-energy factors" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
+                    }
+                }
+                if (EDGE) {
+                    const int j = jb + r;
+                    const bool v0 = j >= 0 && j <= Tp - 1, vk = j >= 0 && j < Tp - 1;   // the last coarse sample has only k = 0
+                    sck[0] = v0 ? sck[0] : 0.f;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) sck[k] = vk ? sck[k] : 0.f;
+                }
+                float* xp = X + oscf2_xaddr(i);
+                if (i < SPAN) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float rf = fmaf((float)k, inv_hop_t, rf0[s]);
+                        const float cf = (float)__builtin_amdgcn_ubfe(hik[s][k], (unsigned)fo, (unsigned)fw) * fscale;
+                        const float t0 = fmaf(rf, e0[s][k][1], e0[s][k][0]), t1 = fmaf(rf, e1[s][k][1], e1[s][k][0]);
+                        float v = fmaf(cf, t1 - t0, t0);
+                        if (EE || EDGE) v *= sck[k];
+                        if (EDGE) v = sck[k] == 0.f ? 0.f : v;   // (a row that is not staged may hold anything: 0 x NaN)
+                        xp[k * XS] = v;
+                    }
+                }
+            }
+        }
+        if (p == 0 && first_unit) OSCF_STAMP(3);
+        if (p == NP - 1 && NP > 1 && first_unit) OSCF_STAMP(6);
+        // this wave's 256-output tiles of the pass: tw = wv - shift (mod NW), tw + NW, ... < NT
+        const int shift = NW > NT ? (p * (NW - NT)) % NW : 0;
+        const int tw0 = (wv - shift + NW) % NW;
+        // the fused addend of the wave's outputs and the Toeplitz fragments of the taps: loads issued before the barrier,
+        // consumed after it.  D rows 4 lk + r, column li  ->  output o0 + p PASS + 256 tw + 16 (4 lk + r) + li
+        float bfrag[4][KS];
+        // (unconditional: behind `if (tw0 < NT)` the 48 fragment registers became values merged across the passes and
+        //  stayed allocated through the renders, 93 -> 140 VGPRs; a wave without a tile in this pass loads 12 words in vain)
+        oscf2_load_frags<KS>(Bf, lane, bfrag);
+        __syncthreads();
+        if (p == 0 && first_unit) OSCF_STAMP(4);
+        // ---- 4. polyphase FIR on the matrix pipe
+        for (int tw = tw0; tw < NT; tw += NW) {
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            // A[m = li][k' = 4 kk + lk]: window element 256 tw + 16 li + 4 kk + lk -> address 288 tw + 18 li + 4 kk + lk + 2 (kk >> 2)
+            const float* ap = X + 288 * tw + 18 * li + lk;
+#pragma unroll
+            for (int phs = 0; phs < 4; ++phs) {
+                float a[KS];
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + 2 * (kk >> 2)];
+#pragma unroll
+                for (int kk = 0; kk < KS; kk += 2) {
+                    if (OSCF2_SKIP & 1) { acc0[kk & 3] += a[kk] * bfrag[phs][kk]; acc1[kk & 3] += a[kk + 1] * bfrag[phs][kk + 1]; continue; }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], bfrag[phs][kk + 1], acc1, 0, 0, 0);
+                }
+            }
+            const int ob = o0 + p * PASS + 256 * tw + 64 * lk + li;
+            float ad[4];
+            if (tw == tw0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ad[r] = pf.ad[p][r];
+            } else {   // (fewer waves than wave tiles: the later tiles' addend is fetched here)
+                const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
+        }
+        if (p == 0 && first_unit) OSCF_STAMP(5);
+        if (p == NP - 1 && first_unit) OSCF_STAMP(7);
+    }
+    if (first_unit) OSCF_RT(1);
+    if (has_next) pf = nx;
+}
+
+#ifndef OSCF2_MIN_WAVES
+#define OSCF2_MIN_WAVES 4
+#endif
+template <int EE, int KS>
+__global__ __launch_bounds__(OSCF2_NTH, OSCF2_MIN_WAVES) void osc_fused2_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
+    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, int units) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    light_wave_priority();
+    typedef Oscf2Geom<KS, OSCF2_NP> G;
+    Oscf2Pref<KS, OSCF2_NTH, OSCF2_NP> pf;
+#if OSCF2_PERSIST
+    // persistent workgroups (measured, not adopted -- see OSCF2_PERSIST): workgroup w of the grid takes the contiguous units
+    // [w U / G, (w + 1) U / G) -- unit u = tile u % ntile of utterance u / ntile -- and keeps one unit's loads in flight ahead
+    const int u_begin = (int)((int64_t)blockIdx.x * units / gridDim.x), u_end = (int)((int64_t)(blockIdx.x + 1) * units / gridDim.x);
+    if (u_begin >= u_end) return;
+    oscf2_prefetch<KS, OSCF2_NTH, OSCF2_NP>(pf, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd,
+                                            u_begin / ntile, u_begin % ntile);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int b = u / ntile, tile = u - b * ntile;
+        const bool has_next = u + 1 < u_end;
+        const int bn = (u + 1) / ntile, tn = (u + 1) - bn * ntile;
+        const bool first = u == u_begin;
+#else
+    {   // one workgroup per unit: grid (ntile, B)
+        const int b = blockIdx.y, tile = blockIdx.x;
+        constexpr bool has_next = false, first = true;
+        constexpr int bn = 0, tn = 0;
+        oscf2_prefetch<KS, OSCF2_NTH, OSCF2_NP>(pf, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd, b, tile);
+#endif
+        const int j_lo = tile * G::TO + dmin;
+        // every coarse sample j_lo .. j_lo + TO + HALO (the last one as a segment's right end) exists and is not the last
+        const bool edge = j_lo < 0 || j_lo + G::TO + G::HALO > Tp - 1;
+        if (edge)
+            oscf2_body<EE, KS, OSCF2_NTH, OSCF2_NP, true>(phase, phase_stride, Ttot, ntile, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t,
+                                                         Bf, out, out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem,
+                                                         b, tile, pf, has_next, bn, tn, first);
+        else
+            oscf2_body<EE, KS, OSCF2_NTH, OSCF2_NP, false>(phase, phase_stride, Ttot, ntile, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t,
+                                                          Bf, out, out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem,
+                                                          b, tile, pf, has_next, bn, tn, first);
+    }
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
@@ -1715,6 +2160,59 @@ static bool osc_fused_fwd_plan(const OscGeom& g, int L, int os, int K, bool want
            f->ldsf <= 80 * 1024 + lds_pad;
 }
 
+// round 5's fused forward (osc_fused2_kernel): the same totals launch, tile count and tap fragments as osc_fused_kernel
+struct OscFused2 { int dmin, dmax, KS, nrows, ntile2, lshift; size_t lds; };
+static int oscf_old_env() {
+    static const int v = [] { const char* e = getenv("GOLF_OSCF_OLD"); return e ? atoi(e) : 0; }();  // A/B knob (dev)
+    return v;
+}
+static bool osc_fused2_plan(const OscGeom& g, const float* table, int L, int os, int K, bool want_pre, int Tout, OscFused2* f) {
+    if (!(os == 4 && g.P == 4 && (L & (L - 1)) == 0 && L >= 8 && !want_pre && !osc_unfused_env() && !oscf_old_env())) return false;
+    if ((uintptr_t)table & 15) return false;                    // table rows are fetched as 16-byte words
+    const int half = (K - 1) / 2;
+    f->dmin = -((half + os - 1) / os);
+    f->dmax = half / os;
+    const int nq = f->dmax - f->dmin + 1;                       // taps per polyphase branch
+    f->KS = nq + 15 <= 48 ? 12 : 16;                            // K-steps of the 16-window Toeplitz product
+    const int span = 2048 + 4 * f->KS;
+    const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
+    f->nrows = nint_touched + 1;
+    const int XS = f->KS == 12 ? Oscf2Geom<12, OSCF2_NP>::XS : Oscf2Geom<16, OSCF2_NP>::XS;
+    f->lds = sizeof(float) * 4 * (size_t)XS + 8 * (size_t)(f->nrows - 1) * (L + 2) + Oscf2Geom<12, OSCF2_NP>::SCRATCH;
+    f->ntile2 = (int)ceil_div(Tout, 2048);                      // <= g.ntile: fits the Ttot region of the workspace
+    f->lshift = 31 - __builtin_clz((unsigned)L);
+    return nq + 15 <= 64 && f->nrows <= OSCF_MAXROWS && -f->dmin < 64 && f->lds <= 120 * 1024;
+}
+
+// persistent grid of osc_fused2_kernel: as many workgroups as the device holds at once (occupancy by LDS and registers x CUs),
+// never more than there are units
+static int oscf2_grid(const void* kernel, size_t lds, int64_t units) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) cus = 256;
+        else cus = prop.multiProcessorCount;
+    }
+    static const int per_cu_env = [] { const char* e = getenv("GOLF_OSCF2_WG_PER_CU"); return e ? atoi(e) : 0; }();   // dev knob
+    int per_cu = per_cu_env;
+    if (per_cu <= 0) {
+        // by hand: the occupancy API of ROCm 7.2 answers 1 for a workgroup with more than 64 KB of dynamic LDS.  160 KB of LDS
+        // per CU in 1280-byte granules; 512 registers per lane and SIMD in granules of 8, at most 8 waves per SIMD
+        hipFuncAttributes at;
+        int regs = 128;
+        size_t stat = 0;
+        if (hipFuncGetAttributes(&at, kernel) == hipSuccess) { regs = at.numRegs > 0 ? at.numRegs : regs; stat = at.sharedSizeBytes; }
+        const int alloc = (regs + 7) / 8 * 8;
+        const int waves_simd = std::min(8, 512 / alloc), nw = OSCF2_NTH / 64;
+        const int by_lds = (int)(163840 / (((lds + stat + 1279) / 1280) * 1280));
+        per_cu = std::min(by_lds, waves_simd * 4 / nw);
+    }
+    if (per_cu < 1) per_cu = 1;
+    const int64_t g = (int64_t)per_cu * cus;
+    return (int)(units < g ? units : g);
+}
+
 extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                         const float* wsel, int Fw, int w_hop, const float* table, int n_tab, int L,
                                         int os, int equal_energy, const float* taps, int K, float* pre, float* out,
@@ -1736,6 +2234,36 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     u64* Cw = (u64*)((char*)ws + g.off_cw);
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
+    OscFused2 f2;
+    if (osc_fused2_plan(g, table, L, os, K, pre != nullptr, Tout, &f2)) {
+        float* Bfr = (float*)((char*)ws + g.off_bfr);
+        static_assert(OSCF_TO == 2048, "osc_fused2 shares the totals launch and the tile count of osc_fused");
+        float* Bf4 = (float*)((char*)ws + g.off_bf4);
+        hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
+                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, Bfr, f2.dmax, Bf4);
+        GOLF_LAUNCH_CHECK();
+#define GOLF_FUSED2(EE, KSV)                                                                                          \
+    do {                                                                                                              \
+        static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
+            (const void*)osc_fused2_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);          \
+        if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
+            return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
+                        hipGetErrorString(lds_attr));                                                                 \
+        const int64_t units = (int64_t)f2.ntile2 * B;                                                                \
+        if (units > 0x7fffffff) return fail(GOLF_EINVAL, "glottal_osc_fwd: too many tiles");                          \
+        const dim3 grid = OSCF2_PERSIST ? dim3(oscf2_grid((const void*)osc_fused2_kernel<EE, KSV>, f2.lds, units))   \
+                                        : dim3(f2.ntile2, B);                                                         \
+        hipLaunchKernelGGL((osc_fused2_kernel<EE, KSV>), grid, dim3(OSCF2_NTH), f2.lds, st, phase,                    \
+                           phase_stride, (const u64*)Ttot, f2.ntile2, wsel, Fw, table, n_tab, L, f2.lshift, Tp,       \
+                           g.hop_t, (const float*)Bf4, out, out_stride, Tout, f2.dmin, f2.nrows, addend, addend_stride, \
+                           Tadd, (int)units);                                                                         \
+    } while (0)
+        if (f2.KS == 12) { if (equal_energy) GOLF_FUSED2(1, 12); else GOLF_FUSED2(0, 12); }
+        else             { if (equal_energy) GOLF_FUSED2(1, 16); else GOLF_FUSED2(0, 16); }
+#undef GOLF_FUSED2
+        GOLF_LAUNCH_CHECK();
+        return GOLF_OK;
+    }
     OscFusedFwd ff;
     if (osc_fused_fwd_plan(g, L, os, K, pre != nullptr, Tout, &ff)) {
         {
@@ -1744,7 +2272,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
             float* Bf = (float*)((char*)ws + g.off_bf);
             float* Bfr = (float*)((char*)ws + g.off_bfr);
             hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2, taps, K, dmin, KS, Bf, Bfr, dmax);
+                               g.P, os, ntile2, taps, K, dmin, KS, Bf, Bfr, dmax, (float*)nullptr);
             GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED(EE, KSV)                                                                                           \
     do {                                                                                                              \
@@ -1836,11 +2364,15 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
             // (5.9 us of the B = 32 training step).  Otherwise -- a caller that does not say, a forward that took the
             // three-kernel path -- they are recomputed: the backward must not depend on which forward variant ran.
             OscFusedFwd ff;
-            const bool have_totals = ws_kept && OSCB_TO == OSCF_TO && osc_fused_fwd_plan(g, L, os, K, false, Tout, &ff) &&
-                                     ff.ntile2 == ntile2 && ff.KS == KS && ff.dmax == dmax;
+            OscFused2 f2;
+            const bool have_totals = ws_kept && OSCB_TO == OSCF_TO &&
+                                     ((osc_fused2_plan(g, table, L, os, K, false, Tout, &f2) && f2.ntile2 == ntile2 && f2.KS == KS &&
+                                       f2.dmax == dmax) ||
+                                      (osc_fused_fwd_plan(g, L, os, K, false, Tout, &ff) && ff.ntile2 == ntile2 && ff.KS == KS &&
+                                       ff.dmax == dmax));
             if (!have_totals) {
                 hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                                   g.P, os, ntile2, taps, K, dmin, KS, (float*)nullptr, Bf, dmax);
+                                   g.P, os, ntile2, taps, K, dmin, KS, (float*)nullptr, Bf, dmax, (float*)nullptr);
                 GOLF_LAUNCH_CHECK();
             }
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \

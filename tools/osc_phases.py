@@ -16,18 +16,30 @@ B = 32
 osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, lf_v2=True, points=2048).cuda()
 inps = [make_inputs(B=B, device="cuda", seed=2434 + i) for i in range(4)]
 run = lambda i: GF.glottal_osc(inps[i]["phase"], inps[i]["wsel"], osc.table, osc.decimater.taps, 1, inps[i]["w_hop"], 4, True, add=inps[i]["noise"])
-n = 24 * B
+n = int(os.environ.get('OSC_PHASES_WGS', 24 * B))   # workgroups that leave stamps (persistent grid: CUs x workgroups per CU)
+import os as _os
+print("library:", _os.environ.get("GOLF_HIP_LIBRARY"), "GOLF_OSCF_OLD =", _os.environ.get("GOLF_OSCF_OLD"))
 def dump(tag):
     torch.cuda.synchronize()
     buf = np.zeros(8 * n, dtype=np.uint64)
     rc = cdll.golf_debug_oscf_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), 8 * n)
     assert rc == 0, rc
-    st = buf.reshape(n, 8).astype(np.int64)
-    d = np.diff(st, axis=1)
-    tot = (st[:, 7] - st[:, 0])
-    print(tag, "per-phase mean ticks:", np.round(d.mean(0), 0), " total mean %.0f p90 %.0f" % (tot.mean(), np.percentile(tot, 90)),
-          " kernel span %.0f ticks; start spread (p10/p50/p90 of start - first start): %s" % (
-              (st[:, 7].max() - st[:, 0].min()), np.percentile(st[:, 0] - st[:, 0].min(), [10, 50, 90]).round(0)))
+    raw = buf.reshape(n, 8)
+    xcc = (raw[:, 0] >> np.uint64(60)).astype(np.int64)
+    st = (raw & np.uint64(0x0fffffffffffffff)).astype(np.int64)
+    rel = st - st[:, :1]
+    ok = [i for i in range(8) if (st[:, i] > 0).all()]
+    print(tag, "stamps relative to entry, mean ticks:", {i: int(rel[:, i].mean()) for i in ok},
+          " lifetime mean %.0f p90 %.0f" % (rel[:, 7].mean(), np.percentile(rel[:, 7], 90)))
+    if hasattr(cdll, "golf_debug_oscf_rt"):
+        rt = np.zeros(2 * n, dtype=np.uint64)
+        assert cdll.golf_debug_oscf_rt(rt.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), 2 * n) == 0
+        rt = rt.reshape(n, 2).astype(np.int64)
+        t0 = rt[:, 0].min()
+        pc = [0, 10, 25, 50, 75, 90, 100]
+        print("    real-time counter (10 ns ticks -> us): kernel first entry -> last exit %.2f us; entries p%s: %s; exits: %s; by XCC first entry: %s" % (
+            (rt[:, 1].max() - t0) / 100, pc, (np.percentile(rt[:, 0] - t0, pc) / 100).round(2), (np.percentile(rt[:, 1] - t0, pc) / 100).round(2),
+            {int(x): round(float((rt[xcc == x, 0].min() - t0) / 100), 2) for x in sorted(set(xcc.tolist()))}))
 for _ in range(3):
     run(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
