@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, off_bf4, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, off_bf4, off_t256, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -50,6 +50,7 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->off_bf = o;   o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused kernel
     g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused backward (transposed FIR)
     g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and the forward's again, four K-steps per 16-byte word (osc_fused2)
+    g->off_t256 = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * ((size_t)g->ntile * 4 + 8), 256);   // phase advance per 256-sample stretch (osc_fused3)
     g->total = o;
 }
 
@@ -586,55 +587,35 @@ __global__ void osc_wsel_reduce_kernel(const float* __restrict__ part, float* __
 // The three-kernel path above moves 105 MB for 12 MB of algorithmic traffic at B=32 (a 64-bit phase prefix per coarse
 // sample written and read back, the 4x oversampled signal on a round trip through HBM) and -- what the counters showed
 // to matter more -- spends 433 VALU lane-instructions per output sample at 75 % VALU-busy: it is instruction-issue
-// bound.  Here one workgroup of 8 waves owns OSCF_TO = 2048 output samples of one utterance:
-//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every tile of OSCF_TO coarse samples -> Ttot[b][tile]
-//   1. base phase of the tile = sum of the earlier tiles' totals (exact: Q0.64 integers, order cannot matter)
+// bound.  Here one workgroup owns a tile of 2048 (or 1536) output samples of one utterance:
+//   0. (separate, tiny) osc_tile_totals_kernel: phase advance of every 256-sample stretch and of every 2048-sample tile
+//   1. base phase of the tile = sum of the earlier stretches' totals (exact: Q0.64 integers, order cannot matter)
 //   2. the tile's coarse phase samples (+ the decimator's halo) are scanned in the block; a thread keeps the converted
 //      increments of its 5 consecutive coarse samples in registers for step 3
-//   3. render into LDS.  Table rows are staged as PAIRS (row_k[c], row_{k+1}[c] - row_k[c]): one ds_read2_b64 brings
+//   3. render into LDS.  Table rows are staged as PAIRS (row_k[c], row_{k+1}[c] - row_k[c]): two 8-byte reads bring
 //      what a bilinear lookup needs, and interpolating along the control frame first makes it 2 + 2 instructions;
 //      the equal-energy factor rsqrt(p) is linear over the 4 fine samples of a coarse sample to 1e-6 whenever p moves by
 //      less than 0.2 % per sample (speech f0; otherwise the exact v_rsq_f32 runs)
-//   4. the 129-tap polyphase FIR runs on the MATRIX pipe, which is idle otherwise: per polyphase branch the outputs of
-//      a 256-sample stretch are the product of 16 overlapping signal windows (A: 16 x 48) with a banded Toeplitz matrix
-//      of the branch's 33 taps (B: 48 x 16), accumulated over the 4 branches in exact fp32 (v_mfma_f32_16x16x4_f32,
-//      48 of them per wave).  The signal tile is laid out with 4 pad words per 16 so that the window fragments are read
-//      without bank conflicts.  132 VALU multiply-adds per output become 12 LDS reads.
-// About 125 VALU lane-instructions per output instead of 433.  Same exact phases as the three-kernel path; the values
-// agree to 1e-6 (tests/test_gpu_osc.py).
-#ifndef OSCF_TO               // (tile geometry as build parameters: occupancy experiments)
-#define OSCF_TO 2048
-#endif
-#ifndef OSCF_THREADS
-#define OSCF_THREADS 512
-#endif
-#ifndef OSCF_CPT
-#define OSCF_CPT 5            // coarse samples per thread: OSCF_THREADS * OSCF_CPT >= OSCF_TO + 4 * KS
-#endif
-#ifndef OSCF_SU
-#define OSCF_SU 4            // 4: the control-frame rows of a tile staged in ONE pass (24 loads in flight per thread, 128 VGPRs: still 4
-                             // waves per SIMD) instead of two: 28.7 -> 27.8 us at B = 32, 8.70 -> 8.45 ms at B = 16 384
-#endif
-#ifndef OSCF_ROWS
-#define OSCF_ROWS 0           // 1: the blended control-frame rows staged as plain rows (nrows x (L+1) floats) instead of
-#endif                        //    (value, difference) pairs: 24.6 instead of 32.8 KB at 3 rows, two more VALU + one more LDS
-                              //    instruction per lookup (occupancy experiments)
-#ifndef OSCF_MIN_WAVES
-#define OSCF_MIN_WAVES 1      // launch bound: waves per SIMD the register allocation must allow
-#endif
+//   4. the 129-tap polyphase FIR runs on the MATRIX pipe: per polyphase branch the outputs of a 256-sample stretch are the
+//      product of 16 overlapping signal windows (A: 16 x 48) with a banded Toeplitz matrix of the branch's 33 taps
+//      (B: 48 x 16), accumulated over the 4 branches in exact fp32 (v_mfma_f32_16x16x4_f32, 48 of them per wave).
+//      132 VALU multiply-adds per output become 12 LDS reads.
+// Same exact phases as the three-kernel path; the values agree to 1e-6 (tests/test_gpu_osc.py).  The kernel itself (round 5's
+// osc_fused2_kernel) follows the totals kernel below.
+#define OSCF_TO 2048          // tile of the totals launch (and of the fused backward, OSCB_TO)
 #define OSCF_MAXROWS 4
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// (block (0,0) also lays the decimation taps out as the MFMA B fragments of osc_fused_kernel:
-//  Bf[(ph*KS + kk)*64 + lane] = tap of branch ph at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
-// threads of the totals kernel: whole passes of the workgroup over a tile (2048 -> 512, 1920 -> 384)
+// (block (0,0) also lays the decimation taps out as the MFMA B fragments of the fused kernels: lane `lane` of K-step kk of
+//  branch ph holds the tap at d = dmin + (4*kk + lane/16 - lane%16), 0 outside the filter)
+// threads of the totals kernel: whole passes of the workgroup over a tile
 constexpr int osct_threads(int TO) { return TO % 512 == 0 ? 512 : (TO % 384 == 0 ? 384 : 256); }
 template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backward's OSCB_TO
 __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
                                                               float* __restrict__ Bf, float* __restrict__ Bfr, int dmax,
-                                                              float* __restrict__ Bf4 = nullptr) {
+                                                              float* __restrict__ Bf4 = nullptr, u64* __restrict__ T256 = nullptr) {
     constexpr int OSCT_THREADS = osct_threads(TO);
     __shared__ u64 wsum[OSCT_THREADS / 64];
     light_wave_priority();
@@ -669,18 +650,21 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
     // B = 16 384 where 512 threads x 4 consecutive samples already took 0.83 ms (tile-geometry experiment).
     constexpr int PER = TO / OSCT_THREADS;
     static_assert(TO % OSCT_THREADS == 0, "tile = whole passes of the workgroup");
-    const int j0 = tile * TO + tid;
+    // (round 5: a wave takes PER x 64 CONSECUTIVE samples -- lane + 64 r inside its stretch -- so that its total is the total
+    //  of one 256-sample stretch of the 2048-sample tile: osc_fused3's waves start from those)
+    constexpr int RS = 64;                                  // sample stride between a thread's loads
+    const int j0 = tile * TO + (tid >> 6) * (PER * 64) + (tid & 63);
     float p0[PER], p1[PER];
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
-        const int j = j0 + r * OSCT_THREADS;
+        const int j = j0 + r * RS;
         p0[r] = prow.ld(min(j, Tp - 1));
         p1[r] = prow.ld(min(j + 1, Tp - 1));
     }
     u64 tsum = 0;
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
-        if (j0 + r * OSCT_THREADS >= Tp - 1) continue;   // segments 0 .. Tp-2 advance the phase
+        if (j0 + r * RS >= Tp - 1) continue;   // segments 0 .. Tp-2 advance the phase
         if (os == 4 && P == 4) {   // (the only configuration osc_fused_kernel serves; the same conversions as there)
             const u64 a0 = osc_fix_a_pow2(p0[r], 2), a1 = osc_fix_a_pow2(p1[r], 2);
             tsum += (a0 << 2) + osc_fix_d_pow2(a0, a1, 2) * (u64)6;
@@ -689,7 +673,10 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
         }
     }
     const u64 incl = wave_incl_scan(tsum, tid & 63);
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    if ((tid & 63) == 63) {
+        wsum[tid >> 6] = incl;
+        if (T256 && PER * 64 == 256) T256[((size_t)b * ntile + tile) * (OSCT_THREADS / 64) + (tid >> 6)] = incl;
+    }
     __syncthreads();
     if (tid == 0) {
         u64 tot = 0;
@@ -719,328 +706,38 @@ extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
 #define OSCF_STAMP(i) do { } while (0)
 #define OSCF_RT(i) do { } while (0)
 #endif
-// KS = K-steps of 4 of the Toeplitz product: 16 + (taps per branch) - 1 <= 4 * KS
-template <int EE, int KS>
-__global__ __launch_bounds__(OSCF_THREADS, OSCF_MIN_WAVES) void osc_fused_kernel(
-    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
-    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout, int /*XS*/,
-    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
-    constexpr int OS = 4, P = 4, NTH = OSCF_THREADS, CPT = OSCF_CPT;
-    constexpr int span = OSCF_TO + 4 * KS;       // coarse samples rendered (index u <-> coarse sample j_lo + u)
-    constexpr int XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;   // padded polyphase row (the host sizes the LDS with the same)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ u64 wtot[NTH / 64];
-    __shared__ u64 base_sh, halo_sh;
-    light_wave_priority();
-    OSCF_STAMP(0);
-    // layout: X polyphase signal tile [4][XS] | row pairs [(nrows-1)][L+1] float2
-    float* X = smem;
-    float2* pairs = reinterpret_cast<float2*>(smem + OS * XS);
-    float* rowsL = smem + OS * XS;               // (OSCF_ROWS) the same region as plain rows [nrows][L+1]
-    const int LR = L + 1;
-    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int o0 = tile * OSCF_TO;
-    const int j_lo = o0 + dmin;                  // may be negative for the first tile
-    // ---- 0. Toeplitz fragments of the taps (laid out by osc_tile_totals_kernel), straight into registers: coalesced
-    //         loads issued now, consumed in step 4
-    float bfrag[OS][KS];   // (loaded after the scans, in flight during the render: 48 registers that need not be live through the
-                           //  staging and the scans -- 128 -> 111 VGPRs, pipelined headline 70.3 -> 68.1 us/step, tools/ab2.sh r12_ab)
-    // ---- 1. base phase: the tiles before this one (wave 0); the thread's own coarse phase samples; the row pairs
-    if (wv == 0) {
-        u64 acc = 0;
-        for (int i = lane; i < tile; i += 64) acc += Ttot[(size_t)b * ntile + i];
-        acc = wave_incl_scan(acc, lane);
-        if (lane == 63) base_sh = acc;
-    }
-    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
-    const int u0 = tid * CPT;
-    float pv[CPT + 1];
-#pragma unroll
-    for (int r = 0; r <= CPT; ++r) {
-        const int j = j_lo + u0 + r;
-        pv[r] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
-    }
-    const int m_first = max(j_lo, 0) * P;        // first fine sample that exists in this tile
-    const int r_first = m_first / hop_t;         // control frame of that sample; rows r_first .. r_first + nrows - 1
-    {   // blended control-frame rows r_first .. r_first + nrows - 1, every column ONCE (a thread keeps its columns' values
-        // of all rows in registers), written as pairs rr = (row rr, row rr+1 - row rr); column L = wrap-around copy of
-        // column 0.  (Round 2 staged pair by pair: every interior row blended twice, the one extra column costing a
-        // whole third pass of the workgroup, clamps on every load -- 30 % of the kernel's instructions.)
-        // rows this tile's samples really touch (the launch sizes the LDS for the worst alignment: nrows)
-        const int m_last = min(j_lo + span - 1, Tp - 1) * P + (P - 1);
-        const int nrw = min(nrows, m_last / hop_t - r_first + 2);
-        const float* t0[OSCF_MAXROWS];
-        float pw[OSCF_MAXROWS];
-        float wsv[OSCF_MAXROWS];                     // (all four weights in flight before the first readfirstlane waits for one)
-#pragma unroll
-        for (int e = 0; e < OSCF_MAXROWS; ++e) {
-            int k = r_first + (e < nrw ? e : nrw - 1);
-            if (k > Fw - 1) k = Fw - 1;
-            wsv[e] = wsel[(size_t)b * Fw + k];
-        }
-#pragma unroll
-        for (int e = 0; e < OSCF_MAXROWS; ++e) {
-            int k = r_first + (e < nrw ? e : nrw - 1);
-            if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
-            // (b, k) is the workgroup's: the row base and the weight are uniform -- say so (the loaded value sits in a VGPR), so
-            // that the row loads below take an SGPR base + one shared lane offset instead of a 64-bit address each
-            const float idx = wsv[e] * (float)(n_tab - 1);
-            int i0 = __builtin_amdgcn_readfirstlane((int)idx);
-            i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
-            pw[e] = idx - (float)i0;
-            t0[e] = table + (size_t)i0 * L;
-        }
-        constexpr int SU = OSCF_SU;   // columns per thread and pass of the row staging: L / (SU * threads) passes, each one round trip
-        for (int cb0 = 0; cb0 < L; cb0 += SU * NTH) {
-            float R[OSCF_MAXROWS][SU];
-#pragma unroll
-            for (int e = 0; e < OSCF_MAXROWS; ++e)
-                if (e < nrw) {                        // uniform
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int c = cb0 + u * NTH + tid;
-                        const int cc = c < L ? c : 0;
-                        const float va = t0[e][cc], vb = t0[e][L + cc];
-                        R[e][u] = fmaf(vb, pw[e], va * (1.0f - pw[e]));
-                    }
-                }
-#if OSCF_ROWS
-#pragma unroll
-            for (int rr = 0; rr < OSCF_MAXROWS; ++rr)
-                if (rr < nrw) {
-                    float* dst = rowsL + (size_t)rr * LR;
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int c = cb0 + u * NTH + tid;
-                        if (c < L) dst[c] = R[rr][u];
-                        if (c == 0) dst[L] = R[rr][u];
-                    }
-                }
-#else
-#pragma unroll
-            for (int rr = 0; rr + 1 < OSCF_MAXROWS; ++rr)
-                if (rr + 1 < nrw) {
-                    float2* dst = pairs + (size_t)rr * LR;
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int c = cb0 + u * NTH + tid;
-                        const float2 pr = make_float2(R[rr][u], R[rr + 1][u] - R[rr][u]);
-                        if (c < L) dst[c] = pr;
-                        if (c == 0) dst[L] = pr;
-                    }
-                }
-#endif
-        }
-    }
-    OSCF_STAMP(1);
-    // ---- 2. in-block scan of the segment totals: thread owns coarse samples u0 .. u0 + CPT - 1
-    // (only the converted increments av[] stay in registers through the render: the second differences d and the segment
-    //  totals 4 a + 6 d are a shift and two adds away and are recomputed where they are used -- 20 VGPRs that round 4 found
-    //  to matter more than the ~15 integer instructions per coarse sample: the oscillator's register footprint is what the
-    //  other batches' waves have to fit beside)
-    u64 av[CPT + 1];
-    u64 tsum = 0;
-#pragma unroll
-    for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[r], 2);   // OS = 4
-    auto seg_total = [&](int r) -> u64 {
-        const int j = j_lo + u0 + r;
-        const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);       // P = 4
-        const bool seg = u0 + r < span && j >= 0 && j < Tp - 1;   // segments 0 .. Tp-2 advance the phase
-        return seg ? (av[r] << 2) + d * (u64)6 : 0;
-    };
-#pragma unroll
-    for (int r = 0; r < CPT; ++r) tsum += seg_total(r);
-    const u64 incl = wave_incl_scan(tsum, lane);
-    if (lane == 63) wtot[wv] = incl;
-    __syncthreads();                             // also: row pairs and base_sh are in place
-    OSCF_STAMP(2);
-    u64 run = incl - tsum;                       // exclusive prefix relative to coarse sample j_lo
-    for (int w = 0; w < wv; ++w) run += wtot[w];
-    {   // base_sh counts the advance of all coarse samples before o0 = the tile start; the halo in front of it
-        // (j_lo .. o0-1) belongs to the previous tile's total: phase at local u = base_sh - prefix(-dmin) + prefix(u)
-        u64 r2 = run;
-#pragma unroll
-        for (int r = 0; r < CPT; ++r) {
-            if (u0 + r == -dmin) halo_sh = r2;
-            r2 += seg_total(r);
-        }
-    }
-    __syncthreads();
-    OSCF_STAMP(3);
-#pragma unroll
-    for (int ph = 0; ph < OS; ++ph)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
-    // ---- 3. render the 4 fine samples of every owned coarse sample (they lie in ONE control interval: hop_t is a
-    //         multiple of 4) into the polyphase tile
-    const float inv_hop_t = 1.0f / (float)hop_t;
-    // nrows - 1 control intervals are staged (pairs 0 .. nrows - 2)
-    const int bnd1 = nrows > 2 ? (r_first + 1) * hop_t : 0x7fffffff, bnd2 = nrows > 3 ? (r_first + 2) * hop_t : 0x7fffffff;
-    u64 ph = base_sh - halo_sh + run;
-    // fraction of the table step: the (at most 24) bits of the phase below the column index, as one bit-field extract
-    const int fw = 32 - lshift < 24 ? 32 - lshift : 24, fo = 32 - lshift - fw;
-    const float fscale = __uint_as_float((unsigned)(127 - fw) << 23);   // 2^-fw
-#pragma unroll
-    for (int r = 0; r < CPT; ++r) {
-        const int u = u0 + r;
-        const u64 dvr = osc_fix_d_pow2(av[r], av[r + 1], 2);
-        const u64 ph_next = ph + seg_total(r);
-        if (u < span) {
-            const int j = j_lo + u;
-            const float p0 = pv[r], p1 = pv[r + 1];
-            // inclusive phases of the 4 fine samples: ph + (k+1) a + d k(k+1)/2; the last one is the next coarse sample's
-            // start (tv = 4 a + 6 d wherever that fine sample exists) -- four independent 64-bit adds instead of a chain of 8
-            const u64 c2 = (av[r] << 1) + dvr, c3 = c2 + av[r] + (dvr << 1);
-            const unsigned hik[P] = {(unsigned)((ph + av[r]) >> 32), (unsigned)((ph + c2) >> 32),
-                                     (unsigned)((ph + c3) >> 32), (unsigned)(ph_next >> 32)};
-            const int m0 = j * P;
-            const int rr = (m0 >= bnd1) + (m0 >= bnd2);
-            const float2* ra = pairs + (size_t)rr * LR;
-            const float* rwa = rowsL + (size_t)rr * LR;
-            (void)ra; (void)rwa;
-            float rf = (float)(m0 - (r_first + rr) * hop_t) * inv_hop_t;
-            const bool v0 = j >= 0 && j <= Tp - 1;     // fine sample k = 0 exists
-            const bool vk = j >= 0 && j < Tp - 1;      // k = 1..3 exist (the last coarse sample has only k = 0)
-            float s0 = 1.0f, ds = 0.f;
-            bool lin = true;
-            const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;   // fine increment q0 + k*dq (cycles per fine sample)
-            if (EE) {
-                s0 = __builtin_amdgcn_rsqf(q0);        // raw v_rsq_f32: q0 is a normal number, rsqrtf() returns the same
-                ds = -0.5f * s0 * s0 * s0 * dq;        // d/dk rsqrt(q0 + k dq) at k = 0
-                lin = fabsf(p1 - p0) <= 0.002f * p0;   // second-order term below 1e-6 (3 steps): speech f0 always is
-            }
-            const bool any_jump = EE && __builtin_amdgcn_ballot_w64(!lin) != 0;
-            float sck[P];
-#pragma unroll
-            for (int k = 0; k < P; ++k) sck[k] = fmaf((float)k, ds, s0);
-            if (any_jump) {
-                // f0 jumps (voicing boundaries): exact.  Wave-uniform and behind an opaque statement, so that the four
-                // quarter-rate v_rsq_f32 are not issued at all in the common case (hipcc if-converted the plain branch: it
-                // evaluated both forms for every sample)
-                asm volatile("; exact equal-energy factors" ::: "memory");
-#pragma unroll
-                for (int k = 0; k < P; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
-            }
-            float* xp = X + oscf_xaddr(u);
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const unsigned hi = hik[k];
-                const int c0 = (int)(hi >> (32 - lshift));
-                const float cf = (float)__builtin_amdgcn_ubfe(hi, (unsigned)fo, (unsigned)fw) * fscale;
-#if OSCF_ROWS
-                const float a0 = rwa[c0], a1 = rwa[c0 + 1], b0 = rwa[LR + c0], b1 = rwa[LR + c0 + 1];
-                const float t0 = fmaf(rf, b0 - a0, a0), t1 = fmaf(rf, b1 - a1, a1);
-#else
-                const float2 e0 = ra[c0], e1 = ra[c0 + 1];
-                const float t0 = fmaf(rf, e0.y, e0.x), t1 = fmaf(rf, e1.y, e1.x);
-#endif
-                float v = fmaf(cf, t1 - t0, t0);
-                if (EE) v *= sck[k];
-                xp[k * XS] = (k == 0 ? v0 : vk) ? v : 0.f;
-                rf += inv_hop_t;
-            }
-        }
-        ph = ph_next;
-    }
-    // the fused addend of this wave's outputs: loads issued before the barrier, consumed after the MFMA chain
-    // D rows 4*lk + r, column li  ->  output o0 + 256*wv + 16*(4*lk + r) + li
-    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
-    const int ob = o0 + 256 * wv + 64 * lk + li;
-    float ad[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
-    OSCF_STAMP(4);
-    __syncthreads();
-    OSCF_STAMP(5);
-    // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256*wv .. +255 as a 16 x 16 tile
-    //         D[m][n] (output 256*wv + 16*m + n) = sum_ph sum_k' X_ph[256*wv + 16*m + k'] * B_ph[k'][n]
-    if (256 * wv >= OSCF_TO) return;   // (tiles shorter than 8 x 256 outputs: build-parameter experiments)
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    {
-        // A[m = li][k' = 4*kk + lk]: element 256*wv + 16*li + 4*kk + lk  ->  address + 4 * (16*wv + li + (kk >> 2))
-        const float* ap = X + 320 * wv + 20 * li + lk;
-#pragma unroll
-        for (int phs = 0; phs < OS; ++phs) {
-            float a[KS];
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + 4 * (kk >> 2)];
-#pragma unroll
-            for (int kk = 0; kk < KS; kk += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], bfrag[phs][kk + 1], acc1, 0, 0, 0);
-            }
-        }
-    }
-    OSCF_STAMP(6);
-    const BufRow orow(out + (size_t)b * out_stride, Tout);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        // (a tile that is not a whole number of 256-output wave tiles, e.g. 1920: the last wave's rows beyond it belong to the
-        //  next workgroup and were not rendered here -- out-of-range offset = dropped by the buffer descriptor)
-        const int o = ob + 16 * r;
-        orow.st((OSCF_TO % 256 == 0 || o < o0 + OSCF_TO) ? o : -1, acc0[r] + acc1[r] + ad[r]);
-    }
-    OSCF_STAMP(7);
-}
-
 // ---- round 5: the fused forward rebuilt (osc_fused2) ----------------------------------------------------------------
-// Same algorithm and the same exact phases as osc_fused_kernel above, reorganised around what round 4's stamps and counters
-// showed it to be bound by -- instruction count (981 VALU instructions per wave), a 5.4 k-cycle global-load prologue, one LDS
-// round trip per table gather, three barriers, and 75 KB of LDS per workgroup (two workgroups per CU, in lock step):
-//   * the tile's NP passes share one staging of the table rows and ONE signal buffer of TO/NP + halo coarse samples: at NP = 2
-//     and 384 threads a workgroup needs 52.6 KB and 3 fit a CU (768 workgroups of the B = 32 configuration = one round);
-//   * table rows arrive as 16-byte loads (6 - 8 per thread instead of 24 - 32 dword loads with a 64-bit address each) and are
-//     written as 16-byte pair stores; the phase samples are loaded first and converted / scanned while the rows are in flight;
-//   * ONE barrier publishes the row pairs, the wave totals of every pass, the tile's base phase and the in-wave prefixes at the
-//     halo and at the pass boundaries; then one barrier after each render and one before the next pass reuses the buffer;
+// Same algorithm and the same exact phases as the round 2 - 4 kernel (osc_fused_kernel, gone), reorganised around what stamps,
+// counters and timing proxies showed it to be bound by:
+//   * table rows arrive as 16-byte loads (6 - 8 per thread instead of 24 - 32 dword loads with a 64-bit address each), all in
+//     flight together, and are written as 16-byte pair stores; the phase samples, the tile's base phase and the fused addend are
+//     fetched first, and the phases are converted and scanned while the rows are in flight;
+//   * ONE barrier publishes the row pairs, the wave totals, the tile's base phase, the in-wave prefix at the halo and the
+//     Toeplitz fragments of the taps; one more stands between the render and the matrix phase;
 //   * the render issues the 4 gathers of a coarse sample (as two 8-byte reads each: ds_read_b64 is served 32 lanes per LDS cycle
 //     on 64 banks, ds_read2_b64 16 lanes on 32) before it consumes the first, and the next coarse sample's before it stores;
 //   * interior tiles (every sample exists) run a body without the existence masks; 64-bit phase steps are single
-//     v_lshl_add_u64; the control-frame position is one multiply + v_fract;
-//   * the signal tile is padded 2 words per 16 (ds_read_b32 is served 32 lanes per cycle on 32 banks: 18 li + lk is a
-//     permutation there, the old 20 li + lk was a 2-way conflict).
-#ifndef OSCF2_NTH
-#define OSCF2_NTH 512
-#endif
-#ifndef OSCF2_NP
-#define OSCF2_NP 1
-#endif
-#ifndef OSCF2_SPLIT_GATHER
-#define OSCF2_SPLIT_GATHER 1
-#endif
-#ifndef OSCF2_PERSIST
-#define OSCF2_PERSIST 0       // 1: a grid of resident workgroups, each walking a contiguous run of units with the next unit's HBM loads
-#endif                        //    in flight.  Measured (B = 4096): 2036 us against 2121 for the same code launched one workgroup per
-                              //    unit -- the round trip it hides is 4 % -- and against 1910 for the plain kernel, whose 80 VGPRs the
-                              //    loop's live ranges turn into 128 (+ 100 SGPR spills): not adopted
-#ifndef OSCF2_SKIP
-#define OSCF2_SKIP 0          // dev: timing proxies with parts of the kernel left out (wrong results): 1 MFMA chain, 2 render, 4 row staging, 8 gathers
-#endif
+//     v_lshl_add_u64; the control-frame position is one multiply + floor;
+//   * the Toeplitz fragments reach the waves through LDS (12 KB staged once per workgroup, 12 ds_read_b128 per wave): as global
+//     loads they were 96 KB per workgroup through the vector cache -- three times the workgroup's own HBM traffic;
+//   * the signal tile is padded 1 word per 16 (17 li + lk leaves one 2-way conflict per 32 lanes of a ds_read_b32; the old
+//     20 li + lk was 2-way throughout), which is what lets tile + row pairs + fragments stay within half a CU's LDS;
+// Measured and not adopted: two half-tile passes per table staging with 3 workgroups per CU; persistent
+// workgroups with the next unit's loads in flight; a wave-autonomous variant (one wave = one 256-output stretch end to end,
+// no barrier after the staging); 1536-output tiles.  What they have in common: a workgroup's lifetime is a latency chain of
+// ~16 k cycles whatever the tile, and the outputs in flight per CU are bounded by LDS (17 B of signal tile per output + 33 - 49 KB
+// of table rows per workgroup), so every variant lands on the same ~0.25 outputs per cycle and CU.
 #ifndef OSCF2_STAGES
 #define OSCF2_STAGES 2        // gathers of the next coarse sample in flight while the current one is blended and stored (1: not)
 #endif
-template <int KS, int NP>
+template <int KS, int TO>
 struct Oscf2Geom {
-    static constexpr int TO = 2048, HALO = 4 * KS, PASS = TO / NP, SPAN = PASS + HALO;
-    static constexpr int XS = (SPAN + 2 * ((SPAN + 15) >> 4) + 3) & ~3;      // padded polyphase row: i + 2 * (i >> 4)
-    static constexpr int SCRATCH = 512;                                      // bytes behind the row pairs: wave totals, bases
+    static constexpr int HALO = 4 * KS, SPAN = TO + HALO;
+    static constexpr int XS = (SPAN + ((SPAN + 15) >> 4) + 3) & ~3;          // padded polyphase row: i + (i >> 4)
+    static constexpr int FRAG = 4 * KS * 64;                                 // floats: Toeplitz fragments behind the row pairs
+    static constexpr int SCRATCH = 256;                                      // bytes behind those: wave totals, bases
 };
-__device__ __forceinline__ int oscf2_xaddr(int i) { return i + 2 * (i >> 4); }
-
-// Toeplitz fragments of the taps as osc_tile_totals_kernel lays them out for 16-byte loads
-template <int KS>
-__device__ __forceinline__ void oscf2_load_frags(const float* __restrict__ Bf4, int lane, float (&bfrag)[4][KS]) {
-#pragma unroll
-    for (int phs = 0; phs < 4; ++phs)
-#pragma unroll
-        for (int q = 0; q < KS / 4; ++q) {
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Bf4 + (((phs * (KS / 4) + q) * 64 + lane) << 2));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfrag[phs][4 * q + j] = v[j];
-        }
-}
+__device__ __forceinline__ int oscf2_xaddr(int i) { return i + (i >> 4); }
 
 // blended control-frame rows r_first .. r_first + NR - 1 of one utterance -> (value, row difference) pairs in LDS
 template <int NR, int NTH>
@@ -1081,93 +778,110 @@ __device__ __forceinline__ void oscf2_stage_rows(const float* __restrict__ wrow,
     }
 }
 
-// What a workgroup fetches from HBM for one unit = (utterance, tile): its threads' coarse phase samples of every pass (clamped at
-// the ends of the utterance), wave 0's share of the earlier tiles' totals, and the fused addend of the wave's output tile of
-// every pass.  A persistent workgroup issues these for its NEXT unit right after the current unit's first barrier, so that they
-// arrive during the render and the matrix phase: only the first unit of a workgroup pays the round trip.
-template <int KS, int NTH, int NP>
-struct Oscf2Pref {
-    static constexpr int CPT = (Oscf2Geom<KS, NP>::SPAN + NTH - 1) / NTH;
-    float pv[NP][CPT + 1];
-    float ad[NP][4];
-    u64 tacc;
-};
-template <int KS, int NTH, int NP>
-__device__ __forceinline__ void oscf2_prefetch(Oscf2Pref<KS, NTH, NP>& pf, const float* __restrict__ phase, int64_t phase_stride,
-                                               const u64* __restrict__ Ttot, int ntile, int Tp, int dmin,
-                                               const float* __restrict__ addend, int64_t addend_stride, int Tadd, int b, int tile) {
-    typedef Oscf2Geom<KS, NP> G;
-    constexpr int CPT = Oscf2Pref<KS, NTH, NP>::CPT, NW = NTH / 64, NT = G::PASS / 256;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lk = lane >> 4;
-    const int o0 = tile * G::TO, j_lo = o0 + dmin;
-    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int r = 0; r <= CPT; ++r) {
-            const int j = j_lo + p * G::PASS + tid * CPT + r;
-            pf.pv[p][r] = prow.ld(j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j));
-        }
-    pf.tacc = 0;
-    if (wv == 0)
-        for (int i = lane; i < tile; i += 64) pf.tacc += Ttot[(size_t)b * ntile + i];
-    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int shift = NW > NT ? (p * (NW - NT)) % NW : 0;
-        const int tw0 = (wv - shift + NW) % NW;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pf.ad[p][r] = arow.ld(o0 + p * G::PASS + 256 * tw0 + 64 * lk + li + 16 * r);
-    }
-}
-
-template <int EE, int KS, int NTH, int NP, bool EDGE>
+template <int EE, int KS, int TO, int NTH, bool EDGE>
 __device__ __forceinline__ void oscf2_body(
-    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ T256, int nt256,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout,
-    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem,
-    int b, int tile, Oscf2Pref<KS, NTH, NP>& pf, bool has_next, int b_next, int tile_next, bool first_unit) {
-    typedef Oscf2Geom<KS, NP> G;
-    constexpr int TO = G::TO, PASS = G::PASS, SPAN = G::SPAN, XS = G::XS;
-    constexpr int CPT = (SPAN + NTH - 1) / NTH, NW = NTH / 64, NT = PASS / 256;
-    static_assert(NTH % 64 == 0 && PASS % 256 == 0, "whole waves, whole 256-output wave tiles");
+    int hop_t, const float* __restrict__ Bf4, float* __restrict__ out, int64_t out_stride, int Tout,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem) {
+    typedef Oscf2Geom<KS, TO> G;
+    constexpr int SPAN = G::SPAN, XS = G::XS;
+    constexpr int CPT = (SPAN + NTH - 1) / NTH, NW = NTH / 64, NT = TO / 256;
+    static_assert(NTH % 64 == 0 && TO % 256 == 0 && NT <= NW, "whole waves; one 256-output wave tile per wave at most");
     const int LRP = L + 2;                       // entries per pair row: L columns + the wrap-around copy of column 0, even
     float* X = smem;
     float2* pairs = reinterpret_cast<float2*>(smem + 4 * XS);
-    u64* scr = reinterpret_cast<u64*>(pairs + (size_t)(nrows - 1) * LRP);
-    u64* wtot = scr;                             // [NP][NW]
-    u64* passin = scr + NP * NW;                 // [NP]: in-wave prefix at index PASS of each pass
-    u64* base_p = passin + NP;                   // base phase of the tile start
-    u64* halo_p = base_p + 1;                    // prefix at index -dmin of pass 0
-    const int tid = threadIdx.x, lane = tid & 63;
+    float* frag = reinterpret_cast<float*>(pairs + (size_t)(nrows - 1) * LRP);
+    u64* scr = reinterpret_cast<u64*>(frag + G::FRAG);
+    u64* wtot = scr;                             // [NW]
+    u64* base_p = scr + NW;                      // base phase of the tile start
+    u64* halo_p = base_p + 1;                    // prefix at index -dmin
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int o0 = tile * TO;
     const int j_lo = o0 + dmin;
-    if (first_unit) { OSCF_STAMP(0); OSCF_RT(0); }
-    // ---- 1. the unit's phase samples, tile totals and addend are in registers (oscf2_prefetch); table rows
+    OSCF_STAMP(0);
+    OSCF_RT(0);
+    // ---- 1. loads: coarse phase samples (clamped at the ends of the utterance), the stretch totals in front of the tile, the
+    //         fused addend of the wave's outputs, the tap fragments, the table rows
+    const BufRow prow(phase + (size_t)b * phase_stride, Tp);
     const int i0t = tid * CPT;
-    float (&pv)[NP][CPT + 1] = pf.pv;
-    u64 tacc = pf.tacc;
+    float pv[CPT + 1];
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) {
+        const int j = j_lo + i0t + r;
+        pv[r] = prow.ld(EDGE ? (j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j)) : j);
+    }
+    u64 tacc = 0;
+    if (wv == 0)                                 // (osc_tile_totals_kernel: one total per 256-sample stretch)
+        for (int i = lane; i < tile * NT; i += 64) tacc += T256[(size_t)b * nt256 + i];
+    // D rows 4 lk + r, column li of wave tile wv  ->  output o0 + 256 wv + 16 (4 lk + r) + li
+    const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
+    const int ob = o0 + 256 * wv + 64 * lk + li;
+    float ad[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ad[r] = wv < NT ? arow.ld(ob + 16 * r) : 0.f;
+    f32x4_t fq[(KS * 64 + NTH - 1) / NTH];
+#pragma unroll
+    for (int q = 0; q < (KS * 64 + NTH - 1) / NTH; ++q) {
+        const int e = tid + q * NTH;
+        fq[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + 4 * (e < KS * 64 ? e : 0));
+    }
     const int m_first = max(j_lo, 0) * 4;        // first fine sample that exists in this tile
     const int r_first = m_first / hop_t;         // its control frame; rows r_first .. r_first + nrows - 1 are staged
     {
-        const int m_last = min(j_lo + TO + G::HALO - 1, Tp - 1) * 4 + 3;
+        const int m_last = min(j_lo + SPAN - 1, Tp - 1) * 4 + 3;
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);   // rows this tile's samples really touch
         // rows beyond nrw repeat row nrw - 1 (their pair rows hold zeros as differences and are never read by a sample that
         // exists): every load below is unconditional, so all of a thread's 16-byte row loads are in flight together
-        if (OSCF2_SKIP & 4) {}
-        else if (nrows <= 2) oscf2_stage_rows<2, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+        if (nrows <= 2)      oscf2_stage_rows<2, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
         else if (nrows == 3) oscf2_stage_rows<3, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
         else                 oscf2_stage_rows<4, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+    }
+#pragma unroll
+    for (int q = 0; q < (KS * 64 + NTH - 1) / NTH; ++q) {
+        const int e = tid + q * NTH;
+        if (e < KS * 64) reinterpret_cast<f32x4_t*>(frag)[e] = fq[q];
     }
     if (wv == 0) {
         tacc = wave_incl_scan(tacc, lane);
         if (lane == 63) *base_p = tacc;
     }
-    if (first_unit) OSCF_STAMP(1);
+    OSCF_STAMP(1);
+    // ---- 2. conversions and the in-wave scan
+    u64 av[CPT + 1];
+#pragma unroll
+    for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[r], 2);
+    const int jb = j_lo + i0t;
+    auto seg_of = [&](int r) -> u64 {
+        const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);
+        const u64 sg = ((av[r] + d) << 2) + (d << 1);             // 4 a + 6 d
+        if (!EDGE) return sg;
+        const int j = jb + r;
+        return (j >= 0 && j < Tp - 1) ? sg : 0;                   // segments 0 .. Tp-2 advance the phase
+    };
+    u64 excl;
+    {
+        u64 tsum = 0;
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) tsum += seg_of(r);
+        const u64 incl = wave_incl_scan(tsum, lane);
+        excl = incl - tsum;
+        if (lane == 63) wtot[wv] = incl;
+        // in-wave prefix at -dmin (the tile's first output, whose phase the totals give): a thread of wave 0
+        const int th = (-dmin) / CPT, rh = (-dmin) % CPT;         // (uniform)
+        u64 r2 = excl;
+#pragma unroll
+        for (int r = 0; r + 1 < CPT; ++r) r2 += r < rh ? seg_of(r) : 0;
+        if (tid == th) *halo_p = r2;
+    }
+    __syncthreads();                             // row pairs, fragments, wave totals, bases
+    OSCF_STAMP(2);
+    u64 ph = *base_p - *halo_p + excl;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) ph += w < wv ? wtot[w] : 0;
+    // ---- 3. render the 4 fine samples of every owned coarse sample into the polyphase tile
     const float inv_hop_t = 1.0f / (float)hop_t;
     const int fw = 32 - lshift < 24 ? 32 - lshift : 24, fo = 32 - lshift - fw;
     const float fscale = __uint_as_float((unsigned)(127 - fw) << 23);   // 2^-fw
@@ -1175,246 +889,145 @@ __device__ __forceinline__ void oscf2_body(
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const f32x2_t lds_cf2;   // (LDS byte offsets as integers: see the gathers)
     const unsigned pbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)reinterpret_cast<const char*>(pairs);
-    const BufRow orow(out + (size_t)b * out_stride, Tout);
-    Oscf2Pref<KS, NTH, NP> nx;                    // the next unit's loads: issued after this unit's first barrier
-    u64 phb = 0;                                 // phase at index 0 of the pass (pass 0: known after the first barrier)
+    if (i0t < SPAN) {
+        // gathers of one coarse sample: (row pair address, column) -> (value, row difference) of columns c0 and c0 + 1
+        f32x2_t e0[2][4], e1[2][4];
+        unsigned hik[2][4];
+        float rf0[2];
+        u64 phn = ph;
+        auto issue = [&](int r) {
+            const int s = r & 1;
+            // (the second difference and the segment total are recomputed from an opaque copy of the increment: kept from the
+            //  scan they are 6 registers per coarse sample, which is what decides the waves per SIMD here)
+            u64 a = av[r];
+            asm volatile("" : "+v"(a));
+            const u64 d = osc_fix_d_pow2(a, av[r + 1], 2), t = a + d;
+            u64 sg = (t << 2) + (d << 1);
+            if (EDGE) {
+                const int j = jb + r;
+                sg = (j >= 0 && j < Tp - 1) ? sg : 0;
+            }
+            hik[s][0] = (unsigned)((phn + a) >> 32);
+            hik[s][1] = (unsigned)((phn + ((a << 1) + d)) >> 32);
+            hik[s][2] = (unsigned)((phn + ((t << 1) + t)) >> 32);
+            phn += sg;
+            hik[s][3] = (unsigned)(phn >> 32);
+            // control-frame position of the coarse sample's first fine sample: frames from r_first, integer + fraction
+            const float x = (float)(4 * (jb + r) - r_first * hop_t) * inv_hop_t;
+            const float xi = floorf(x);
+            rf0[s] = x - xi;
+            const unsigned rowaddr = pbase + (int)xi * row_bytes;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        // ---- 2. conversions and the in-wave scan of this pass (pass 0: while the table rows are in flight; later passes:
-        //         before the barrier that frees the signal buffer)
-        u64 av[CPT + 1];
-#pragma unroll
-        for (int r = 0; r <= CPT; ++r) av[r] = osc_fix_a_pow2(pv[p][r], 2);
-        const int jb = j_lo + p * PASS + i0t;
-        auto seg_of = [&](int r) -> u64 {
-            const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);
-            const u64 sg = ((av[r] + d) << 2) + (d << 1);             // 4 a + 6 d
-            if (!EDGE) return sg;
-            const int j = jb + r;
-            return (j >= 0 && j < Tp - 1) ? sg : 0;                   // segments 0 .. Tp-2 advance the phase
+            for (int k = 0; k < 4; ++k) {
+                const unsigned c0 = hik[s][k] >> (32 - lshift);
+                const unsigned q = rowaddr + c0 * 8;
+                e0[s][k] = *(lds_cf2*)(uintptr_t)q;
+                unsigned q1 = q;
+                asm volatile("" : "+v"(q1));       // an opaque copy of the address: two ds_read_b64, not one ds_read2_b64
+                e1[s][k] = *(lds_cf2*)(uintptr_t)(q1 + 8);
+            }
         };
-        u64 excl;
-        {
-            u64 tsum = 0;
+        if (OSCF2_STAGES == 2) issue(0);
 #pragma unroll
-            for (int r = 0; r < CPT; ++r) tsum += seg_of(r);
-            const u64 incl = wave_incl_scan(tsum, lane);
-            excl = incl - tsum;
-            if (lane == 63) wtot[p * NW + wv] = incl;
-            // in-wave prefix at index PASS (the next pass starts there) and, in pass 0, at -dmin (the tile's first output)
-            if (p + 1 < NP) {
-                constexpr int TB = PASS / CPT, RB = PASS % CPT;
-                u64 r2 = excl;
+        for (int r = 0; r < CPT; ++r) {
+            const int s = r & 1;
+            const int i = i0t + r;
+            if (OSCF2_STAGES == 2) { if (r + 1 < CPT) issue(r + 1); } else issue(r);
+            const float p0 = pv[r], p1 = pv[r + 1];
+            float sck[4] = {1.f, 1.f, 1.f, 1.f};
+            if (EE) {
+                const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;   // fine increment q0 + k dq (cycles per fine sample)
+                const float s0 = __builtin_amdgcn_rsqf(q0);              // raw v_rsq_f32: q0 is a normal number
+                const float ds = -0.5f * s0 * s0 * s0 * dq;              // d/dk rsqrt(q0 + k dq) at k = 0
+                const bool lin = fabsf(p1 - p0) <= 0.002f * p0;          // second-order term below 1e-6: speech f0 always is
 #pragma unroll
-                for (int r = 0; r < RB; ++r) r2 += seg_of(r);
-                if (tid == TB) passin[p] = r2;
-            }
-            if (p == 0) {
-                const int th = (-dmin) / CPT, rh = (-dmin) % CPT;   // (uniform)
-                u64 r2 = excl;
+                for (int k = 0; k < 4; ++k) sck[k] = fmaf((float)k, ds, s0);
+                if (__builtin_amdgcn_ballot_w64(!lin) != 0) {
+                    // f0 jumps (voicing boundaries): exact, wave-uniform and behind an opaque statement so that the four
+                    // quarter-rate v_rsq_f32 are not issued in the common case
+                    asm volatile("; exact equal-energy factors" ::: "memory");
 #pragma unroll
-                for (int r = 0; r + 1 < CPT; ++r) r2 += r < rh ? seg_of(r) : 0;
-                if (tid == th) *halo_p = r2;
-            }
-        }
-        __syncthreads();                         // pass 0: row pairs, bases; every pass: wave totals; later passes: buffer free
-        if (p == 0 && first_unit) OSCF_STAMP(2);
-        if (p == 0) phb = *base_p - *halo_p;
-        if (p == 0 && has_next)
-            oscf2_prefetch<KS, NTH, NP>(nx, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd, b_next, tile_next);
-        u64 ph = phb + excl;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) ph += w < wv ? wtot[p * NW + w] : 0;
-        if (p + 1 < NP) {   // the next pass starts at this pass's index PASS
-            constexpr int WB = (PASS / CPT) / 64;
-            u64 nb = phb + passin[p];
-#pragma unroll
-            for (int w = 0; w < WB; ++w) nb += wtot[p * NW + w];
-            phb = nb;
-        }
-        // ---- 3. render the 4 fine samples of every owned coarse sample into the polyphase tile
-        if (i0t < SPAN && !(OSCF2_SKIP & 2)) {
-            // gathers of one coarse sample: (row pair address, column) -> (value, row difference) of columns c0 and c0 + 1
-            f32x2_t e0[2][4], e1[2][4];
-            unsigned hik[2][4];
-            float rf0[2];
-            u64 phn = ph;
-            auto issue = [&](int r) {
-                const int s = r & 1;
-                // (the second difference and the segment total are recomputed from an opaque copy of the increment: kept from the
-                //  scan they are 6 registers per coarse sample, which is what decides the waves per SIMD here)
-                u64 a = av[r];
-                asm volatile("" : "+v"(a));
-                const u64 d = osc_fix_d_pow2(a, av[r + 1], 2), t = a + d;
-                u64 sg = (t << 2) + (d << 1);
-                if (EDGE) {
-                    const int j = jb + r;
-                    sg = (j >= 0 && j < Tp - 1) ? sg : 0;
+                    for (int k = 0; k < 4; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
                 }
-                hik[s][0] = (unsigned)((phn + a) >> 32);
-                hik[s][1] = (unsigned)((phn + ((a << 1) + d)) >> 32);
-                hik[s][2] = (unsigned)((phn + ((t << 1) + t)) >> 32);
-                phn += sg;
-                hik[s][3] = (unsigned)(phn >> 32);
-                // control-frame position of the coarse sample's first fine sample: frames from r_first, integer + fraction
-                const float x = (float)(4 * (jb + r) - r_first * hop_t) * inv_hop_t;
-                const float xi = floorf(x);
-                rf0[s] = x - xi;
-                const unsigned rowaddr = pbase + (int)xi * row_bytes;
+            }
+            if (EDGE) {
+                const int j = jb + r;
+                const bool v0 = j >= 0 && j <= Tp - 1, vk = j >= 0 && j < Tp - 1;   // the last coarse sample has only k = 0
+                sck[0] = v0 ? sck[0] : 0.f;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) sck[k] = vk ? sck[k] : 0.f;
+            }
+            float* xp = X + oscf2_xaddr(i);
+            if (i < SPAN) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned c0 = hik[s][k] >> (32 - lshift);
-                    const unsigned q = rowaddr + c0 * 8;
-                    if (OSCF2_SKIP & 8) { e0[s][k] = (f32x2_t){__uint_as_float(q), 1.f}; e1[s][k] = (f32x2_t){__uint_as_float(q + 8), 2.f}; continue; }
-                    e0[s][k] = *(lds_cf2*)(uintptr_t)q;
-#if OSCF2_SPLIT_GATHER
-                    unsigned q1 = q;
-                    asm volatile("" : "+v"(q1));   // an opaque copy of the address: two ds_read_b64, not one ds_read2_b64
-                    e1[s][k] = *(lds_cf2*)(uintptr_t)(q1 + 8);
-#else
-                    e1[s][k] = *(lds_cf2*)(uintptr_t)(q + 8);
-#endif
-                }
-            };
-            if (OSCF2_STAGES == 2) issue(0);
-#pragma unroll
-            for (int r = 0; r < CPT; ++r) {
-                const int s = r & 1;
-                const int i = i0t + r;
-                if (OSCF2_STAGES == 2) { if (r + 1 < CPT) issue(r + 1); } else issue(r);
-                const float p0 = pv[p][r], p1 = pv[p][r + 1];
-                float sck[4] = {1.f, 1.f, 1.f, 1.f};
-                if (EE) {
-                    const float q0 = p0 * 0.25f, dq = (p1 - p0) * 0.0625f;   // fine increment q0 + k dq (cycles per fine sample)
-                    const float s0 = __builtin_amdgcn_rsqf(q0);              // raw v_rsq_f32: q0 is a normal number
-                    const float ds = -0.5f * s0 * s0 * s0 * dq;              // d/dk rsqrt(q0 + k dq) at k = 0
-                    const bool lin = fabsf(p1 - p0) <= 0.002f * p0;          // second-order term below 1e-6: speech f0 always is
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sck[k] = fmaf((float)k, ds, s0);
-                    if (__builtin_amdgcn_ballot_w64(!lin) != 0) {
-                        // f0 jumps (voicing boundaries): exact, wave-uniform and behind an opaque statement so that the four
-                        // quarter-rate v_rsq_f32 are not issued in the common case
-                        asm volatile("; exact equal-energy factors" ::: "memory");
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) sck[k] = lin ? sck[k] : __builtin_amdgcn_rsqf(fmaf((float)k, dq, q0));
-                    }
-                }
-                if (EDGE) {
-                    const int j = jb + r;
-                    const bool v0 = j >= 0 && j <= Tp - 1, vk = j >= 0 && j < Tp - 1;   // the last coarse sample has only k = 0
-                    sck[0] = v0 ? sck[0] : 0.f;
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) sck[k] = vk ? sck[k] : 0.f;
-                }
-                float* xp = X + oscf2_xaddr(i);
-                if (i < SPAN) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float rf = fmaf((float)k, inv_hop_t, rf0[s]);
-                        const float cf = (float)__builtin_amdgcn_ubfe(hik[s][k], (unsigned)fo, (unsigned)fw) * fscale;
-                        const float t0 = fmaf(rf, e0[s][k][1], e0[s][k][0]), t1 = fmaf(rf, e1[s][k][1], e1[s][k][0]);
-                        float v = fmaf(cf, t1 - t0, t0);
-                        if (EE || EDGE) v *= sck[k];
-                        if (EDGE) v = sck[k] == 0.f ? 0.f : v;   // (a row that is not staged may hold anything: 0 x NaN)
-                        xp[k * XS] = v;
-                    }
+                    const float rf = fmaf((float)k, inv_hop_t, rf0[s]);
+                    const float cf = (float)__builtin_amdgcn_ubfe(hik[s][k], (unsigned)fo, (unsigned)fw) * fscale;
+                    const float t0 = fmaf(rf, e0[s][k][1], e0[s][k][0]), t1 = fmaf(rf, e1[s][k][1], e1[s][k][0]);
+                    float v = fmaf(cf, t1 - t0, t0);
+                    if (EE || EDGE) v *= sck[k];
+                    if (EDGE) v = sck[k] == 0.f ? 0.f : v;   // (a row that is not staged may hold anything: 0 x NaN)
+                    xp[k * XS] = v;
                 }
             }
         }
-        if (p == 0 && first_unit) OSCF_STAMP(3);
-        if (p == NP - 1 && NP > 1 && first_unit) OSCF_STAMP(6);
-        // this wave's 256-output tiles of the pass: tw = wv - shift (mod NW), tw + NW, ... < NT
-        const int shift = NW > NT ? (p * (NW - NT)) % NW : 0;
-        const int tw0 = (wv - shift + NW) % NW;
-        // the fused addend of the wave's outputs and the Toeplitz fragments of the taps: loads issued before the barrier,
-        // consumed after it.  D rows 4 lk + r, column li  ->  output o0 + p PASS + 256 tw + 16 (4 lk + r) + li
-        float bfrag[4][KS];
-        // (unconditional: behind `if (tw0 < NT)` the 48 fragment registers became values merged across the passes and
-        //  stayed allocated through the renders, 93 -> 140 VGPRs; a wave without a tile in this pass loads 12 words in vain)
-        oscf2_load_frags<KS>(Bf, lane, bfrag);
-        __syncthreads();
-        if (p == 0 && first_unit) OSCF_STAMP(4);
-        // ---- 4. polyphase FIR on the matrix pipe
-        for (int tw = tw0; tw < NT; tw += NW) {
-            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            // A[m = li][k' = 4 kk + lk]: window element 256 tw + 16 li + 4 kk + lk -> address 288 tw + 18 li + 4 kk + lk + 2 (kk >> 2)
-            const float* ap = X + 288 * tw + 18 * li + lk;
-#pragma unroll
-            for (int phs = 0; phs < 4; ++phs) {
-                float a[KS];
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + 2 * (kk >> 2)];
-#pragma unroll
-                for (int kk = 0; kk < KS; kk += 2) {
-                    if (OSCF2_SKIP & 1) { acc0[kk & 3] += a[kk] * bfrag[phs][kk]; acc1[kk & 3] += a[kk + 1] * bfrag[phs][kk + 1]; continue; }
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], bfrag[phs][kk + 1], acc1, 0, 0, 0);
-                }
-            }
-            const int ob = o0 + p * PASS + 256 * tw + 64 * lk + li;
-            float ad[4];
-            if (tw == tw0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ad[r] = pf.ad[p][r];
-            } else {   // (fewer waves than wave tiles: the later tiles' addend is fetched here)
-                const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ad[r] = arow.ld(ob + 16 * r);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
-        }
-        if (p == 0 && first_unit) OSCF_STAMP(5);
-        if (p == NP - 1 && first_unit) OSCF_STAMP(7);
     }
-    if (first_unit) OSCF_RT(1);
-    if (has_next) pf = nx;
+    OSCF_STAMP(3);
+    __syncthreads();
+    OSCF_STAMP(4);
+    // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256 wv .. + 255 as a 16 x 16 tile
+    //         D[m][n] (output 256 wv + 16 m + n) = sum_ph sum_k' X_ph[256 wv + 16 m + k'] * B_ph[k'][n]
+    if (wv < NT) {
+        float bfrag[4][KS];
+#pragma unroll
+        for (int phs = 0; phs < 4; ++phs)
+#pragma unroll
+            for (int q = 0; q < KS / 4; ++q) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(frag + (((phs * (KS / 4) + q) * 64 + lane) << 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfrag[phs][4 * q + j] = v[j];
+            }
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // A[m = li][k' = 4 kk + lk]: window element 256 wv + 16 li + 4 kk + lk -> address 272 wv + 17 li + 4 kk + lk + (kk >> 2)
+        const float* ap = X + 272 * wv + 17 * li + lk;
+#pragma unroll
+        for (int phs = 0; phs < 4; ++phs) {
+            float a[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + (kk >> 2)];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], bfrag[phs][kk + 1], acc1, 0, 0, 0);
+            }
+        }
+        OSCF_STAMP(5);
+        const BufRow orow(out + (size_t)b * out_stride, Tout);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) orow.st(ob + 16 * r, acc0[r] + acc1[r] + ad[r]);
+    }
+    OSCF_STAMP(7);
+    OSCF_RT(1);
 }
 
-#ifndef OSCF2_MIN_WAVES
-#define OSCF2_MIN_WAVES 4
-#endif
-template <int EE, int KS>
-__global__ __launch_bounds__(OSCF2_NTH, OSCF2_MIN_WAVES) void osc_fused2_kernel(
-    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ Ttot, int ntile,
+template <int EE, int KS, int TO, int NTH>
+__global__ __launch_bounds__(NTH, 4) void osc_fused2_kernel(
+    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ T256, int nt256,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
-    int hop_t, const float* __restrict__ Bf, float* __restrict__ out, int64_t out_stride, int Tout,
-    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, int units) {
+    int hop_t, const float* __restrict__ Bf4, float* __restrict__ out, int64_t out_stride, int Tout,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     light_wave_priority();
-    typedef Oscf2Geom<KS, OSCF2_NP> G;
-    Oscf2Pref<KS, OSCF2_NTH, OSCF2_NP> pf;
-#if OSCF2_PERSIST
-    // persistent workgroups (measured, not adopted -- see OSCF2_PERSIST): workgroup w of the grid takes the contiguous units
-    // [w U / G, (w + 1) U / G) -- unit u = tile u % ntile of utterance u / ntile -- and keeps one unit's loads in flight ahead
-    const int u_begin = (int)((int64_t)blockIdx.x * units / gridDim.x), u_end = (int)((int64_t)(blockIdx.x + 1) * units / gridDim.x);
-    if (u_begin >= u_end) return;
-    oscf2_prefetch<KS, OSCF2_NTH, OSCF2_NP>(pf, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd,
-                                            u_begin / ntile, u_begin % ntile);
-    for (int u = u_begin; u < u_end; ++u) {
-        const int b = u / ntile, tile = u - b * ntile;
-        const bool has_next = u + 1 < u_end;
-        const int bn = (u + 1) / ntile, tn = (u + 1) - bn * ntile;
-        const bool first = u == u_begin;
-#else
-    {   // one workgroup per unit: grid (ntile, B)
-        const int b = blockIdx.y, tile = blockIdx.x;
-        constexpr bool has_next = false, first = true;
-        constexpr int bn = 0, tn = 0;
-        oscf2_prefetch<KS, OSCF2_NTH, OSCF2_NP>(pf, phase, phase_stride, Ttot, ntile, Tp, dmin, addend, addend_stride, Tadd, b, tile);
-#endif
-        const int j_lo = tile * G::TO + dmin;
-        // every coarse sample j_lo .. j_lo + TO + HALO (the last one as a segment's right end) exists and is not the last
-        const bool edge = j_lo < 0 || j_lo + G::TO + G::HALO > Tp - 1;
-        if (edge)
-            oscf2_body<EE, KS, OSCF2_NTH, OSCF2_NP, true>(phase, phase_stride, Ttot, ntile, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t,
-                                                         Bf, out, out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem,
-                                                         b, tile, pf, has_next, bn, tn, first);
-        else
-            oscf2_body<EE, KS, OSCF2_NTH, OSCF2_NP, false>(phase, phase_stride, Ttot, ntile, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t,
-                                                          Bf, out, out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem,
-                                                          b, tile, pf, has_next, bn, tn, first);
-    }
+    typedef Oscf2Geom<KS, TO> G;
+    const int j_lo = blockIdx.x * TO + dmin;
+    // every coarse sample j_lo .. j_lo + SPAN (the last one as a segment's right end) exists and is not the last
+    const bool edge = j_lo < 0 || j_lo + G::SPAN > Tp - 1;
+    if (edge)
+        oscf2_body<EE, KS, TO, NTH, true>(phase, phase_stride, T256, nt256, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out,
+                                         out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem);
+    else
+        oscf2_body<EE, KS, TO, NTH, false>(phase, phase_stride, T256, nt256, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out,
+                                          out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem);
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
@@ -2129,88 +1742,35 @@ extern "C" size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop,
     return g.total;
 }
 
-// The fused forward's geometry, and whether it serves this call (the backward asks too: a workspace the fused forward
-// filled still holds the tile totals and both tap-fragment layouts, GOLF_OSC_WS_KEPT).
-struct OscFusedFwd { int dmin, dmax, KS, nrows, XS, ntile2, lshift; size_t ldsf; };
+// The fused forward's geometry, and whether it serves this call (the backward asks too: a workspace the fused forward filled
+// still holds the tile totals and the transposed tap fragments, GOLF_OSC_WS_KEPT).
+struct OscFused2 { int dmin, dmax, KS, nrows, ntile2, lshift, TO, ntile_f; size_t lds; };
 static int osc_unfused_env() {
     static const int v = [] { const char* e = getenv("GOLF_OSC_UNFUSED"); return e ? atoi(e) : 0; }();  // A/B knob
     return v;
 }
-static bool osc_fused_fwd_plan(const OscGeom& g, int L, int os, int K, bool want_pre, int Tout, OscFusedFwd* f) {
-    if (!(os == 4 && g.P == 4 && (L & (L - 1)) == 0 && !want_pre && !osc_unfused_env())) return false;
-    const int half = (K - 1) / 2;
-    f->dmin = -((half + os - 1) / os);
-    f->dmax = half / os;
-    const int nq = f->dmax - f->dmin + 1;                       // taps per polyphase branch
-    f->KS = nq + 15 <= 48 ? 12 : 16;                            // K-steps of the 16-window Toeplitz product
-    const int span = OSCF_TO + 4 * f->KS;
-    const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
-    static const int nrows_force = [] { const char* e = getenv("GOLF_OSCF_NROWS"); return e ? atoi(e) : 0; }();   // dev knob: timing proxies only (wrong results)
-    f->nrows = nrows_force > 0 ? nrows_force : nint_touched + 1;
-    f->XS = (span + 4 * (span >> 4) + 4 + 3) & ~3;              // padded polyphase row: i + 4 * (i >> 4)
-    static const size_t lds_pad = [] { const char* e = getenv("GOLF_OSCF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // dev knob: occupancy experiments
-#if OSCF_ROWS
-    f->ldsf = sizeof(float) * ((size_t)os * f->XS + (size_t)f->nrows * (L + 1)) + lds_pad;
-#else
-    f->ldsf = sizeof(float) * ((size_t)os * f->XS + 2 * (size_t)(f->nrows - 1) * (L + 1)) + lds_pad;
-#endif
-    f->ntile2 = (int)ceil_div(Tout, OSCF_TO);                   // <= g.ntile: fits the Ttot region of the workspace
-    f->lshift = 31 - __builtin_clz((unsigned)L);
-    return nq + 15 <= 64 && f->nrows <= OSCF_MAXROWS && span <= OSCF_THREADS * OSCF_CPT && -f->dmin < span &&
-           f->ldsf <= 80 * 1024 + lds_pad;
-}
-
-// round 5's fused forward (osc_fused2_kernel): the same totals launch, tile count and tap fragments as osc_fused_kernel
-struct OscFused2 { int dmin, dmax, KS, nrows, ntile2, lshift; size_t lds; };
-static int oscf_old_env() {
-    static const int v = [] { const char* e = getenv("GOLF_OSCF_OLD"); return e ? atoi(e) : 0; }();  // A/B knob (dev)
-    return v;
-}
-static bool osc_fused2_plan(const OscGeom& g, const float* table, int L, int os, int K, bool want_pre, int Tout, OscFused2* f) {
-    if (!(os == 4 && g.P == 4 && (L & (L - 1)) == 0 && L >= 8 && !want_pre && !osc_unfused_env() && !oscf_old_env())) return false;
+static bool osc_fused2_plan(const OscGeom& g, const float* table, int L, int os, int K, bool want_pre, int Tout, int B, OscFused2* f) {
+    if (!(os == 4 && g.P == 4 && (L & (L - 1)) == 0 && L >= 8 && !want_pre && !osc_unfused_env())) return false;
     if ((uintptr_t)table & 15) return false;                    // table rows are fetched as 16-byte words
     const int half = (K - 1) / 2;
     f->dmin = -((half + os - 1) / os);
     f->dmax = half / os;
     const int nq = f->dmax - f->dmin + 1;                       // taps per polyphase branch
     f->KS = nq + 15 <= 48 ? 12 : 16;                            // K-steps of the 16-window Toeplitz product
-    const int span = 2048 + 4 * f->KS;
-    const int nint_touched = (span * 4 - 2) / g.hop_t + 2;      // a run of span*4 fine samples at any alignment
-    f->nrows = nint_touched + 1;
-    const int XS = f->KS == 12 ? Oscf2Geom<12, OSCF2_NP>::XS : Oscf2Geom<16, OSCF2_NP>::XS;
-    f->lds = sizeof(float) * 4 * (size_t)XS + 8 * (size_t)(f->nrows - 1) * (L + 2) + Oscf2Geom<12, OSCF2_NP>::SCRATCH;
-    f->ntile2 = (int)ceil_div(Tout, 2048);                      // <= g.ntile: fits the Ttot region of the workspace
+    f->ntile2 = (int)ceil_div(Tout, OSCF_TO);                   // tiles of the totals launch (<= g.ntile: fits the workspace)
     f->lshift = 31 - __builtin_clz((unsigned)L);
-    return nq + 15 <= 64 && f->nrows <= OSCF_MAXROWS && -f->dmin < 64 && f->lds <= 120 * 1024;
-}
-
-// persistent grid of osc_fused2_kernel: as many workgroups as the device holds at once (occupancy by LDS and registers x CUs),
-// never more than there are units
-static int oscf2_grid(const void* kernel, size_t lds, int64_t units) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) cus = 256;
-        else cus = prop.multiProcessorCount;
-    }
-    static const int per_cu_env = [] { const char* e = getenv("GOLF_OSCF2_WG_PER_CU"); return e ? atoi(e) : 0; }();   // dev knob
-    int per_cu = per_cu_env;
-    if (per_cu <= 0) {
-        // by hand: the occupancy API of ROCm 7.2 answers 1 for a workgroup with more than 64 KB of dynamic LDS.  160 KB of LDS
-        // per CU in 1280-byte granules; 512 registers per lane and SIMD in granules of 8, at most 8 waves per SIMD
-        hipFuncAttributes at;
-        int regs = 128;
-        size_t stat = 0;
-        if (hipFuncGetAttributes(&at, kernel) == hipSuccess) { regs = at.numRegs > 0 ? at.numRegs : regs; stat = at.sharedSizeBytes; }
-        const int alloc = (regs + 7) / 8 * 8;
-        const int waves_simd = std::min(8, 512 / alloc), nw = OSCF2_NTH / 64;
-        const int by_lds = (int)(163840 / (((lds + stat + 1279) / 1280) * 1280));
-        per_cu = std::min(by_lds, waves_simd * 4 / nw);
-    }
-    if (per_cu < 1) per_cu = 1;
-    const int64_t g = (int64_t)per_cu * cus;
-    return (int)(units < g ? units : g);
+    if (!(nq + 15 <= 64 && -f->dmin < 64)) return false;
+    // (a 1536-output tile on 384 threads quantises B = 32 x 2 s better -- 1024 tiles = two full rounds of the chip's 512 workgroup
+    //  slots instead of 768 = one and a half -- and measured WORSE, 21.0 against 18.0 us, and 29 % worse at B = 16 384: a
+    //  workgroup's lifetime is a latency chain that does not shorten with the tile, so the rate is tiles in flight x outputs per
+    //  tile.  One shape.)
+    const int span = 2048 + 4 * f->KS;
+    f->TO = 2048;
+    f->nrows = (span * 4 - 2) / g.hop_t + 3;                    // a run of span*4 fine samples at any alignment touches so many frames
+    const int XS = (span + ((span + 15) >> 4) + 3) & ~3;
+    f->lds = sizeof(float) * (4 * (size_t)XS + 4 * (size_t)f->KS * 64) + 8 * (size_t)(f->nrows - 1) * (L + 2) + 256;
+    f->ntile_f = (int)ceil_div(Tout, 2048);
+    return f->nrows <= OSCF_MAXROWS && f->lds <= 160 * 1024;
 }
 
 extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
@@ -2235,62 +1795,32 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     u64* Ttot = (u64*)((char*)ws + g.off_ttot);
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
     OscFused2 f2;
-    if (osc_fused2_plan(g, table, L, os, K, pre != nullptr, Tout, &f2)) {
+    if (osc_fused2_plan(g, table, L, os, K, pre != nullptr, Tout, B, &f2)) {
         float* Bfr = (float*)((char*)ws + g.off_bfr);
-        static_assert(OSCF_TO == 2048, "osc_fused2 shares the totals launch and the tile count of osc_fused");
         float* Bf4 = (float*)((char*)ws + g.off_bf4);
+        u64* T256 = (u64*)((char*)ws + g.off_t256);
         hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
-                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, Bfr, f2.dmax, Bf4);
+                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, Bfr, f2.dmax, Bf4, T256);
         GOLF_LAUNCH_CHECK();
-#define GOLF_FUSED2(EE, KSV)                                                                                          \
+#define GOLF_FUSED2(EE, KSV, TOV, NTHV)                                                                               \
     do {                                                                                                              \
         static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
-            (const void*)osc_fused2_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);          \
+            (const void*)osc_fused2_kernel<EE, KSV, TOV, NTHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
             return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
                         hipGetErrorString(lds_attr));                                                                 \
-        const int64_t units = (int64_t)f2.ntile2 * B;                                                                \
-        if (units > 0x7fffffff) return fail(GOLF_EINVAL, "glottal_osc_fwd: too many tiles");                          \
-        const dim3 grid = OSCF2_PERSIST ? dim3(oscf2_grid((const void*)osc_fused2_kernel<EE, KSV>, f2.lds, units))   \
-                                        : dim3(f2.ntile2, B);                                                         \
-        hipLaunchKernelGGL((osc_fused2_kernel<EE, KSV>), grid, dim3(OSCF2_NTH), f2.lds, st, phase,                    \
-                           phase_stride, (const u64*)Ttot, f2.ntile2, wsel, Fw, table, n_tab, L, f2.lshift, Tp,       \
-                           g.hop_t, (const float*)Bf4, out, out_stride, Tout, f2.dmin, f2.nrows, addend, addend_stride, \
-                           Tadd, (int)units);                                                                         \
+        hipLaunchKernelGGL((osc_fused2_kernel<EE, KSV, TOV, NTHV>), dim3(f2.ntile_f, B), dim3(NTHV), f2.lds, st, phase, \
+                           phase_stride, (const u64*)T256, f2.ntile2 * (OSCF_TO / 256), wsel, Fw, table, n_tab, L,    \
+                           f2.lshift, Tp, g.hop_t, (const float*)Bf4, out, out_stride, Tout, f2.dmin, f2.nrows,       \
+                           addend, addend_stride, Tadd);                                                              \
     } while (0)
-        if (f2.KS == 12) { if (equal_energy) GOLF_FUSED2(1, 12); else GOLF_FUSED2(0, 12); }
-        else             { if (equal_energy) GOLF_FUSED2(1, 16); else GOLF_FUSED2(0, 16); }
+#define GOLF_FUSED2_T(EE, KSV) GOLF_FUSED2(EE, KSV, 2048, 512)
+        if (f2.KS == 12) { if (equal_energy) GOLF_FUSED2_T(1, 12); else GOLF_FUSED2_T(0, 12); }
+        else             { if (equal_energy) GOLF_FUSED2_T(1, 16); else GOLF_FUSED2_T(0, 16); }
+#undef GOLF_FUSED2_T
 #undef GOLF_FUSED2
         GOLF_LAUNCH_CHECK();
         return GOLF_OK;
-    }
-    OscFusedFwd ff;
-    if (osc_fused_fwd_plan(g, L, os, K, pre != nullptr, Tout, &ff)) {
-        {
-            const int dmin = ff.dmin, dmax = ff.dmax, KS = ff.KS, nrows = ff.nrows, XS = ff.XS, ntile2 = ff.ntile2, lshift = ff.lshift;
-            const size_t ldsf = ff.ldsf;
-            float* Bf = (float*)((char*)ws + g.off_bf);
-            float* Bfr = (float*)((char*)ws + g.off_bfr);
-            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                               g.P, os, ntile2, taps, K, dmin, KS, Bf, Bfr, dmax, (float*)nullptr);
-            GOLF_LAUNCH_CHECK();
-#define GOLF_FUSED(EE, KSV)                                                                                           \
-    do {                                                                                                              \
-        static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
-            (const void*)osc_fused_kernel<EE, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);           \
-        if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
-            return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
-                        hipGetErrorString(lds_attr));                                                                 \
-        hipLaunchKernelGGL((osc_fused_kernel<EE, KSV>), dim3(ntile2, B), dim3(OSCF_THREADS), ldsf, st, phase,         \
-                           phase_stride, (const u64*)Ttot, ntile2, wsel, Fw, table, n_tab, L, lshift, Tp, g.hop_t,    \
-                           (const float*)Bf, out, out_stride, Tout, XS, dmin, nrows, addend, addend_stride, Tadd);    \
-    } while (0)
-            if (KS == 12) { if (equal_energy) GOLF_FUSED(1, 12); else GOLF_FUSED(0, 12); }
-            else          { if (equal_energy) GOLF_FUSED(1, 16); else GOLF_FUSED(0, 16); }
-#undef GOLF_FUSED
-            GOLF_LAUNCH_CHECK();
-            return GOLF_OK;
-        }
     }
     if (int rc = launch_phase_tiles(phase, phase_stride, Cw, Ttot, Tp, g.P, os, g.ntile, B, st)) return rc;
     float* fine = os > 1 ? (pre ? pre : (float*)((char*)ws + g.off_pre)) : out;
@@ -2363,13 +1893,9 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
             // the transposed tap fragments next to its own: with its workspace intact the backward is two launches, not three
             // (5.9 us of the B = 32 training step).  Otherwise -- a caller that does not say, a forward that took the
             // three-kernel path -- they are recomputed: the backward must not depend on which forward variant ran.
-            OscFusedFwd ff;
             OscFused2 f2;
-            const bool have_totals = ws_kept && OSCB_TO == OSCF_TO &&
-                                     ((osc_fused2_plan(g, table, L, os, K, false, Tout, &f2) && f2.ntile2 == ntile2 && f2.KS == KS &&
-                                       f2.dmax == dmax) ||
-                                      (osc_fused_fwd_plan(g, L, os, K, false, Tout, &ff) && ff.ntile2 == ntile2 && ff.KS == KS &&
-                                       ff.dmax == dmax));
+            const bool have_totals = ws_kept && OSCB_TO == OSCF_TO && osc_fused2_plan(g, table, L, os, K, false, Tout, B, &f2) &&
+                                     f2.ntile2 == ntile2 && f2.KS == KS && f2.dmax == dmax;
             if (!have_totals) {
                 hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
                                    g.P, os, ntile2, taps, K, dmin, KS, (float*)nullptr, Bf, dmax, (float*)nullptr);
