@@ -103,6 +103,10 @@ def parse():
                     help="also time a stream of this many consecutive recipe batches (seeds 2434, 2435, ...: benign and hot "
                          "ones alike, each its own captured graph) through the same S streams; -1: 64 for the default "
                          "single-GPU golf-ss-synth run, 0 otherwise")
+    ap.add_argument("--refresh-inputs", type=int, default=-1,
+                    help="also time the serving mode in which EVERY step first copies a new batch (one of this many resident "
+                         "packed batches, round-robin) into its slot's static inputs on the slot's stream, device-to-device, "
+                         "and -- side figure -- from pinned host memory; -1: 8 for the default single-GPU golf-ss-synth run, 0 otherwise")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
@@ -441,6 +445,26 @@ def stream_set_time(streams, issue):
     return wall, max(e0.elapsed_time(e) for e in ends) * 1e-3
 
 
+def smi_clocks():
+    """Shader / memory clock and power state of device 0 as rocm-smi reports them right now (None if the tool is missing):
+    recorded before the first and after the last timed region, so that a run that comes out slow in ALL its regions (one in
+    six of the driver's command) can be told from a normal one by more than its time."""
+    import subprocess
+
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showperflevel", "--showpower", "--json"],
+                             capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "performance level" in kl or "power" in kl:
+                keep[k] = v
+        return keep
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -481,11 +505,29 @@ def main():
     _GFm.THROUGHPUT_MODE = throughput_chain   # read when a step is issued or captured: the headline's graphs carry it
 
     # ---- every in-flight slot owns its inputs (seed 2434 + slot; slot 0 = the SURVEY §8d tensors) and its output
-    def slot_inputs(slot):
+    PACK_KEYS = ("phase", "wsel", "noise", "gain", "a")   # what the synthesis step reads: one flat buffer per slot, so that a
+    slot_flat = []                                        # serving loop refreshes a slot's inputs with ONE copy (--refresh-inputs)
+
+    def pack_inputs(inp, dev):
+        off, lay = 0, {}
+        for k in PACK_KEYS:
+            lay[k] = off
+            off += (inp[k].numel() + 63) // 64 * 64       # 256-byte aligned pieces
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for k in PACK_KEYS:
+            view = flat[lay[k]:lay[k] + inp[k].numel()].view(inp[k].shape)
+            view.copy_(inp[k])
+            inp[k] = view
+        return flat
+
+    def slot_inputs(slot, dev=None, pack=True):
+        dev = device if dev is None else dev
         inp_all = make_inputs(B=B * world, device="cpu", with_noise_filter="decoder" in args.workload,
                               seed=2434 + slot)
-        return {k: (v.to(device) if isinstance(v, torch.Tensor) else v)
-                for k, v in shard_inputs(inp_all, rank, world).items()}
+        inp = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v)
+               for k, v in shard_inputs(inp_all, rank, world).items()}
+        flat = pack_inputs(inp, dev) if pack else None
+        return inp, flat
 
     steps_fn, samples, t_out = [], None, None
     slot_cond = []   # per in-flight slot: the filter's conditioning words on that slot's coefficient tracks
@@ -494,7 +536,8 @@ def main():
             steps_fn.append(steps_fn[0])
             slot_cond.append(slot_cond[0])
             continue
-        inp_i = slot_inputs(i)
+        inp_i, flat_i = slot_inputs(i)
+        slot_flat.append(flat_i)
         fn, samples, t_out = make_step(args.workload, inp_i, osc, ss, ff, fast=not args.fp64_transitions,
                                        overlap=args.overlap_transitions, mode=args.lpc_mode)
         steps_fn.append(fn)
@@ -575,24 +618,28 @@ def main():
         torch.cuda.synchronize()
 
     step_no = [0]
+    refresh_pool = [None]   # --refresh-inputs: packed batches (device or pinned host) copied into the slot before every replay
+    gather_on = [True]      # N > 1: the same regions once more without the exchange (exchange.ms_per_step_no_gather)
 
     def full_step():
         i = step_no[0] % S
         step_no[0] += 1
         with torch.cuda.stream(streams[i]):
+            if refresh_pool[0] is not None:   # ordered on the slot's stream: after its previous replay, before this one
+                slot_flat[i].copy_(refresh_pool[0][step_no[0] % len(refresh_pool[0])], non_blocking=True)
             if use_graphs:
                 graphs[i].replay()
                 y = outs[i]
             else:
                 y = steps_fn[i]()
-            if do_gather:   # copy into the slot's staging buffer; every GE-th step starts one all-gather (async)
+            if do_gather and gather_on[0]:   # copy into the slot's staging buffer; every GE-th step starts one all-gather (async)
                 handle = stagers[i].push(y.detach())
                 if handle is not None and not pipelined:
                     handle.wait()
         return y
 
     def drain():
-        if do_gather:
+        if do_gather and gather_on[0]:
             for i in range(S):
                 with torch.cuda.stream(streams[i]):
                     stagers[i].flush()   # a partial group at the end of a region is exchanged too, then all are waited for
@@ -608,9 +655,36 @@ def main():
             full_step()
         drain()  # every gather issued inside the timed region completes inside it
 
+    def timed_regions(n):
+        """n regions, each EXACTLY --steps steps between barrier + synchronize; (wall, HIP events) per region, max over ranks"""
+        out = []
+        for _ in range(max(1, n)):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, ev_s = stream_set_time(streams, issue_region)
+            barrier()
+            wall = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+
+                t = torch.tensor([wall, ev_s], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall, ev_s = float(t[0].item()), float(t[1].item())
+            out.append((wall, ev_s))
+        return out
+
+    def median_ms(regs):
+        w = sorted(x for x, _ in regs)
+        return w[len(w) // 2] / args.steps * 1e3
+
     for _ in range(args.warmup):
         full_step()
     drain()
+    # the protocol of rounds 1 - 3: the timed regions straight after --warmup (reported as ms_per_step_unsettled); the headline's
+    # regions follow the settling regions below.  Both are in the line so that rounds stay comparable (VERDICT r4 #2).
+    clocks_before = smi_clocks() if rank == 0 else None
+    regions_unsettled = timed_regions(args.repeats)
     settle = []
     for _ in range(max(0, args.settle)):   # untimed regions through the timed path (see --settle)
         barrier()
@@ -627,25 +701,60 @@ def main():
             spent = float(t.item())
         if spent > 0.3:
             break
-    regions = []
-    for _ in range(max(1, args.repeats)):   # each region: EXACTLY --steps steps between barrier + synchronize
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        _, ev_s = stream_set_time(streams, issue_region)
-        barrier()
-        wall = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-
-            t = torch.tensor([wall, ev_s], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall, ev_s = float(t[0].item()), float(t[1].item())
-        regions.append((wall, ev_s))
+    regions = timed_regions(args.repeats)
+    clocks_after = smi_clocks() if rank == 0 else None
     walls = sorted(w for w, _ in regions)
     elapsed = walls[len(walls) // 2]   # median region (max over ranks inside each region)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * samples / (elapsed / args.steps)
+    ms_unsettled = median_ms(regions_unsettled)
+    # steps that ran before the first headline region (the JSON's "warmup" echoes the flag only)
+    effective_warmup = (args.warmup + (args.prereplay * S if use_graphs else 0)
+                        + len(regions_unsettled) * args.steps + len(settle) * args.steps)
+
+    # ---- N > 1: the same regions without the exchange, so that one line shows what the gather costs
+    ms_no_gather = None
+    if do_gather:
+        gather_on[0] = False
+        ms_no_gather = median_ms(timed_regions(args.repeats))
+        gather_on[0] = True
+
+    # ---- serving mode with refreshed inputs: every step copies a new packed batch into its slot first
+    refreshed = None
+    n_ref = args.refresh_inputs if args.refresh_inputs >= 0 else (8 if (world == 1 and args.workload == "golf-ss-synth"
+                                                                       and use_graphs and not args.shared_inputs) else 0)
+    if n_ref > 0 and use_graphs and world == 1 and all(f is not None for f in slot_flat):
+        pool_dev = [slot_inputs(S + k)[1] for k in range(n_ref)]            # resident in HBM: an encoder on the same GPU
+        pool_host = [f.cpu().pin_memory() for f in pool_dev[:min(4, n_ref)]]  # side figure: batches arriving over PCIe
+        keep = [f.clone() for f in slot_flat]
+        refresh_pool[0] = pool_dev
+        timed_regions(2)
+        ms_d2d = median_ms(timed_regions(args.repeats))
+        # the last batch each slot received, replayed: its output must be the eager result on exactly that batch
+        torch.cuda.synchronize()
+        last = [outs[i].clone() for i in range(S)]
+        for i in range(S):
+            ref_i = steps_fn[i]()
+            torch.cuda.synchronize()
+            assert torch.equal(last[i], ref_i), "refreshed slot %d: replay differs from eager on the refreshed inputs" % i
+            assert not torch.equal(slot_flat[i], keep[i]), "slot %d was not refreshed" % i
+        refresh_pool[0] = pool_host
+        timed_regions(1)
+        ms_h2d = median_ms(timed_regions(3))
+        refresh_pool[0] = None
+        for f, k in zip(slot_flat, keep):
+            f.copy_(k)
+        torch.cuda.synchronize()
+        nbytes = int(slot_flat[0].numel() * 4)
+        refreshed = {"pool_batches": n_ref, "bytes_copied_per_step": nbytes, "copies_per_step": 1,
+                     "ms_per_step_d2d": round(ms_d2d, 5), "value_d2d": samples / (ms_d2d * 1e-3),
+                     "vs_fixed_inputs": round(ms_per_step / ms_d2d, 4),
+                     # what the copy cannot go below: its own HBM traffic (read + write) at the achievable ~5 TB/s
+                     "hbm_floor_us_per_step": round(2 * nbytes / 5e12 * 1e6, 2),
+                     "ms_per_step_h2d_pinned": round(ms_h2d, 5), "h2d_GBps": round(nbytes / (ms_h2d * 1e-3) / 1e9, 2),
+                     "note": "each step: one device-to-device copy (hipMemcpyDtoDAsync) of the packed batch (phase, wsel, noise, gain, a) into the slot's "
+                             "static inputs on the slot's stream, then the graph replay; outputs asserted equal to eager runs on the "
+                             "refreshed inputs.  golf_amd.pipeline.ReplayPipeline.submit(batch) is this mode."}
 
     # ---- conditioning of the slots' filters, per rank (N > 1: the first SCALE run must be readable)
     cond_ranks = None
@@ -733,16 +842,16 @@ def main():
             lat_step_us = event_time_us(step)
             _GFm.THROUGHPUT_MODE = throughput_chain
         # HBM bytes per launch and issued VALU instructions per step come from separate rocprofv3 --pmc passes (counters
-        # cannot be read in this run): the committed round-4 summaries only -- no fallback to an older round's file
+        # cannot be read in this run): the committed round-5 summaries only -- no fallback to an older round's file
         traffic, valu = None, None
         try:
-            fn = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+            fn = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
             if os.path.exists(fn):
                 tr = json.load(open(fn))
                 for kname, v in tr.get("kernels", {}).items():
                     if kname in dom and tr.get("batch") == B:
                         traffic = v["hbm_bytes_per_launch"]
-            fn = os.path.join(ROOT, "profiles", "r04_sq_counters_4stream.json")
+            fn = os.path.join(ROOT, "profiles", "r05_sq_counters_4stream.json")
             if os.path.exists(fn):
                 sq = json.load(open(fn))
                 if sq.get("batch") == B and sq.get("workload") == args.workload:
@@ -757,7 +866,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/r04_hbm_traffic.json (separate rocprofv3 --pmc passes, not measured in this run)",
+                    "traffic_source": None if traffic is None else "profiles/r05_hbm_traffic.json (separate rocprofv3 --pmc passes, not measured in this run)",
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "stage_frac": round(alg_bytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "stage_us": round(stage_us, 2),
@@ -781,7 +890,7 @@ def main():
                 pk = float(valu["packed_insts_per_step"])
                 roofline["valu_pipe_frac"] = round((pk * 4.0 + (insts - pk) * 2.0) / (n_simd * clk * step_s), 4)
             roofline["valu_insts_per_step"] = int(insts)
-            roofline["valu_source"] = "profiles/r04_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
+            roofline["valu_source"] = "profiles/r05_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
         single_us = lat_graph_us if lat_graph_us is not None else lat_step_us
         result = {
@@ -799,7 +908,11 @@ def main():
                        "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
                        "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),
+            "ms_per_step_unsettled": ms_unsettled,   # the same regions straight after --warmup: the protocol of rounds 1 - 3
             "timing": {"regions": len(regions), "statistic": "median region wall time (max over ranks per region)",
+                       "effective_warmup_steps": int(effective_warmup),
+                       "smi_before_first_region": clocks_before, "smi_after_last_region": clocks_after,
+                       "ms_per_step_regions_unsettled_wall": [round(w / args.steps * 1e3, 5) for w, _ in regions_unsettled],
                        "ms_per_step_regions_wall": [round(w / args.steps * 1e3, 5) for w, _ in regions],
                        "ms_per_step_regions_hip_events": [round(e / args.steps * 1e3, 5) for _, e in regions],
                        "prereplay_per_graph": args.prereplay if use_graphs else 0,
@@ -813,7 +926,10 @@ def main():
                               "headline_chain": "throughput" if throughput_chain else "latency",
                               "us_per_step_graph_headline_chain": None if graph_us is None else round(graph_us, 2),
                               "us_per_step_eager_headline_chain": round(step_us, 2)},
-            "single_batch_latency_us": round(lat_step_us, 2),  # one batch alone, eager, latency chain, HIP events on the launch stream
+            # one batch alone, eager, HIP events on the launch stream: in the HEADLINE's launch chain (what a caller of the
+            # headline configuration gets for a lone batch), and in the latency chain (a caller without batches in flight)
+            "single_batch_latency_us": round(step_us, 2),
+            "single_batch_latency_us_latency_chain": round(lat_step_us, 2),
             "roofline": roofline,
             "stages_us": stages,
         }
@@ -830,12 +946,20 @@ def main():
                                "tier3_G3": float(os.environ.get("GOLF_SS_PHI_GUARD3", 256))}}
         if recipe_stream is not None:
             result["recipe_stream"] = recipe_stream
+        if refreshed is not None:
+            result["refreshed_inputs"] = refreshed
+        knobs = {k: v for k, v in os.environ.items() if k.startswith("GOLF_")}
+        if knobs:   # a library override or build flags change what was measured: say so in the line
+            result["env"] = knobs
         if world > 1:
             result["exchange"] = {"backend": args.dist_backend, "world_size": world,
                                   "bytes_in_per_rank_per_step": int((world - 1) * B * t_out * 4) if do_gather else 0,
                                   "bytes_per_collective_per_rank": int(GE * B * t_out * 4) if do_gather and not peer_store else 0,
                                   "collectives_per_step": (1.0 / GE) if do_gather and not peer_store else 0.0,
                                   "mode": args.gather_mode if do_gather else "none",
+                                  # the same timed regions without the exchange: what the gather costs, in one line
+                                  "ms_per_step_no_gather": None if ms_no_gather is None else round(ms_no_gather, 5),
+                                  "value_no_gather": None if ms_no_gather is None else world * samples / (ms_no_gather * 1e-3),
                                   # hot utterances cost their rank ~13 us more per step: the ranks a synchronous gather waits for
                                   "flagged_utterances_per_rank": None if cond_ranks is None else [sum(c[0] for c in r) for r in cond_ranks],
                                   "tier3_utterances_per_rank": None if cond_ranks is None else [sum(c[1] for c in r) for r in cond_ranks]}

@@ -398,22 +398,34 @@ __global__ __launch_bounds__(64) void lpc_fwdq_kernel(const float* __restrict__ 
 // loaded while frame f is being processed (a lone wave would otherwise stall ~1 us on dependent loads at each of the
 // 200 frame boundaries).  No transition matrices, no scan, no redundant arithmetic: 1x the reference's FMA count.
 // ------------------------------------------------------------------------------------------
-// (one wave = `unit`: utterances 16 unit .. 16 unit + 15)
-template <int W, int NT>
+// Round 5: LPU lanes per utterance, 4 or 8.  A lone wave issues one instruction per ~7 cycles whatever it is, so a wave's time per
+// sample is its instruction count: 6 + 6 FMAs + 2 butterfly adds + 5 with a quad, 3 + 3 + 3 + 5 with eight lanes (the third
+// butterfly step is row_half_mirror; the history shifts by row_shr:1, lane 0 of each group being overwritten anyway).  Eight
+// lanes halve the utterances per wave, which costs nothing while there are fewer waves than SIMDs (B < 8192): the serial
+// filter's ~3.0 ms per batch becomes ~2.1.
+// (one wave = `unit`: utterances (64 / LPU) unit .. + 64 / LPU - 1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {   // row-level DPP move (row_shr / row_half_mirror): every lane has a source or reads 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int W, int NT, int LPU>
 __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt, float* __restrict__ yt,
                                                 const float* __restrict__ ex, int64_t ex_stride,
                                                 const float* __restrict__ gain, const float* __restrict__ a,
                                                 float* __restrict__ y, int64_t y_stride, int B, int T, int F, int M,
                                                 int hop) {
-    constexpr int TPL = quad_tpl(W, NT);
-    using TL = Tile<W, 16>;
+    static_assert(LPU == 4 || LPU == 8, "a quad or half a DPP row per utterance");
+    constexpr int ROWS = 64 / LPU;
+    constexpr int TPL = LPU == 4 ? quad_tpl(W, NT) : (NT + LPU - 1) / LPU;
+    static_assert(W % LPU == 0 && W % TPL == 0, "the unrolled block is whole turns of the history ring and of the output slots");
+    using TL = Tile<W, ROWS>;
     const int lane = threadIdx.x & 63;
     const int lq = lane / W, lr = lane % W;
-    const int row = lane >> 2, r = lane & 3;
-    const int b0 = unit * 16;
+    const int row = lane / LPU, r = lane % LPU;
+    const int b0 = unit * ROWS;
     if (b0 >= B) return;   // wave-uniform
-    const int nrow = B - b0 < 16 ? B - b0 : 16;
-    const int b = b0 + (row < nrow ? row : nrow - 1);  // idle quads shadow the last utterance; their stores are masked
+    const int nrow = B - b0 < ROWS ? B - b0 : ROWS;
+    const int b = b0 + (row < nrow ? row : nrow - 1);  // idle groups shadow the last utterance; their stores are masked
     const int xs = (int)ex_stride, ys = (int)y_stride;
     const BufRow xblk(ex + (size_t)b0 * ex_stride, nrow * xs);
     const BufRow yblk(y + (size_t)b0 * y_stride, nrow * ys);
@@ -466,9 +478,9 @@ __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt
             load_row(an, fn);
             gn = gb[fn];
         }
-        float keep[W / 4];
+        float keep[W / LPU];
 #pragma unroll
-        for (int j = 0; j < W / 4; ++j) keep[j] = 0.f;
+        for (int j = 0; j < W / LPU; ++j) keep[j] = 0.f;
         const float nb = (float)n0;
 #pragma unroll
         for (int s = 0; s < W; ++s) {
@@ -487,15 +499,16 @@ __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt
             float part = fmaf(cf[0], w[(s - 1 + TPL) % TPL], pa + pb);
             part += dppf<DPP_XOR1>(part);
             part += dppf<DPP_XOR2>(part);
+            if (LPU == 8) part += dpp_row<0x141>(part);          // row_half_mirror: lane i <-> 7 - i, the other quad's sum
             const float yv = x - part;
             const float oldest = w[s % TPL];
-            const float inc = dppf<DPP_SHR1>(oldest);
+            const float inc = LPU == 4 ? dppf<DPP_SHR1>(oldest) : dpp_row<0x111>(oldest);   // row_shr:1
             w[s % TPL] = r == 0 ? yv : inc;
-            keep[s >> 2] = ((s & 3) == r) ? yv : keep[s >> 2];
+            keep[s / LPU] = ((s % LPU) == r) ? yv : keep[s / LPU];
         }
         n0 += W;
 #pragma unroll
-        for (int j = 0; j < W / 4; ++j) yt[row * TL::LD + 4 * j + r] = keep[j];
+        for (int j = 0; j < W / LPU; ++j) yt[row * TL::LD + LPU * j + r] = keep[j];
         wave_lds_fence();
         float o[TL::ITS];
         TL::gather(o, yt, lq, lr);
@@ -510,18 +523,18 @@ __device__ __forceinline__ void serial_fwd_unit(int unit, float* __restrict__ xt
     }
 }
 
-template <int W, int NT>
+template <int W, int NT, int LPU>
 __global__ __launch_bounds__(256) void lpc_serial_fwd_kernel(const float* __restrict__ ex, int64_t ex_stride,
                                                             const float* __restrict__ gain,
                                                             const float* __restrict__ a, float* __restrict__ y,
                                                             int64_t y_stride, int B, int T, int F, int M, int hop) {
-    using TL = Tile<W, 16>;
+    using TL = Tile<W, 64 / LPU>;
     // workgroups of 4 INDEPENDENT waves (one per SIMD of a CU; they never synchronise): single-wave workgroups are
     // placed unevenly by the dispatcher once there are about as many waves as SIMDs (measured on the transition kernel)
     __shared__ float xt_all[4][TL::SIZE];
     __shared__ float yt_all[4][TL::SIZE];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    serial_fwd_unit<W, NT>(blockIdx.x * 4 + wv, xt_all[wv], yt_all[wv], ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop);
+    serial_fwd_unit<W, NT, LPU>(blockIdx.x * 4 + wv, xt_all[wv], yt_all[wv], ex, ex_stride, gain, a, y, y_stride, B, T, F, M, hop);
 }
 
 // Final pass of the flat-scan path: every chunk runs from its boundary state S_c (first pass + correction, or the fp64
@@ -761,9 +774,6 @@ __device__ __forceinline__ void p1_hom_body(int qblk, int grp, const float* __re
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int P1F_WPB = 4;  // waves per workgroup of the fp32 transition kernel
-#ifndef P1F_CHAINS
-#define P1F_CHAINS 2
-#endif
 template <int W, int NT, int NR = 2>
 struct P1fGeom {
     static constexpr int KT = 2 * NR;               // trajectories per lane: NR float2 rings
@@ -842,7 +852,7 @@ __device__ __forceinline__ void p1f_body(const float* __restrict__ a, float* __r
             // NCH independent accumulation chains per ring (NR x NCH in flight).  Measured: 2 and 4 chains per ring run
             // the same 41.5 us -- the loop is bound by v_pk_fma_f32 issue (~6.4 cycles each for a lone wave), not by the
             // dependent-result latency
-            constexpr int NCH = P1F_CHAINS;
+            constexpr int NCH = 2;
             f32x2 acc[NR][NCH];
 #pragma unroll
             for (int r = 0; r < NR; ++r)
@@ -1571,20 +1581,15 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the chunk kernels
 // prefetch depths of the two-level prologues (maps fetched ahead of the matvec that uses them): chunk maps / composites
-#ifndef GOLF_GP_DC
-#define GOLF_GP_DC 6
-#endif
-#ifndef GOLF_GP_D
-#define GOLF_GP_D 4
-#endif
+// (measured round 4: 8 + 8 and 6 + 8 deep were slower -- the prologue's matvec steps are issue-bound, not fetch-bound)
+constexpr int kPrefetchMaps = 6, kPrefetchComposites = 4;
 
 // s' = rows . s + add with the state broadcast by v_readlane (lane i = component i, `rw` = row i of the matrix)
 template <int W, int NT>
 __device__ __forceinline__ float matvec_step(const float4* rw, float s, float add, bool act) {
-#ifndef GOLF_MATVEC_SCALAR
     // Four partial sums (columns j mod 4), written as two packed accumulators over the (x, y) / (z, w) halves of the row's
-    // float4s: the pairs are the registers the loads filled, so each v_pk_fma_f32 takes them as they are.  (Left to hipcc, the
-    // scalar form below is SLP-packed too, but across the accumulators -- columns (3, 5), (7, 9) ... -- and every pair costs two
+    // float4s: the pairs are the registers the loads filled, so each v_pk_fma_f32 takes them as they are.  (Left to hipcc, a
+    // scalar four-accumulator form is SLP-packed too, but across the accumulators -- columns (3, 5), (7, 9) ... -- and every pair costs two
     // v_mov to assemble: ~70 instructions per step instead of ~38 for the same 22 FMAs, on the critical path of every scan.)
     typedef float pk2 __attribute__((ext_vector_type(2)));
     static_assert(NT % 2 == 0, "column pairs");
@@ -1598,19 +1603,6 @@ __device__ __forceinline__ float matvec_step(const float4* rw, float s, float ad
         else       accA = __builtin_elementwise_fma(pj, sj, accA);
     }
     return act ? (accA.x + accA.y) + (accB.x + accB.y) : 0.f;
-#else
-    float acc0 = add, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const float pj = f4get(rw[j / 4], j % 4);
-        const float sj = lane_bcast(s, j);
-        if ((j & 3) == 0) acc0 = fmaf(pj, sj, acc0);
-        else if ((j & 3) == 1) acc1 = fmaf(pj, sj, acc1);
-        else if ((j & 3) == 2) acc2 = fmaf(pj, sj, acc2);
-        else acc3 = fmaf(pj, sj, acc3);
-    }
-    return act ? (acc0 + acc1) + (acc2 + acc3) : 0.f;
-#endif
 }
 
 // Composite map of a group, M_g = Phi_{c1-1} ... Phi_{c0}, accumulated in DOUBLE precision on the matrix pipe.
@@ -2110,7 +2102,7 @@ __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, c
 // kernel's outputs) -- and, round 4, the zero-state pass itself (`parts` bit 2): the wave that scans group g's zero-state
 // responses first COMPUTES them (fwdq_body MODE 0 on the group's 16 chunks; z stays in its LDS tile, a copy goes to HBM for the
 // refinement pass) and then scans them through the group's maps.  The transition kernel is then a launch of its own that
-// needs only the coefficients -- the form in which it can run beside the oscillator (golf_source_transitions_f32).
+// needs only the coefficients -- the form in which it can run beside the oscillator's launches (ltv_allpole_prepare(maps_only=True)).
 // Workgroup ranges, in grid order (`parts` bit 0: fix-up + composites, bit 1: zero-state scans, bit 2: ... preceded by the
 // zero-state pass):
 //   B*KF1               leading fix-up workgroups (fixup_wave; 4 independent waves each): every wave derives its utterance's
@@ -2240,7 +2232,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     // the wave's own chunk maps: first fetches issued before the fold below, so they are in flight during it
     // THIN (GOLF_SS_THROUGHPUT): 4 + 2 maps ahead instead of 6 + 4 -- 196 / 246 VGPRs instead of 290 / 269, so that two chunk-pass
     // waves (or one and a transition wave) share a SIMD's registers; costs a lone batch ~1.3 us per pass (tools/ab2.sh ab_regs)
-    constexpr int DC = THIN ? 4 : GOLF_GP_DC;
+    constexpr int DC = THIN ? 4 : kPrefetchMaps;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NP * W + ii;
     const int c0 = g * kGroup;
@@ -2255,7 +2247,7 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
 #pragma unroll
     for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
     {   // (a) the groups before this one
-        constexpr int D = THIN ? 2 : GOLF_GP_D;
+        constexpr int D = THIN ? 2 : kPrefetchComposites;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
         const float* vb = V + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
@@ -2693,7 +2685,7 @@ __device__ __forceinline__ void adj_group_prologue(const float* __restrict__ Phi
     const int gt = NG - 1;                                   // top group with chunk maps
     const int ct = c0 + kGroup - 1 < NP - 1 ? c0 + kGroup - 1 : NP - 1;   // top chunk map of this group (if any)
     // the wave's own chunk maps (rows of Phi: lane j holds row j = column j of Phi^T), first fetches before the fold
-    constexpr int DC = GOLF_GP_DC;
+    constexpr int DC = kPrefetchMaps;
     const float4* rows = reinterpret_cast<const float4*>(Phi + ((size_t)b * NP * NT + ii) * W);
     const float* xb = x + (size_t)b * NC * W + ii;
     float4 pb[DC][W / 4];
@@ -2709,7 +2701,7 @@ __device__ __forceinline__ void adj_group_prologue(const float* __restrict__ Phi
     // state entering the top group: L(NP-1) = zadj_NP (first pass) or 0 (correction pass)
     float t = (with_top && act) ? x[((size_t)b * NC + NP) * W + ii] : 0.f;
     if (g < gt) {   // (a) the groups above this one, from the top down
-        constexpr int D = GOLF_GP_D;
+        constexpr int D = kPrefetchComposites;
         const float4* mrows = reinterpret_cast<const float4*>(MTt + ((size_t)b * NG * NT + ii) * W);
         const float* vb = Wv + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
@@ -3650,7 +3642,21 @@ static int launch_bwd(const SsPlan& p, const float* gy, int64_t gy_stride, const
 template <int W, int NT>
 static int launch_serial_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const float* gain, const float* a,
                              float* y, int64_t y_stride, int B, int T, int F, int M, int hop, hipStream_t st) {
-    hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, ex, ex_stride,
+    // eight lanes per utterance while that leaves at most one wave per SIMD (the wave's time per sample falls from ~19 to ~14
+    // instructions): measured 2673 -> 2381 us at B = 2048, 2785 -> 2481 at 8192; at 16 384 (two waves per SIMD) the quad wins,
+    // 3071 vs 3351 -- there the chip is busy either way and the quad does the least total work
+    static const int lpu_env = [] { const char* e = getenv("GOLF_SS_SERIAL_LPU"); return e ? atoi(e) : 0; }();   // A/B knob (dev)
+    constexpr bool can8 = W % 8 == 0 && W % ((NT + 7) / 8) == 0;
+    const bool use8 = can8 && (lpu_env ? lpu_env == 8 : (int64_t)B * 8 <= (int64_t)64 * 1024);
+    if constexpr (can8) {
+        if (use8) {
+            hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT, 8>), dim3((unsigned)ceil_div(B, 32)), dim3(256), 0, st, ex, ex_stride,
+                               gain, a, y, y_stride, B, T, F, M, hop);
+            GOLF_LAUNCH_CHECK();
+            return GOLF_OK;
+        }
+    }
+    hipLaunchKernelGGL((lpc_serial_fwd_kernel<W, NT, 4>), dim3((unsigned)ceil_div(B, 64)), dim3(256), 0, st, ex, ex_stride,
                        gain, a, y, y_stride, B, T, F, M, hop);
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;

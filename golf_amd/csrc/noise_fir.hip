@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * FIR_WAVES) void fir_frames_bwd_kern_kernel(
     const int limz = min(FIR_TILE, KS - k0);   // the row's padding taps [N, KS) (last pass) get their zero gradient here:
                                                // the caller used to fill them with a strided torch kernel of its own
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (f >= 0 && f < nfr) {  // wave-uniform
+    if (f >= 0 && f < nfr && k0 < N) {  // wave-uniform (a pass that holds padding taps only has nothing to correlate)
         float* sig = fir_lds + wv * RS;
         const int P = (N - 1) >> 1;
         const int span = 256 + hop + 4;
@@ -649,7 +649,9 @@ int golf_ltv_fir_frames_bwd_f32(const float* gy, int64_t gy_stride, const float*
     const int RS = fir_region(256 + hop + 4);
     hipStream_t st = (hipStream_t)stream;
     if (g_kern) {
-        const int npass = (N + FIR_TILE - 1) / FIR_TILE;
+        // passes over the whole ROW (kern_row_stride >= N): the padding taps [N, KS) are part of the contract ("zeroed") and a
+        // pass count taken from N left [npass * 252, KS) unwritten whenever N sat just under a multiple of 252
+        const int npass = (kern_row_stride + FIR_TILE - 1) / FIR_TILE;
         const long long units = (long long)B * F * npass;
         hipLaunchKernelGGL(fir_frames_bwd_kern_kernel, dim3((unsigned)((units + FIR_WAVES - 1) / FIR_WAVES)),
                            dim3(64 * FIR_WAVES), FIR_WAVES * RS * sizeof(float), st, gy, gy_stride, ex, ex_stride,

@@ -171,6 +171,9 @@ class _DeviceView:
                                          "version": 2, "strides": None}
 
 
+_LEAKED_ON_ERROR: list = []   # receive buffers of PeerStoreGather objects left by an exception (see __exit__)
+
+
 class PeerStoreGather:
     """The audio exchange as peer-to-peer stores over xGMI instead of an all-gather (flag-gated alternative to
     StagedGather / gather_audio; include/golf_amd.h golf_peer_*).
@@ -316,15 +319,17 @@ class PeerStoreGather:
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        # leaving by an exception: the peers may be gone, do not add a barrier they will never join -- free what is local
+        # leaving by an exception: the peers may be gone, do not add a barrier they will never join.  Our mappings of THEIR buffers
+        # are closed; our OWN receive buffers are deliberately NOT freed: a peer that is still alive -- the exception
+        # may be this rank's alone -- can still be storing into them, and a store into freed or re-used memory is worse than
+        # depth x B x T floats held until the process exits.  They stay referenced from a module-level list.
         if exc_type is None:
             self.close()
         else:
             torch.cuda.synchronize(self.device)
             for p in self._opened:
                 self.lib.golf_peer_close(p)
-            for p in self._local:
-                self.lib.golf_peer_free(p)
+            _LEAKED_ON_ERROR.extend(self._local)
             self._opened, self._local, self.recv = [], [], None
         return False
 

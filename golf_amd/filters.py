@@ -107,21 +107,24 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
     health_check = False
 
     def health(self, wait: bool = False) -> dict:
-        """Status words of the most recent monitored forward that has reached the host (``wait=True``: synchronise on it).
-        Warns once per occurrence of a fix-up timeout, a scan mismatch or non-finite output."""
+        """Status words of the most recent monitored forward that has reached the host (``wait=True``: synchronise on all that
+        are queued).  Every monitored forward is looked at exactly once -- the pending copies wait in a queue (a GPU-bound loop
+        runs ahead of the device, so a single slot overwritten per call dropped every status but the last: ADVICE r4) -- and
+        this is the one place that warns about a fix-up timeout, a scan mismatch or non-finite output."""
         import warnings
 
-        pend = getattr(self, "_health_pending", None)
-        if pend is not None:
-            host, ev = pend
+        q = self.__dict__.setdefault("_health_queue", [])
+        while q:
+            host, ev = q[0]
             if wait:
                 ev.synchronize()
-            if ev.query():
-                self._health_pending = None
-                self._health_last = w = GF.ss_status(host)
-                bad = [k for k in ("fixup_timeout", "scan_mismatch", "nonfinite") if w[k]]
-                if bad:
-                    warnings.warn(f"golf_amd: sample-wise LPC filter reported {', '.join(bad)} (status {w})", RuntimeWarning)
+            if not ev.query():
+                break
+            q.pop(0)
+            self._health_last = w = GF.ss_status(host, warn=False)
+            bad = [k for k in ("fixup_timeout", "scan_mismatch", "nonfinite") if w[k]]
+            if bad:
+                warnings.warn(f"golf_amd: sample-wise LPC filter reported {', '.join(bad)} (status {w})", RuntimeWarning)
         return getattr(self, "_health_last", None)
 
     def forward(self, ex: AudioTensor, gain: AudioTensor, a: AudioTensor) -> AudioTensor:
@@ -138,7 +141,10 @@ class LTVMinimumPhaseFilterPrecise(LTVFilterInterface):
             host.copy_(st, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(x.device))
-            self._health_pending = (host, ev)
+            q = self.__dict__.setdefault("_health_queue", [])
+            q.append((host, ev))
+            if len(q) > 64:      # (a caller that never comes back to look: keep the newest)
+                del q[0]
         return AudioTensor(y)
 
     def reverse(self, ex: AudioTensor, y: AudioTensor, gain: AudioTensor, a: AudioTensor

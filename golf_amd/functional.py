@@ -156,6 +156,8 @@ class _LTVAllPoleSS(torch.autograd.Function):
             if prepared.fast:
                 flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0) | (MAPS_ONLY if prepared.maps_only else 0)
         else:
+            if THROUGHPUT_MODE and mode == 0 and not needs_grad and B >= SS_THROUGHPUT_SERIAL_MIN:
+                mode = SS_MODES["serial"]   # several batches in flight: the plan that costs the least CHIP time (see the constant)
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
             flags = mode | (THROUGHPUT if THROUGHPUT_MODE else 0)
             if fast_inference:
@@ -215,6 +217,13 @@ SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32
 # is added to every sample-wise filter call.  Bit-identical results; a lone batch takes ~10 us longer, four in flight
 # finish ~2 % more per second (include/golf_amd.h).
 THROUGHPUT_MODE = False
+# With batches in flight (THROUGHPUT_MODE) an inference forward of this many utterances or more takes the batch-parallel
+# serial kernels instead of the time-chunked scan (the library's own switch, for a lone batch, is at 2048).  The chunked
+# scan does ~12 x the sequential arithmetic to finish ONE batch soon and saturates the chip at ~29 G samples/s whatever the
+# batch; the serial kernels do 1 x, take ~2.4 ms per batch whatever its size, and leave the chip to the other batches.
+# Whole synthesis step, MI355X, G samples/s (round 5): B = 256 chunked 28.8 | serial x 8 streams 24.5;  B = 1024 chunked 29.0 |
+# serial x 4 streams 42.6, x 8 streams 57.4;  B = 2048 (serial either way) x 1 stream 29.0, x 4 streams 57.4.
+SS_THROUGHPUT_SERIAL_MIN = 512
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
@@ -226,8 +235,11 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
     fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
     ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
-    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one, "flat-scan" is
-    the chunked algorithm with the flat boundary scan instead of the two-level one (A/B).
+    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one.  "flat-scan" --
+    the chunked algorithm with the flat boundary scan instead of the two-level one -- is a DIAGNOSTIC for A/B runs and
+    tests, not a product mode: it is slower at every batch size (78 vs 69 us/step, 171 vs 128 alone) and its accuracy is
+    bounded by 1.5 x the two-level path's bound (3 e_sequential_fp32 + 2e-4 of the float64 oracle), not by the bound itself:
+    tools/fuzz_tiers.py's worst case (hop 480, sigma 1.3 tracks) sits at 1.27 x.  No module of this package selects it.
     ``length``: filter only the first ``length`` samples of ``ex`` (output (B, min(length, natural length))): what
     ``ltv_allpole_ss(ex[:, :length], ...)`` computes, without the slice -- whose backward would be a full-size fill and a
     full-size copy in front of the producer's backward (the gradient of the unused tail is written as zeros by the filter's
@@ -246,10 +258,11 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     return _LTVAllPoleSS.apply(ex, gain, a, int(hop), prepared, bool(fast_inference), SS_MODES[mode], status, length)
 
 
-def ss_status(status: torch.Tensor) -> dict:
-    """Decode the 4 status words of ltv_allpole_ss(..., status=t) (synchronises: reads the device tensor)."""
+def ss_status(status: torch.Tensor, warn: bool = True) -> dict:
+    """Decode the 4 status words of ltv_allpole_ss(..., status=t) (synchronises: reads the device tensor).  ``warn=False``:
+    the caller reports a fix-up timeout itself (the module's health monitor: one warning per event, not two)."""
     w = status.detach().to("cpu").view(torch.int32)[:4]
-    if int(w[2]) & 2:   # never observed; a wait that ran out means the maps of a hot utterance may be half-updated
+    if warn and int(w[2]) & 2:   # never observed; a wait that ran out means the maps of a hot utterance may be half-updated
         import warnings
 
         warnings.warn("golf_amd: a device-side wait for the chunk-map fix-up ran out (golf_ltv_allpole_status_u32 bit 1): "

@@ -104,8 +104,9 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
 /*          GOLF_SS_MAPS_ONLY  (ABI 4, with GOLF_SS_FAST_TRANSITIONS) golf_ltv_allpole_transitions_f32 computes the transition
  *                matrices and nothing else; the forward, given HAVE_TRANSITIONS | MAPS_ONLY, runs what is still missing (the
  *                fix-up of ill-conditioned matrices, the group composites) in the launch that holds its zero-state pass.
- *                The matrices need only `a`: this is the part of the filter that golf_source_transitions_f32 runs in the
- *                oscillator's launch. */
+ *                The matrices need only `a`: a caller that has the coefficient tracks before the excitation (the decoder: they
+ *                come from the encoder, the excitation from the oscillator) issues this call beside the source's launches
+ *                (golf_amd.functional.ltv_allpole_prepare(maps_only=True)). */
 #define GOLF_SS_MAPS_ONLY 128
 /*          GOLF_SS_THROUGHPUT  (ABI 4) the caller keeps SEVERAL batches in flight on the device (a serving loop on a few HIP
  *                streams): prefer the launch structure that costs the least chip time over the one that finishes a lone

@@ -315,6 +315,53 @@ def test_replay_pipeline_matches_eager():
         assert torch.equal(y, fn(v))
 
 
+def test_replay_pipeline_submit_refreshes_inputs_vs_oracle():
+    """The serving API: ``ReplayPipeline.submit(batch)`` copies the batch into the slot's static inputs on the
+    slot's stream and replays the captured GOLF-ss synthesis step behind it.  Five DIFFERENT batches through two slots -- as
+    dicts (one copy per tensor) and packed (one copy) -- and every output is checked against the float64 oracle of ITS batch
+    (oscillator + injected noise -> sample-wise LPC filter), so a stale or half-refreshed slot cannot pass."""
+    from golf_amd import functional as GF
+    from golf_amd.pipeline import ReplayPipeline
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    B, T = 3, 7200
+    osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, lf_v2=True,
+                                             points=2048).cuda()
+    table, taps = osc.table, osc.decimater.taps
+    keys = ("phase", "wsel", "noise", "gain", "a")
+    batches = [make_inputs(B=B, T=T, device="cuda", seed=100 + k) for k in range(5)]
+    w_hop = batches[0]["w_hop"]
+
+    def fn(inp):
+        src = GF.glottal_osc(inp["phase"], inp["wsel"], table, taps, 1, w_hop, 4, True, add=inp["noise"])
+        return GF.ltv_allpole_ss(src, inp["gain"], inp["a"], 240, fast_inference=True)
+
+    def oracle(bt):
+        c = {k: bt[k].cpu().numpy() for k in keys}
+        src = O.indexed_glottal_forward(c["phase"], 1, c["wsel"], w_hop, table.cpu().numpy(), 4, True,
+                                        decim_taps=taps.cpu().numpy())["out"]
+        n = min(src.shape[1], c["noise"].shape[1])
+        return O.ltv_allpole_ss_forward(src[:, :n] + c["noise"][:, :n], c["gain"], c["a"], 240)
+
+    refs = [oracle(bt) for bt in batches]
+    for packed in (False, True):
+        pipe = ReplayPipeline(fn, lambda: {k: batches[0][k].clone() for k in keys}, n_slots=2, packed=packed)
+        got = []
+        for bt in batches:
+            s = pipe.submit(pipe.pack(bt) if packed else {k: bt[k] for k in keys})
+            s.stream.synchronize()
+            got.append(s.output.cpu().numpy())
+        for k, (y, r) in enumerate(zip(got, refs)):
+            n = min(y.shape[1], r.shape[1])
+            err = np.abs(y[:, :n] - r[:, :n]).max() / np.abs(r).max()
+            print(f"submit(batch {k}, packed={packed}): rel-max err vs oracle {err:.2e}")
+            assert err < 1e-4, (k, packed, err)
+        # different batches really gave different outputs (a slot replaying stale inputs would repeat itself)
+        assert np.abs(got[0] - got[2]).max() > 1e-3 and np.abs(got[1] - got[3]).max() > 1e-3
+
+
 def test_long_utterance_decoder_vs_oracle():
     """One 12.5 s utterance through the whole golf-precise decoder (293 phase-scan tiles, 1250 LPC chunks) against the
     float64 oracle: nothing in the path is sized for 2 s clips."""

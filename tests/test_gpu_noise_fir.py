@@ -157,6 +157,43 @@ def test_generic_frames_match_torch_conv():
     check(y, ref, "generic frames", 1e-5)
 
 
+@pytest.mark.parametrize("N,KS", [(250, 256), (252, 256), (242, 256), (500, 512), (50, 64)])
+def test_kernel_gradient_writes_every_padding_tap(N, KS):
+    """the kernel-gradient launch took its pass count from N, so with N just under a multiple of 252 and rows padded
+    beyond it (N = 250 / 252 with 256-tap rows, 500 with 512) the taps [npass * 252, KS) of g_kern were never written and the
+    caller's torch.empty memory came back as a gradient.  Through the C ABI with a NaN-poisoned gradient buffer: every tap below N
+    equals the float64 correlation, every padding tap is exactly 0."""
+    from golf_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(N)
+    B, F, hop = 2, 3, 120
+    T = F * hop + 40
+    nfr = lib.golf_ltv_fir_frames_length(T, F, N, hop) // hop      # frames the excitation reaches (the last kernel rows may go unused)
+    assert 1 <= nfr <= F
+    ex = rng.normal(0, 1, (B, T))
+    kern = np.zeros((B * F, KS))
+    kern[:, :N] = rng.normal(0, 1, (B * F, N))
+    gy = rng.normal(0, 1, (B, nfr * hop))
+    ex_d, kern_d, gy_d = dev(ex), dev(kern), dev(gy)
+    g_kern = torch.full((B * F, KS), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(lib.golf_ltv_fir_frames_bwd_f32(gy_d.data_ptr(), gy_d.stride(0), ex_d.data_ptr(), ex_d.stride(0), kern_d.data_ptr(), KS,
+                                               None, 0, g_kern.data_ptr(), B, T, F, N, hop, 0, _lib.stream_ptr()),
+               "golf_ltv_fir_frames_bwd_f32")
+    torch.cuda.synchronize()
+    got = g_kern.cpu().numpy().reshape(B, F, KS)
+    assert np.isfinite(got).all(), "unwritten taps: %s" % np.argwhere(~np.isfinite(got))[:4]
+    assert np.all(got[:, :, N:] == 0.0)
+    P = (N - 1) // 2
+    xp = np.pad(ex, ((0, 0), (P, N)))
+    ref = np.zeros((B, F, N))
+    for f in range(nfr):
+        for n in range(hop):
+            ref[:, f] += gy[:, f * hop + n, None] * xp[:, f * hop + n: f * hop + n + N]
+    check(got[:, :nfr, :N], ref[:, :nfr], f"g_kern N={N} KS={KS} ({nfr} of {F} frames used)", 2e-5)
+    assert np.all(got[:, nfr:] == 0.0)
+
+
 def run_precise(ex, log_mag, hop, gy=None):
     from golf_amd.audiotensor import AudioTensor
     from golf_amd.filters import LTVZeroPhaseFIRFilterPrecise
