@@ -26,6 +26,8 @@ for f in glob.glob(os.path.join(SRC, "bench_*.json")):
     shutil.copy(f, os.path.join(DST, RND + "_" + os.path.basename(f)))
 if os.path.exists(os.path.join(SRC, "recipe_latency.txt")):
     shutil.copy(os.path.join(SRC, "recipe_latency.txt"), os.path.join(DST, RND + "_recipe_latency.txt"))
+if os.path.exists(os.path.join(SRC, "osc_pmc_b2048.txt")):
+    shutil.copy(os.path.join(SRC, "osc_pmc_b2048.txt"), os.path.join(DST, RND + "_osc_pmc_b2048.txt"))
 if os.path.exists(os.path.join(SRC, "train_step_profile.json")):
     shutil.copy(os.path.join(SRC, "train_step_profile.json"), os.path.join(DST, RND + "_train_step_profile.json"))
 for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh

@@ -11,9 +11,15 @@ b() { python bench.py "$@" 2>/dev/null | tail -1; }
 b > $O/bench_golf_ss_synth.json
 b --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_golf_ss_synth_driver_cmd.json     # the driver's command line
 b --streams 1 --no-graphs --no-cpu-baseline > $O/bench_single_stream.json
-b --batch 2048 --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b2048.json
-b --batch 8192 --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b8192.json
-b --batch 16384 --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b16384.json
+# batch sweep of the whole synthesis step, 4 batches in flight like the headline (round 5: rounds 2 - 4 ran these on ONE stream,
+# which is what made B = 2048 look slower than B = 256: the serial filter leaves most of the chip to the other batches)
+b --batch 256 --no-cpu-baseline --steps 48 --warmup 8 --settle 2 --refresh-inputs 0 --recipe-stream 0 > $O/bench_b256.json
+b --batch 1024 --no-cpu-baseline --steps 24 --warmup 8 --settle 2 --refresh-inputs 0 --recipe-stream 0 > $O/bench_b1024.json
+b --batch 2048 --steps 16 --warmup 4 --repeats 3 --prereplay 2 --settle 1 --no-cpu-baseline --refresh-inputs 0 --recipe-stream 0 > $O/bench_b2048.json
+b --batch 8192 --steps 12 --warmup 4 --repeats 3 --prereplay 2 --settle 1 --no-cpu-baseline --refresh-inputs 0 --recipe-stream 0 > $O/bench_b8192.json
+b --batch 16384 --steps 8 --warmup 4 --repeats 3 --prereplay 1 --settle 1 --no-cpu-baseline --refresh-inputs 0 --recipe-stream 0 > $O/bench_b16384.json
+b --batch 2048 --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --settle 1 --no-cpu-baseline > $O/bench_b2048_1stream.json
+b --batch 16384 --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --settle 1 --no-cpu-baseline > $O/bench_b16384_1stream.json
 b --batch 8192 --workload lpc-ss-fast --streams 1 --steps 10 --warmup 2 --repeats 3 --prereplay 2 --no-cpu-baseline > $O/bench_b8192_lpc_only.json
 b --batch 16384 --workload lpc-ss-fast --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b16384_lpc_only.json
 b --batch 2048 --workload golf-ss-train --streams 1 --steps 6 --warmup 2 --repeats 3 --prereplay 1 --no-cpu-baseline > $O/bench_b2048_train.json
@@ -22,7 +28,6 @@ b --workload golf-ff-synth --no-cpu-baseline > $O/bench_ff.json
 b --workload golf-ff-train --no-cpu-baseline --steps 100 > $O/bench_ff_train.json
 b --workload golf-ss-decoder --no-cpu-baseline > $O/bench_decoder.json
 b --workload golf-ss-decoder-train --no-cpu-baseline --steps 100 > $O/bench_decoder_train.json
-b --batch 256 --no-cpu-baseline --steps 50 > $O/bench_b256.json
 b --workload ddsp-decoder --no-cpu-baseline > $O/bench_ddsp_decoder.json
 b --workload golf-ss-decoder-logits --no-cpu-baseline > $O/bench_decoder_logits.json
 b --fp64-transitions --no-cpu-baseline > $O/bench_fp64_transitions.json
@@ -57,6 +62,8 @@ bash tools/prof_pmc.sh $O/sq4_synth SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES S
 b --lpc-chain latency --no-cpu-baseline --recipe-stream 0 > $O/bench_golf_ss_synth_latency_chain.json
 b --workload golf-ss-synth-have-maps --no-cpu-baseline --recipe-stream 0 > $O/bench_synth_have_maps.json
 b --workload osc-only --no-cpu-baseline > $O/bench_osc_only.json
+# the oscillator's own counters (LDS bank conflicts, instruction counts) at a saturating batch
+bash tools/osc_pmc2.sh osc 2048 > $O/osc_pmc_b2048.txt 2>&1; rm -rf $R/gpurun_out/pmc_osc_[0-9] $R/gpurun_out/pmc_osc_*.log
 b --workload lpc-ss-fast --no-cpu-baseline > $O/bench_lpc_only.json
 # keep the merge-back small: summarise the rocpd databases here, drop them and the per-dispatch traces of the counter passes
 for d in $O/trace_*; do
