@@ -91,15 +91,18 @@ if sq:
                "kernels": dict(sq)}, open(os.path.join(DST, RND + "_sq_counters.json"), "w"), indent=1)
 # ---- the headline run (4 batches in flight): issued VALU wave-instructions per step, for bench.py's roofline.valu_issue_frac
 sq4 = collections.defaultdict(lambda: collections.defaultdict(list))
+sq4n = {}
 for f in glob.glob(os.path.join(SRC, "sq4_synth", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "golf::" in r["Kernel_Name"]:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             sq4[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "Dispatches" in r:   # rows reduced on the GPU box: one per (kernel, counter), the mean over its dispatches
+                sq4n[k] = int(float(r["Dispatches"]))
 if sq4:
     kern4 = {k: {c: round(sum(v) / len(v)) for c, v in d.items()} for k, d in sq4.items()}
     for k, d in sq4.items():
-        kern4[k]["launches"] = len(next(iter(d.values())))
+        kern4[k]["launches"] = sq4n.get(k, len(next(iter(d.values()))))
     # every kernel of the step is launched once per step: the per-launch averages add up to the step
     per_step = sum(d.get("SQ_INSTS_VALU", 0) for d in kern4.values())
     json.dump({"batch": 32, "workload": "golf-ss-synth", "streams": 4,

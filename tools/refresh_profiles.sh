@@ -73,5 +73,20 @@ for d in $O/trace_*; do
   rm -rf $d
 done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+# the counter passes write one row per dispatch and counter (100 MB over a refresh: gpurun merges back at most 64 MiB): keep the
+# per-kernel means (tools/collect_profiles.py averages them anyway) and the dispatch counts
+python - $O <<'PY'
+import collections, csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    with open(f, "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value", "Dispatches"])
+        for (k, c), v in acc.items():
+            w.writerow([k, c, sum(v) / len(v), len(v)])
+PY
+find $O -name "*.db" -delete
 ls -R $O | head -60
 du -sh $O
