@@ -602,7 +602,13 @@ def main():
             g_lat.replay()
             graphs[0].replay()
             torch.cuda.synchronize()
-            assert torch.equal(y_lat, outs[0]), "latency and throughput chains differ"
+            if _GFm.SS_THROUGHPUT_SERIAL_MIN <= B < 2048 and args.lpc_mode == "auto":
+                # with batches in flight the filter takes the serial kernels from B = 512, a lone batch the chunked scan up to
+                # 2048: two algorithms, equal to rounding (each within the tests' bound of the float64 oracle), not bit for bit
+                err = float((y_lat - outs[0]).abs().max() / outs[0].abs().max())
+                assert err < 2e-4, f"latency (chunked) and throughput (serial) plans differ by {err:.2e}"
+            else:
+                assert torch.equal(y_lat, outs[0]), "latency and throughput chains differ"
             _GFm.THROUGHPUT_MODE = throughput_chain
     # replay streams are created after capture: ROCm maps streams round-robin onto a few hardware queues, and
     # streams that alias one queue serialise (measured: 131 vs 105 us/step at S=4 depending on creation order)

@@ -718,26 +718,34 @@ extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
 //     on 64 banks, ds_read2_b64 16 lanes on 32) before it consumes the first, and the next coarse sample's before it stores;
 //   * interior tiles (every sample exists) run a body without the existence masks; 64-bit phase steps are single
 //     v_lshl_add_u64; the control-frame position is one multiply + floor;
-//   * the Toeplitz fragments reach the waves through LDS (12 KB staged once per workgroup, 12 ds_read_b128 per wave): as global
-//     loads they were 96 KB per workgroup through the vector cache -- three times the workgroup's own HBM traffic;
-//   * the signal tile is padded 1 word per 16 (17 li + lk leaves one 2-way conflict per 32 lanes of a ds_read_b32; the old
-//     20 li + lk was 2-way throughout), which is what lets tile + row pairs + fragments stay within half a CU's LDS;
+//   * three of the four branches' Toeplitz fragments reach the waves through LDS (9 KB staged once per workgroup, 9
+//     ds_read_b128 per wave): as global loads all four were 96 KB per workgroup through the vector cache -- three times the
+//     workgroup's own HBM traffic; the fourth stays a global load because 12 KB would not fit beside the tile in half a CU's LDS;
+//   * the signal tile is padded 2 words per 16 (18 li + lk is a permutation of the 32 banks a ds_read_b32 is served on; the
+//     old 20 li + lk was 2-way throughout; 1 word per 16 was tried to make room for all four branches' fragments and made the
+//     render's stores FIVE-way: +76 M conflict cycles at B = 2048);
 // Measured and not adopted: two half-tile passes per table staging with 3 workgroups per CU; persistent
 // workgroups with the next unit's loads in flight; a wave-autonomous variant (one wave = one 256-output stretch end to end,
 // no barrier after the staging); 1536-output tiles.  What they have in common: a workgroup's lifetime is a latency chain of
 // ~16 k cycles whatever the tile, and the outputs in flight per CU are bounded by LDS (17 B of signal tile per output + 33 - 49 KB
 // of table rows per workgroup), so every variant lands on the same ~0.25 outputs per cycle and CU.
+#ifndef OSCF2_XPAD
+#define OSCF2_XPAD 2          // pad words per 16 of the signal tile: 2 = reads conflict-free (18 li + lk is a permutation of the 32 banks),
+#endif                        // render stores 2-way (free); 1 = one 2-way pair per read and FIVE-way stores (measured: +76 M conflict cycles at B = 2048)
+#ifndef OSCF2_FRAG_LDS
+#define OSCF2_FRAG_LDS 3      // polyphase branches whose Toeplitz fragments reach the waves through LDS (the rest by 16-byte global loads):
+#endif                        // 3 is what fits beside a 2-padded tile within half a CU's LDS
 #ifndef OSCF2_STAGES
 #define OSCF2_STAGES 2        // gathers of the next coarse sample in flight while the current one is blended and stored (1: not)
 #endif
 template <int KS, int TO>
 struct Oscf2Geom {
     static constexpr int HALO = 4 * KS, SPAN = TO + HALO;
-    static constexpr int XS = (SPAN + ((SPAN + 15) >> 4) + 3) & ~3;          // padded polyphase row: i + (i >> 4)
-    static constexpr int FRAG = 4 * KS * 64;                                 // floats: Toeplitz fragments behind the row pairs
-    static constexpr int SCRATCH = 256;                                      // bytes behind those: wave totals, bases
+    static constexpr int XS = (SPAN + OSCF2_XPAD * ((SPAN + 15) >> 4) + 3) & ~3;   // padded polyphase row: i + XPAD * (i >> 4)
+    static constexpr int FRAG = OSCF2_FRAG_LDS * KS * 64;                    // floats: Toeplitz fragments behind the row pairs
+    static constexpr int SCRATCH = 160;                                      // bytes behind those: wave totals, bases
 };
-__device__ __forceinline__ int oscf2_xaddr(int i) { return i + (i >> 4); }
+__device__ __forceinline__ int oscf2_xaddr(int i) { return i + OSCF2_XPAD * (i >> 4); }
 
 // blended control-frame rows r_first .. r_first + NR - 1 of one utterance -> (value, row difference) pairs in LDS
 template <int NR, int NTH>
@@ -822,11 +830,19 @@ __device__ __forceinline__ void oscf2_body(
     float ad[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ad[r] = wv < NT ? arow.ld(ob + 16 * r) : 0.f;
-    f32x4_t fq[(KS * 64 + NTH - 1) / NTH];
+    constexpr int NFQ4 = OSCF2_FRAG_LDS * (KS / 4) * 64;      // 16-byte words of the branches staged in LDS
+    f32x4_t fq[NFQ4 > 0 ? (NFQ4 + NTH - 1) / NTH : 1];
 #pragma unroll
-    for (int q = 0; q < (KS * 64 + NTH - 1) / NTH; ++q) {
+    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
         const int e = tid + q * NTH;
-        fq[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + 4 * (e < KS * 64 ? e : 0));
+        fq[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + 4 * (e < NFQ4 ? e : 0));
+    }
+    // (the remaining branches' fragments: 16-byte global loads of the waves that multiply, in flight through scan and render)
+    f32x4_t fg[OSCF2_FRAG_LDS < 4 ? (4 - OSCF2_FRAG_LDS) * (KS / 4) : 1];
+    if (OSCF2_FRAG_LDS < 4 && wv < NT) {
+#pragma unroll
+        for (int q = 0; q < (4 - OSCF2_FRAG_LDS) * (KS / 4); ++q)
+            fg[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + (((OSCF2_FRAG_LDS * (KS / 4) + q) * 64 + lane) << 2));
     }
     const int m_first = max(j_lo, 0) * 4;        // first fine sample that exists in this tile
     const int r_first = m_first / hop_t;         // its control frame; rows r_first .. r_first + nrows - 1 are staged
@@ -840,9 +856,9 @@ __device__ __forceinline__ void oscf2_body(
         else                 oscf2_stage_rows<4, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
     }
 #pragma unroll
-    for (int q = 0; q < (KS * 64 + NTH - 1) / NTH; ++q) {
+    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
         const int e = tid + q * NTH;
-        if (e < KS * 64) reinterpret_cast<f32x4_t*>(frag)[e] = fq[q];
+        if (e < NFQ4) reinterpret_cast<f32x4_t*>(frag)[e] = fq[q];
     }
     if (wv == 0) {
         tacc = wave_incl_scan(tacc, lane);
@@ -983,18 +999,21 @@ __device__ __forceinline__ void oscf2_body(
         for (int phs = 0; phs < 4; ++phs)
 #pragma unroll
             for (int q = 0; q < KS / 4; ++q) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(frag + (((phs * (KS / 4) + q) * 64 + lane) << 2));
+                const f32x4_t v = phs < OSCF2_FRAG_LDS
+                    ? *reinterpret_cast<const f32x4_t*>(frag + (((phs * (KS / 4) + q) * 64 + lane) << 2))
+                    : fg[(phs - OSCF2_FRAG_LDS) * (KS / 4) + q];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bfrag[phs][4 * q + j] = v[j];
             }
         f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // A[m = li][k' = 4 kk + lk]: window element 256 wv + 16 li + 4 kk + lk -> address 272 wv + 17 li + 4 kk + lk + (kk >> 2)
-        const float* ap = X + 272 * wv + 17 * li + lk;
+        // A[m = li][k' = 4 kk + lk]: window element e = 256 wv + 16 li + 4 kk + lk -> address e + XPAD (e >> 4)
+        constexpr int XP = OSCF2_XPAD;
+        const float* ap = X + (256 + 16 * XP) * wv + (16 + XP) * li + lk;
 #pragma unroll
         for (int phs = 0; phs < 4; ++phs) {
             float a[KS];
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + (kk >> 2)];
+            for (int kk = 0; kk < KS; ++kk) a[kk] = ap[phs * XS + 4 * kk + XP * (kk >> 2)];
 #pragma unroll
             for (int kk = 0; kk < KS; kk += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bfrag[phs][kk], acc0, 0, 0, 0);
@@ -1767,8 +1786,8 @@ static bool osc_fused2_plan(const OscGeom& g, const float* table, int L, int os,
     const int span = 2048 + 4 * f->KS;
     f->TO = 2048;
     f->nrows = (span * 4 - 2) / g.hop_t + 3;                    // a run of span*4 fine samples at any alignment touches so many frames
-    const int XS = (span + ((span + 15) >> 4) + 3) & ~3;
-    f->lds = sizeof(float) * (4 * (size_t)XS + 4 * (size_t)f->KS * 64) + 8 * (size_t)(f->nrows - 1) * (L + 2) + 256;
+    const int XS = (span + OSCF2_XPAD * ((span + 15) >> 4) + 3) & ~3;
+    f->lds = sizeof(float) * (4 * (size_t)XS + OSCF2_FRAG_LDS * (size_t)f->KS * 64) + 8 * (size_t)(f->nrows - 1) * (L + 2) + 160;
     f->ntile_f = (int)ceil_div(Tout, 2048);
     return f->nrows <= OSCF_MAXROWS && f->lds <= 160 * 1024;
 }
