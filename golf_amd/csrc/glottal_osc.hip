@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, off_bf, off_bfr, off_bf4, off_t256, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bfr, off_bf4, off_t256, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -47,9 +47,8 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->pre_stride = (g->N + 3) & ~3;
     g->off_pre = o;  o = align_up(o + sizeof(float) * (size_t)B * g->pre_stride, 256);
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
-    g->off_bf = o;   o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused kernel
-    g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused backward (transposed FIR)
-    g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and the forward's again, four K-steps per 16-byte word (osc_fused2)
+    g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused backward (transposed FIR)
+    g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused forward, four K-steps per 16-byte word (osc_fused2)
     g->off_t256 = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * ((size_t)g->ntile * 4 + 8), 256);   // phase advance per 256-sample stretch (osc_fused3)
     g->total = o;
 }
@@ -614,8 +613,8 @@ template <int TO>   // coarse samples per tile: the forward's OSCF_TO, the backw
 __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const float* __restrict__ phase, int64_t phase_stride,
                                                               u64* __restrict__ Ttot, int Tp, int P, int os, int ntile,
                                                               const float* __restrict__ taps, int K, int dmin, int KS,
-                                                              float* __restrict__ Bf, float* __restrict__ Bfr, int dmax,
-                                                              float* __restrict__ Bf4 = nullptr, u64* __restrict__ T256 = nullptr) {
+                                                              float* __restrict__ Bfr, int dmax,
+                                                              float* __restrict__ Bf4, u64* __restrict__ T256) {
     constexpr int OSCT_THREADS = osct_threads(TO);
     __shared__ u64 wsum[OSCT_THREADS / 64];
     light_wave_priority();
@@ -627,12 +626,9 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
             const int q = 4 * kk + (lane >> 4) - (lane & 15);
             // forward: tap of branch ph at d = dmin + q; backward (transposed FIR, osc_fused_bwd_kernel): at d = dmax - q.
             // The forward leaves both behind: a backward handed the untouched workspace needs no totals launch of its own.
-            if (Bf || Bf4) {
+            if (Bf4) {   // osc_fused2 reads four K-steps of a lane as one 16-byte word: [(ph * KS/4 + kk/4) * 64 + lane][kk % 4]
                 const int d = dmin + q, k = half + 4 * d + ph;
-                const float v = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
-                if (Bf) Bf[e] = v;
-                // osc_fused2 reads four K-steps of a lane as one 16-byte word: [(ph * KS/4 + kk/4) * 64 + lane][kk % 4]
-                if (Bf4) Bf4[(((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3)] = v;
+                Bf4[(((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3)] = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
             }
             if (Bfr) {
                 const int d = dmax - q, k = half + 4 * d + ph;
@@ -1819,7 +1815,7 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         float* Bf4 = (float*)((char*)ws + g.off_bf4);
         u64* T256 = (u64*)((char*)ws + g.off_t256);
         hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
-                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, Bfr, f2.dmax, Bf4, T256);
+                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, Bfr, f2.dmax, Bf4, T256);
         GOLF_LAUNCH_CHECK();
 #define GOLF_FUSED2(EE, KSV, TOV, NTHV)                                                                               \
     do {                                                                                                              \
@@ -1917,7 +1913,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
                                      f2.ntile2 == ntile2 && f2.KS == KS && f2.dmax == dmax;
             if (!have_totals) {
                 hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                                   g.P, os, ntile2, taps, K, dmin, KS, (float*)nullptr, Bf, dmax, (float*)nullptr);
+                                   g.P, os, ntile2, taps, K, dmin, KS, Bf, dmax, (float*)nullptr, (u64*)nullptr);
                 GOLF_LAUNCH_CHECK();
             }
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \
