@@ -605,8 +605,12 @@ def main():
             if _GFm.SS_THROUGHPUT_SERIAL_MIN <= B < 2048 and args.lpc_mode == "auto":
                 # with batches in flight the filter takes the serial kernels from B = 512, a lone batch the chunked scan up to
                 # 2048: two algorithms, equal to rounding (each within the tests' bound of the float64 oracle), not bit for bit
-                err = float((y_lat - outs[0]).abs().max() / outs[0].abs().max())
-                assert err < 2e-4, f"latency (chunked) and throughput (serial) plans differ by {err:.2e}"
+                # (per utterance: on the recipe's ill-conditioned utterances two correct fp32 evaluations differ by more than
+                #  1e-4 -- the tests bound each by 2 - 3 x the sequential recursion's own error against float64)
+                rows = (y_lat - outs[0]).abs().amax(1) / outs[0].abs().amax(1).clamp_min(1e-30)
+                med, q90, worst = (float(v) for v in (rows.median(), rows.quantile(0.9), rows.max()))
+                assert med < 1e-4 and q90 < 3e-4 and worst < 2e-2, \
+                    f"latency (chunked) and throughput (serial) plans differ: median {med:.2e}, 90 % {q90:.2e}, worst row {worst:.2e}"
             else:
                 assert torch.equal(y_lat, outs[0]), "latency and throughput chains differ"
             _GFm.THROUGHPUT_MODE = throughput_chain
