@@ -617,6 +617,10 @@ def main():
     # replay streams are created after capture: ROCm maps streams round-robin onto a few hardware queues, and
     # streams that alias one queue serialise (measured: 131 vs 105 us/step at S=4 depending on creation order)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
+    # rocm-smi's figures BEFORE the set-up replays and the warm-up: the tool takes most of a second, and a second of idle device
+    # in front of the first timed regions put them at the top of the post-idle transient (unsettled 79 - 84 us/step instead of the
+    # 72 - 75 the same protocol read in round 4)
+    clocks_before = smi_clocks() if rank == 0 else None
     if use_graphs:   # setup, not steps: upload every executable graph and bring the device out of its idle state
         for _ in range(max(0, args.prereplay)):
             for i in range(S):
@@ -693,7 +697,6 @@ def main():
     drain()
     # the protocol of rounds 1 - 3: the timed regions straight after --warmup (reported as ms_per_step_unsettled); the headline's
     # regions follow the settling regions below.  Both are in the line so that rounds stay comparable.
-    clocks_before = smi_clocks() if rank == 0 else None
     regions_unsettled = timed_regions(args.repeats)
     settle = []
     for _ in range(max(0, args.settle)):   # untimed regions through the timed path (see --settle)
@@ -921,7 +924,7 @@ def main():
             "ms_per_step_unsettled": ms_unsettled,   # the same regions straight after --warmup: the protocol of rounds 1 - 3
             "timing": {"regions": len(regions), "statistic": "median region wall time (max over ranks per region)",
                        "effective_warmup_steps": int(effective_warmup),
-                       "smi_before_first_region": clocks_before, "smi_after_last_region": clocks_after,
+                       "smi_before_setup_replays": clocks_before, "smi_after_last_region": clocks_after,
                        "ms_per_step_regions_unsettled_wall": [round(w / args.steps * 1e3, 5) for w, _ in regions_unsettled],
                        "ms_per_step_regions_wall": [round(w / args.steps * 1e3, 5) for w, _ in regions],
                        "ms_per_step_regions_hip_events": [round(e / args.steps * 1e3, 5) for _, e in regions],

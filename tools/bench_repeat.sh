@@ -8,7 +8,7 @@ import json
 a = json.load(open("$O/run_$i.json")); t = a["timing"]
 print("run %2d  settled %6.2f  unsettled %6.2f  regions %s  sclk before/after %s / %s" % ($i, a["ms_per_step"] * 1e3, a["ms_per_step_unsettled"] * 1e3,
       [round(x * 1e3, 1) for x in t["ms_per_step_regions_wall"]],
-      {k: v for k, v in (t.get("smi_before_first_region") or {}).items() if "sclk" in k.lower() or "ower" in k},
+      {k: v for k, v in (t.get("smi_before_setup_replays") or {}).items() if "sclk" in k.lower() or "ower" in k},
       {k: v for k, v in (t.get("smi_after_last_region") or {}).items() if "sclk" in k.lower() or "ower" in k}))
 PY
 done 2>&1 | tee $O/summary.txt
