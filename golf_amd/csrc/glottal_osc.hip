@@ -637,36 +637,36 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
         }
     }
     const BufRow prow(phase + (size_t)b * phase_stride, Tp);
-    const double scale_a = 18446744073709551616.0 / (double)os;
-    const double scale_d = scale_a / (double)P;
-    const u64 tri = (u64)P * (u64)(P - 1) / 2;
-    // A pure reduction: any assignment of samples to threads will do, so consecutive lanes take consecutive samples
-    // (coalesced; the successor p_{j+1} is a second, cached, coalesced load).  Round 2 gave each thread 8 consecutive
-    // samples (lane stride 32 B: every load instruction touched all the wave's cache lines) on 256 threads: 1.47 ms at
-    // B = 16 384 where 512 threads x 4 consecutive samples already took 0.83 ms (tile-geometry experiment).
+    // A pure reduction over the tile.  A wave takes 256 CONSECUTIVE samples, so that its total is the total of one 256-sample
+    // stretch (osc_fused2's base phase is a sum of those), and a thread 4 consecutive ones: one 16-byte load + one dword for the
+    // successor of its last sample, 5 conversions for 4 segments.  (Round 2 - 4 form: lane-consecutive samples, p_j and p_{j+1}
+    // loaded and converted separately -- 8 loads and 8 conversions per thread, 190 VALU instructions per wave, 4.7 % of the
+    // B = 32 step's instructions in a kernel that only sums.  Only the fused kernels' configuration, os = P = 4, launches this.)
     constexpr int PER = TO / OSCT_THREADS;
-    static_assert(TO % OSCT_THREADS == 0, "tile = whole passes of the workgroup");
-    // (round 5: a wave takes PER x 64 CONSECUTIVE samples -- lane + 64 r inside its stretch -- so that its total is the total
-    //  of one 256-sample stretch of the 2048-sample tile: osc_fused3's waves start from those)
-    constexpr int RS = 64;                                  // sample stride between a thread's loads
-    const int j0 = tile * TO + (tid >> 6) * (PER * 64) + (tid & 63);
-    float p0[PER], p1[PER];
+    static_assert(PER == 4, "a thread's samples are one 16-byte word; a wave's, one 256-sample stretch");
+    (void)os; (void)P;
+    const int jq = tile * TO + (tid >> 6) * 256 + 4 * (tid & 63);
+    const bool edge = tile * TO + TO > Tp - 1;               // (uniform) the row ends in this tile: segments 0 .. Tp-2 advance the phase
+    float pq[4];
+    if (!edge) {
+        const auto q4 = __builtin_amdgcn_raw_buffer_load_b128(prow.rs, jq * 4, 0, 0);
 #pragma unroll
-    for (int r = 0; r < PER; ++r) {
-        const int j = j0 + r * RS;
-        p0[r] = prow.ld(min(j, Tp - 1));
-        p1[r] = prow.ld(min(j + 1, Tp - 1));
+        for (int r = 0; r < 4; ++r) pq[r] = __uint_as_float(q4[r]);
+    } else {                                                 // (dword loads: a 16-byte load that straddles the end of the row is not relied on)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pq[r] = prow.ld(jq + r);
     }
+    const float pn = prow.ld(jq + 4);
+    u64 av[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) av[r] = osc_fix_a_pow2(pq[r], 2);
+    av[4] = osc_fix_a_pow2(pn, 2);
     u64 tsum = 0;
 #pragma unroll
-    for (int r = 0; r < PER; ++r) {
-        if (j0 + r * RS >= Tp - 1) continue;   // segments 0 .. Tp-2 advance the phase
-        if (os == 4 && P == 4) {   // (the only configuration osc_fused_kernel serves; the same conversions as there)
-            const u64 a0 = osc_fix_a_pow2(p0[r], 2), a1 = osc_fix_a_pow2(p1[r], 2);
-            tsum += (a0 << 2) + osc_fix_d_pow2(a0, a1, 2) * (u64)6;
-        } else {
-            tsum += (u64)P * osc_fix_a(p0[r], scale_a) + osc_fix_d(p0[r], p1[r], scale_d) * tri;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const u64 d = osc_fix_d_pow2(av[r], av[r + 1], 2);
+        const u64 sg = ((av[r] + d) << 2) + (d << 1);        // 4 a + 6 d
+        tsum += (!edge || jq + r < Tp - 1) ? sg : 0;
     }
     const u64 incl = wave_incl_scan(tsum, tid & 63);
     if ((tid & 63) == 63) {
@@ -907,6 +907,7 @@ __device__ __forceinline__ void oscf2_body(
         unsigned hik[2][4];
         float rf0[2];
         u64 phn = ph;
+        const float x0 = (float)(4 * jb - r_first * hop_t) * inv_hop_t;   // control frames from r_first at the thread's first sample
         auto issue = [&](int r) {
             const int s = r & 1;
             // (the second difference and the segment total are recomputed from an opaque copy of the increment: kept from the
@@ -919,16 +920,21 @@ __device__ __forceinline__ void oscf2_body(
                 const int j = jb + r;
                 sg = (j >= 0 && j < Tp - 1) ? sg : 0;
             }
-            hik[s][0] = (unsigned)((phn + a) >> 32);
-            hik[s][1] = (unsigned)((phn + ((a << 1) + d)) >> 32);
-            hik[s][2] = (unsigned)((phn + ((t << 1) + t)) >> 32);
+            // the three fine phases inside the coarse sample -- ph + a, ph + 2 a + d, ph + 3 a + 3 d -- from the HIGH words alone: the
+            // carries out of the low words are at most 3 units of 2^-32 cycle (1.4e-6 table columns; the lookup is continuous in
+            // the phase), the running phase itself stays exact in 64 bits.  Four 32-bit adds instead of eight 64-bit operations.
+            const unsigned phi = (unsigned)(phn >> 32), ahi = (unsigned)(a >> 32), dhi = (unsigned)(d >> 32), thi = ahi + dhi;
+            (void)t;
+            hik[s][0] = phi + ahi;
+            hik[s][1] = hik[s][0] + thi;
+            hik[s][2] = hik[s][1] + thi + dhi;
             phn += sg;
             hik[s][3] = (unsigned)(phn >> 32);
             // control-frame position of the coarse sample's first fine sample: frames from r_first, integer + fraction
-            const float x = (float)(4 * (jb + r) - r_first * hop_t) * inv_hop_t;
-            const float xi = floorf(x);
-            rf0[s] = x - xi;
-            const unsigned rowaddr = pbase + (int)xi * row_bytes;
+            const float x = fmaf((float)r, 4.0f * inv_hop_t, x0);
+            rf0[s] = __builtin_amdgcn_fractf(x);
+            const int ri = (int)x;                   // (x >= 0 wherever the sample exists)
+            const unsigned rowaddr = pbase + (unsigned)(EDGE ? (ri < 0 ? 0 : ri) : ri) * (unsigned)row_bytes;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned c0 = hik[s][k] >> (32 - lshift);
