@@ -359,6 +359,31 @@ def test_fused_kernel_matches_three_kernel_path(Tp, w_hop, eq):
         assert err <= 5e-6, (Tp, w_hop, eq, a is not None, err)
 
 
+def test_fused_kernel_needs_an_aligned_table_and_falls_back_otherwise():
+    """osc_fused2 fetches the table rows as 16-byte words: a table whose storage starts off a 16-byte boundary (a view into a
+    larger buffer) takes the three-kernel path instead -- same result to the few 1e-7 the two paths differ by, no fault."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    rng = np.random.default_rng(3)
+    B, Tp, w_hop = 2, 6000, 2400
+    f0 = rng.uniform(80, 400, (B, 1)) * np.ones((1, Tp))
+    phase = dev((f0 / 24000).astype(np.float32))
+    w = dev(rng.uniform(0, 1, (B, 4)).astype(np.float32))
+    m = IndexedGlottalFlowTable(table_size=50, lf_v2=True, points=1024, oversampling=4, equal_energy=True)
+    table, taps = m.table.cuda().contiguous(), m.decimater.taps.cuda()
+    buf = torch.zeros(table.numel() + 1, device="cuda")
+    off = buf[1:].view_as(table)                    # same values, storage offset 4 bytes
+    off.copy_(table)
+    assert table.data_ptr() % 16 == 0 and off.data_ptr() % 16 == 4
+    a = GF.glottal_osc(phase, w, table, taps, 1, w_hop, 4, True)
+    b = GF.glottal_osc(phase, w, off, taps, 1, w_hop, 4, True)
+    torch.cuda.synchronize()
+    err = float((a - b).abs().max() / a.abs().max())
+    print(f"aligned (fused) vs misaligned (three-kernel) table: rel-max {err:.2e}")
+    assert torch.isfinite(b).all() and err <= 5e-6
+
+
 def test_fused_kernel_other_tap_counts():
     """193 taps (zeros = 24, kazane's default design length at q = 4): the 16-step Toeplitz instance; 257 taps exceed it
     and take the three-kernel path -- either way equal to the float64 oracle."""
