@@ -630,9 +630,10 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
                 const int d = dmin + q, k = half + 4 * d + ph;
                 Bf4[(((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3)] = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
             }
-            if (Bfr) {
+            if (Bfr) {   // (the same 16-byte layout)
                 const int d = dmax - q, k = half + 4 * d + ph;
-                Bfr[e] = (q >= 0 && d >= dmin && d <= dmax && k >= 0 && k < K) ? taps[k] : 0.f;
+                Bfr[(((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3)] =
+                    (q >= 0 && d >= dmin && d <= dmax && k >= 0 && k < K) ? taps[k] : 0.f;
             }
         }
     }
@@ -682,8 +683,6 @@ __global__ __launch_bounds__(osct_threads(TO)) void osc_tile_totals_kernel(const
     }
 }
 
-// signal tile: polyphase branch ph, coarse index i  ->  X[ph * XS + i + 4 * (i >> 4)]
-__device__ __forceinline__ int oscf_xaddr(int i) { return i + 4 * (i >> 4); }
 
 #ifdef OSCF_TIMING   // dev build (tools/osc_phases.py): s_memtime stamps of the workgroup's phases, thread 0 of every workgroup
 __device__ unsigned long long g_oscf_stamps[8 * 4096];
@@ -1064,6 +1063,49 @@ __global__ __launch_bounds__(NTH, 4) void osc_fused2_kernel(
 //      part[b][tile][row].  osc_wsel_reduce_tiles_kernel adds the tiles' rows into g_wsel.
 // Replaces osc_phase_tile + osc_decimate_T4 + osc_render<1> (46 us and a 12 MB prefix + a 24 MB oversampled gradient on a
 // round trip through HBM at B = 32) for the GOLF configuration; everything else keeps the three-kernel path.
+// Toeplitz fragments of the taps as osc_tile_totals_kernel lays them out: four K-steps of a lane per 16-byte word
+template <int KS>
+__device__ __forceinline__ void osc_load_frags4(const float* __restrict__ Bf4, int lane, float (&bfrag)[4][KS]) {
+#pragma unroll
+    for (int phs = 0; phs < 4; ++phs)
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Bf4 + (((phs * (KS / 4) + q) * 64 + lane) << 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfrag[phs][4 * q + j] = v[j];
+        }
+}
+
+// difference rows D_k = T[i0_k + 1] - T[i0_k] of control frames r_first .. r_first + NR - 1 -> LDS rows of LR floats
+template <int NR, int NTH>
+__device__ __forceinline__ void oscb_stage_rows(const float* __restrict__ wrow, int Fw, const float* __restrict__ table, int n_tab,
+                                                int L, int r_first, int nrw, float* rows, int LR, int tid) {
+    const float* t0[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        int k = r_first + (e < nrw ? e : nrw - 1);
+        if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
+        const float idx = wrow[k] * (float)(n_tab - 1);
+        int i0 = __builtin_amdgcn_readfirstlane((int)idx);
+        i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
+        t0[e] = table + (size_t)i0 * L;
+    }
+    for (int c4 = tid; 4 * c4 < L; c4 += NTH) {
+        f32x4_t va[NR], vb[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            va[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + 4 * c4);
+            vb[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + L + 4 * c4);
+        }
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            const f32x4_t dv = vb[e] - va[e];
+            *reinterpret_cast<f32x4_t*>(rows + (size_t)e * LR + 4 * c4) = dv;
+            if (c4 == 0) rows[(size_t)e * LR + L] = dv[0];   // column L = wrap-around copy of column 0
+        }
+    }
+}
+
 #define OSCB_TO 2048          // the backward's own tile geometry (independent of the forward's build parameters)
 #define OSCB_THREADS 512
 #define OSCB_CPT (OSCB_TO / OSCB_THREADS)
@@ -1076,27 +1118,24 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
     constexpr int P = 4, NTH = OSCB_THREADS, CPT = OSCB_CPT;
     static_assert(OSCB_TO == 2048 && OSCB_THREADS == 512, "4 consecutive coarse samples per thread, 8 waves x 256 outputs");
     constexpr int spanY = OSCB_TO + 4 * KS;                     // gradient samples the windows reach
-    constexpr int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;  // padded like the forward's signal tile
+    constexpr int YS = (spanY + 2 * (spanY >> 4) + 2 + 3) & ~3;  // padded like the forward's signal tile: i + 2 * (i >> 4)
     constexpr int GR = 20;                                       // words per thread row of the fine-gradient tile: 16 + 4, so
     // that a thread reads its row as four 16-byte words and 16 consecutive lanes cover all 64 banks exactly once
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u64 wtot[NTH / 64];
     __shared__ u64 base_sh;
     __shared__ float red[OSCF_MAXROWS][NTH / 64];
-    // layout: Y [YS] | G [NTH][17] | difference rows [nrows][L + 1]
+    // layout: Y [YS] | G [NTH][20] | difference rows [nrows][L + 4] (column L = column 0; rows 16-byte aligned)
     float* Y = smem;
     float* G = smem + YS;
     float* rows = G + NTH * GR;
-    const int LR = L + 1;
+    const int LR = L + 4;
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int o0 = tile * OSCB_TO;
     // ---- 0. reversed Toeplitz fragments (osc_tile_totals_kernel, reversed = 1)
     float bfrag[4][KS];
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bfrag[ph][kk] = Bf[(ph * KS + kk) * 64 + lane];
+    osc_load_frags4<KS>(Bf, lane, bfrag);            // 12 - 16 loads of 16 bytes (round 5; were 48 - 64 dword loads)
     // ---- 1. base phase, own phase samples, gradient tile, difference rows
     if (wv == 0) {
         u64 acc = 0;
@@ -1124,7 +1163,7 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < NY; ++q) {
             const int v = tid + q * NTH, o = o0 - dmax + v;
-            if (v < spanY) Y[oscf_xaddr(v)] = o >= 0 ? xv[q] : 0.f;
+            if (v < spanY) Y[oscf2_xaddr(v)] = o >= 0 ? xv[q] : 0.f;
         }
     }
     const int m_first = o0 * P;
@@ -1132,45 +1171,12 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
     {
         const int m_last = min(o0 + OSCB_TO - 1, Tp - 1) * P + (P - 1);
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);
-        const float* t0[OSCF_MAXROWS];
-        float wsv[OSCF_MAXROWS];                                 // (all four weights in flight before the first readfirstlane)
-#pragma unroll
-        for (int e = 0; e < OSCF_MAXROWS; ++e) {
-            int k = r_first + (e < nrw ? e : nrw - 1);
-            if (k > Fw - 1) k = Fw - 1;
-            wsv[e] = wsel[(size_t)b * Fw + k];
-        }
-#pragma unroll
-        for (int e = 0; e < OSCF_MAXROWS; ++e) {
-            const float idx = wsv[e] * (float)(n_tab - 1);       // (replicate-padded frames: k clamped above)
-            int i0 = __builtin_amdgcn_readfirstlane((int)idx);
-            i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
-            t0[e] = table + (size_t)i0 * L;
-        }
-        constexpr int SU = 4;                                    // all loads of a batch in flight before the first store
-        for (int cb0 = 0; cb0 < L; cb0 += SU * NTH) {
-            float dvv[OSCF_MAXROWS][SU];
-#pragma unroll
-            for (int e = 0; e < OSCF_MAXROWS; ++e)
-                if (e < nrw) {                                   // uniform
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int c = cb0 + u * NTH + tid;
-                        const int cc = c < L ? c : 0;
-                        dvv[e][u] = t0[e][L + cc] - t0[e][cc];
-                    }
-                }
-#pragma unroll
-            for (int e = 0; e < OSCF_MAXROWS; ++e)
-                if (e < nrw) {
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int c = cb0 + u * NTH + tid;
-                        if (c < L) rows[(size_t)e * LR + c] = dvv[e][u];
-                        if (c == 0) rows[(size_t)e * LR + L] = dvv[e][u];   // column L = wrap-around copy of column 0
-                    }
-                }
-        }
+        // difference rows D_k = T[i0_k + 1] - T[i0_k] as 16-byte loads and stores, every row's loads in flight together (rows
+        // beyond nrw repeat row nrw - 1: never read by a sample that exists) -- the forward's staging, round 5
+        const float* wrow = wsel + (size_t)b * Fw;
+        if (nrows <= 2)      oscb_stage_rows<2, NTH>(wrow, Fw, table, n_tab, L, r_first, nrw, rows, LR, tid);
+        else if (nrows == 3) oscb_stage_rows<3, NTH>(wrow, Fw, table, n_tab, L, r_first, nrw, rows, LR, tid);
+        else                 oscb_stage_rows<4, NTH>(wrow, Fw, table, n_tab, L, r_first, nrw, rows, LR, tid);
     }
     // ---- 2. phase scan: thread owns coarse samples u0 .. u0 + 3
     u64 av[CPT + 1], dv[CPT], tv[CPT];
@@ -1194,10 +1200,10 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
         f32x4_t acc[4];
 #pragma unroll
         for (int phs = 0; phs < 4; ++phs) acc[phs] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const float* ap = Y + 320 * wv + 20 * li + lk;           // A[m = li][k' = 4 kk + lk]: see the forward
+        const float* ap = Y + 288 * wv + 18 * li + lk;           // A[m = li][k' = 4 kk + lk]: see the forward
         float a[KS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a[kk] = ap[4 * kk + 4 * (kk >> 2)];
+        for (int kk = 0; kk < KS; ++kk) a[kk] = ap[4 * kk + 2 * (kk >> 2)];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -1227,9 +1233,10 @@ __global__ __launch_bounds__(OSCB_THREADS) void osc_fused_bwd_kernel(
         const int j = o0 + u0 + r;
         const u64 ph_next = ph + tv[r];
         const float p0 = pv[r], p1 = pv[r + 1];
-        const u64 c2 = (av[r] << 1) + dv[r], c3 = c2 + av[r] + (dv[r] << 1);
-        const unsigned hik[P] = {(unsigned)((ph + av[r]) >> 32), (unsigned)((ph + c2) >> 32),
-                                 (unsigned)((ph + c3) >> 32), (unsigned)(ph_next >> 32)};
+        // (the three fine phases inside the coarse sample from the high words alone, as in the forward: <= 3 units of 2^-32 cycle)
+        const unsigned phi = (unsigned)(ph >> 32), ahi = (unsigned)(av[r] >> 32), dhi = (unsigned)(dv[r] >> 32), thi = ahi + dhi;
+        const unsigned h0 = phi + ahi, h1 = h0 + thi, h2 = h1 + thi + dhi;
+        const unsigned hik[P] = {h0, h1, h2, (unsigned)(ph_next >> 32)};
         const int m0 = j * P;
         const int rr = (m0 >= bnd1) + (m0 >= bnd2);
         const float* ra = rows + (size_t)rr * LR;
@@ -1901,10 +1908,10 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
         const int nint_touched = (OSCB_TO * 4 - 2) / g.hop_t + 2;
         const int nrows = nint_touched + 1;
         const int spanY = OSCB_TO + 4 * KS;
-        const int YS = (spanY + 4 * (spanY >> 4) + 4 + 3) & ~3;
-        const size_t ldsb = sizeof(float) * ((size_t)YS + (size_t)OSCB_THREADS * 20 + (size_t)nrows * (L + 1));
+        const int YS = (spanY + 2 * (spanY >> 4) + 2 + 3) & ~3;
+        const size_t ldsb = sizeof(float) * ((size_t)YS + (size_t)OSCB_THREADS * 20 + (size_t)nrows * (L + 4));
         const int ntile2 = (int)ceil_div(Tp, OSCB_TO);            // tiles of COARSE SAMPLES here (Tp = Tout at hop 1)
-        if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && ldsb <= 80 * 1024 && ntile2 <= g.ntile &&
+        if (nq + 15 <= 64 && nrows <= OSCF_MAXROWS && ldsb <= 80 * 1024 && ntile2 <= g.ntile && L >= 8 && !((uintptr_t)table & 15) &&
             sizeof(float) * (size_t)B * ntile2 * OSCF_MAXROWS <= sizeof(float) * (size_t)B * g.pre_stride) {
             const int lshift = 31 - __builtin_clz((unsigned)L);
             u64* Ttot = (u64*)((char*)ws + g.off_ttot);
