@@ -49,7 +49,7 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
     g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused backward (transposed FIR)
     g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused forward, four K-steps per 16-byte word (osc_fused2)
-    g->off_t256 = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * ((size_t)g->ntile * 4 + 8), 256);   // phase advance per 256-sample stretch (osc_fused3)
+    g->off_t256 = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * ((size_t)g->ntile * 4 + 8), 256);   // phase advance per 256-sample stretch (osc_fused2's base phase)
     g->total = o;
 }
 
