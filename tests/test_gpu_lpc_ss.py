@@ -372,6 +372,28 @@ def test_large_batch_defaults_to_serial_and_matches_chunked():
     assert torch.equal(y[:32], y[-32:])          # identical rows -> identical results whatever wave they ran in
 
 
+@pytest.mark.parametrize("B,F,M,hop", [(37, 9, 22, 240), (8200, 5, 22, 240), (45, 30, 12, 24), (21, 6, 30, 256)])
+def test_serial_kernels_eight_lanes_and_quads(B, F, M, hop):
+    """The batch-parallel serial forward in both of its forms (round 5): eight lanes per utterance while that leaves at most one
+    wave per SIMD (B <= 8192: 37 utterances = a ragged last wave of 5 of 8 rows), a quad beyond (B = 8200), other ring widths
+    (W = 24 with 12 taps: two per lane; W = 32 with 30 taps: four per lane) -- every row against the float64 oracle, rows being
+    tiled copies of a small batch so that the oracle stays cheap, and equal rows giving equal results whatever wave ran them."""
+    from oracle import golf_oracle as O
+
+    nb = min(B, 8)
+    ex, gain, a = smooth_case(nb, F, M, hop, seed=B + M, walk=0.01)
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    rep = (B + nb - 1) // nb
+    tile = lambda x: np.tile(x, (rep,) + (1,) * (x.ndim - 1))[:B]
+    y = run_mode(tile(ex), tile(gain), tile(a), hop, "serial")
+    assert y.shape == (B, ref.shape[1])
+    for lo in (0, (B // nb - 1) * nb):
+        check(y[lo:lo + nb], ref, f"serial B={B} M={M} hop={hop} rows {lo}..{lo + nb - 1}")
+    assert np.array_equal(y[:nb], y[(B // nb - 1) * nb:(B // nb) * nb])
+    if B % nb:
+        check(y[(B // nb) * nb:], ref[:B % nb], "the ragged tail")
+
+
 @pytest.mark.parametrize("B,F,M,hop", [(3, 520, 12, 24), (2, 1500, 4, 8), (2, 800, 14, 16), (5, 60, 22, 240),
                                        (2, 210, 20, 240), (2, 65, 22, 240), (3, 49, 16, 240), (2, 60, 22, 256),
                                        (2, 400, 22, 40), (2, 80, 16, 160)])
