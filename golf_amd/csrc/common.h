@@ -45,6 +45,7 @@ struct SsPlan {
     size_t off_tier, off_S1, off_status, off_phi64, off_fixcnt;
     size_t off_m64, off_v64, off_g64;   // tier 3 on the two-level path: fp64 group composites, group responses, group start states
     size_t off_mtT, off_L1, off_wadj, off_dadj;   // backward: two-level adjoint scan
+    size_t off_gflag;   // merged chunk pass (lpc_fwdq2m_kernel): [B][NG] "defect response published" + [B] "fp64 states ready" words
 };
 bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode = 0);
 int ss_serial_min_batch();

@@ -100,6 +100,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
         p->off_tier = p->off_S1 = p->off_status = p->off_phi64 = p->off_fixcnt = 0;
         p->off_m64 = p->off_v64 = p->off_g64 = 0;
         p->off_mtT = p->off_L1 = p->off_wadj = p->off_dadj = 0;
+        p->off_gflag = 0;
         p->off_g = o;    o = align_up(o + sizeof(float) * (size_t)B * T, 256);
         p->off_pa = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2 * W, 256);
         p->off_pg = o;   o = align_up(o + sizeof(float) * (size_t)B * p->NSEG * 2, 256);
@@ -146,6 +147,7 @@ bool make_ss_plan(int B, int T, int F, int M, int hop, SsPlan* p, int mode) {
     p->off_m64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG > 0 ? p->NG : 1) * p->NT * W, 256);
     p->off_v64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG > 0 ? p->NG : 1) * 32, 256);
     p->off_g64 = o;  o = align_up(o + sizeof(double) * (size_t)B * (p->NG + 1) * 32, 256);
+    p->off_gflag = o; o = align_up(o + sizeof(unsigned) * (size_t)B * (p->NG + 1), 256);   // zeroed by every forward's pre-pass launch
     p->total = o;
     return true;
 }
@@ -364,6 +366,7 @@ __device__ __forceinline__ void fwdq_body(const float* __restrict__ ex, int64_t 
                 if constexpr (MODE == 3) {
                     v -= lst[(row + 1) * 32 + i];
                     ldl[row * 32 + i] = v;
+                    if (!out) continue;   // wave-uniform (merged chunk pass: the defects stay in LDS)
                 }
                 if constexpr (MODE == 0) {   // zero-state pass inside the pre-pass launch: z also stays in LDS for the group scan
                     if (ldl) ldl[row * 32 + i] = v;
@@ -1580,6 +1583,7 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the chunk kernels
+template <int W> constexpr int kMapRow = W + 4;   // row stride of a group's maps kept in LDS (lpc_fwdq2m_kernel), in words
 // prefetch depths of the two-level prologues (maps fetched ahead of the matvec that uses them): chunk maps / composites
 // (measured round 4: 8 + 8 and 6 + 8 deep were slower -- the prologue's matvec steps are issue-bound, not fetch-bound)
 constexpr int kPrefetchMaps = 6, kPrefetchComposites = 4;
@@ -2000,7 +2004,10 @@ template <int W, int NT>
 __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi64, const float* __restrict__ z,
                                                   double* __restrict__ M64, double* __restrict__ V64,
                                                   double* __restrict__ G64, unsigned* __restrict__ arrived, int b, int g,
-                                                  int NP, int NG, int lane, int B, float* __restrict__ S1) {
+                                                  int NP, int NG, int lane, int B, float* __restrict__ S1,
+                                                  unsigned* __restrict__ ready = nullptr) {
+    // ready (merged chunk pass): word b is set once the utterance's group start states (or flat-scan states) are in memory --
+    // the utterance's chunk waves of the SAME launch wait for it
     const double* P64b = Phi64 + (size_t)b * NP * NT * W;
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     double* m64 = M64 + ((size_t)b * NG + g) * NT * W;
@@ -2028,6 +2035,10 @@ __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi
     else
         precise_scan_range<W, NT, double, double>(M64 + (size_t)b * NG * NT * W, V64 + (size_t)b * NG * 32, 32,
                                                    G64 + (size_t)b * (NG + 1) * 32, 32, NG, lane, (const double*)nullptr);
+    if (ready) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(ready + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Group-local scan from a zero state: v = zero-state response of the group's chunk maps to the inputs x ([b][NP][W]).
@@ -2067,21 +2078,28 @@ __device__ __forceinline__ void group_zscan_body(const float* __restrict__ PhiT,
 // Group-local scan from a zero state with the inputs in LDS (x[k][32], k = chunk of the group): v = the response of the
 // group's chunk maps -> V[b][g].  Epilogue of the refinement pass (inputs = its defects) and of the zero-state units that
 // run inside the pre-pass launch (inputs = their z).
-template <int W, int NT, int D = 4>
+template <int W, int NT, int D = 4, bool FROMLDS = false, bool WT = false>
 __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, const float* __restrict__ xl,
-                                               float* __restrict__ Vout, int b, int g, int NP, int NG, int lane) {
+                                               float* __restrict__ Vout, int b, int g, int NP, int NG, int lane,
+                                               const float* mapl = nullptr) {
+    // FROMLDS: the group's maps were left in LDS by the prologue (group_prologue MAPIO 1): row ii of map k at mapl[(k * NT + ii) * kMapRow]
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
     const int c0 = g * kGroup;
     const size_t cstride4 = (size_t)NT * W / 4;
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
+    const float4* lrows = reinterpret_cast<const float4*>(mapl) + ii * (kMapRow<W> / 4);
+    auto row4 = [&](int cl, int k) -> float4 {
+        if constexpr (FROMLDS) return lrows[(cl - c0) * (NT * kMapRow<W> / 4) + k];
+        else                   return rows[(size_t)cl * cstride4 + k];
+    };
     const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
     float4 pb[D][W / 4];   // D maps ahead
 #pragma unroll
     for (int u = 0; u < D; ++u) {
         const int cl = c0 + u < c1 ? c0 + u : c1 - 1;
 #pragma unroll
-        for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
+        for (int k = 0; k < W / 4; ++k) pb[u][k] = row4(cl, k);
     }
     float s = 0.f;
     for (int cb = c0; cb < c1; cb += D) {
@@ -2091,11 +2109,15 @@ __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, c
                 s = matvec_step<W, NT>(pb[u], s, xl[(cb + u - c0) * 32 + ii], act);
                 const int cn = cb + u + D < c1 ? cb + u + D : c1 - 1;
 #pragma unroll
-                for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cn * cstride4 + k];
+                for (int k = 0; k < W / 4; ++k) pb[u][k] = row4(cn, k);
             }
         }
     }
-    if (lane < 32) Vout[((size_t)b * NG + g) * 32 + lane] = s;
+    if constexpr (WT) {   // written THROUGH to memory (agent-scope store): read by other waves of the same launch
+        if (lane < 32) __hip_atomic_store(Vout + ((size_t)b * NG + g) * 32 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lane < 32) Vout[((size_t)b * NG + g) * 32 + lane] = s;
+    }
 }
 
 // Both pre-passes of the two-level scan AND the fix-up of hot chunk maps in ONE launch (they depend only on the transition
@@ -2121,6 +2143,8 @@ __device__ __forceinline__ void group_scan_lds(const float* __restrict__ PhiT, c
 // rate; with all its workgroups leading this grid, 7 us), and a hot one pays about one fix-up pass inside this launch.
 struct ZPassArgs {            // the zero-state pass of `parts` bit 2 (fwdq_body MODE 0)
     const float* ex; int64_t ex_stride; const float* gain; int T;
+    // merged chunk pass (lpc_fwdq2m_kernel) next in the stream: its flag words and the non-finite status word start at zero
+    unsigned* gflag; int ngflag; unsigned* nonfinite;
 };
 template <int W, int NT>
 struct PrepassLds {           // one workgroup is a fix-up, a zero-state or a composite workgroup: the regions overlap
@@ -2142,6 +2166,10 @@ __global__ __launch_bounds__(256) void lpc_group_prepass_kernel(const float* __r
     unsigned short (*hot_lds)[kHotListMax] = reinterpret_cast<unsigned short (*)[kHotListMax]>(lds_raw);
     double* pb_lds = reinterpret_cast<double*>(lds_raw + PL::HOT);
     light_wave_priority();
+    if (zp.gflag && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < zp.ngflag; i += 256) zp.gflag[i] = 0u;
+        if (threadIdx.x == 0 && zp.nonfinite) zp.nonfinite[0] = 0u;
+    }
     const bool fix = fa.pmax != nullptr && (parts & 1);   // (no fix-up at all: diagnostic switch GOLF_SS_NO_FIXUP)
     const int nu = NG * B;
     const int nf1 = fix ? B * KF1 : 0, nz = (parts & 2) ? (nu + 3) / 4 : 0, nc = (parts & 1) ? nu : 0;
@@ -2220,11 +2248,18 @@ extern "C" int golf_debug_fwdq2_stamps(unsigned long long* host_out, int n) {
 // Prologue of the two-level chunk kernels: start states of the wave's chunks c0 .. c0+16 -> st[17][32] (LDS).
 //   t = fold of (M_g', v_g') over the groups before g, then the wave's own chunk maps with inputs x
 //   (first pass: v = zero-state group responses, x = z; correction pass: v = the groups' responses to the defects, x = defects).
-template <int W, int NT, bool THIN = false>
+//   SAMEK (merged chunk pass, lpc_fwdq2m_kernel): the group responses V ([g'][32], this utterance's) and the inputs x of the own
+//   maps ([k][32]) are in LDS; `pre` runs between the first map fetches and the fold.
+struct NoWait { __device__ __forceinline__ void operator()() const {} };
+//   MAPIO 1: the own maps' rows are also left in LDS (mapl[k][NT][W + 4], the lane's row where the lane will look for it: with the
+//   4 words of padding sixteen lanes' 16-byte accesses fall on 64 different banks for every ring width) for the
+//   stages that need them again; MAPIO 2: they are taken from there (no global fetch: a CU pulls ~11 B/cycle, so four waves
+//   re-streaming 34 KB each cost ~5 us per stage however deep the prefetch).
+template <int W, int NT, bool THIN = false, bool SAMEK = false, typename PRE = NoWait, int MAPIO = 0>
 __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, const float* __restrict__ MT,
-                                               const float* __restrict__ V, const float* __restrict__ x,
+                                               const float* V, const float* x,
                                                float* __restrict__ st, int b, int g, int NP, int NG, int lane,
-                                               unsigned long long* fqs = nullptr) {
+                                               unsigned long long* fqs = nullptr, PRE pre = PRE(), float* mapl = nullptr) {
     const bool act = lane < NT;
     const int ii = act ? lane : 0;
     const size_t cstride4 = (size_t)NT * W / 4;
@@ -2232,24 +2267,30 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
     // the wave's own chunk maps: first fetches issued before the fold below, so they are in flight during it
     // THIN (GOLF_SS_THROUGHPUT): 4 + 2 maps ahead instead of 6 + 4 -- 196 / 246 VGPRs instead of 290 / 269, so that two chunk-pass
     // waves (or one and a transition wave) share a SIMD's registers; costs a lone batch ~1.3 us per pass (tools/ab2.sh ab_regs)
-    constexpr int DC = THIN ? 4 : kPrefetchMaps;
+    constexpr int DC = MAPIO == 2 ? 2 : THIN ? 4 : kPrefetchMaps;
+    float4* mapl4 = reinterpret_cast<float4*>(mapl) + ii * (kMapRow<W> / 4);   // the lane's row of map k at + k * NT * kMapRow / 4
     const float4* rows = reinterpret_cast<const float4*>(PhiT + ((size_t)b * NP * NT + ii) * W);
-    const float* xb = x + (size_t)b * NP * W + ii;
+    const float* xb = SAMEK ? x : x + (size_t)b * NP * W + ii;
     const int c0 = g * kGroup;
     float4 pb[DC][W / 4];
     float xx[DC];
     auto fetchc = [&](int u, int c) {
         const int cl = c < NP ? c : NP - 1;
 #pragma unroll
-        for (int k = 0; k < W / 4; ++k) pb[u][k] = rows[(size_t)cl * cstride4 + k];
-        xx[u] = xb[(size_t)cl * W];
+        for (int k = 0; k < W / 4; ++k) {
+            if constexpr (MAPIO == 2) pb[u][k] = mapl4[(cl >= c0 ? cl - c0 : 0) * (NT * kMapRow<W> / 4) + k];
+            else                      pb[u][k] = rows[(size_t)cl * cstride4 + k];
+        }
+        if constexpr (SAMEK) xx[u] = x[(cl >= c0 ? cl - c0 : 0) * 32 + ii];
+        else                 xx[u] = xb[(size_t)cl * W];
     };
 #pragma unroll
     for (int u = 0; u < DC; ++u) fetchc(u, c0 + u);
+    pre();   // (SAMEK: the wait for the groups before this one, behind the map fetches just issued; leaves their responses in V)
     {   // (a) the groups before this one
         constexpr int D = THIN ? 2 : kPrefetchComposites;
         const float4* mrows = reinterpret_cast<const float4*>(MT + ((size_t)b * NG * NT + ii) * W);
-        const float* vb = V + (size_t)b * NG * 32 + ii;
+        const float* vb = SAMEK ? V + ii : V + (size_t)b * NG * 32 + ii;
         float4 mb[D][W / 4];
         float vv[D];
         auto fetch = [&](int u, int gg) {
@@ -2279,6 +2320,10 @@ __device__ __forceinline__ void group_prologue(const float* __restrict__ PhiT, c
             const int c = c0 + k;
             if (lane < 32) st[k * 32 + lane] = t;
             if (c < NP) t = matvec_step<W, NT>(pb[u], t, xx[u], act);   // wave-uniform
+            if constexpr (MAPIO == 1) {
+#pragma unroll
+                for (int q = 0; q < W / 4; ++q) mapl4[k * (NT * kMapRow<W> / 4) + q] = pb[u][q];
+            }
             if (k + DC < kGroup) fetchc(u, c + DC);
         }
         if (lane < 32) st[kGroup * 32 + lane] = t;
@@ -2427,6 +2472,163 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
         group_scan_lds<W, NT>(PhiT, dl, V2out, b, g, NP, NG, lane);
     }
     FQ_STAMP(fqs, 5);
+}
+
+// Round 5: refinement pass AND final pass in ONE launch (the third read of the 13.5 MB of chunk maps, the second
+// read of the excitation, the S1 / defect round trips through HBM and a launch).  A wave keeps its 16 chunks for both sweeps:
+//   phase A = MODE 3 above (first-pass states S1 -> LDS, re-run of the chunks, defects -> LDS, the group's response to them ->
+//             Vd[b][g], then ONE release + flag word (b, g));
+//   wait      for the flag words of the groups BEFORE g of the same utterance.  Those waves have lower workgroup ids (grid x = group,
+//             y = utterance) and are therefore dispatched first: whatever is waited for is resident or finished -- the look-back
+//             rule of single-pass scans.  They started together and did the same work, so the wait is short; it is bounded like
+//             wait_for_fixup (status word 2 bit 1 when it runs out);
+//   phase B = MODE 1 above: the same prologue on the defects (Vd read past the caches, the own defects from LDS; the maps and the
+//             excitation tile come from this XCD's L2, where phase A left them), S1 + delta, chunks -> y.
+// Tier-3 utterances: their fp64 jobs ride in the FIRST rows of the grid (dispatched before every wave that waits for them); the
+// wave that completes an utterance sets its `ready` word, which the utterance's chunk waves wait for before phase B.
+// The flag words are zeroed by the pre-pass launch of the same forward (as is the non-finite status word: here the pass that
+// raises it and the pass that used to clear it are one launch).
+constexpr int kMergedMaxGroups = 32;   // (the waiting wave stages the earlier groups' responses in LDS: 128 bytes each)
+template <int W, int NT>
+__global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2m_kernel(
+    const float* __restrict__ ex, int64_t ex_stride, const float* __restrict__ gain, const float* __restrict__ a,
+    float* __restrict__ y, int64_t y_stride, int T, int F, int M, int hop, int L, int NC, const float* __restrict__ PhiT,
+    const float* __restrict__ MT, const float* __restrict__ Vz, float* Vd, const float* __restrict__ z, int NP, int NG,
+    float* __restrict__ S1, const unsigned* __restrict__ tier, unsigned* __restrict__ nonfinite, int B,
+    const double* __restrict__ Phi64, double* __restrict__ M64, double* __restrict__ V64, double* __restrict__ G64,
+    unsigned* __restrict__ arrived, unsigned* gflag, unsigned* __restrict__ timeout_word) {
+    light_wave_priority();
+    using TL = Tile<W, 16>;
+    __shared__ float xt[TL::SIZE];
+    __shared__ float yt[TL::SIZE];
+    __shared__ float st[(kGroup + 1) * 32];
+    __shared__ float dl[kGroup * 32];
+    __shared__ float s1l[(kGroup + 1) * 32];
+    __shared__ float vdl[kMergedMaxGroups * 32];
+    // the group's maps, fetched ONCE and kept for the two stages that need them again (where they fit: not the 40-wide ring)
+    constexpr bool LM = kGroup * NT * kMapRow<W> * 4 <= 48 * 1024;
+    constexpr bool THIN = false;
+    __shared__ __attribute__((aligned(16))) float mapl[LM ? kGroup * NT * kMapRow<W> : 4];
+    const int lane = threadIdx.x;
+    const int nextra = (int)gridDim.y - B;
+    unsigned* ready = gflag + (size_t)B * NG;
+    if ((int)blockIdx.y < nextra) {   // fp64 boundary states of tier-3 utterances (see lpc_fwdq2_kernel), FIRST in dispatch order
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) record_scan_kind(tier, B, kScanTwoLevel);
+        const int w = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        const int nw = nextra * (int)gridDim.x;
+        for (int job = w; job < B * NG; job += nw) {
+            const int bp = job / NG;
+            if (tier3(tier, bp))   // wave-uniform
+                precise_group_job<W, NT>(Phi64, z, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, lane, B, S1, ready);
+        }
+        return;
+    }
+    const int b = (int)blockIdx.y - nextra, g = blockIdx.x;
+    const int c0 = g * kGroup;
+    const bool precise = tier3(tier, b);   // wave-uniform
+    float* s1b = S1 + (size_t)b * (NP + 1) * 32;
+    unsigned* fl = gflag + (size_t)b * NG;
+    auto timed_out = [&]() { if (lane == 0) atomicOr(timeout_word, 1u); };
+#ifdef FWDQ2_TIMING
+    unsigned long long* fqs = (b < 64 && g < 64) ? g_fq_stamps + ((size_t)b * 64 + g) * 8 : nullptr;
+#define FQM_STAMP(i) do { if (fqs && lane == 0) fqs[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FQM_STAMP(i) do { } while (0)
+#endif
+    FQM_STAMP(0);
+    if (!precise) {
+        // ---- phase A: first-pass states, chunks re-run from them, defects (see MODE 3 of lpc_fwdq2_kernel)
+        const bool fold_next = c0 + kGroup <= NP;   // wave-uniform
+        float4 mb[W / 4];
+        float vv = 0.f;
+        {
+            const int ii = lane < NT ? lane : 0;
+            const int gc = fold_next ? g : 0;
+            const float4* mrow = reinterpret_cast<const float4*>(MT + (((size_t)b * NG + gc) * NT + ii) * W);
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) mb[k] = mrow[k];
+            vv = Vz[((size_t)b * NG + gc) * 32 + ii];
+        }
+        group_prologue<W, NT, THIN, false, NoWait, LM ? 1 : 0>(PhiT, MT, Vz, z, st, b, g, NP, NG, lane, nullptr, NoWait(), mapl);
+        FQM_STAMP(1);
+        if (fold_next) {
+            const bool act = lane < NT;
+            const float t0 = lane < 32 ? st[lane] : 0.f;
+            const float t1 = matvec_step<W, NT>(mb, t0, vv, act);
+            if (lane < 32) st[kGroup * 32 + lane] = t1;
+            wave_lds_fence();
+        }
+        for (int e = lane; e < (kGroup + 1) * 32; e += 64) s1l[e] = st[e];
+        for (int e = lane; e < kGroup * 32; e += 64) dl[e] = 0.f;
+        wave_lds_fence();
+        if (g < NG) {   // (the final partial chunk in a group of its own, NP a multiple of 16, has no map and no defect)
+            fwdq_body<W, NT, 3, true>(ex, ex_stride, gain, a, nullptr, nullptr, (int64_t)0, T, F, M, hop, L, NP, 0, nullptr, xt,
+                                      nullptr, b, g, lane, st, dl, nullptr);
+            wave_lds_fence();
+            FQM_STAMP(2);
+            group_scan_lds<W, NT, LM ? 2 : 4, LM, true>(PhiT, dl, Vd, b, g, NP, NG, lane, mapl);
+            FQM_STAMP(3);
+            // (no agent-scope release: that is a write-back of this XCD's whole L2 -- with other batches' kernels on the chip,
+            //  of THEIR output; the 32 words went through to memory, the flag follows once they are acknowledged)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            if (lane == 0) __hip_atomic_store(fl + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FQM_STAMP(4);
+        // ---- phase B: the correction from the same prologue run on the defects, S1 + delta.  Between its first map fetches and
+        // its fold: the wait for the groups before this one, then their responses Vd -> LDS in ONE batch of agent-scope loads
+        // (each XCD has its own L2; as loads of the fold they sat in the in-order return queue in front of every map)
+        const int npred = g < NG ? g : NG;
+        auto wait_and_stage = [&]() {
+            for (unsigned it = 0u;; ++it) {
+                bool ok = true;
+                for (int l = lane; l < npred; l += 64)
+                    ok = ok && __hip_atomic_load(fl + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (it > (1u << 17)) { timed_out(); break; }
+            }
+            FQM_STAMP(5);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (ordering only)
+            const float* vsrc = Vd + (size_t)b * NG * 32;
+            float tmp[kMergedMaxGroups / 2];
+#pragma unroll
+            for (int u = 0; u < kMergedMaxGroups / 2; ++u) {
+                const int e = lane + 64 * u;
+                tmp[u] = e < npred * 32 ? __hip_atomic_load(vsrc + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kMergedMaxGroups / 2; ++u) vdl[lane + 64 * u] = tmp[u];
+            wave_lds_fence();
+        };
+        group_prologue<W, NT, THIN, true, decltype(wait_and_stage), LM ? 2 : 0>(PhiT, MT, vdl, dl, st, b, g, NP, NG, lane, nullptr,
+                                                                               wait_and_stage, mapl);
+        for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] += s1l[e];
+    } else {
+        for (unsigned it = 0u; __hip_atomic_load(ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) {
+            __builtin_amdgcn_s_sleep(8);
+            if (it > (1u << 16)) { timed_out(); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (__hip_atomic_load(arrived + 2 * B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // S1 from the flat fp64 scan
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64)
+                st[e] = c0 + e / 32 <= NP ? s1b[(size_t)c0 * 32 + e] : 0.f;
+        } else {
+            for (int e = lane; e < (kGroup + 1) * 32; e += 64) st[e] = 0.f;
+            wave_lds_fence();
+            const int c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
+            const int n = c1 > c0 ? c1 - c0 : 0;
+            const int cs = c0 < NP ? c0 : (NP > 0 ? NP - 1 : 0);
+            precise_scan_range<W, NT, float, float>(Phi64 + ((size_t)b * NP + cs) * NT * W, z + ((size_t)b * NP + cs) * W, W, st,
+                                                    32, n, lane, G64 + ((size_t)b * (NG + 1) + g) * 32);
+        }
+    }
+    wave_lds_fence();
+    FQM_STAMP(6);
+    fwdq_body<W, NT, 1, true>(ex, ex_stride, gain, a, nullptr, y, y_stride, T, F, M, hop, L, NC, 0, nullptr, xt, yt, b, g, lane,
+                              st, dl, nonfinite);
+    FQM_STAMP(7);
+#undef FQM_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3514,6 +3716,11 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             double* G64 = (double*)(ws + p.off_g64);
             unsigned* arrived = (unsigned*)(ws + p.off_fixcnt) + 2 * (size_t)B + 1;
             const int gxf = (int)ceil_div(p.NC, kGroup);
+            unsigned* gflag = (unsigned*)(ws + p.off_gflag);
+            // One batch alone (latency chain): the two chunk passes as ONE launch.  With batches in flight (GOLF_SS_THROUGHPUT) the
+            // pair of thin launches stays: measured 68.4 vs 70.5 us/step -- a wave that lives through both sweeps holds its registers
+            // for 44 us, waiting included.
+            const bool merged = !(flags & GOLF_SS_THROUGHPUT) && p.NG <= kMergedMaxGroups;
             // transitions prepared ahead (HAVE_TRANSITIONS) or forked onto the side stream: their composites came with them
             FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1, training);
             fa.B = B;
@@ -3523,11 +3730,20 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             const int parts = (fused_p1 ? 3 : 2) | (zin ? 4 : 0), count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
                                (const float*)PhiT, z, MT, Vz, p.NP, p.NG, B, parts, fa, k1, k2,
-                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr, ZPassArgs{ex, ex_stride, gain, T});
+                               training ? (float*)(ws + p.off_mtT) : (float*)nullptr,
+                               ZPassArgs{ex, ex_stride, gain, T, merged ? gflag : (unsigned*)nullptr, B * (p.NG + 1), nonfinite});
             GOLF_LAUNCH_CHECK();
             // refinement pass (both precisions of the maps: the sweep is what makes the states the sequential recursion's)
             const int gx3 = (int)ceil_div(p.NP, kGroup);
             const bool thin = (flags & GOLF_SS_THROUGHPUT) != 0;
+            if (merged) {   // refinement + final pass in one launch (lpc_fwdq2m_kernel)
+                hipLaunchKernelGGL((lpc_fwdq2m_kernel<W, NT>), dim3((unsigned)gxf, B + (int)ceil_div(B, gxf)), dim3(64), 0, st, ex,
+                                   ex_stride, gain, a, y, y_stride, T, F, M, hop, p.L, p.NC, (const float*)PhiT, (const float*)MT,
+                                   (const float*)Vz, Vd, (const float*)z, p.NP, p.NG, S1, tier, nonfinite, B, Phi64, M64, V64, G64,
+                                   arrived, gflag, (unsigned*)(ws + p.off_fixcnt) + 2 * (size_t)B);
+                GOLF_LAUNCH_CHECK();
+                return GOLF_OK;
+            }
 #define GOLF_FWDQ2_LAUNCH(THINV)                                                                                              \
             hipLaunchKernelGGL((lpc_fwdq2_kernel<W, NT, 3, THINV>), dim3((unsigned)gx3, B + (int)ceil_div(B, gx3)), dim3(64), 0,  \
                                st, ex, ex_stride, gain, a, dfc, (int64_t)0, T, F, M, hop, p.L, p.NP, (const float*)PhiT,        \

@@ -931,6 +931,35 @@ def test_throughput_chain_is_bit_identical(seed, train, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,F,M,hop,groups", [(3, 8001, 6, 8, 17), (2, 15300, 4, 8, 32), (2, 15626, 4, 8, 33), (2, 3842, 12, 16, 16)])
+def test_merged_chunk_pass_and_its_fallback(B, F, M, hop, groups, monkeypatch):
+    """Round 5: one batch alone runs the refinement and the final pass as ONE launch (lpc_fwdq2m_kernel: flag words between the
+    waves of an utterance, the earlier groups' defect responses staged in LDS -- 32 groups of them at most).  17 groups, exactly 32
+    (the staging buffer full), 33 (the pair of launches with the deep prefetch rings takes over) and 16 whole groups (the final
+    partial chunk in a group of its own: a wave with no map and no defect): against the float64 oracle, and bit-identical to the
+    pair of thin launches a caller with batches in flight gets."""
+    from oracle import golf_oracle as O
+    from golf_amd import functional as GF
+
+    ex, gain, a = smooth_case(B, F, M, hop, seed=F + M, walk=0.004)
+    T = ex.shape[1]
+    L = hop * (240 // hop)
+    assert -(-(-(-T // L) - 1) // 16) == groups
+    ref = O.ltv_allpole_ss_forward(ex, gain, a, hop)
+    t = [dev(v) for v in (ex, gain, a)]
+    out = []
+    for throughput in (False, True):
+        monkeypatch.setattr(GF, "THROUGHPUT_MODE", throughput)
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        y = GF.ltv_allpole_ss(t[0], t[1], t[2], hop, status=st)
+        s = GF.ss_status(st)
+        assert not s["nonfinite"] and not s["fixup_timeout"], s
+        out.append(y)
+    check(out[0].cpu().numpy(), ref, f"one launch / fallback, {groups} groups")
+    assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,mode", [(3, 0), (3, 8)])
 def test_backward_zeroes_the_excitation_tail_when_asked(B, mode):
     """ABI 5, GOLF_SS_ZERO_TAIL: the excitation is longer than the output (the oscillator's 48 000 samples against

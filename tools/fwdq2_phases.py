@@ -1,12 +1,15 @@
 """dev: phase timing of the two-level chunk passes (build with -DFWDQ2_TIMING: tools/build_variant.sh fqt lpc_ss.hip
 -DFWDQ2_TIMING; GOLF_HIP_LIBRARY=.../libgolf_fqt.so).  s_memtime stamps (100 MHz ticks) of lane 0 of every (utterance, group)
 wave: 0 entry, 1 fold over the earlier groups done, 2 prologue done, 3 states written / added, 4 chunk recursion done,
-5 epilogue done.  Printed per group index (mean over the batch), refinement pass and final pass, one batch alone."""
+5 epilogue done.  Printed per group index (mean over the batch), refinement pass and final pass, one batch alone.
+(The pair of launches is what a caller with batches in flight gets -- THROUGHPUT_MODE; one batch alone otherwise takes the
+merged kernel: tools/fwdq2m_phases.py.)"""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from golf_amd import _lib, functional as GF
 from golf_amd.synthetic import make_inputs
 
+GF.THROUGHPUT_MODE = True
 lib = _lib.load()
 cdll = ctypes.CDLL(os.environ["GOLF_HIP_LIBRARY"])
 cdll.golf_debug_fwdq2_stamps.restype = ctypes.c_int
