@@ -2004,23 +2004,28 @@ template <int W, int NT>
 __device__ __forceinline__ void precise_group_job(const double* __restrict__ Phi64, const float* __restrict__ z,
                                                   double* __restrict__ M64, double* __restrict__ V64,
                                                   double* __restrict__ G64, unsigned* __restrict__ arrived, int b, int g,
-                                                  int NP, int NG, int lane, int B, float* __restrict__ S1,
+                                                  int NP, int NG, int lane, int B, float* __restrict__ S1, int part,
                                                   unsigned* __restrict__ ready = nullptr) {
+    // part 0: the group's composite, part 1: its zero-state response -- two waves per group (round 5: one wave did both, 16 + 13 us
+    // of dependent fp64 steps in a row, and the batch of a tier-3 utterance waited for it)
     // ready (merged chunk pass): word b is set once the utterance's group start states (or flat-scan states) are in memory --
     // the utterance's chunk waves of the SAME launch wait for it
     const double* P64b = Phi64 + (size_t)b * NP * NT * W;
     const int c0 = g * kGroup, c1 = c0 + kGroup < NP ? c0 + kGroup : NP;
-    double* m64 = M64 + ((size_t)b * NG + g) * NT * W;
-    const float pmx = precise_group_composite<W, NT>(P64b, c0, c1, m64, lane);
-    if (lane == 0) atomicMax(arrived + B + b, pmx == pmx ? __float_as_uint(pmx) : 0x7fc00000u);   // non-negative floats order as their bits
-    const double v = precise_scan_range<W, NT, float, float>(P64b + (size_t)c0 * NT * W, z + ((size_t)b * NP + c0) * W, W,
-                                                              (float*)nullptr, 0, c1 - c0, lane, (const double*)nullptr);
-    if (lane < 32) V64[((size_t)b * NG + g) * 32 + lane] = v;
+    if (part == 0) {   // wave-uniform
+        double* m64 = M64 + ((size_t)b * NG + g) * NT * W;
+        const float pmx = precise_group_composite<W, NT>(P64b, c0, c1, m64, lane);
+        if (lane == 0) atomicMax(arrived + B + b, pmx == pmx ? __float_as_uint(pmx) : 0x7fc00000u);   // non-negative floats order as their bits
+    } else {
+        const double v = precise_scan_range<W, NT, float, float>(P64b + (size_t)c0 * NT * W, z + ((size_t)b * NP + c0) * W, W,
+                                                                  (float*)nullptr, 0, c1 - c0, lane, (const double*)nullptr);
+        if (lane < 32) V64[((size_t)b * NG + g) * 32 + lane] = v;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     unsigned old = 0u;
     if (lane == 0) old = atomicAdd(arrived + b, 1u);
     old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-    if (old + 1u != (unsigned)NG) return;   // wave-uniform
+    if (old + 1u != 2u * (unsigned)NG) return;   // wave-uniform
     // this wave completed the utterance: every composite and response is visible after the acquire
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const unsigned mxbits = __hip_atomic_load(arrived + B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2374,10 +2379,10 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2_kernel(const f
             // extra rows' waves share the (utterance, group) jobs -- one utterance's groups land on different waves
             const int w = ((int)blockIdx.y - B) * (int)gridDim.x + (int)blockIdx.x;
             const int nw = ((int)gridDim.y - B) * (int)gridDim.x;
-            for (int job = w; job < B * NG; job += nw) {
-                const int bp = job / NG;
+            for (int job = w; job < 2 * B * NG; job += nw) {
+                const int bp = job / (2 * NG), r = job - bp * 2 * NG;
                 if (tier3(tier, bp))   // wave-uniform
-                    precise_group_job<W, NT>(Phi64, x, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, threadIdx.x, B, S1);
+                    precise_group_job<W, NT>(Phi64, x, M64, V64, G64, arrived, bp, r >> 1, NP, NG, threadIdx.x, B, S1, r & 1);
             }
             return;
         }
@@ -2516,10 +2521,10 @@ __global__ __launch_bounds__(64, GOLF_FWDQ2_WAVES) void lpc_fwdq2m_kernel(
         if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) record_scan_kind(tier, B, kScanTwoLevel);
         const int w = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
         const int nw = nextra * (int)gridDim.x;
-        for (int job = w; job < B * NG; job += nw) {
-            const int bp = job / NG;
+        for (int job = w; job < 2 * B * NG; job += nw) {
+            const int bp = job / (2 * NG), r = job - bp * 2 * NG;
             if (tier3(tier, bp))   // wave-uniform
-                precise_group_job<W, NT>(Phi64, z, M64, V64, G64, arrived, bp, job - bp * NG, NP, NG, lane, B, S1, ready);
+                precise_group_job<W, NT>(Phi64, z, M64, V64, G64, arrived, bp, r >> 1, NP, NG, lane, B, S1, r & 1, ready);
         }
         return;
     }

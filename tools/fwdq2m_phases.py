@@ -11,7 +11,7 @@ lib = _lib.load()
 cdll = ctypes.CDLL(os.environ["GOLF_HIP_LIBRARY"])
 cdll.golf_debug_fwdq2_stamps.restype = ctypes.c_int
 B = 32
-inp = make_inputs(B=B, device="cuda", seed=2434)
+inp = make_inputs(B=B, device="cuda", seed=int(os.environ.get("PHASES_SEED", "2434")))   # 2476 / 2488: a tier-3 utterance
 T = (inp["a"].shape[1] - 1) * 240 + 1
 ex = torch.randn(B, T, device="cuda")
 run = lambda: GF.ltv_allpole_ss(ex, inp["gain"], inp["a"], 240)
@@ -30,6 +30,12 @@ s = st[:B, :NG, :] / 100.0
 t0 = s[:, :, 0].min()
 print("groups", NG, " kernel span %.1f us" % (s[:, :, 7].max() - t0))
 print("   g   entry  prologueA  bodyA  response  release   wait  prologueB  bodyB   exit")
+t3 = [b for b in range(B) if st[b, 0, 1] == 0]   # tier-3 utterances have no phase A: stamps 0, 6, 7 only
+cold = [b for b in range(B) if b not in t3]
+for b in t3:
+    print("  tier-3 utterance %d: per group  wait + fp64 prologue / chunks / exit (us):" % b,
+          " ".join("%.1f/%.1f/%.1f" % (s[b, g, 6] - s[b, g, 0], s[b, g, 7] - s[b, g, 6], s[b, g, 7] - t0) for g in range(NG)))
+s = s[cold]
 for g in range(NG):
     d = np.diff(s[:, g, :], axis=1).mean(0)
     print("  %2d  %6.2f   %6.2f  %6.2f   %6.2f  %6.2f  %6.2f   %6.2f  %6.2f  %6.2f" % ((g, s[:, g, 0].mean() - t0) + tuple(d) + (s[:, g, 7].mean() - t0,)))
