@@ -152,7 +152,9 @@ class _LTVAllPoleSS(torch.autograd.Function):
                 f"(e.g. hop 240 -> orders up to 38, hop 256 -> up to 30, hop 100 -> none)")
         if (prepared is not None and prepared.key == (B, T, F, M, hop, a.data_ptr(), a._version, mode)
                 and not (prepared.fast and needs_grad and not prepared.training)):
-            ws, flags, side = prepared.ws, HAVE_TRANSITIONS | mode, prepared.stream
+            # (a caller with batches in flight keeps the thin pair of chunk passes with prepared maps too: without the flag the
+            #  forward would take the one-launch form meant for a lone batch -- 50 vs 43 us/step measured, round 5)
+            ws, flags, side = prepared.ws, HAVE_TRANSITIONS | mode | (THROUGHPUT if THROUGHPUT_MODE else 0), prepared.stream
             if prepared.fast:
                 flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0) | (MAPS_ONLY if prepared.maps_only else 0)
         else:
