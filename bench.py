@@ -964,8 +964,9 @@ def main():
                 "nonfinite_per_slot": [[c[2] for c in r] for r in cond_ranks],
                 "max_phi_per_slot_rank0": [None if c is None else round(c["max_phi"], 2) for c in slot_cond],
                 "thresholds": {"hot_utterance_G1": float(os.environ.get("GOLF_SS_PHI_GUARD", 30)),
-                               "hot_chunk_G2": float(os.environ.get("GOLF_SS_PHI_GUARD2", 16)),
-                               "tier3_G3": float(os.environ.get("GOLF_SS_PHI_GUARD3", 256))}}
+                               "hot_chunk_G2": float(os.environ.get("GOLF_SS_PHI_GUARD2", 10)),
+                               "tier3_G3": float(os.environ.get("GOLF_SS_PHI_GUARD3", 256)),
+                               "tier3_group_log2": float(os.environ.get("GOLF_SS_GROUP_LOG2", 96))}}
         if recipe_stream is not None:
             result["recipe_stream"] = recipe_stream
         if refreshed is not None:

@@ -1085,6 +1085,26 @@ def test_length_argument_equals_a_slice_of_the_excitation():
 
 
 @pytest.mark.gpu
+def test_groups_of_large_maps_just_under_the_round4_guard():
+    """Found by tools/fuzz_tiers.py (round 5, seed 101 case 114): utterance 3 has groups whose chunk maxima sum to just under the
+    round-4 guard (104 in log2); through the two-level path it came out at 4.7 x the sequential recursion's error (2.5e-3 against
+    5.2e-4), through the flat scan at 0.8 x.  The guard is 96: tier 3, within the usual bound on both paths."""
+    B, F, M, hop, sigma, seed = 6, 222, 20, 240, 1.3, 1006530546
+    ex, gain, a = harsh_case(B, F, M, hop, sigma, seed)
+    ref = oracle_rows(ex, gain, a, hop)
+    ok = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e12)
+    scale = np.abs(ref).max(1) + 1e-300
+    e_ser = np.abs(run_mode(ex, gain, a, hop, "serial") - ref).max(1) / scale
+    good = ok & (e_ser < 0.05)
+    assert good[3]
+    for mode in (None, "flat-scan"):
+        y, st = run_status(ex, gain, a, hop, fast=True, mode=mode)
+        e = np.abs(y - ref).max(1) / scale
+        assert st["tier3_utterances"] >= 4, st
+        assert np.all(e[good] <= 3 * e_ser[good] + 1e-4), (mode, e[good], e_ser[good])
+
+
+@pytest.mark.gpu
 def test_sustained_large_maps_under_g3_take_tier3():
     """Found by tools/fuzz_tiers.py (round 4): utterance 3 of this batch has no map entry beyond G3 = 256 (largest 203) but a
     whole group of large maps; their products cancel from ~2^115 down, and the two-level path with fp32 composites returned it

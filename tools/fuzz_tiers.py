@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import test_gpu_lpc_ss as T
 
+if os.environ.get("FUZZ_THROUGHPUT"):   # the launch chain of a caller with batches in flight (pair of thin chunk passes)
+    from golf_amd import functional as _GF
+    _GF.THROUGHPUT_MODE = True
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
