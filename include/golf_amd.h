@@ -111,8 +111,9 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
 /*          GOLF_SS_THROUGHPUT  (ABI 4) the caller keeps SEVERAL batches in flight on the device (a serving loop on a few HIP
  *                streams): prefer the launch structure that costs the least chip time over the one that finishes a lone
  *                batch soonest.  Today: the zero-state pass runs inside the pre-pass launch instead of inside the transition
- *                kernel's -- one batch alone 130 -> 140 us, four in flight 71 -> 69.5 us/step (20-step regions 81 -> 78.5),
- *                MI355X, B = 32 x 2 s.  Results are bit-identical either way.  The library cannot see how many batches its
+ *                kernel's, and the two chunk passes are two thin launches instead of the one launch a lone batch gets (whose
+ *                waves live through both sweeps, waiting for each other in between) -- one batch alone 123 -> 134 us, four in
+ *                flight 75 -> 68.5 us/step, MI355X, B = 32 x 2 s (round 5).  Results are bit-identical either way.  The library cannot see how many batches its
  *                caller keeps in flight, hence a flag (cf. GOLF_SS_SERIAL). */
 #define GOLF_SS_THROUGHPUT 256
 /*          GOLF_SS_ZERO_TAIL  (ABI 5, golf_ltv_allpole_bwd_f32 only) the excitation rows were longer than the output (the
