@@ -77,7 +77,7 @@ class ReplayPipeline:
 
     def __init__(self, fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  make_inputs: Callable[[], Dict[str, torch.Tensor]], n_slots: int = 4, check: bool = True,
-                 use_graphs: bool = True, packed: bool = False):
+                 use_graphs: bool = True, packed: bool = False, throughput: Optional[bool] = None):
         self.fn, self.use_graphs, self.packed = fn, use_graphs, packed
         self.slots: List[Slot] = [Slot(make_inputs()) for _ in range(max(1, n_slots))]
         if packed:
@@ -86,7 +86,9 @@ class ReplayPipeline:
         # several batches in flight: ask the sample-wise filter for the launch chain that costs the least chip time
         # (GOLF_SS_THROUGHPUT, include/golf_amd.h; bit-identical results).  The flag is read when a step is issued or
         # captured, so it is set around the capture / the eager submits of THIS pipeline only.
-        self.throughput = len(self.slots) > 1
+        # (``throughput=False`` keeps the lone-batch chain whatever the slot count: a diagnostic -- tools/soak.py runs four of
+        #  the one-launch chunk-pass kernels concurrently that way)
+        self.throughput = len(self.slots) > 1 if throughput is None else bool(throughput)
         from . import functional as _GF
 
         prev_mode, _GF.THROUGHPUT_MODE = _GF.THROUGHPUT_MODE, self.throughput

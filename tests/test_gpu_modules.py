@@ -362,6 +362,48 @@ def test_replay_pipeline_submit_refreshes_inputs_vs_oracle():
         assert np.abs(got[0] - got[2]).max() > 1e-3 and np.abs(got[1] - got[3]).max() > 1e-3
 
 
+@pytest.mark.gpu
+def test_replay_pipeline_lone_batch_chain_in_flight_is_bit_identical():
+    """``ReplayPipeline(throughput=False)`` keeps the filter's lone-batch launch chain with several slots: the two chunk passes are
+    then ONE launch whose waves wait for each other's flag words (lpc_fwdq2m_kernel), and three of those launches are in flight at
+    once -- the placement its look-back rule has to survive.  Six different batches through three slots of either pipeline: the
+    same bits from both chains, every time, and the oracle's values."""
+    from golf_amd import functional as GF
+    from golf_amd.pipeline import ReplayPipeline
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    B, T = 4, 24000   # 99 chunk maps = 7 groups: the two-level scan and with it the merged kernel
+    keys = ("noise", "gain", "a")
+    batches = [make_inputs(B=B, T=T, device="cuda", seed=300 + k) for k in range(6)]
+
+    def fn(inp):
+        return GF.ltv_allpole_ss(inp["noise"], inp["gain"], inp["a"], 240, fast_inference=True)
+
+    outs = {}
+    for throughput in (None, False):
+        pipe = ReplayPipeline(fn, lambda: {k: batches[0][k].clone() for k in keys}, n_slots=3, throughput=throughput)
+        assert pipe.throughput == (throughput is None)
+        got = []
+        for rep in range(3):
+            slots = [pipe.submit({k: bt[k] for k in keys}) for bt in batches[:3]] if rep % 2 == 0 else \
+                    [pipe.submit({k: bt[k] for k in keys}) for bt in batches[3:]]
+            pipe.synchronize()
+            got.append([s.output.clone() for s in slots])
+        outs[throughput] = got
+    for ga, gb in zip(outs[None], outs[False]):
+        for u, v in zip(ga, gb):
+            assert torch.equal(u, v)
+    for u, v in zip(outs[False][0], outs[False][2]):      # the same three batches, two rounds apart
+        assert torch.equal(u, v)
+    c = {k: batches[1][k].cpu().numpy() for k in keys}
+    ref = O.ltv_allpole_ss_forward(c["noise"], c["gain"], c["a"], 240)
+    y = outs[False][0][1].cpu().numpy()
+    n = min(y.shape[1], ref.shape[1])
+    err = np.abs(y[:, :n] - ref[:, :n]).max() / np.abs(ref).max()
+    assert err < 1e-4, err
+
+
 def test_long_utterance_decoder_vs_oracle():
     """One 12.5 s utterance through the whole golf-precise decoder (293 phase-scan tiles, 1250 LPC chunks) against the
     float64 oracle: nothing in the path is sized for 2 s clips."""
