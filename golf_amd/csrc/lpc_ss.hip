@@ -1595,6 +1595,9 @@ __device__ __forceinline__ void precise_adj_scan(const double* __restrict__ P64,
 //       with an epilogue that scans the group's 16 defects (-> v'_g), so the second scan needs no launch of its own:
 //       the final pass folds (M_g, v_g + v'_g) and scans with inputs z + defect.
 //   16 + <= 12 + 16 dependent steps on the critical path of each pass instead of 199 per scan.
+//   lpc_fwdq2m_kernel           (round 5) both chunk passes in ONE launch for a batch that runs alone: the waves of an utterance
+//       hand their defect responses to each other through flag words (a wave waits only for workgroups dispatched before it)
+//       and keep their 16 maps in LDS between the three stages that need them.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGroup = 16;   // chunk maps per group = chunks per wave of the chunk kernels
