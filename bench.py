@@ -107,6 +107,9 @@ def parse():
                     help="also time the serving mode in which EVERY step first copies a new batch (one of this many resident "
                          "packed batches, round-robin) into its slot's static inputs on the slot's stream, device-to-device, "
                          "and -- side figure -- from pinned host memory; -1: 8 for the default single-GPU golf-ss-synth run, 0 otherwise")
+    ap.add_argument("--no-compare-gather-modes", action="store_true",
+                    help="N>1: skip the comparison passes that time the SAME regions under each exchange (RCCL all-gather per "
+                         "step, staged RCCL all-gather, peer-to-peer stores) after the headline -- exchange.modes in the line")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
@@ -465,13 +468,44 @@ def smi_clocks():
         return None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's documented command does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`), and
+    pass rank 0's JSON line and the launcher's exit code through.  (the flag used to be parsed and ignored.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:   # a free port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the peer-store exchange need it across processes
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.single_device:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (one rank per GPU; --single-device maps "
+                     f"every rank to cuda:0 for a control-flow dry run)")
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a launcher that started a different number of ranks than the command line names: the line would carry the wrong n_gpus
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.single_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} has LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)   # before the communicator exists: RCCL's first collective binds to the current device
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -479,6 +513,8 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.dist_backend)  # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} were asked for")
 
     if args.fork_transitions:
         import golf_amd.functional as _GF
@@ -606,7 +642,10 @@ def main():
                 # with batches in flight the filter takes the serial kernels from B = 512, a lone batch the chunked scan up to
                 # 2048: two algorithms, equal to rounding (each within the tests' bound of the float64 oracle), not bit for bit
                 # (per utterance: on the recipe's ill-conditioned utterances two correct fp32 evaluations differ by more than
-                #  1e-4 -- the tests bound each by 2 - 3 x the sequential recursion's own error against float64)
+                #  1e-4 -- the tests bound each by 2 - 3 x the sequential recursion's own error against float64.  The 2e-2 for the
+                #  worst row is that bound twice over for the recipe's worst-conditioned utterances, whose sequential fp32
+                #  recursion is 3e-3 - 5e-3 from float64 (tier-3 rows of tests/test_gpu_lpc_ss.py::test_recipe_fuzz_every_utterance);
+                #  the median and 90 % figures are what a plan-level bug would move.)
                 rows = (y_lat - outs[0]).abs().amax(1) / outs[0].abs().amax(1).clamp_min(1e-30)
                 med, q90, worst = (float(v) for v in (rows.median(), rows.quantile(0.9), rows.max()))
                 assert med < 1e-4 and q90 < 3e-4 and worst < 2e-2, \
@@ -740,6 +779,53 @@ def main():
         gather_on[0] = False
         ms_no_gather = median_ms(timed_regions(args.repeats))
         gather_on[0] = True
+
+    # ---- N > 1: the same regions under every exchange this package has, so that ONE scaling lease yields the comparison DESIGN.md
+    # section 7 predicts: an RCCL all-gather per step, the staged all-gather (GE steps per collective), and
+    # peer-to-peer stores over xGMI.  Setup failures and timeouts are agreed on by all ranks (a mode that fails is reported, not fatal).
+    gather_modes = None
+    if do_gather and not args.no_compare_gather_modes:
+        import torch.distributed as dist
+        from golf_amd.dist import PeerStoreGather, StagedGather
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        gather_modes = {}
+        headline_stagers, headline_pipelined = stagers, pipelined
+        ge_staged = max(1, min(8, args.steps // S))
+        for name, make in (("rccl_all_gather_per_step", lambda: [StagedGather(B, t_out, 1, device, world=world) for _ in range(S)]),
+                           (f"rccl_all_gather_staged_{ge_staged}", lambda: [StagedGather(B, t_out, ge_staged, device, world=world) for _ in range(S)]),
+                           ("peer_store", lambda: [PeerStoreGather(B, t_out, depth=4, device=device) for _ in range(S)])):
+            err, made = None, None
+            try:
+                made = make()
+            except Exception as e:   # noqa: BLE001 -- reported in the line
+                err = repr(e)
+            if not all_ok(err is None):
+                gather_modes[name] = {"error": err or "failed on another rank"}
+                continue
+            stagers, pipelined = made, True
+            try:
+                timed_regions(1)
+                ms = median_ms(timed_regions(args.repeats))
+            except Exception as e:   # noqa: BLE001
+                err, ms = repr(e), None
+            if all_ok(err is None):
+                inb = (world - 1) * B * t_out * 4
+                gather_modes[name] = {"ms_per_step": round(ms, 5), "value": world * samples / (ms * 1e-3),
+                                      "inbound_GBps_per_rank": round(inb / (ms * 1e-3) / 1e9, 1)}
+            else:
+                gather_modes[name] = {"error": err or "failed on another rank"}
+            if name == "peer_store":
+                try:
+                    for st_ in made:
+                        st_.close()
+                except Exception:   # noqa: BLE001
+                    pass
+        stagers, pipelined = headline_stagers, headline_pipelined
 
     # ---- serving mode with refreshed inputs: every step copies a new packed batch into its slot first
     refreshed = None
@@ -983,6 +1069,8 @@ def main():
                                   # the same timed regions without the exchange: what the gather costs, in one line
                                   "ms_per_step_no_gather": None if ms_no_gather is None else round(ms_no_gather, 5),
                                   "value_no_gather": None if ms_no_gather is None else world * samples / (ms_no_gather * 1e-3),
+                                  # the same regions under each exchange (all-gather per step / staged / peer-to-peer stores)
+                                  "modes": gather_modes,
                                   # hot utterances cost their rank ~13 us more per step: the ranks a synchronous gather waits for
                                   "flagged_utterances_per_rank": None if cond_ranks is None else [sum(c[0] for c in r) for r in cond_ranks],
                                   "tier3_utterances_per_rank": None if cond_ranks is None else [sum(c[1] for c in r) for r in cond_ranks]}

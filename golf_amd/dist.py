@@ -214,38 +214,60 @@ class PeerStoreGather:
         data_bytes = 4 * D * W * self.slot_elems
         # flags: [0, D*W) data-arrived sequence numbers (slot, source); [D*W, 2*D*W) slot-released ones (slot, consumer)
         flag_bytes = 4 * 2 * D * W
-        with torch.cuda.device(self.device):
-            self._local = []
-            for nbytes in (data_bytes, flag_bytes):
-                p = ctypes.c_void_p()
-                _lib.check(self.lib.golf_peer_alloc(nbytes, ctypes.byref(p)), "golf_peer_alloc")
-                self._local.append(p.value)
-            handles = []
-            for ptr in self._local:
-                h = ctypes.create_string_buffer(64)
-                _lib.check(self.lib.golf_peer_export(ptr, h), "golf_peer_export")
-                handles.append(h.raw)
-            everyone = [None] * W
-            dist.all_gather_object(everyone, handles)
-            self._data, self._flags, self._opened = [None] * W, [None] * W, []
-            for r in range(W):
-                if r == self.rank:
-                    self._data[r], self._flags[r] = self._local
-                    continue
-                mapped = []
-                for raw in everyone[r]:
+        self._local, self._opened, failure, handles = [], [], None, None
+        self._data, self._flags = [None] * W, [None] * W
+        try:
+            with torch.cuda.device(self.device):
+                for nbytes in (data_bytes, flag_bytes):
                     p = ctypes.c_void_p()
-                    _lib.check(self.lib.golf_peer_open(raw, ctypes.byref(p)), "golf_peer_open")
-                    mapped.append(p.value)
-                    self._opened.append(p.value)
-                self._data[r], self._flags[r] = mapped
+                    _lib.check(self.lib.golf_peer_alloc(nbytes, ctypes.byref(p)), "golf_peer_alloc")
+                    self._local.append(p.value)
+                hs = []
+                for ptr in self._local:
+                    h = ctypes.create_string_buffer(64)
+                    _lib.check(self.lib.golf_peer_export(ptr, h), "golf_peer_export")
+                    hs.append(h.raw)
+                handles = hs
+        except Exception as e:   # noqa: BLE001 -- agreed on below
+            failure = e
+        everyone = [None] * W
+        dist.all_gather_object(everyone, handles)   # every rank reaches this, with or without handles
+        try:
+            if failure is None and any(h is None for h in everyone):
+                raise RuntimeError("a peer could not allocate or export its buffers")
+            with torch.cuda.device(self.device):
+                for r in range(W if failure is None else 0):
+                    if r == self.rank:
+                        self._data[r], self._flags[r] = self._local
+                        continue
+                    mapped = []
+                    for raw in everyone[r]:
+                        p = ctypes.c_void_p()
+                        _lib.check(self.lib.golf_peer_open(raw, ctypes.byref(p)), "golf_peer_open")
+                        mapped.append(p.value)
+                        self._opened.append(p.value)
+                    self._data[r], self._flags[r] = mapped
+        except Exception as e:   # noqa: BLE001 -- a rank that cannot map a peer must not leave the others in a barrier
+            failure = e
+        # every rank has mapped every buffer before the first store -- or every rank learns that one could not (the exchange of
+        # the 64-byte handles above is a collective all ranks reach; an IPC error after it used to strand the peers in the barrier)
+        ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32,
+                          device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            for p in self._opened:
+                self.lib.golf_peer_close(p)
+            for p in self._local:
+                self.lib.golf_peer_free(p)
+            self._opened, self._local = [], []
+            raise RuntimeError(f"PeerStoreGather: rank {self.rank}: " + (repr(failure) if failure is not None
+                                                                         else "another rank could not map its peers' buffers"))
         self.recv = torch.as_tensor(_DeviceView(self._local[0], (D, W, self.rows, self.T), "<f4"), device=self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.pushed = 0       # steps pushed so far; step k uses slot k % depth and sequence number k + 1
         self.consumed = 0     # steps waited for
         self.released = 0     # steps released
         self._PtrArray = ctypes.c_void_p * W
-        dist.barrier()        # every rank has mapped every buffer before the first store
 
     # ---- addresses ----------------------------------------------------------------------------
     def _flag_addr(self, owner: int, kind: int, slot: int, who: int) -> int:

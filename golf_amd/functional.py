@@ -158,8 +158,12 @@ class _LTVAllPoleSS(torch.autograd.Function):
             if prepared.fast:
                 flags |= FAST_TRANSITIONS | (TRAINING if prepared.training else 0) | (MAPS_ONLY if prepared.maps_only else 0)
         else:
-            if THROUGHPUT_MODE and mode == 0 and not needs_grad and B >= SS_THROUGHPUT_SERIAL_MIN:
-                mode = SS_MODES["serial"]   # several batches in flight: the plan that costs the least CHIP time (see the constant)
+            if (THROUGHPUT_MODE and mode == 0 and not needs_grad and B >= SS_THROUGHPUT_SERIAL_MIN
+                    and ex.stride(0) < SS_SERIAL_MAX_STRIDE):
+                # several batches in flight: the plan that costs the least CHIP time (see the constant).  An explicit GOLF_SS_SERIAL
+                # turns the library's quiet fallback for huge row strides into GOLF_EUNSUPPORTED, hence the stride test here (the
+                # output is allocated dense above) -- a caller who asked for "auto" never sees that error.
+                mode = SS_MODES["serial"]
             ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, hop, mode), ex.device)
             flags = mode | (THROUGHPUT if THROUGHPUT_MODE else 0)
             if fast_inference:
@@ -216,8 +220,11 @@ class _LTVAllPoleSS(torch.autograd.Function):
 
 SS_MODES = {None: 0, "auto": 0, "serial": 8, "chunked": 16, "flat-scan": 16 | 32}   # GOLF_SS_SERIAL / _CHUNKED / _FLAT_SCAN
 # Set by a caller that keeps several batches in flight (bench.py's pipelined loop, a serving loop): GOLF_SS_THROUGHPUT
-# is added to every sample-wise filter call.  Bit-identical results; a lone batch takes ~10 us longer, four in flight
-# finish ~2 % more per second (include/golf_amd.h).
+# is added to every sample-wise filter call.  Bit-identical results WITHIN one algorithm (the flag only changes the launch
+# chain of the time-chunked scan); from SS_THROUGHPUT_SERIAL_MIN utterances on this module additionally switches an inference
+# forward to the serial kernels, which are another algorithm: same accuracy class, different bits (and a forward through a
+# PreparedTransitions handle keeps the chunked scan its maps were made for).  A lone batch takes ~10 us longer, four in
+# flight finish ~2 % more per second (include/golf_amd.h).
 THROUGHPUT_MODE = False
 # With batches in flight (THROUGHPUT_MODE) an inference forward of this many utterances or more takes the batch-parallel
 # serial kernels instead of the time-chunked scan (the library's own switch, for a lone batch, is at 2048).  The chunked
@@ -226,6 +233,7 @@ THROUGHPUT_MODE = False
 # Whole synthesis step, MI355X, G samples/s (round 5): B = 256 chunked 28.8 | serial x 8 streams 24.5;  B = 1024 chunked 29.0 |
 # serial x 4 streams 42.6, x 8 streams 57.4;  B = 2048 (serial either way) x 1 stream 29.0, x 4 streams 57.4.
 SS_THROUGHPUT_SERIAL_MIN = 512
+SS_SERIAL_MAX_STRIDE = 1 << 24   # the serial kernels address 16 rows through one 32-bit buffer descriptor (lpc_ss.hip serial_strides_ok)
 
 
 def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: int,
@@ -237,11 +245,13 @@ def ltv_allpole_ss(ex: torch.Tensor, gain: torch.Tensor, a: torch.Tensor, hop: i
     ``fast_inference``: when no input requires grad, use fp32 transition matrices + one refinement sweep instead of
     fp64 matrices (same accuracy class as a sequential fp32 recursion, ~4x less work in the dominant kernel).
     ``mode``: None/"auto" picks the algorithm by batch size (time-chunked scan below 2048 utterances, batch-parallel
-    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one.  "flat-scan" --
-    the chunked algorithm with the flat boundary scan instead of the two-level one -- is a DIAGNOSTIC for A/B runs and
-    tests, not a product mode: it is slower at every batch size (78 vs 69 us/step, 171 vs 128 alone) and its accuracy is
-    bounded by 1.5 x the two-level path's bound (3 e_sequential_fp32 + 2e-4 of the float64 oracle), not by the bound itself:
-    tools/fuzz_tiers.py's worst case (hop 480, sigma 1.3 tracks) sits at 1.27 x.  No module of this package selects it.
+    serial recursion from there on: include/golf_amd.h GOLF_SS_SERIAL); "serial" / "chunked" force one.  "flat-scan"
+    forces the chunked algorithm's flat boundary scan.  That is not only a diagnostic: "auto" itself takes the flat scan for
+    every lone batch of more than ~40 utterances below the serial threshold (lpc_ss.hip use_two_level_scan; the two-level scan
+    is the faster form only while B x groups <= 2 x the CU count) and whenever an utterance has fewer than 48 chunk maps.  Both
+    scans are held to the same bound -- 3 e_sequential_fp32 + 1e-4 of the float64 oracle forward, + 2e-4 for the gradients -- by
+    the suite's soak (tests/test_gpu_lpc_ss.py::test_conditioning_soak_bounded, ::test_round5_soak_exceedances) and by
+    tools/fuzz_tiers.py over eleven seeds x 120 cases (round 6: no row beyond it on either scan).
     ``length``: filter only the first ``length`` samples of ``ex`` (output (B, min(length, natural length))): what
     ``ltv_allpole_ss(ex[:, :length], ...)`` computes, without the slice -- whose backward would be a full-size fill and a
     full-size copy in front of the producer's backward (the gradient of the unused tail is written as zeros by the filter's

@@ -32,11 +32,32 @@ class Slot:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.stream: Optional[torch.cuda.Stream] = None
 
-    def load(self, **tensors: torch.Tensor) -> None:
-        """Copy new data into the static inputs, ordered on this slot's stream (after its previous replay)."""
+    def _order_after_producer(self, sources, producer) -> None:
+        """The copies run on this slot's stream; the data they read was produced elsewhere.  ``producer``: the stream (or an
+        event recorded on it) behind which the batch is complete -- default: the caller's current stream, which is where
+        ``pipe.pack``, a ``torch.full`` or an encoder's forward enqueue their writes.  Device-side sources are also handed to
+        the caching allocator as in use on this stream, so that a batch freed by the caller right after ``submit`` is not
+        recycled under the copy."""
+        if producer is None:
+            producer = torch.cuda.current_stream(self.stream.device)
+        if isinstance(producer, torch.cuda.Event):
+            self.stream.wait_event(producer)
+        elif producer != self.stream:
+            self.stream.wait_stream(producer)
+        for t in sources:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.stream)
+
+    def load(self, _producer=None, **tensors: torch.Tensor) -> None:
+        """Copy new data into the static inputs, ordered on this slot's stream after its previous replay AND after the
+        producer of the data (see ``_order_after_producer``)."""
+        self._order_after_producer(tensors.values(), _producer)
         with torch.cuda.stream(self.stream):
             for name, value in tensors.items():
-                self.inputs[name].copy_(value, non_blocking=True)
+                dst = self.inputs[name]
+                if tuple(value.shape) != tuple(dst.shape):
+                    raise ValueError(f"input {name!r}: batch has shape {tuple(value.shape)}, the slot's static input {tuple(dst.shape)}")
+                dst.copy_(value, non_blocking=True)
 
     # ---- packed inputs: one flat fp32 buffer, the tensors of ``inputs`` are views of it ------------------------------
     flat: Optional[torch.Tensor] = None
@@ -46,6 +67,8 @@ class Slot:
         """Re-home every fp32 tensor of ``inputs`` in one flat buffer (64-float = 256-byte aligned pieces; call before the
         capture).  Other entries (ints, tensors of other types) stay as they are."""
         names = [k for k, v in self.inputs.items() if isinstance(v, torch.Tensor) and v.dtype == torch.float32]
+        if not names:
+            raise ValueError("packed=True needs at least one fp32 tensor among the slot's inputs")
         off, layout = 0, {}
         for k in names:
             layout[k] = (off, tuple(self.inputs[k].shape))
@@ -58,9 +81,18 @@ class Slot:
             view.copy_(self.inputs[k])
             self.inputs[k] = view
         self.flat, self.layout = flat, layout
+        # tensor inputs the flat buffer does NOT cover (other dtypes): submit(flat) leaves them as they are -- they have to be
+        # refreshed through the dict form; ReplayPipeline.submit refuses a flat batch for a slot that has any unless told so
+        self.unpacked = [k for k, v in self.inputs.items() if isinstance(v, torch.Tensor) and k not in layout]
 
-    def load_flat(self, flat_src: torch.Tensor) -> None:
-        """One copy refreshes every packed input (ordered on this slot's stream); ``flat_src`` has this slot's layout."""
+    unpacked: List[str] = []
+
+    def load_flat(self, flat_src: torch.Tensor, _producer=None) -> None:
+        """One copy refreshes every packed input (ordered on this slot's stream, after the producer of ``flat_src``);
+        ``flat_src`` has this slot's layout."""
+        if flat_src.shape != self.flat.shape or flat_src.dtype != self.flat.dtype:
+            raise ValueError(f"flat batch of {tuple(flat_src.shape)} {flat_src.dtype}, the slot's buffer is {tuple(self.flat.shape)} {self.flat.dtype}")
+        self._order_after_producer((flat_src,), _producer)
         with torch.cuda.stream(self.stream):
             # (a copy kernel of our own -- 16 bytes per lane, a grid over the whole chip -- was measured against this
             #  hipMemcpyDtoDAsync with four batches in flight: 82.7 vs 78.9 us/step; the runtime's copy stays)
@@ -121,15 +153,24 @@ class ReplayPipeline:
         for slot in self.slots:                                 # streams AFTER capture (see module docstring)
             slot.stream = torch.cuda.Stream(device=device)
 
-    def pack(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def pack(self, batch: Dict[str, torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A batch laid out like a packed slot (one flat fp32 tensor on the slots' device): what ``submit`` takes for the
-        single-copy refresh.  A producer on the same GPU can instead write into ``views(flat)`` of a buffer it owns."""
+        single-copy refresh.  ``out``: a flat buffer to reuse (``pipe.new_flat()`` once, then no allocation and no fill per
+        batch; the alignment gaps between the pieces are never read).  A producer on the same GPU can instead write into
+        ``views(flat)`` of a buffer it owns."""
         lay = self.slots[0].layout
         assert lay is not None, "ReplayPipeline(packed=True) packs its slots"
-        flat = torch.zeros_like(self.slots[0].flat)
+        flat = self.new_flat() if out is None else out
+        if flat.shape != self.slots[0].flat.shape or flat.dtype != torch.float32:
+            raise ValueError("out= must come from new_flat()")
         for k, view in self.views(flat).items():
             view.copy_(batch[k])
         return flat
+
+    def new_flat(self) -> torch.Tensor:
+        """An uninitialised flat buffer with the slots' layout (for ``pack(out=)`` / ``views``)."""
+        assert self.slots[0].layout is not None, "ReplayPipeline(packed=True) packs its slots"
+        return torch.empty_like(self.slots[0].flat)
 
     def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Named views of a flat buffer with the slots' layout."""
@@ -141,22 +182,29 @@ class ReplayPipeline:
             out[k] = flat[o:o + n].view(shp)
         return out
 
-    def submit(self, batch=None) -> Slot:
+    def submit(self, batch=None, producer=None, partial_ok: bool = False) -> Slot:
         """Launch the next slot's step on its stream (asynchronous) and return the slot; its ``output`` is complete once
         ``slot.stream`` has been waited on / synchronised, and stays valid until ``n_slots`` further submits.
 
         ``batch``: None replays the slot on whatever its static inputs hold; a dict of tensors (device or pinned host) is
         copied into them first, tensor by tensor; a flat tensor (``pack``) refreshes a packed slot with one copy.  The copies
         are issued on the slot's stream: ordered after the slot's previous replay (which read the old values) and before the
-        new one, overlapping the other slots' work.  The caller keeps ``batch`` alive until the slot's stream has passed the
-        copy (e.g. until the slot's output is consumed)."""
+        new one, overlapping the other slots' work -- and after ``producer``, the stream (or an event on it) that wrote the
+        batch; default: the caller's current stream (without that edge the copy could read a batch still being
+        written).  Device tensors of the batch are marked as in use on the slot's stream (``record_stream``), so the caller may
+        drop them right after the call; pinned host tensors must stay alive until the slot's stream has passed the copy.
+        A flat batch for a slot that also has tensor inputs outside the flat buffer (non-fp32) raises unless ``partial_ok``:
+        those would silently keep their old values."""
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         if batch is not None:
             if isinstance(batch, torch.Tensor):
-                slot.load_flat(batch)
+                if slot.unpacked and not partial_ok:
+                    raise ValueError(f"a flat batch does not refresh the slot's non-fp32 inputs {slot.unpacked}: "
+                                     "submit them as a dict, or pass partial_ok=True")
+                slot.load_flat(batch, producer)
             else:
-                slot.load(**{k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k in slot.inputs})
+                slot.load(producer, **{k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k in slot.inputs})
         with torch.cuda.stream(slot.stream):
             if self.use_graphs:
                 slot.graph.replay()

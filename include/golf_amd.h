@@ -113,7 +113,10 @@ size_t golf_ltv_allpole_workspace_bytes_ex(int B, int T, int F, int M, int hop, 
  *                batch soonest.  Today: the zero-state pass runs inside the pre-pass launch instead of inside the transition
  *                kernel's, and the two chunk passes are two thin launches instead of the one launch a lone batch gets (whose
  *                waves live through both sweeps, waiting for each other in between) -- one batch alone 123 -> 134 us, four in
- *                flight 75 -> 68.5 us/step, MI355X, B = 32 x 2 s (round 5).  Results are bit-identical either way.  The library cannot see how many batches its
+ *                flight 75 -> 68.5 us/step, MI355X, B = 32 x 2 s (round 5).  Results are bit-identical either way: the flag changes launches, never
+ *                the algorithm.  (The Python host additionally switches an inference forward of >= 512 utterances to GOLF_SS_SERIAL
+ *                while it sets this flag -- golf_amd.functional.SS_THROUGHPUT_SERIAL_MIN -- and that IS another algorithm: same
+ *                accuracy class, different bits.)  The library cannot see how many batches its
  *                caller keeps in flight, hence a flag (cf. GOLF_SS_SERIAL). */
 #define GOLF_SS_THROUGHPUT 256
 /*          GOLF_SS_ZERO_TAIL  (ABI 5, golf_ltv_allpole_bwd_f32 only) the excitation rows were longer than the output (the

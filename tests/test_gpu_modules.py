@@ -363,6 +363,77 @@ def test_replay_pipeline_submit_refreshes_inputs_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True])
+def test_replay_pipeline_submit_waits_for_the_producer_of_the_batch(packed):
+    """``submit(batch)`` copies on the slot's stream; the batch is produced on the caller's stream.  A long
+    kernel in front of the producer's writes makes the race deterministic: without the stream edge the copy reads the
+    poison the buffers held before.  The batch is dropped right after ``submit`` (``record_stream`` keeps the allocator from
+    recycling it under the copy), and a second submit takes an explicit event as the producer."""
+    from golf_amd import functional as GF
+    from golf_amd.pipeline import ReplayPipeline
+    from golf_amd.synthetic import make_inputs
+
+    B, T = 4, 24000
+    keys = ("noise", "gain", "a")
+    base = make_inputs(B=B, T=T, device="cuda", seed=500)
+    fresh = [make_inputs(B=B, T=T, device="cuda", seed=501 + k) for k in range(2)]
+
+    def fn(inp):
+        return GF.ltv_allpole_ss(inp["noise"], inp["gain"], inp["a"], 240, fast_inference=True)
+
+    want = [fn({k: bt[k] for k in keys}).clone() for bt in fresh]
+    pipe = ReplayPipeline(fn, lambda: {k: base[k].clone() for k in keys}, n_slots=2, packed=packed)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep, bt in enumerate(fresh):
+        prod = torch.cuda.current_stream() if rep == 0 else side
+        with torch.cuda.stream(prod):
+            staged = {k: torch.full_like(bt[k], float("nan")) for k in keys}     # poison first ...
+            flat = pipe.new_flat().fill_(float("nan")) if packed else None
+            torch.cuda._sleep(200_000_000)                                        # ... ~0.1 s of nothing ...
+            for k in keys:
+                staged[k].copy_(bt[k])                                            # ... then the real batch
+            if packed:
+                pipe.pack(staged, out=flat)
+            ev = torch.cuda.Event()
+            ev.record(prod)
+        batch = flat if packed else staged
+        slot = pipe.submit(batch, producer=None if rep == 0 else ev)
+        del batch, staged, flat
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # would land in the freed blocks
+        slot.stream.synchronize()
+        assert torch.equal(slot.output, want[rep]), f"submit {rep}: the copy ran ahead of the producer"
+        del junk
+
+
+@pytest.mark.gpu
+def test_replay_pipeline_flat_submit_refuses_uncovered_inputs():
+    """a flat batch refreshes the fp32 inputs only; a slot with other tensor inputs says so instead of
+    replaying them stale."""
+    from golf_amd import functional as GF
+    from golf_amd.pipeline import ReplayPipeline
+    from golf_amd.synthetic import make_inputs
+
+    base = make_inputs(B=2, T=4800, device="cuda", seed=7)
+
+    def fn(inp):
+        return GF.ltv_allpole_ss(inp["noise"] * inp["scale"].float(), inp["gain"], inp["a"], 240, fast_inference=True)
+
+    def mk():
+        d = {k: base[k].clone() for k in ("noise", "gain", "a")}
+        d["scale"] = torch.ones(1, dtype=torch.float16, device="cuda")
+        return d
+
+    pipe = ReplayPipeline(fn, mk, n_slots=1, packed=True)
+    assert pipe.slots[0].unpacked == ["scale"]
+    with pytest.raises(ValueError, match="non-fp32"):
+        pipe.submit(pipe.new_flat())
+    pipe.submit(pipe.pack(base), partial_ok=True).stream.synchronize()
+    with pytest.raises(ValueError, match="fp32"):
+        ReplayPipeline(lambda i: i["x"].float(), lambda: {"x": torch.ones(4, dtype=torch.int32, device="cuda")}, n_slots=1, packed=True)
+
+
+@pytest.mark.gpu
 def test_replay_pipeline_lone_batch_chain_in_flight_is_bit_identical():
     """``ReplayPipeline(throughput=False)`` keeps the filter's lone-batch launch chain with several slots: the two chunk passes are
     then ONE launch whose waves wait for each other's flag words (lpc_fwdq2m_kernel), and three of those launches are in flight at
