@@ -60,10 +60,12 @@ SIGNATURES = {
     "golf_glottal_osc_workspace_bytes": (_sz, [_int] * 7),
     "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
                                         _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _i64,
-                                        _int]),
+                                        _int, _vp]),
+    "golf_glottal_osc_tap_fragments_bytes": (_sz, [_int] * 2),
+    "golf_glottal_osc_tap_fragments_f32": (_int, [_c_f32p, _int, _int, _vp, _sz, _vp]),
     "golf_glottal_osc_bwd_wsel_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p,
                                              _int, _int, _int, _int, _c_f32p, _int, _c_f32p, _int, _int, _vp, _sz,
-                                             _vp]),
+                                             _vp, _vp]),
     "golf_wavetable_lookup_fwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64, _int, _int, _vp]),
     "golf_wavetable_lookup_bwd_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _c_f32p, _i64,
                                              _c_f32p, _int, _int, _vp]),
@@ -107,52 +109,81 @@ SIGNATURES = {
     "golf_peer_wait_u32": (_int, [_vp, _int, _int, ctypes.c_uint32, _i64, _vp, _vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lock = threading.Lock()
 _lib = None
 
 
+def _hipcc_version(hipcc: str) -> str:
+    try:
+        return subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout.decode()
+    except Exception as e:   # noqa: BLE001 -- an unknown compiler is its own stamp
+        return repr(e)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into golf_amd/lib/libgolf_hip.so (hipcc cross-compiles
-    without a GPU).  Rebuilds only when a source/header is newer than the library."""
+    """Compile every HIP source for gfx950 into golf_amd/lib/libgolf_hip.so (hipcc cross-compiles without a GPU).
+    Incremental: a translation unit is recompiled when its source or a header is newer than its object OR when the object was
+    built by another command line or another hipcc (a stamp file next to every object holds both -- ADVICE r5: objects from
+    before a flag change used to be linked silently).  A build with GOLF_HIPCC_FLAGS (kernel-tuning A/B builds) goes to its
+    own objects and its own library, libgolf_hip.flags.so -- load it with GOLF_HIP_LIBRARY -- and never replaces the product
+    library."""
+    import hashlib
+
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_common.h"),
                    os.path.join(INCLUDE, "golf_amd.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    extra = os.environ.get("GOLF_HIPCC_FLAGS", "").split()
+    lib_path = os.path.join(LIB_DIR, "libgolf_hip.flags.so") if extra else LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
+    version = None
+    objs, procs, stamps = [], [], []
     hdr_time = max(os.path.getmtime(d) for d in deps[len(srcs):])
     for s in srcs:
-        o = os.path.join(LIB_DIR, os.path.basename(s) + (".flags.o" if os.environ.get("GOLF_HIPCC_FLAGS") else ".o"))
+        o = os.path.join(LIB_DIR, os.path.basename(s) + (".flags.o" if extra else ".o"))
         objs.append(o)
-        # only the translation units that changed (lpc_ss.hip alone takes three minutes); GOLF_HIPCC_FLAGS builds are always whole
-        if (not force and not os.environ.get("GOLF_HIPCC_FLAGS") and os.path.exists(o)
-                and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_time)):
-            continue
         # -falign-loops=64: the transition kernel's unrolled loop is ~1 300 8-byte packed-FMA encodings; when an unrelated edit
         # moved its start to 4 mod 8 bytes the kernel went from 38.8 to 43.0 us with an otherwise identical instruction stream
         # (round 4, tools/ab2.sh ab_place2) -- aligned loop heads take the placement lottery out of every kernel
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-falign-loops=64", "-I" + INCLUDE, "-I" + CSRC,
-               "-c", s, "-o", o] + os.environ.get("GOLF_HIPCC_FLAGS", "").split()   # kernel-tuning A/B builds (-DP1F_CHAINS=2 ...)
+               "-c", s, "-o", o] + extra   # kernel-tuning A/B builds (-DP1F_CHAINS=2 ...)
+        fresh = os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_time)
+        stamp_file = o + ".cmd"
+        if fresh and not force:
+            if version is None:
+                version = _hipcc_version(hipcc)
+            stamp = hashlib.sha256((" ".join(cmd) + "\n" + version).encode()).hexdigest()
+            try:
+                same = open(stamp_file).read().strip() == stamp
+            except OSError:
+                same = False   # an object without a stamp (built before round 6, or by hand): not trusted
+            if same:
+                continue       # only the translation units that changed (lpc_ss.hip alone takes five minutes)
+        if version is None:
+            version = _hipcc_version(hipcc)
+        stamp = hashlib.sha256((" ".join(cmd) + "\n" + version).encode()).hexdigest()
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        stamps.append((stamp_file, stamp))
+    if not procs and not force and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
+        return lib_path
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    for stamp_file, stamp in stamps:
+        with open(stamp_file, "w") as f:
+            f.write(stamp + "\n")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
     for f in os.listdir(LIB_DIR):   # clang-offload-bundler leaves its temporaries next to the output
-        if f.startswith("libgolf_hip.so.") and ("hipv4-" in f or "host-" in f):
+        if f.startswith(os.path.basename(lib_path) + ".") and ("hipv4-" in f or "host-" in f):
             os.remove(os.path.join(LIB_DIR, f))
-    return LIB_PATH
+    return lib_path
 
 
 def load():

@@ -31,7 +31,7 @@ struct OscGeom {
     int nint;     // control intervals = ceil(N / hop_t)
     int ntile;    // phase-scan tiles of OSC_SCAN_TILE coarse samples
     int pre_stride;  // row stride of the internal oversampled buffer (multiple of 4 floats)
-    size_t off_cw, off_ttot, off_pre, off_part, off_bfr, off_bf4, off_t256, total;
+    size_t off_cw, off_ttot, off_pre, off_part, off_bfr, off_bf4, off_look, total;
 };
 #define OSC_SCAN_TILE 1024
 
@@ -49,7 +49,9 @@ static void osc_geom(int B, int Tp, int phase_hop, int Fw, int w_hop, int os, Os
     g->off_part = o; o = align_up(o + sizeof(float) * (size_t)B * g->nint * 2, 256);
     g->off_bfr = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // Toeplitz tap fragments of the fused backward (transposed FIR)
     g->off_bf4 = o;  o = align_up(o + sizeof(float) * 4 * 16 * 64, 256);   // ... and of the fused forward, four K-steps per 16-byte word (osc_fused2)
-    g->off_t256 = o; o = align_up(o + sizeof(unsigned long long) * (size_t)B * ((size_t)g->ntile * 4 + 8), 256);   // phase advance per 256-sample stretch (osc_fused2's base phase)
+    // round 6: the single-pass phase scan of osc_fused2 (decoupled look-back): B launch counters + one tagged 16-byte entry per
+    // (utterance, 2048-sample tile, wave) -- see OscLook
+    g->off_look = o; o = align_up(o + 256 * ceil_div((size_t)B * 4, 256) + 16 * (size_t)B * ((size_t)(g->ntile + 1) / 2 + 1) * 8, 256);
     g->total = o;
 }
 
@@ -724,6 +726,57 @@ extern "C" int golf_debug_oscf_stamps(unsigned long long* host_out, int n) {
 // no barrier after the staging); 1536-output tiles.  What they have in common: a workgroup's lifetime is a latency chain of
 // ~16 k cycles whatever the tile, and the outputs in flight per CU are bounded by LDS (17 B of signal tile per output + 33 - 49 KB
 // of table rows per workgroup), so every variant lands on the same ~0.25 outputs per cycle and CU.
+// ---- round 6: the phase scan inside the kernel --------------------------------------------------------
+// osc_tile_totals_kernel read the whole phase a second time (6.4 MB at B = 32, 13 % of the oscillator's time at B = 4096) and was
+// a launch on the critical path of a lone batch.  Now every wave of a workgroup, as soon as its phase samples are converted,
+// PUBLISHES the phase advance of the tile's segments it owns -- one 16-byte entry per (utterance, tile, wave) -- and wave 0 sums
+// the entries of the tiles in front of its own (same utterance) before the workgroup's first barrier: a single-pass scan with
+// decoupled look-back.  Integer adds: the base phase is the bit pattern the totals kernel gave.
+//   * An entry is two 8-byte words, each (32 bits of the 64-bit advance | 32-bit tag << 32), stored and polled at agent scope
+//     (the XCDs' L2s are not coherent with each other for ordinary accesses).  An 8-byte access is single-copy atomic, and the
+//     tags are in the words they guard: no flag word, no fence, no second round trip.
+//   * Tags are a hash of (launch counter of the utterance, entry index).  The counter gen[b] lives in the workspace and is
+//     incremented by the workgroup of the utterance's LAST tile after its look-back has seen every other tile's entries -- i.e.
+//     after every wave of every workgroup of that utterance has read gen[b] for this launch (a wave reads it before it can
+//     publish).  Entries of earlier launches therefore never validate, whatever the workspace held before (a fresh, zeroed or
+//     NaN-poisoned buffer is as good as a used one: 2^-64 per entry for random contents), with no clearing pass and nothing
+//     per launch from the host -- which a captured hipGraph could not supply.
+//   * Progress: a workgroup only waits for lower workgroup ids of its own utterance (<= ntile - 1 of them), each of which
+//     publishes in its first microsecond without waiting for anything.  The lowest unfinished id of a launch is always next in
+//     its XCD's dispatch order, and at most ntile - 1 workgroups per utterance can be waiting at any time, so other kernels on
+//     the chip (batches in flight) delay a launch but cannot wedge it.  The poll is bounded all the same; running out puts NaN
+//     into the tile's output.
+struct OscLook {
+    unsigned* gen;           // [B] launch counters
+    unsigned long long* ent; // [B][ntile][8][2]
+};
+__device__ __forceinline__ unsigned osc_look_tag(unsigned gen, unsigned idx, int half) {
+    const unsigned a = (gen + 0x9E3779B1u) * (half ? 0xC2B2AE3Du : 0x85EBCA77u);
+    const unsigned h = a ^ (idx * (half ? 0x27D4EB2Fu : 0x165667B1u)) ^ (half ? 0x5BD1E995u : 0xA54FF53Au);
+    return h ^ (h >> 15);
+}
+// the decimation taps as the MFMA B fragments of the fused kernels (lane `lane` of K-step kk of branch ph holds the tap at
+// d = dmin + (4 kk + lane/16 - lane%16), 0 outside the filter), four K-steps of a lane per 16-byte word:
+// [(ph * KS/4 + kk/4) * 64 + lane][kk % 4].  Bf4: forward; Bfr: backward (transposed FIR: the tap at d = dmax - q).
+// A function of the taps alone: golf_glottal_osc_tap_fragments_f32 builds them ONCE per tap set (round 5 re-laid them every step).
+__global__ __launch_bounds__(256) void osc_tap_frags_kernel(const float* __restrict__ taps, int K, int dmin, int dmax, int KS,
+                                                            float* __restrict__ Bf4, float* __restrict__ Bfr) {
+    const int half = (K - 1) / 2;
+    for (int e = threadIdx.x + blockIdx.x * 256; e < 4 * KS * 64; e += 256 * gridDim.x) {
+        const int lane = e & 63, kk = (e >> 6) % KS, ph = (e >> 6) / KS;
+        const int q = 4 * kk + (lane >> 4) - (lane & 15);
+        const int o = (((ph * (KS >> 2) + (kk >> 2)) * 64 + lane) << 2) + (kk & 3);
+        if (Bf4) {
+            const int d = dmin + q, k = half + 4 * d + ph;
+            Bf4[o] = (q >= 0 && d >= dmin && k >= 0 && k < K) ? taps[k] : 0.f;
+        }
+        if (Bfr) {
+            const int d = dmax - q, k = half + 4 * d + ph;
+            Bfr[o] = (q >= 0 && d >= dmin && d <= dmax && k >= 0 && k < K) ? taps[k] : 0.f;
+        }
+    }
+}
+
 #ifndef OSCF2_XPAD
 #define OSCF2_XPAD 2          // pad words per 16 of the signal tile: 2 = reads conflict-free (18 li + lk is a permutation of the 32 banks),
 #endif                        // render stores 2-way (free); 1 = one 2-way pair per read and FIVE-way stores (measured: +76 M conflict cycles at B = 2048)
@@ -742,38 +795,65 @@ struct Oscf2Geom {
 };
 __device__ __forceinline__ int oscf2_xaddr(int i) { return i + OSCF2_XPAD * (i >> 4); }
 
-// blended control-frame rows r_first .. r_first + NR - 1 of one utterance -> (value, row difference) pairs in LDS
-template <int NR, int NTH>
-__device__ __forceinline__ void oscf2_stage_rows(const float* __restrict__ wrow, int Fw, const float* __restrict__ table, int n_tab,
-                                                 int L, int r_first, int nrw, float2* pairs, int LRP, int tid) {
-    const float* t0[NR];
-    float pw[NR];
+// blended control-frame rows r_first .. r_first + NR - 1 of one utterance -> (value, row difference) pairs in LDS.
+// Round 6: the table-select weights of the rows are fetched at entry (oscf2_row_weights: a dependent round trip in front of the
+// row loads), the rows themselves after the phase scan -- which is where the scan sat anyway, behind the wait for the rows: the
+// sum is the same, but the wave's share of the tile's phase advance is published ~1.3 us after the workgroup started instead of
+// ~2.5, and the row registers do not live through the scan.
+template <int NR>
+__device__ __forceinline__ void oscf2_row_weights(const float* __restrict__ wrow, int Fw, int r_first, int nrw, float (&wk)[OSCF_MAXROWS]) {
 #pragma unroll
     for (int e = 0; e < NR; ++e) {
         int k = r_first + (e < nrw ? e : nrw - 1);
         if (k > Fw - 1) k = Fw - 1;              // replicate-padded frames (models/synth.py:141-146)
-        const float idx = wrow[k] * (float)(n_tab - 1);
+        wk[e] = wrow[k];
+    }
+}
+template <int NR>
+struct OscRows {                                 // a thread's first 16-byte row loads, in flight through the phase scan
+    int i0[NR];                                  // (uniform) first of the two table rows a control frame blends
+    float pw[NR];
+    f32x4_t va[NR], vb[NR];
+};
+template <int NR, int NTH>
+__device__ __forceinline__ void oscf2_rows_issue(const float (&wk)[OSCF_MAXROWS], const float* __restrict__ table, int n_tab, int L,
+                                                 int tid, OscRows<NR>& R) {
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+        const float idx = wk[e] * (float)(n_tab - 1);
         int i0 = __builtin_amdgcn_readfirstlane((int)idx);
         i0 = i0 < 0 ? 0 : (i0 > n_tab - 2 ? n_tab - 2 : i0);
-        pw[e] = idx - (float)i0;
-        t0[e] = table + (size_t)i0 * L;
+        R.pw[e] = idx - (float)i0;
+        R.i0[e] = i0;
     }
-    for (int c4 = tid; 4 * c4 < L; c4 += NTH) {
-        f32x4_t va[NR], vb[NR], R[NR];
+    const int c4 = 4 * tid < L ? tid : 0;
 #pragma unroll
-        for (int e = 0; e < NR; ++e) {
-            va[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + 4 * c4);
-            vb[e] = *reinterpret_cast<const f32x4_t*>(t0[e] + L + 4 * c4);
+    for (int e = 0; e < NR; ++e) {
+        const float* t0 = table + (size_t)R.i0[e] * L;
+        R.va[e] = *reinterpret_cast<const f32x4_t*>(t0 + 4 * c4);
+        R.vb[e] = *reinterpret_cast<const f32x4_t*>(t0 + L + 4 * c4);
+    }
+}
+template <int NR, int NTH>
+__device__ __forceinline__ void oscf2_rows_finish(const float* __restrict__ table, int L, float2* pairs, int LRP, int tid, OscRows<NR>& R) {
+    for (int c4 = tid; 4 * c4 < L; c4 += NTH) {
+        if (c4 != tid) {
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const float* t0 = table + (size_t)__builtin_amdgcn_readfirstlane(R.i0[e]) * L;
+                R.va[e] = *reinterpret_cast<const f32x4_t*>(t0 + 4 * c4);
+                R.vb[e] = *reinterpret_cast<const f32x4_t*>(t0 + L + 4 * c4);
+            }
         }
 #pragma unroll
         for (int e = 0; e < NR; ++e)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) R[e][q] = fmaf(vb[e][q], pw[e], va[e][q] * (1.0f - pw[e]));
+            for (int q = 0; q < 4; ++q) R.va[e][q] = fmaf(R.vb[e][q], R.pw[e], R.va[e][q] * (1.0f - R.pw[e]));
 #pragma unroll
         for (int rr = 0; rr + 1 < NR; ++rr) {
             f32x4_t* dst = reinterpret_cast<f32x4_t*>(pairs + (size_t)rr * LRP + 4 * c4);
-            const f32x4_t lo = {R[rr][0], R[rr + 1][0] - R[rr][0], R[rr][1], R[rr + 1][1] - R[rr][1]};
-            const f32x4_t hi = {R[rr][2], R[rr + 1][2] - R[rr][2], R[rr][3], R[rr + 1][3] - R[rr][3]};
+            const f32x4_t lo = {R.va[rr][0], R.va[rr + 1][0] - R.va[rr][0], R.va[rr][1], R.va[rr + 1][1] - R.va[rr][1]};
+            const f32x4_t hi = {R.va[rr][2], R.va[rr + 1][2] - R.va[rr][2], R.va[rr][3], R.va[rr + 1][3] - R.va[rr][3]};
             dst[0] = lo;
             dst[1] = hi;
             if (c4 == 0) pairs[(size_t)rr * LRP + L] = make_float2(lo[0], lo[1]);   // column L = column 0
@@ -781,12 +861,13 @@ __device__ __forceinline__ void oscf2_stage_rows(const float* __restrict__ wrow,
     }
 }
 
-template <int EE, int KS, int TO, int NTH, bool EDGE>
+template <int EE, int KS, int TO, int NTH, bool EDGE, int NRT>   // NRT: control-frame rows staged (= nrows, 2 .. OSCF_MAXROWS)
 __device__ __forceinline__ void oscf2_body(
-    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ T256, int nt256,
+    const float* __restrict__ phase, int64_t phase_stride, OscLook look, u64* __restrict__ Ttot,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
     int hop_t, const float* __restrict__ Bf4, float* __restrict__ out, int64_t out_stride, int Tout,
-    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem) {
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem,
+    int tile, int b, int ntile) {
     typedef Oscf2Geom<KS, TO> G;
     constexpr int SPAN = G::SPAN, XS = G::XS;
     constexpr int CPT = (SPAN + NTH - 1) / NTH, NW = NTH / 64, NT = TO / 256;
@@ -799,7 +880,12 @@ __device__ __forceinline__ void oscf2_body(
     u64* wtot = scr;                             // [NW]
     u64* base_p = scr + NW;                      // base phase of the tile start
     u64* halo_p = base_p + 1;                    // prefix at index -dmin
-    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    u64* wown = halo_p + 1;                      // [NW] the waves' shares of the tile's own phase advance (-> Ttot)
+    unsigned* lost_p = reinterpret_cast<unsigned*>(wown + NW);   // the look-back ran out
+    static_assert((NW + 2 + NW) * 8 + 4 <= G::SCRATCH, "scratch behind the fragments");
+    const int tid = threadIdx.x, lane = tid & 63;
+    // this launch's counter of the utterance (scalar load; see OscLook)
+    const unsigned gnow = (unsigned)__builtin_amdgcn_readfirstlane((int)look.gen[b]);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int o0 = tile * TO;
@@ -816,49 +902,69 @@ __device__ __forceinline__ void oscf2_body(
         const int j = j_lo + i0t + r;
         pv[r] = prow.ld(EDGE ? (j < 0 ? 0 : (j > Tp - 1 ? Tp - 1 : j)) : j);
     }
-    u64 tacc = 0;
-    if (wv == 0)                                 // (osc_tile_totals_kernel: one total per 256-sample stretch)
-        for (int i = lane; i < tile * NT; i += 64) tacc += T256[(size_t)b * nt256 + i];
     // D rows 4 lk + r, column li of wave tile wv  ->  output o0 + 256 wv + 16 (4 lk + r) + li
     const BufRow arow(addend ? addend + (size_t)b * addend_stride : nullptr, addend ? Tadd : 0);
     const int ob = o0 + 256 * wv + 64 * lk + li;
-    float ad[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ad[r] = wv < NT ? arow.ld(ob + 16 * r) : 0.f;
     constexpr int NFQ4 = OSCF2_FRAG_LDS * (KS / 4) * 64;      // 16-byte words of the branches staged in LDS
-    f32x4_t fq[NFQ4 > 0 ? (NFQ4 + NTH - 1) / NTH : 1];
-#pragma unroll
-    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
-        const int e = tid + q * NTH;
-        fq[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + 4 * (e < NFQ4 ? e : 0));
-    }
-    // (the remaining branches' fragments: 16-byte global loads of the waves that multiply, in flight through scan and render)
-    f32x4_t fg[OSCF2_FRAG_LDS < 4 ? (4 - OSCF2_FRAG_LDS) * (KS / 4) : 1];
-    if (OSCF2_FRAG_LDS < 4 && wv < NT) {
-#pragma unroll
-        for (int q = 0; q < (4 - OSCF2_FRAG_LDS) * (KS / 4); ++q)
-            fg[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + (((OSCF2_FRAG_LDS * (KS / 4) + q) * 64 + lane) << 2));
-    }
     const int m_first = max(j_lo, 0) * 4;        // first fine sample that exists in this tile
     const int r_first = m_first / hop_t;         // its control frame; rows r_first .. r_first + nrows - 1 are staged
+    float wk[OSCF_MAXROWS];
     {
         const int m_last = min(j_lo + SPAN - 1, Tp - 1) * 4 + 3;
         const int nrw = min(nrows, m_last / hop_t - r_first + 2);   // rows this tile's samples really touch
-        // rows beyond nrw repeat row nrw - 1 (their pair rows hold zeros as differences and are never read by a sample that
-        // exists): every load below is unconditional, so all of a thread's 16-byte row loads are in flight together
-        if (nrows <= 2)      oscf2_stage_rows<2, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
-        else if (nrows == 3) oscf2_stage_rows<3, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
-        else                 oscf2_stage_rows<4, NTH>(wsel + (size_t)b * Fw, Fw, table, n_tab, L, r_first, nrw, pairs, LRP, tid);
+        // rows beyond nrw repeat row nrw - 1 (their pair rows hold zeros as differences and are never read by a sample that exists)
+        oscf2_row_weights<NRT>(wsel + (size_t)b * Fw, Fw, r_first, nrw, wk);
     }
+    constexpr int LBQ = 3;                       // polls in flight per lane: 3 x 64 entries = 24 tiles (2 s of audio) per round
+    const int nent = tile * NW;
+    u64 lw0[LBQ], lw1[LBQ];
+    // `optimistic`: ordinary loads, served from this XCD's L2 -- which may hold a line from before its owner wrote it (another
+    // workgroup of this XCD polled it too early).  That is harmless: the tags are in the words they guard, a stale line can only
+    // fail to validate, and what fails is polled again at agent scope.  At a device-saturating batch the tiles in front finished
+    // rounds ago and the cheap poll is the only one.
+    auto look_poll = [&](int e0, unsigned pend, bool optimistic = false) {
 #pragma unroll
-    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
-        const int e = tid + q * NTH;
-        if (e < NFQ4) reinterpret_cast<f32x4_t*>(frag)[e] = fq[q];
-    }
-    if (wv == 0) {
-        tacc = wave_incl_scan(tacc, lane);
-        if (lane == 63) *base_p = tacc;
-    }
+        for (int u = 0; u < LBQ; ++u) {
+            const unsigned idx = (unsigned)(b * ntile * NW + (((pend >> u) & 1u) ? e0 + 64 * u + lane : 0));
+            const u64* e = look.ent + 2 * (size_t)idx;
+            if (optimistic) {
+                lw0[u] = __builtin_nontemporal_load(e);
+                lw1[u] = __builtin_nontemporal_load(e + 1);
+            } else {
+                lw0[u] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lw1[u] = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto look_pending = [&](int e0) {
+        unsigned pend = 0;
+#pragma unroll
+        for (int u = 0; u < LBQ; ++u) pend |= (e0 + 64 * u + lane < nent) ? 1u << u : 0u;
+        return pend;
+    };
+    // The look-back's first poll (wave 0) goes out HERE, behind the phase samples and the row weights and in front of everything
+    // else: an agent-scope load takes 1 - 2 us and loads return in order, so whatever is issued behind it waits for it -- the rows,
+    // ~1.3 us from now, by which time it is nearly back (measured the other way round, the poll issued with the rows: every
+    // workgroup 10 % longer at B = 16 384).  In every round of workgroups but the first the tiles in front published long ago
+    // and this poll is the only one.
+    u64 lacc = 0;                                // (wave 0) advances collected so far
+    unsigned lpend = look_pending(0);            // entries of the first round still missing
+    auto look_eval = [&](int e0) {
+#pragma unroll
+        for (int u = 0; u < LBQ; ++u) {
+            const unsigned idx = (unsigned)(b * ntile * NW + e0 + 64 * u + lane);
+            const bool ok = (unsigned)(lw0[u] >> 32) == osc_look_tag(gnow, idx, 0) &&
+                            (unsigned)(lw1[u] >> 32) == osc_look_tag(gnow, idx, 1);
+            if (((lpend >> u) & 1u) && ok) {
+                lacc += (lw0[u] & 0xffffffffull) | (lw1[u] << 32);
+                lpend &= ~(1u << u);
+            }
+        }
+    };
+    if (wv == 0 && nent > 0) look_poll(0, lpend, true);
+    // the rows: their weights were fetched with the phase samples; the loads go out now and are consumed behind the scan
+    OscRows<NRT> rows;
+    oscf2_rows_issue<NRT, NTH>(wk, table, n_tab, L, tid, rows);
     OSCF_STAMP(1);
     // ---- 2. conversions and the in-wave scan
     u64 av[CPT + 1];
@@ -887,8 +993,79 @@ __device__ __forceinline__ void oscf2_body(
         for (int r = 0; r + 1 < CPT; ++r) r2 += r < rh ? seg_of(r) : 0;
         if (tid == th) *halo_p = r2;
     }
+    {   // ---- 2b. publish this wave's share of the tile's OWN advance (segments o0 .. o0 + TO - 1 = indices -dmin .. -dmin + TO - 1)
+        u64 own = 0;
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            const int i = i0t + r;
+            own += (i >= -dmin && i < -dmin + TO) ? seg_of(r) : 0;
+        }
+        own = wave_incl_scan(own, lane);
+        if (lane == 63) {
+            wown[wv] = own;
+            const unsigned idx = (unsigned)((b * ntile + tile) * NW + wv);
+            u64* e = look.ent + 2 * (size_t)idx;
+            const u64 w0 = (own & 0xffffffffull) | ((u64)osc_look_tag(gnow, idx, 0) << 32);
+            const u64 w1 = (own >> 32) | ((u64)osc_look_tag(gnow, idx, 1) << 32);
+            __hip_atomic_store(e, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // A workgroup whose neighbours in front started with it (a lone batch: 512 of its 768 workgroups enter within a microsecond)
+    // finds nothing in its first poll.  By now those neighbours have published as well: the second poll goes out at once and is
+    // back with the rows, instead of starting behind them.
+    if (wv == 0 && nent > 0) {
+        look_eval(0);
+        if (__builtin_amdgcn_ballot_w64(lpend != 0u) != 0ull) look_poll(0, lpend);
+    }
+    // ---- 2c. the rows and the LDS-staged fragments
+    f32x4_t fq[NFQ4 > 0 ? (NFQ4 + NTH - 1) / NTH : 1];
+#pragma unroll
+    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
+        const int e = tid + q * NTH;
+        fq[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + 4 * (e < NFQ4 ? e : 0));
+    }
+    oscf2_rows_finish<NRT, NTH>(table, L, pairs, LRP, tid, rows);
+#pragma unroll
+    for (int q = 0; q < (NFQ4 + NTH - 1) / NTH; ++q) {
+        const int e = tid + q * NTH;
+        if (e < NFQ4) reinterpret_cast<f32x4_t*>(frag)[e] = fq[q];
+    }
+    if (wv == 0) {   // ---- 2d. look back: the base phase = the advance of every tile in front of this one
+        bool lost = false;
+        for (int e0 = 0; e0 < nent; e0 += 64 * LBQ) {
+            if (e0 > 0) lpend = look_pending(e0);
+            for (unsigned it = 0u;; ++it) {
+                // (round 0: whatever is still pending has a poll in flight since the publication above)
+                if (e0 > 0 || it > 0) look_poll(e0, lpend);
+                look_eval(e0);
+                if (__builtin_amdgcn_ballot_w64(lpend != 0u) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (it > (1u << 18)) { lost = true; break; }       // (never observed; bounded like every device-side wait here)
+            }
+        }
+        lacc = wave_incl_scan(lacc, lane);
+        if (lane == 63) { *base_p = lacc; *lost_p = lost ? 1u : 0u; }
+    }
     __syncthreads();                             // row pairs, fragments, wave totals, bases
+    if (tid == 64) {                             // the tile's own total, for the backward (golf_glottal_osc_bwd_wsel_f32, GOLF_OSC_WS_KEPT)
+        u64 t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += wown[w];
+        Ttot[(size_t)b * ntile + tile] = t;
+    }
+    // every wave of every workgroup of this utterance has read gen[b] by now (wave 0 saw all their entries): the next launch's value
+    if (tile == ntile - 1 && tid == 0) look.gen[b] = gnow + 1u;
+    const bool lost = *lost_p != 0u;             // (uniform) the look-back ran out: this tile's output is NaN, not a wrong phase
     OSCF_STAMP(2);
+    // (the remaining branches' fragments: 16-byte global loads of the waves that multiply, in flight through the render.  Round 6:
+    //  issued here, not at entry -- the row registers now live through the scan, and these twelve were what spilled)
+    f32x4_t fg[OSCF2_FRAG_LDS < 4 ? (4 - OSCF2_FRAG_LDS) * (KS / 4) : 1];
+    if (OSCF2_FRAG_LDS < 4 && wv < NT) {
+#pragma unroll
+        for (int q = 0; q < (4 - OSCF2_FRAG_LDS) * (KS / 4); ++q)
+            fg[q] = *reinterpret_cast<const f32x4_t*>(Bf4 + (((OSCF2_FRAG_LDS * (KS / 4) + q) * 64 + lane) << 2));
+    }
     u64 ph = *base_p - *halo_p + excl;
 #pragma unroll
     for (int w = 0; w < NW; ++w) ph += w < wv ? wtot[w] : 0;
@@ -995,6 +1172,11 @@ __device__ __forceinline__ void oscf2_body(
     // ---- 4. polyphase FIR on the matrix pipe: wave wv owns outputs o0 + 256 wv .. + 255 as a 16 x 16 tile
     //         D[m][n] (output 256 wv + 16 m + n) = sum_ph sum_k' X_ph[256 wv + 16 m + k'] * B_ph[k'][n]
     if (wv < NT) {
+        // the fused addend of the wave's outputs (round 6: fetched here, behind the render, not at entry -- four registers that
+        // lived through every phase; the matrix phase below hides the round trip)
+        float ad[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ad[r] = lost ? __builtin_nanf("") : arow.ld(ob + 16 * r);
         float bfrag[4][KS];
 #pragma unroll
         for (int phs = 0; phs < 4; ++phs)
@@ -1030,24 +1212,43 @@ __device__ __forceinline__ void oscf2_body(
     OSCF_RT(1);
 }
 
+// one (utterance, tile) unit: the body of osc_fused2_kernel, and of the oscillator workgroups of the source + transition-map launch
+template <int EE, int KS, int TO, int NTH>
+__device__ __forceinline__ void osc_fused2_tile(
+    const float* __restrict__ phase, int64_t phase_stride, OscLook look, u64* __restrict__ Ttot,
+    const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
+    int hop_t, const float* __restrict__ Bf4, float* __restrict__ out, int64_t out_stride, int Tout,
+    int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd, float* smem, int tile, int b,
+    int ntile) {
+    typedef Oscf2Geom<KS, TO> G;
+    const int j_lo = tile * TO + dmin;
+    // every coarse sample j_lo .. j_lo + SPAN (the last one as a segment's right end) exists and is not the last
+    const bool edge = j_lo < 0 || j_lo + G::SPAN > Tp - 1;
+#define OSCF2_BODY(EDGEV, NRV)                                                                                                  \
+    oscf2_body<EE, KS, TO, NTH, EDGEV, NRV>(phase, phase_stride, look, Ttot, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out, \
+                                            out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem, tile, b, ntile)
+    // (the row count is a property of the launch, the edge of the tile: one of these six bodies runs per workgroup)
+    if (nrows <= 2)      { if (edge) OSCF2_BODY(true, 2); else OSCF2_BODY(false, 2); }
+    else if (nrows == 3) { if (edge) OSCF2_BODY(true, 3); else OSCF2_BODY(false, 3); }
+    else                 { if (edge) OSCF2_BODY(true, 4); else OSCF2_BODY(false, 4); }
+#undef OSCF2_BODY
+}
+
 template <int EE, int KS, int TO, int NTH>
 __global__ __launch_bounds__(NTH, 4) void osc_fused2_kernel(
-    const float* __restrict__ phase, int64_t phase_stride, const u64* __restrict__ T256, int nt256,
+    const float* __restrict__ phase, int64_t phase_stride, OscLook look, u64* __restrict__ Ttot,
     const float* __restrict__ wsel, int Fw, const float* __restrict__ table, int n_tab, int L, int lshift, int Tp,
     int hop_t, const float* __restrict__ Bf4, float* __restrict__ out, int64_t out_stride, int Tout,
     int dmin, int nrows, const float* __restrict__ addend, int64_t addend_stride, int Tadd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     light_wave_priority();
-    typedef Oscf2Geom<KS, TO> G;
-    const int j_lo = blockIdx.x * TO + dmin;
-    // every coarse sample j_lo .. j_lo + SPAN (the last one as a segment's right end) exists and is not the last
-    const bool edge = j_lo < 0 || j_lo + G::SPAN > Tp - 1;
-    if (edge)
-        oscf2_body<EE, KS, TO, NTH, true>(phase, phase_stride, T256, nt256, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out,
-                                         out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem);
-    else
-        oscf2_body<EE, KS, TO, NTH, false>(phase, phase_stride, T256, nt256, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out,
-                                          out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem);
+    // grid x = utterance, y = tile: workgroup ids run TILE-major, so that the tiles a workgroup looks back to were dispatched a
+    // whole batch of workgroups earlier -- at a device-saturating batch, many rounds earlier: their entries are there at the first
+    // poll.  (Utterance-major, all tiles of an utterance enter within a fraction of a microsecond of each other whatever the
+    // batch, and every workgroup pays the second poll: measured 7.7 - 8.0 ms against 7.05 for round 5's two launches at B = 16 384.)
+    osc_fused2_tile<EE, KS, TO, NTH>(phase, phase_stride, look, Ttot, wsel, Fw, table, n_tab, L, lshift, Tp, hop_t, Bf4, out,
+                                     out_stride, Tout, dmin, nrows, addend, addend_stride, Tadd, smem, (int)blockIdx.y,
+                                     (int)blockIdx.x, (int)gridDim.y);
 }
 
 // ---- fused backward w.r.t. table_select_weight (round 3): the forward's structure run the other way ----------------
@@ -1801,11 +2002,38 @@ static bool osc_fused2_plan(const OscGeom& g, const float* table, int L, int os,
     return f->nrows <= OSCF_MAXROWS && f->lds <= 160 * 1024;
 }
 
+// The taps' Toeplitz fragments, prepared once per tap set (ABI 6): [Bfr: 4 x 16 x 64 floats][Bf4: the same].
+static constexpr size_t kTapFragFloats = 4 * 16 * 64;
+struct TapGeom { int dmin, dmax, KS; bool ok; };
+static TapGeom tap_geom(int K, int os) {
+    TapGeom t;
+    const int half = (K - 1) / 2;
+    t.dmin = -((half + os - 1) / os);
+    t.dmax = half / os;
+    const int nq = t.dmax - t.dmin + 1;
+    t.KS = nq + 15 <= 48 ? 12 : 16;
+    t.ok = os == 4 && K >= 1 && (K & 1) && nq + 15 <= 64 && -t.dmin < 64;
+    return t;
+}
+extern "C" size_t golf_glottal_osc_tap_fragments_bytes(int K, int os) {
+    return tap_geom(K, os).ok ? 2 * kTapFragFloats * sizeof(float) : 0;
+}
+extern "C" int golf_glottal_osc_tap_fragments_f32(const float* taps, int K, int os, void* frags, size_t frags_bytes, void* stream) {
+    const TapGeom t = tap_geom(K, os);
+    if (!t.ok) return fail(GOLF_EUNSUPPORTED, "glottal_osc_tap_fragments: the fused oscillator takes os = 4 and an odd tap count of at most 195 (K=%d, os=%d)", K, os);
+    if (!taps || !frags || frags_bytes < 2 * kTapFragFloats * sizeof(float) || ((uintptr_t)frags & 15))
+        return fail(GOLF_EINVAL, "glottal_osc_tap_fragments: needs taps and a 16-byte aligned buffer of %zu bytes", 2 * kTapFragFloats * sizeof(float));
+    float* Bfr = (float*)frags;
+    hipLaunchKernelGGL(osc_tap_frags_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, taps, K, t.dmin, t.dmax, t.KS, Bfr + kTapFragFloats, Bfr);
+    GOLF_LAUNCH_CHECK();
+    return GOLF_OK;
+}
+
 extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                                         const float* wsel, int Fw, int w_hop, const float* table, int n_tab, int L,
                                         int os, int equal_energy, const float* taps, int K, float* pre, float* out,
                                         int64_t out_stride, int B, int Tout, void* ws, size_t ws_bytes, void* stream,
-                                        const float* addend, int64_t addend_stride, int Tadd) {
+                                        const float* addend, int64_t addend_stride, int Tadd, const void* tap_frags) {
     if (int rc = osc_check(B, Tp, phase_hop, Fw, w_hop, n_tab, L, os, K, taps)) return rc;
     if (!phase || !wsel || !table || !out) return fail(GOLF_EINVAL, "glottal_osc_fwd: null pointer");
     OscGeom g;
@@ -1824,12 +2052,17 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
     // ---- fused path (the GOLF configuration): phase at hop 1, 4x oversampling, power-of-two table, no `pre` wanted
     OscFused2 f2;
     if (osc_fused2_plan(g, table, L, os, K, pre != nullptr, Tout, B, &f2)) {
-        float* Bfr = (float*)((char*)ws + g.off_bfr);
-        float* Bf4 = (float*)((char*)ws + g.off_bf4);
-        u64* T256 = (u64*)((char*)ws + g.off_t256);
-        hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
-                           Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, Bfr, f2.dmax, Bf4, T256);
-        GOLF_LAUNCH_CHECK();
+        // ONE launch (round 6): the phase scan is inside the kernel (OscLook).  The taps' fragments come prepared (tap_frags,
+        // golf_glottal_osc_tap_fragments_f32: once per tap set) or are laid out into the workspace by a small launch of their own.
+        const float* Bf4 = tap_frags ? (const float*)tap_frags + kTapFragFloats : (const float*)((char*)ws + g.off_bf4);
+        if (!tap_frags) {
+            hipLaunchKernelGGL(osc_tap_frags_kernel, dim3(4), dim3(256), 0, st, taps, K, f2.dmin, f2.dmax, f2.KS,
+                               (float*)((char*)ws + g.off_bf4), (float*)((char*)ws + g.off_bfr));
+            GOLF_LAUNCH_CHECK();
+        }
+        OscLook look;
+        look.gen = (unsigned*)((char*)ws + g.off_look);
+        look.ent = (unsigned long long*)((char*)ws + g.off_look + 256 * ceil_div((size_t)B * 4, 256));
 #define GOLF_FUSED2(EE, KSV, TOV, NTHV)                                                                               \
     do {                                                                                                              \
         static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
@@ -1837,8 +2070,8 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         if (lds_attr != hipSuccess) /* > 64 KB of dynamic LDS per workgroup needs the opt-in */                       \
             return fail((int)lds_attr, "glottal_osc_fwd: cannot raise the dynamic LDS limit: %s",                     \
                         hipGetErrorString(lds_attr));                                                                 \
-        hipLaunchKernelGGL((osc_fused2_kernel<EE, KSV, TOV, NTHV>), dim3(f2.ntile_f, B), dim3(NTHV), f2.lds, st, phase, \
-                           phase_stride, (const u64*)T256, f2.ntile2 * (OSCF_TO / 256), wsel, Fw, table, n_tab, L,    \
+        hipLaunchKernelGGL((osc_fused2_kernel<EE, KSV, TOV, NTHV>), dim3(B, f2.ntile_f), dim3(NTHV), f2.lds, st, phase, \
+                           phase_stride, look, Ttot, wsel, Fw, table, n_tab, L,                                       \
                            f2.lshift, Tp, g.hop_t, (const float*)Bf4, out, out_stride, Tout, f2.dmin, f2.nrows,       \
                            addend, addend_stride, Tadd);                                                              \
     } while (0)
@@ -1884,7 +2117,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
                                              int64_t phase_stride, int Tp, int phase_hop, const float* wsel, int Fw,
                                              int w_hop, const float* table, int n_tab, int L, int os, int equal_energy,
                                              const float* taps, int K, float* g_wsel, int B, int Tout, void* ws,
-                                             size_t ws_bytes, void* stream) {
+                                             size_t ws_bytes, void* stream, const void* tap_frags) {
     if (int rc = osc_check(B, Tp, phase_hop, Fw, w_hop, n_tab, L, os, K, taps)) return rc;
     if (!g_out || !phase || !wsel || !table || !g_wsel) return fail(GOLF_EINVAL, "glottal_osc_bwd: null pointer");
     OscGeom g;
@@ -1915,7 +2148,8 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
             sizeof(float) * (size_t)B * ntile2 * OSCF_MAXROWS <= sizeof(float) * (size_t)B * g.pre_stride) {
             const int lshift = 31 - __builtin_clz((unsigned)L);
             u64* Ttot = (u64*)((char*)ws + g.off_ttot);
-            float* Bf = (float*)((char*)ws + g.off_bfr);
+            float* Bfw = (float*)((char*)ws + g.off_bfr);
+            const float* Bf = tap_frags ? (const float*)tap_frags : (const float*)Bfw;   // prepared fragments (ABI 6) or the workspace's
             float* part2 = (float*)((char*)ws + g.off_pre);      // the oversampled-gradient buffer is not needed here
             // The fused forward computed exactly these totals (same tiles: OSCB_TO == OSCF_TO, Tp == Tout at hop 1) and wrote
             // the transposed tap fragments next to its own: with its workspace intact the backward is two launches, not three
@@ -1926,7 +2160,7 @@ extern "C" int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_s
                                      f2.ntile2 == ntile2 && f2.KS == KS && f2.dmax == dmax;
             if (!have_totals) {
                 hipLaunchKernelGGL(osc_tile_totals_kernel<OSCB_TO>, dim3(ntile2, B), dim3(osct_threads(OSCB_TO)), 0, st, phase, phase_stride, Ttot, Tp,
-                                   g.P, os, ntile2, taps, K, dmin, KS, Bf, dmax, (float*)nullptr, (u64*)nullptr);
+                                   g.P, os, ntile2, taps, K, dmin, KS, tap_frags ? (float*)nullptr : Bfw, dmax, (float*)nullptr, (u64*)nullptr);
                 GOLF_LAUNCH_CHECK();
             }
 #define GOLF_FUSED_BWD(EE, KSV)                                                                                       \

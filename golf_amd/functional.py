@@ -481,6 +481,33 @@ def osc_lengths(Tp: int, phase_hop: int, os: int):
     return N, Tout
 
 
+_TAP_FRAGS: dict = {}   # (taps pointer, version, K, os, device) -> the taps' Toeplitz fragments (golf_glottal_osc_tap_fragments_f32)
+
+
+def osc_tap_fragments(taps: torch.Tensor, os: int):
+    """The decimation taps laid out for the matrix pipe, prepared once per tap set (ABI 6; the module's taps are a constant
+    buffer, so this runs once per module and device).  None where the fused oscillator does not apply, and -- so that no
+    allocation of a graph's private pool ends up in a process-wide cache -- when asked for the first time during a hipGraph
+    capture: the library then lays them out inside the call, as it did every step until round 5."""
+    if taps is None or taps.numel() == 0:
+        return None
+    key = (taps.data_ptr(), taps._version, taps.numel(), int(os), taps.device)
+    hit = _TAP_FRAGS.get(key)
+    if hit is not None:
+        return hit[0]
+    lib = _lib.load()
+    n = lib.golf_glottal_osc_tap_fragments_bytes(taps.numel(), int(os))
+    if n == 0 or torch.cuda.is_current_stream_capturing():
+        return None
+    frags = torch.empty(n, dtype=torch.uint8, device=taps.device)
+    _lib.check(lib.golf_glottal_osc_tap_fragments_f32(taps.data_ptr(), taps.numel(), int(os), frags.data_ptr(), n,
+                                                      _lib.stream_ptr()), "golf_glottal_osc_tap_fragments_f32")
+    if len(_TAP_FRAGS) >= 16:
+        _TAP_FRAGS.pop(next(iter(_TAP_FRAGS)))
+    _TAP_FRAGS[key] = (frags, taps)   # (the taps tensor is kept alive with its fragments: the key is its address)
+    return frags
+
+
 class _GlottalOsc(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
@@ -509,12 +536,15 @@ class _GlottalOsc(torch.autograd.Function):
         out = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
         pre = torch.empty(B, N, dtype=torch.float32, device=phase.device) if (want_pre and os > 1) else None
         ws = _workspace(lib.golf_glottal_osc_workspace_bytes(B, Tp, phase_hop, Fw, w_hop, L, os), phase.device)
+        frags = osc_tap_fragments(taps, os) if (os > 1 and not want_pre) else None
         rc = lib.golf_glottal_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, wsel.data_ptr(), Fw, w_hop,
                                           table.data_ptr(), n_tab, L, os, int(bool(equal_energy)), _lib.ptr(taps), K,
                                           _lib.ptr(pre), out.data_ptr(), out.stride(0), B, Tout, ws.data_ptr(),
                                           ws.numel(), _lib.stream_ptr(), _lib.ptr(add),
-                                          0 if add is None else add.stride(0), 0 if add is None else add.shape[1])
+                                          0 if add is None else add.stride(0), 0 if add is None else add.shape[1],
+                                          _lib.ptr(frags))
         _lib.check(rc, "golf_glottal_osc_fwd_f32")
+        ctx.frags = frags   # a backward that reuses the workspace takes the fragments its forward took
         ctx.cfg = (phase_hop, w_hop, os, bool(equal_energy))
         ctx.ws_kept = pre is None   # the saved workspace is private to this node: the backward may reuse the forward's totals
         ctx.add_len = None if add is None else add.shape[1]
@@ -538,7 +568,8 @@ class _GlottalOsc(torch.autograd.Function):
                                                phase_hop, wsel.data_ptr(), Fw, w_hop, table.data_ptr(), n_tab, L, os,
                                                int(eq) | (OSC_WS_KEPT if ctx.ws_kept else 0), _lib.ptr(taps) if K else 0, K,
                                                g_w.data_ptr(), B,
-                                               g_out.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                               g_out.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr(),
+                                               _lib.ptr(ctx.frags))
         _lib.check(rc, "golf_glottal_osc_bwd_wsel_f32")
         g_add = None
         if ctx.add_len is not None and ctx.needs_input_grad[9]:   # out[:, :Tadd] += add

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GOLF_ABI_VERSION 5
+#define GOLF_ABI_VERSION 6
 
 enum {
     GOLF_OK = 0,
@@ -273,13 +273,26 @@ int golf_sos2lpc_bwd_f32(const float* logits, const float* g_a, float* g_logits,
  *   decimator's epilogue (one full-tensor round trip and one launch less per step). */
 size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fw, int w_hop, int L, int os);
 
+/* ABI 6: the decimation taps laid out for the matrix pipe, ONCE per tap set instead of once per step.  The fused oscillator
+ * (os = 4, phase at hop 1, power-of-two table) multiplies the 4x oversampled signal by Toeplitz fragments of the taps
+ * (v_mfma_f32_16x16x4_f32); they are a function of the taps alone -- kazane.Decimate's kernel is a constant buffer of the module,
+ * models/synth.py:208-211 -- so a caller prepares them when the taps change and hands them to every forward / backward as
+ * `tap_frags`.  NULL is always allowed: the call then lays them out itself (one small launch more).  A backward with
+ * GOLF_OSC_WS_KEPT takes the same `tap_frags` its forward took.  _bytes returns 0 where the fused path does not apply. */
+size_t golf_glottal_osc_tap_fragments_bytes(int K, int os);
+int golf_glottal_osc_tap_fragments_f32(const float* taps, int K, int os, void* frags, size_t frags_bytes, void* stream);
+
+/* Round 6: ONE launch for the fused configuration.  The running phase is a single-pass scan inside the kernel (decoupled
+ * look-back over tagged entries in `ws`; no totals launch, the phase is read once) -- the workspace may hold anything on entry
+ * (no zero-fill is required, stale entries of earlier launches never validate) but must not be shared by launches in flight
+ * at the same time. */
 int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
                              const float* wsel, int Fw, int w_hop,
                              const float* table, int n_tab, int L,
                              int os, int equal_energy, const float* taps, int K,
                              float* pre, float* out, int64_t out_stride, int B, int Tout,
                              void* ws, size_t ws_bytes, void* stream,
-                             const float* addend, int64_t addend_stride, int Tadd);
+                             const float* addend, int64_t addend_stride, int Tadd, const void* tap_frags);
 
 /* Backward w.r.t. table_select_weight only (phase is data in GOLF training: train_with_true_f0,
  * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = a workspace of the forward's size.
@@ -294,7 +307,7 @@ int golf_glottal_osc_bwd_wsel_f32(const float* g_out, int64_t g_out_stride,
                                   const float* table, int n_tab, int L,
                                   int os, int equal_energy, const float* taps, int K,
                                   float* g_wsel, int B, int Tout,
-                                  void* ws, size_t ws_bytes, void* stream);
+                                  void* ws, size_t ws_bytes, void* stream, const void* tap_frags);
 
 /* Generic wavetable lookup = GlottalFlowTable.generate, models/synth.py:124-177 (F.grid_sample bilinear over
  * (control frame, phase)), for arbitrary per-frame tables (B,K,L) at hop hop_t and a given wrapped phase (B,N) in [0,1):

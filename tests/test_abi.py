@@ -50,7 +50,7 @@ def test_argument_checks_without_gpu():
     rc = lib.golf_lti_frames_ola_fwd_f32(None, 0, None, None, None, None, 0, 1, 100, 5, 4, 8, 12, 0, None, 0, None)
     assert rc == -1
     rc = lib.golf_glottal_osc_fwd_f32(None, 0, 10, 1, None, 2, 8, None, 1, 16, 1, 0, None, 0, None, None, 0, 1, 10,
-                                      None, 0, None, None, 0, 0)
+                                      None, 0, None, None, 0, 0, None)
     assert rc == -1
     # peer-exchange entry points: null pointers / too many destinations are refused before anything touches a device
     assert lib.golf_peer_store_f32(None, 0, 1, 1, None, 0, 1, None) == -1 and b"null" in lib.golf_last_error()

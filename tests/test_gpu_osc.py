@@ -459,8 +459,105 @@ def test_backward_reuses_the_forward_totals_only_when_told(Tp, eq):
     rc = lib.golf_glottal_osc_bwd_wsel_f32(gy.data_ptr(), gy.stride(0), phase.data_ptr(), phase.stride(0), Tp, 1,
                                            wt.data_ptr(), Fw, w_hop, table.data_ptr(), n_tab, L, 4, int(eq), taps.data_ptr(),
                                            taps.numel(), g_w.data_ptr(), B, gy.shape[1], ws.data_ptr(), ws.numel(),
-                                           _lib.stream_ptr())
+                                           _lib.stream_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.isfinite(g_w).all()
     assert torch.equal(g_w, wt.grad)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: the phase scan inside the kernel (decoupled look-back over tagged entries in the workspace; lpc.. glottal_osc.hip OscLook)
+# and the taps' fragments prepared once (ABI 6).  Reference: the cumsum of models/synth.py:250-251.
+# ---------------------------------------------------------------------------------------------
+def _osc_raw(lib, phase, wt, table, taps, w_hop, eq, ws, frags=None, add=None):
+    from golf_amd import _lib
+
+    B, Tp = phase.shape
+    n_tab, L = table.shape
+    out = torch.full((B, Tp), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.golf_glottal_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, 1, wt.data_ptr(), wt.shape[1], w_hop,
+                                      table.data_ptr(), n_tab, L, 4, int(eq), taps.data_ptr(), taps.numel(), None,
+                                      out.data_ptr(), out.stride(0), B, Tp, ws.data_ptr(), ws.numel(), _lib.stream_ptr(),
+                                      _lib.ptr(add), 0 if add is None else add.stride(0), 0 if add is None else add.shape[1],
+                                      _lib.ptr(frags))
+    assert rc == 0, lib.golf_last_error()
+    return out
+
+
+@pytest.mark.parametrize("Tp", [48000, 70001, 2048, 2049, 300])
+def test_single_pass_scan_on_a_reused_workspace(Tp):
+    """The look-back's entries live in the caller's workspace and are never cleared: a launch must not take an earlier launch's
+    entries for its own.  One workspace through six launches with changing phases (every fill a fresh allocation could hold
+    first: zeros, 0xFF, 0x7F, random bytes), each compared bit for bit with the same call on a workspace of its own, and the
+    first against the float64 oracle.  70 001 samples = 35 tiles: the second round of polls; 2048 / 2049: the tile edge."""
+    from golf_amd import _lib
+    from golf_amd.synth import IndexedGlottalFlowTable
+    from oracle import golf_oracle as O
+
+    lib = _lib.load()
+    rng = np.random.default_rng(Tp)
+    B, w_hop, eq = 5, 2400, True
+    Fw = (Tp - 1) // w_hop + 2
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=eq)
+    table, taps = dev(m.table.numpy()), dev(m.decimater.taps.numpy())
+    nbytes = lib.golf_glottal_osc_workspace_bytes(B, Tp, 1, Fw, w_hop, table.shape[1], 4)
+
+    def batch(k):
+        f0 = rng.uniform(80, 400, (B, 1)) * (1 + 0.03 * np.sin(2 * np.pi * 5.5 * np.arange(Tp) / 24000 + k))
+        return dev((f0 / 24000).astype(np.float32)), dev(rng.uniform(0.02, 0.98, (B, Fw)).astype(np.float32))
+
+    fills = [lambda: torch.zeros(nbytes, dtype=torch.uint8, device="cuda"),
+             lambda: torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda"),
+             lambda: torch.full((nbytes,), 0x7F, dtype=torch.uint8, device="cuda"),
+             lambda: torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda")]
+    for fill in fills:
+        ws = fill()
+        for k in range(6):
+            phase, wt = batch(k)
+            got = _osc_raw(lib, phase, wt, table, taps, w_hop, eq, ws)
+            want = _osc_raw(lib, phase, wt, table, taps, w_hop, eq, fill())
+            torch.cuda.synchronize()
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, want), (k, float((got - want).abs().max()))
+    phase, wt = batch(0)
+    got = _osc_raw(lib, phase, wt, table, taps, w_hop, eq, ws).cpu().numpy()
+    ref = O.indexed_glottal_forward(phase.cpu().numpy(), 1, wt.cpu().numpy(), w_hop, table.cpu().numpy(), 4, eq,
+                                    decim_taps=taps.cpu().numpy())["out"]
+    check(got, ref, f"single-pass scan Tp {Tp}")
+
+
+def test_prepared_tap_fragments_equal_the_inline_layout():
+    """ABI 6: the taps' Toeplitz fragments prepared once (golf_glottal_osc_tap_fragments_f32) or laid out inside the call (tap_frags
+    NULL): the same output bit for bit, forward and -- through the autograd node, which hands the backward the forward's
+    fragments -- the same gradient as a backward that recomputes everything on a poisoned workspace."""
+    from golf_amd import _lib, functional as GF
+    from golf_amd.synth import IndexedGlottalFlowTable
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    B, Tp, w_hop, eq = 3, 9000, 2400, True
+    Fw = (Tp - 1) // w_hop + 2
+    m = IndexedGlottalFlowTable(table_size=100, lf_v2=True, points=2048, oversampling=4, equal_energy=eq)
+    table, taps = dev(m.table.numpy()), dev(m.decimater.taps.numpy())
+    phase = dev((rng.uniform(80, 400, (B, 1)) / 24000 * np.ones((1, Tp))).astype(np.float32))
+    wt = dev(rng.uniform(0.02, 0.98, (B, Fw)).astype(np.float32))
+    add = dev(rng.normal(0, 1, (B, Tp - 7)).astype(np.float32))
+    n = lib.golf_glottal_osc_tap_fragments_bytes(taps.numel(), 4)
+    assert n == 2 * 4 * 16 * 64 * 4 and lib.golf_glottal_osc_tap_fragments_bytes(taps.numel(), 2) == 0
+    frags = torch.full((n,), 0xFF, dtype=torch.uint8, device="cuda")
+    assert lib.golf_glottal_osc_tap_fragments_f32(taps.data_ptr(), taps.numel(), 4, frags.data_ptr(), n, _lib.stream_ptr()) == 0
+    assert lib.golf_glottal_osc_tap_fragments_f32(taps.data_ptr(), taps.numel(), 4, frags.data_ptr(), n - 1, _lib.stream_ptr()) == -1
+    nbytes = lib.golf_glottal_osc_workspace_bytes(B, Tp, 1, Fw, w_hop, table.shape[1], 4)
+    mk = lambda: torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")
+    a = _osc_raw(lib, phase, wt, table, taps, w_hop, eq, mk(), frags=frags, add=add)
+    b = _osc_raw(lib, phase, wt, table, taps, w_hop, eq, mk(), frags=None, add=add)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert GF.osc_tap_fragments(taps, 4) is GF.osc_tap_fragments(taps, 4)          # cached per tap set
+    k = 4 * 12 * 64 * 4    # (129 taps: 12 K-steps per branch are laid out, the rest of either block is never read)
+    half = frags.numel() // 2
+    cached = GF.osc_tap_fragments(taps, 4)
+    assert torch.equal(cached[:k], frags[:k]) and torch.equal(cached[half:half + k], frags[half:half + k])
+    y = GF.glottal_osc(phase, wt, table, taps, 1, w_hop, 4, eq, add=add)
+    assert torch.equal(y, a)
