@@ -110,9 +110,15 @@ def parse():
     ap.add_argument("--no-compare-gather-modes", action="store_true",
                     help="N>1: skip the comparison passes that time the SAME regions under each exchange (RCCL all-gather per "
                          "step, staged RCCL all-gather, peer-to-peer stores) after the headline -- exchange.modes in the line")
+    ap.add_argument("--fuse-source-maps", default="auto", choices=["auto", "on", "off"],
+                    help="golf-ss-synth: oscillator and the filter's transition maps as ONE launch (golf_source_transitions_f32, ABI 6); "
+                         "auto = where the lone-batch launch chain is used (single_stream, --streams 1), off = the composition everywhere")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="diagnostic: all in-flight slots read the SAME input tensors (round 1 behaviour)")
     return ap.parse_args()
+
+
+FUSE_SOURCE_MAPS = "auto"   # --fuse-source-maps
 
 
 def build_modules(device):
@@ -145,6 +151,11 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
 
     if workload == "golf-ss-synth":
         def step():
+            # round 6: the oscillator and the filter's transition maps as ONE launch (golf_source_transitions_f32) -- what a caller
+            # WITHOUT batches in flight gets (FUSE_SOURCE_MAPS "auto": the lone-batch chain, i.e. THROUGHPUT_MODE off when the
+            # step is issued or captured); bit-identical to the composition, which the headline's four-in-flight chain keeps
+            if fast and not overlap and (FUSE_SOURCE_MAPS == "on" or (FUSE_SOURCE_MAPS == "auto" and not GF.THROUGHPUT_MODE)):
+                return GF.source_filter_ss(phase, wsel, table, taps, 1, w_hop, 4, True, gain, a, hop, add=noise, mode=mode)
             # --overlap-transitions: the filter's excitation-independent phase (transition matrices + group composites)
             # on a second stream beside the oscillator -- shortens a lone batch's latency, not the pipelined rate
             prep = GF.ltv_allpole_prepare(a, hop, t_ss, overlap=True, fast=fast, mode=mode) if overlap else None
@@ -487,7 +498,9 @@ def spawn_ranks(n):
 
 
 def main():
+    global FUSE_SOURCE_MAPS
     args = parse()
+    FUSE_SOURCE_MAPS = args.fuse_source_maps
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1013,6 +1026,7 @@ def main():
                        "samples_out_per_utterance": t_out,
                        "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode}, every {GE} step(s))" if do_gather else ""),
                        "lpc_mode": args.lpc_mode, "lpc_chain": "throughput" if throughput_chain else "latency",
+                       "fuse_source_maps": args.fuse_source_maps,
                        "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
                        "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),

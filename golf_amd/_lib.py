@@ -61,6 +61,9 @@ SIGNATURES = {
     "golf_glottal_osc_fwd_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
                                         _c_f32p, _int, _c_f32p, _c_f32p, _i64, _int, _int, _vp, _sz, _vp, _c_f32p, _i64,
                                         _int, _vp]),
+    "golf_source_transitions_f32": (_int, [_c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p, _int, _int, _int, _int,
+                                           _c_f32p, _int, _c_f32p, _i64, _int, _int, _vp, _sz, _c_f32p, _i64, _int, _vp,
+                                           _c_f32p, _int, _int, _int, _int, _vp, _sz, _int, _vp]),
     "golf_glottal_osc_tap_fragments_bytes": (_sz, [_int] * 2),
     "golf_glottal_osc_tap_fragments_f32": (_int, [_c_f32p, _int, _int, _vp, _sz, _vp]),
     "golf_glottal_osc_bwd_wsel_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _c_f32p, _int, _int, _c_f32p,
@@ -131,7 +134,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import hashlib
 
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_common.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_common.h"), os.path.join(CSRC, "lpc_p1f.h"),
                    os.path.join(INCLUDE, "golf_amd.h")]
     extra = os.environ.get("GOLF_HIPCC_FLAGS", "").split()
     lib_path = os.path.join(LIB_DIR, "libgolf_hip.flags.so") if extra else LIB_PATH

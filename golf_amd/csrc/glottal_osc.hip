@@ -19,6 +19,7 @@
 //   The running phase is exact to ~1e-19 cycles per term (the reference's fp32 cumsum drifts ~3e-5 cycles).
 #include "common.h"
 #include "device_common.h"
+#include "lpc_p1f.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -885,7 +886,9 @@ __device__ __forceinline__ void oscf2_body(
     static_assert((NW + 2 + NW) * 8 + 4 <= G::SCRATCH, "scratch behind the fragments");
     const int tid = threadIdx.x, lane = tid & 63;
     // this launch's counter of the utterance (scalar load; see OscLook)
-    const unsigned gnow = (unsigned)__builtin_amdgcn_readfirstlane((int)look.gen[b]);
+    // (look.gen == nullptr: the two-launch form -- osc_tile_totals_kernel ran first and Ttot holds every tile's advance)
+    const bool lookback = look.gen != nullptr;   // (uniform)
+    const unsigned gnow = lookback ? (unsigned)__builtin_amdgcn_readfirstlane((int)look.gen[b]) : 0u;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int o0 = tile * TO;
@@ -961,7 +964,7 @@ __device__ __forceinline__ void oscf2_body(
             }
         }
     };
-    if (wv == 0 && nent > 0) look_poll(0, lpend, true);
+    if (wv == 0 && nent > 0 && lookback) look_poll(0, lpend, true);
     // the rows: their weights were fetched with the phase samples; the loads go out now and are consumed behind the scan
     OscRows<NRT> rows;
     oscf2_rows_issue<NRT, NTH>(wk, table, n_tab, L, tid, rows);
@@ -1000,8 +1003,8 @@ __device__ __forceinline__ void oscf2_body(
             const int i = i0t + r;
             own += (i >= -dmin && i < -dmin + TO) ? seg_of(r) : 0;
         }
-        own = wave_incl_scan(own, lane);
-        if (lane == 63) {
+        if (lookback) own = wave_incl_scan(own, lane);
+        if (lane == 63 && lookback) {
             wown[wv] = own;
             const unsigned idx = (unsigned)((b * ntile + tile) * NW + wv);
             u64* e = look.ent + 2 * (size_t)idx;
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void oscf2_body(
     // A workgroup whose neighbours in front started with it (a lone batch: 512 of its 768 workgroups enter within a microsecond)
     // finds nothing in its first poll.  By now those neighbours have published as well: the second poll goes out at once and is
     // back with the rows, instead of starting behind them.
-    if (wv == 0 && nent > 0) {
+    if (wv == 0 && nent > 0 && lookback) {
         look_eval(0);
         if (__builtin_amdgcn_ballot_w64(lpend != 0u) != 0ull) look_poll(0, lpend);
     }
@@ -1033,7 +1036,9 @@ __device__ __forceinline__ void oscf2_body(
     }
     if (wv == 0) {   // ---- 2d. look back: the base phase = the advance of every tile in front of this one
         bool lost = false;
-        for (int e0 = 0; e0 < nent; e0 += 64 * LBQ) {
+        if (!lookback)
+            for (int i = lane; i < tile; i += 64) lacc += Ttot[(size_t)b * ntile + i];
+        for (int e0 = 0; lookback && e0 < nent; e0 += 64 * LBQ) {
             if (e0 > 0) lpend = look_pending(e0);
             for (unsigned it = 0u;; ++it) {
                 // (round 0: whatever is still pending has a poll in flight since the publication above)
@@ -1048,14 +1053,14 @@ __device__ __forceinline__ void oscf2_body(
         if (lane == 63) { *base_p = lacc; *lost_p = lost ? 1u : 0u; }
     }
     __syncthreads();                             // row pairs, fragments, wave totals, bases
-    if (tid == 64) {                             // the tile's own total, for the backward (golf_glottal_osc_bwd_wsel_f32, GOLF_OSC_WS_KEPT)
+    if (tid == 64 && lookback) {                 // the tile's own total, for the backward (golf_glottal_osc_bwd_wsel_f32, GOLF_OSC_WS_KEPT)
         u64 t = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += wown[w];
         Ttot[(size_t)b * ntile + tile] = t;
     }
     // every wave of every workgroup of this utterance has read gen[b] by now (wave 0 saw all their entries): the next launch's value
-    if (tile == ntile - 1 && tid == 0) look.gen[b] = gnow + 1u;
+    if (tile == ntile - 1 && tid == 0 && lookback) look.gen[b] = gnow + 1u;
     const bool lost = *lost_p != 0u;             // (uniform) the look-back ran out: this tile's output is NaN, not a wrong phase
     OSCF_STAMP(2);
     // (the remaining branches' fragments: 16-byte global loads of the waves that multiply, in flight through the render.  Round 6:
@@ -1960,6 +1965,64 @@ static int harm_check(const char* who, const float* phase, int B, int Tp, int ph
     return GOLF_OK;
 }
 
+// ---- round 6: the source and the filter's transition maps in ONE launch -------------------------------------
+// A lone batch used to walk oscillator totals -> oscillator -> transition maps (|| zero-state pass) -> pre-pass -> chunk passes.
+// The maps need only the coefficients, not the source: their 637 issue-bound waves (one per SIMD of 160 CUs, 38 us) and the
+// oscillator's LDS-heavy, latency-bound workgroups are complementary, and the HIP graph executor does not run two branches of a
+// graph side by side to any effect (round 5) -- so the two kernels are one grid:
+//   workgroups [0, nblk_f)   p1f_body: waves 0..3 run a transition-map wave each (one per SIMD), waves 4..7 leave at once;
+//   the rest                 one oscillator unit (utterance, 2048-output tile) each, tile-major like osc_fused2_kernel's grid.
+// The transition workgroups come FIRST in dispatch order: they are the long pole and want a CU each; the oscillator's workgroups
+// fill what is left -- the 96 idle CUs and, beside the transition waves, the two free wave slots per SIMD of the 160 busy ones (the
+// register allocation is held to three waves per SIMD for that).  LDS: one launch-wide dynamic size (the oscillator's ~80 KB), so
+// a transition workgroup and an oscillator workgroup share a CU's 160 KB.
+struct SrcArgs {
+    const float* phase; int64_t phase_stride; OscLook look; u64* Ttot; const float* wsel; int Fw; const float* table; int n_tab, L,
+        lshift, Tp, hop_t; const float* Bf4; float* out; int64_t out_stride; int Tout, dmin, nrows; const float* addend;
+    int64_t addend_stride; int Tadd, B, ntile;
+};
+struct MapArgs { const float* a; float* PhiT; int F, M, hop, L, NP, nq; float* pmax; unsigned* fixcnt; int B; float* Phi; };
+#ifdef SRCMAPS_TIMING   // dev build (tools/srcmaps_timeline.py): entry / exit on the 100 MHz clock all XCDs share + where the workgroup ran
+__device__ unsigned long long g_srcmaps_rt[4 * 2048];
+extern "C" int golf_debug_srcmaps_rt(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_srcmaps_rt), sizeof(unsigned long long) * (size_t)n);
+}
+#define SRCMAPS_RT(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048 && (threadIdx.x == 0 || (i) == 3)) g_srcmaps_rt[4 * blockIdx.x + (i)] = (v); } while (0)
+#else
+#define SRCMAPS_RT(i, v) do { } while (0)
+#endif
+template <int EE, int KS, int W, int NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void source_maps_kernel(SrcArgs o, MapArgs m,
+                                                                                                     int nblk_f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    SRCMAPS_RT(0, __builtin_amdgcn_s_memrealtime());
+    SRCMAPS_RT(2, ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))) | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 32));
+    if ((int)blockIdx.x < nblk_f) {
+        if (threadIdx.x >= 64 * P1F_WPB) return;   // (the waves of a transition workgroup never synchronise with each other)
+#ifndef SRCMAPS_PRIO_MAPS
+#define SRCMAPS_PRIO_MAPS 0
+#endif
+        __builtin_amdgcn_s_setprio(SRCMAPS_PRIO_MAPS);
+        p1f_body<W, NT>(m.a, m.PhiT, m.F, m.M, m.hop, m.L, m.NP, m.nq, smem, (int)blockIdx.x, m.pmax, m.fixcnt, m.B, m.Phi);
+        SRCMAPS_RT(1, __builtin_amdgcn_s_memrealtime());
+    } else {
+#ifndef SRCMAPS_PRIO_OSC
+#define SRCMAPS_PRIO_OSC 1
+#endif
+        const int u = (int)blockIdx.x - nblk_f;
+#ifdef SRCMAPS_HI_UNITS
+        if (u < SRCMAPS_HI_UNITS) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(SRCMAPS_PRIO_OSC);
+#else
+        __builtin_amdgcn_s_setprio(SRCMAPS_PRIO_OSC);
+#endif
+        const int tile = u / o.B, b = u - tile * o.B;
+        osc_fused2_tile<EE, KS, 2048, 512>(o.phase, o.phase_stride, o.look, o.Ttot, o.wsel, o.Fw, o.table, o.n_tab, o.L, o.lshift,
+                                           o.Tp, o.hop_t, o.Bf4, o.out, o.out_stride, o.Tout, o.dmin, o.nrows, o.addend,
+                                           o.addend_stride, o.Tadd, smem, tile, b, o.ntile);
+        SRCMAPS_RT(1, __builtin_amdgcn_s_memrealtime());
+    }
+}
+
 }  // namespace golf
 
 using namespace golf;
@@ -2063,6 +2126,13 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         OscLook look;
         look.gen = (unsigned*)((char*)ws + g.off_look);
         look.ent = (unsigned long long*)((char*)ws + g.off_look + 256 * ceil_div((size_t)B * 4, 256));
+        static const bool two_launch = [] { const char* e = getenv("GOLF_OSC_TWO_LAUNCH"); return e && atoi(e) != 0; }();   // A/B knob
+        if (two_launch) {   // round 5's form: the tile totals by a launch of their own (the phase is read twice)
+            hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
+                               Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, f2.dmax, (float*)nullptr, (u64*)nullptr);
+            GOLF_LAUNCH_CHECK();
+            look.gen = nullptr;
+        }
 #define GOLF_FUSED2(EE, KSV, TOV, NTHV)                                                                               \
     do {                                                                                                              \
         static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
@@ -2110,6 +2180,79 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
                                      addend_stride, Tadd, st))
             return rc;
     }
+    return GOLF_OK;
+}
+
+// golf_glottal_osc_fwd_f32 + golf_ltv_allpole_transitions_f32(.. | GOLF_SS_FAST_TRANSITIONS | GOLF_SS_MAPS_ONLY) as ONE launch where
+// the shapes allow it (the fused oscillator's configuration, filter ring 24 / 22 taps: lpc_order 19 .. 22 at a hop that is a
+// multiple of 24), as the two calls everywhere else: the results are the two calls' results bit for bit either way.
+extern "C" int golf_source_transitions_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop, const float* wsel,
+                                           int Fw, int w_hop, const float* table, int n_tab, int L, int os, int equal_energy,
+                                           const float* taps, int K, float* out, int64_t out_stride, int B, int Tout,
+                                           void* osc_ws, size_t osc_ws_bytes, const float* addend, int64_t addend_stride,
+                                           int Tadd, const void* tap_frags, const float* a, int T, int F, int M, int hop,
+                                           void* ss_ws, size_t ss_ws_bytes, int ss_flags, void* stream) {
+    static const bool split_env = [] { const char* e = getenv("GOLF_SOURCE_MAPS_SPLIT"); return e && atoi(e) != 0; }();   // A/B knob
+    OscGeom g;
+    OscFused2 f2;
+    SsPlan p;
+    bool fuse = !split_env && phase && wsel && table && out && a && osc_ws && ss_ws && B >= 1 && Tp >= 1 && phase_hop >= 1 &&
+                Fw >= 1 && w_hop >= 1 && os >= 1 && T >= 1 && F >= 1 && M >= 1 && hop >= 1 &&
+                (ss_flags & GOLF_SS_FAST_TRANSITIONS) && (ss_flags & GOLF_SS_MAPS_ONLY) && !(ss_flags & GOLF_SS_SERIAL);
+    if (fuse) fuse = osc_check(B, Tp, phase_hop, Fw, w_hop, n_tab, L, os, K, taps) == GOLF_OK;
+    if (fuse) {
+        osc_geom(B, Tp, phase_hop, Fw, w_hop, os, &g);
+        const int tout = os > 1 ? (g.N - 1) / os + 1 : g.N;
+        fuse = Tout == tout && phase_stride >= Tp && out_stride >= Tout && osc_ws_bytes >= g.total && !((uintptr_t)osc_ws & 255) &&
+               (!addend || (Tadd >= 0 && addend_stride >= Tadd)) && osc_fused2_plan(g, table, L, os, K, false, Tout, B, &f2);
+    }
+    if (fuse) {
+        const int mode = (ss_flags & GOLF_SS_CHUNKED) ? GOLF_SS_CHUNKED : 0;
+        fuse = make_ss_plan(B, T, F, M, hop, &p, mode) && !p.serial && p.NP > 0 && p.W == 24 && p.NT == 22 &&
+               ss_ws_bytes >= p.total && !((uintptr_t)ss_ws & 255);
+    }
+    if (!fuse) {   // the two calls, with their own argument checks and messages
+        if (int rc = golf_glottal_osc_fwd_f32(phase, phase_stride, Tp, phase_hop, wsel, Fw, w_hop, table, n_tab, L, os, equal_energy,
+                                              taps, K, nullptr, out, out_stride, B, Tout, osc_ws, osc_ws_bytes, stream, addend,
+                                              addend_stride, Tadd, tap_frags))
+            return rc;
+        return golf_ltv_allpole_transitions_f32(a, B, T, F, M, hop, ss_ws, ss_ws_bytes, ss_flags, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float* Bf4 = tap_frags ? (const float*)tap_frags + kTapFragFloats : (const float*)((char*)osc_ws + g.off_bf4);
+    if (!tap_frags) {
+        hipLaunchKernelGGL(osc_tap_frags_kernel, dim3(4), dim3(256), 0, st, taps, K, f2.dmin, f2.dmax, f2.KS,
+                           (float*)((char*)osc_ws + g.off_bf4), (float*)((char*)osc_ws + g.off_bfr));
+        GOLF_LAUNCH_CHECK();
+    }
+    SrcArgs o;
+    o.phase = phase; o.phase_stride = phase_stride;
+    o.look.gen = (unsigned*)((char*)osc_ws + g.off_look);
+    o.look.ent = (unsigned long long*)((char*)osc_ws + g.off_look + 256 * ceil_div((size_t)B * 4, 256));
+    o.Ttot = (u64*)((char*)osc_ws + g.off_ttot);
+    o.wsel = wsel; o.Fw = Fw; o.table = table; o.n_tab = n_tab; o.L = L; o.lshift = f2.lshift; o.Tp = Tp; o.hop_t = g.hop_t;
+    o.Bf4 = Bf4; o.out = out; o.out_stride = out_stride; o.Tout = Tout; o.dmin = f2.dmin; o.nrows = f2.nrows;
+    o.addend = addend; o.addend_stride = addend_stride; o.Tadd = Tadd; o.B = B; o.ntile = f2.ntile_f;
+    char* sw = (char*)ss_ws;
+    MapArgs m;
+    m.a = a; m.PhiT = (float*)(sw + p.off_phiT); m.F = F; m.M = M; m.hop = hop; m.L = p.L; m.NP = p.NP; m.nq = B * p.NP;
+    m.pmax = (float*)(sw + p.off_pmax); m.fixcnt = (unsigned*)(sw + p.off_fixcnt); m.B = B;
+    m.Phi = (ss_flags & GOLF_SS_TRAINING) ? (float*)(sw + p.off_phi) : (float*)nullptr;
+    const int nblk_f = (int)ceil_div(m.nq, P1fGeom<24, 22, 2>::CPW * P1F_WPB);
+    const unsigned grid = (unsigned)(nblk_f + B * f2.ntile_f);
+#define GOLF_SRC_MAPS(EE, KSV)                                                                                        \
+    do {                                                                                                              \
+        static const hipError_t lds_attr = hipFuncSetAttribute(                                                       \
+            (const void*)source_maps_kernel<EE, KSV, 24, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (lds_attr != hipSuccess)                                                                                   \
+            return fail((int)lds_attr, "source_transitions: cannot raise the dynamic LDS limit: %s",                  \
+                        hipGetErrorString(lds_attr));                                                                 \
+        hipLaunchKernelGGL((source_maps_kernel<EE, KSV, 24, 22>), dim3(grid), dim3(512), f2.lds, st, o, m, nblk_f);   \
+    } while (0)
+    if (f2.KS == 12) { if (equal_energy) GOLF_SRC_MAPS(1, 12); else GOLF_SRC_MAPS(0, 12); }
+    else             { if (equal_energy) GOLF_SRC_MAPS(1, 16); else GOLF_SRC_MAPS(0, 16); }
+#undef GOLF_SRC_MAPS
+    GOLF_LAUNCH_CHECK();
     return GOLF_OK;
 }
 

@@ -599,6 +599,56 @@ def glottal_osc(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampli
     return (out, pre) if return_pre else out
 
 
+def source_filter_ss(phase, wsel, table, taps, phase_hop: int, w_hop: int, oversampling: int, equal_energy: bool,
+                     gain, a, hop: int, add=None, mode: str = None, status: torch.Tensor = None,
+                     length: int = None) -> torch.Tensor:
+    """``ltv_allpole_ss(glottal_osc(phase, wsel, table, taps, ..., add=add), gain, a, hop)`` -- the decoder's source into its end
+    filter (reference: SourceFilterSynth.forward, models/sf.py:47-64) -- with the oscillator and the filter's chunk transition
+    maps in ONE launch (include/golf_amd.h golf_source_transitions_f32, ABI 6): the maps need only ``a``, and for a lone batch
+    they are the long pole of the chain (38 us of issue-bound waves on 160 of 256 CUs, which the oscillator's workgroups fill).
+    Inference only and bit-identical to the composition; whenever a gradient is required, or the shapes fall outside the fused
+    launch, this IS the composition.  ``length``: as ``ltv_allpole_ss(..., length=)`` -- filter only the first ``length`` samples of
+    the source (the decoder's common length of oscillator and filtered noise)."""
+    ts = (phase, wsel, table, gain, a) + ((add,) if add is not None else ())
+    if (torch.is_grad_enabled() and any(t.requires_grad for t in ts)) or oversampling <= 1 or phase.dim() != 2 or phase.shape[0] == 0:
+        src = glottal_osc(phase, wsel, table, taps, phase_hop, w_hop, oversampling, equal_energy, add=add)
+        return ltv_allpole_ss(src, gain, a, hop, mode=mode, status=status, length=length)
+    _lib.require_device(phase, wsel, table, taps, gain, a)
+    lib = _lib.load()
+    phase, wsel, table, taps = _rows(phase.float()), wsel.float().contiguous(), table.float().contiguous(), taps.float().contiguous()
+    gain, a = gain.float().contiguous(), a.float().contiguous()
+    if add is not None:
+        _lib.require_device(add)
+        add = _rows(add.float())
+    B, Tp = phase.shape
+    Fw = wsel.shape[1]
+    n_tab, L = table.shape
+    K = taps.numel()
+    os_ = int(oversampling)
+    _, Tout = osc_lengths(Tp, int(phase_hop), os_)
+    F, M = a.shape[1], a.shape[2]
+    T = ss_output_length(Tout, F, int(hop))
+    if length is not None:
+        T = min(T, int(length))
+        if T < 1:
+            raise _lib.GolfError(f"source_filter_ss: length={length} leaves nothing to filter")
+    flags = SS_MODES[mode] | FAST_TRANSITIONS | MAPS_ONLY
+    src = torch.empty(B, Tout, dtype=torch.float32, device=phase.device)
+    osc_ws = _workspace(lib.golf_glottal_osc_workspace_bytes(B, Tp, int(phase_hop), Fw, int(w_hop), L, os_), phase.device)
+    ss_ws = _workspace(lib.golf_ltv_allpole_workspace_bytes_ex(B, T, F, M, int(hop), flags), phase.device)
+    frags = osc_tap_fragments(taps, os_)
+    rc = lib.golf_source_transitions_f32(phase.data_ptr(), phase.stride(0), Tp, int(phase_hop), wsel.data_ptr(), Fw, int(w_hop),
+                                         table.data_ptr(), n_tab, L, os_, int(bool(equal_energy)), taps.data_ptr(), K,
+                                         src.data_ptr(), src.stride(0), B, Tout, osc_ws.data_ptr(), osc_ws.numel(),
+                                         _lib.ptr(add), 0 if add is None else add.stride(0), 0 if add is None else add.shape[1],
+                                         _lib.ptr(frags), a.data_ptr(), T, F, M, int(hop), ss_ws.data_ptr(), ss_ws.numel(), flags,
+                                         _lib.stream_ptr())
+    _lib.check(rc, "golf_source_transitions_f32")
+    handle = PreparedTransitions(ss_ws, (B, T, F, M, int(hop), a.data_ptr(), a._version, SS_MODES[mode]), None, a, True, False, True)
+    with torch.no_grad():
+        return ltv_allpole_ss(src, gain, a, hop, prepared=handle, fast_inference=True, mode=mode, status=status, length=length)
+
+
 # ------------------------------------------------------------------------------------------------
 # generic (fully differentiable) table oscillator: wrapped phase -> bilinear table lookup (-> decimation)
 # ------------------------------------------------------------------------------------------------

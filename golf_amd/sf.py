@@ -12,6 +12,11 @@ from .ctrl import PassThrough, Synth
 
 __all__ = ["SourceFilterSynth", "HarmonicPlusNoiseSynth"]
 
+# Round 6: in inference, for a caller without batches in flight, the glottal oscillator and the sample-wise end filter's transition
+# maps run as ONE launch (functional.source_filter_ss / golf_source_transitions_f32, ABI 6): bit-identical to the composition,
+# a lone B = 32 batch ~4 us sooner.  False: always the composition.
+FUSE_SOURCE_MAPS = True
+
 
 class SourceFilterSynth(Synth):
     """GOLF-ss / GOLF-ff decoder: (oscillator + filtered noise) -> end filter -> room filter."""
@@ -45,6 +50,9 @@ class SourceFilterSynth(Synth):
             n = self.harm_oscillator.output_length(phase)
             ref = AudioTensor(phase.as_tensor().new_empty((phase.shape[0], n)))   # shape/device carrier, never read
             nz = self.noise_filter(self.noise_generator(ref, *noise_generator_params), *noise_filter_params)
+            fused = self._source_and_end_filter(phase, harm_oscillator_params, end_filter_params, nz) if target is None else None
+            if fused is not None:
+                return self.room_filter(fused)
             src = self.harm_oscillator(phase, *harm_oscillator_params, add=nz)
         else:
             harm_osc = self.harm_oscillator(phase, *harm_oscillator_params)
@@ -59,6 +67,34 @@ class SourceFilterSynth(Synth):
         if target is not None:
             return self.end_filter.reverse(src, target, *end_filter_params)
         return self.room_filter(self.end_filter(src, *end_filter_params))
+
+
+    def _source_and_end_filter(self, phase, osc_params, filt_params, nz) -> Optional[AudioTensor]:
+        """``end_filter(harm_oscillator(phase, w, add=nz), gain, a)`` through functional.source_filter_ss where that is the same
+        computation: the indexed glottal oscillator on its fused path (oversampled, no phase offset), the sample-wise end filter
+        (not its frame-wise subclass) with nothing prefetched and no health monitor, inference, no batches in flight.  None:
+        the caller composes the modules as ever."""
+        from . import functional as GF
+        from .filters import LTVMinimumPhaseFilterPrecise
+        from .synth import IndexedGlottalFlowTable
+
+        osc, filt = self.harm_oscillator, self.end_filter
+        if not (FUSE_SOURCE_MAPS and not GF.THROUGHPUT_MODE and type(filt) is LTVMinimumPhaseFilterPrecise
+                and isinstance(osc, IndexedGlottalFlowTable) and osc.oversampling > 1 and len(osc_params) == 1
+                and len(filt_params) == 2 and getattr(filt, "_prepared", None) is None and not filt.health_check
+                and not osc.check_ranges and phase.ndim == 2 and nz.hop_length == 1):
+            return None
+        w, (gain, a) = osc_params[0], filt_params
+        ts = [t.as_tensor() for t in (phase, w, nz, gain, a)] + [osc.table]
+        if not all(t.is_cuda for t in ts) or (torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
+            return None
+        if w.dim() != 2 or a.dim() != 3 or gain.dim() != 2 or int(gain.hop_length) != int(a.hop_length):
+            return None
+        n_osc = osc.output_length(phase)
+        y = GF.source_filter_ss(ts[0], ts[1], osc.table, osc.decimater.taps, int(phase.hop_length), int(w.hop_length),
+                                osc.oversampling, osc.equal_energy, ts[3], ts[4], int(a.hop_length), add=ts[2],
+                                length=nz.shape[1] if nz.shape[1] < n_osc else None)
+        return AudioTensor(y)
 
 
 class HarmonicPlusNoiseSynth(Synth):

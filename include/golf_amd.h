@@ -294,6 +294,26 @@ int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride, int Tp, i
                              void* ws, size_t ws_bytes, void* stream,
                              const float* addend, int64_t addend_stride, int Tadd, const void* tap_frags);
 
+/* ABI 6 (round 6): the source and the end filter's transition maps in ONE launch -- SourceFilterSynth.forward's
+ * `harm_osc(...) + noise` followed by `end_filter(...)`, models/sf.py:47-64, where the filter's chunk transition maps
+ * (golf_ltv_allpole_transitions_f32) depend on the coefficients only and not on the source.
+ *   == golf_glottal_osc_fwd_f32(phase .. tap_frags; pre = NULL)  then
+ *      golf_ltv_allpole_transitions_f32(a, B, T, F, M, hop, ss_ws, ss_ws_bytes, ss_flags, stream)
+ * bit for bit; as one grid (oscillator workgroups beside the transition-map waves: a lone B = 32 batch ~42 us instead of
+ * 6 + 18 + 38) when ss_flags holds GOLF_SS_FAST_TRANSITIONS | GOLF_SS_MAPS_ONLY, the oscillator's fused configuration applies
+ * and the filter runs on its 24-sample ring with 22 taps (lpc_order 19 .. 22, hop % 24 == 0); as the two calls otherwise.
+ * The caller then runs golf_ltv_allpole_fwd_f32(out as ex, .., ss_ws, ss_flags | GOLF_SS_HAVE_TRANSITIONS).
+ * osc_ws / ss_ws: the two calls' workspaces (golf_glottal_osc_workspace_bytes / golf_ltv_allpole_workspace_bytes_ex). */
+int golf_source_transitions_f32(const float* phase, int64_t phase_stride, int Tp, int phase_hop,
+                                const float* wsel, int Fw, int w_hop,
+                                const float* table, int n_tab, int L,
+                                int os, int equal_energy, const float* taps, int K,
+                                float* out, int64_t out_stride, int B, int Tout,
+                                void* osc_ws, size_t osc_ws_bytes,
+                                const float* addend, int64_t addend_stride, int Tadd, const void* tap_frags,
+                                const float* a, int T, int F, int M, int hop,
+                                void* ss_ws, size_t ss_ws_bytes, int ss_flags, void* stream);
+
 /* Backward w.r.t. table_select_weight only (phase is data in GOLF training: train_with_true_f0,
  * cfg/ae/vctk.yaml:72):  g_wsel (B,Fw) overwritten.  ws = a workspace of the forward's size.
  * equal_energy | GOLF_OSC_WS_KEPT (ABI 5): the caller vouches that `ws` is exactly as golf_glottal_osc_fwd_f32 left it for

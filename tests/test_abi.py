@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_symbol():
 
     _lib.build()
     lib = _lib.load()  # getattr on every declared symbol
-    assert lib.golf_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.golf_abi_version() == _lib.ABI_VERSION == 6
     assert lib.golf_target_arch() == b"gfx950"
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (golf_[a-z0-9_]+)", out))

@@ -1247,3 +1247,51 @@ def test_conditioning_soak_bounded(seed):
         res = soak_case(params, gy)
         bad += [(case, params, l, r) for l, r, f in res if f]
     assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: the source and the filter's transition maps in ONE launch (golf_source_transitions_f32, ABI 6)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,seed,M,with_add", [(32, 2434, 22, True), (32, 2435, 22, True), (5, 7, 20, False), (3, 8, 12, True)])
+def test_source_and_transition_maps_in_one_launch_is_bit_identical(B, seed, M, with_add, monkeypatch):
+    """``source_filter_ss`` = oscillator || transition maps as one grid, then the pre-pass with the zero-state pass in front and
+    the merged chunk pass: the same bits as the composition ``ltv_allpole_ss(glottal_osc(...))`` on either launch chain, the
+    split fallback (GOLF_SOURCE_MAPS_SPLIT semantics: M = 12 takes the two calls by itself -- ring 16) included, and the float64
+    oracle's values.  Seed 2435 holds a hot utterance (fix-up inside the pre-pass)."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+    from oracle import golf_oracle as O
+
+    inp = make_inputs(B=B, M=M, device="cuda", seed=seed)
+    osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, lf_v2=True,
+                                             points=2048).cuda()
+    table, taps = osc.table, osc.decimater.taps
+    add = inp["noise"] if with_add else None
+    st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    y1 = GF.source_filter_ss(inp["phase"], inp["wsel"], table, taps, 1, inp["w_hop"], 4, True, inp["gain"], inp["a"], 240, add=add,
+                             status=st)
+    torch.cuda.synchronize()
+    for thr in (False, True):
+        monkeypatch.setattr(GF, "THROUGHPUT_MODE", thr)
+        src = GF.glottal_osc(inp["phase"], inp["wsel"], table, taps, 1, inp["w_hop"], 4, True, add=add)
+        y0 = GF.ltv_allpole_ss(src, inp["gain"], inp["a"], 240, fast_inference=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0), (thr, float((y1 - y0).abs().max()))
+    monkeypatch.setattr(GF, "THROUGHPUT_MODE", False)
+    assert not GF.ss_status(st)["nonfinite"]
+    if B <= 5:
+        c = {k: inp[k].cpu().numpy() for k in ("phase", "wsel", "noise", "gain", "a")}
+        s = O.indexed_glottal_forward(c["phase"], 1, c["wsel"], inp["w_hop"], table.cpu().numpy(), 4, True,
+                                      decim_taps=taps.cpu().numpy())["out"]
+        if with_add:
+            n = min(s.shape[1], c["noise"].shape[1])
+            s = s[:, :n] + c["noise"][:, :n]
+        ref = O.ltv_allpole_ss_forward(s, c["gain"], c["a"], 240)
+        check(y1.cpu().numpy(), ref, f"source + maps in one launch B{B} M{M}")
+    # a gradient pending: the composition (and its custom backward) takes over
+    a = inp["a"].clone().requires_grad_(True)
+    y2 = GF.source_filter_ss(inp["phase"], inp["wsel"], table, taps, 1, inp["w_hop"], 4, True, inp["gain"], a, 240, add=add)
+    y2.square().mean().backward()
+    assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
