@@ -119,6 +119,7 @@ def parse():
 
 
 FUSE_SOURCE_MAPS = "auto"   # --fuse-source-maps
+PROFILE_ROUND = "r06"       # profiles/<round>_hbm_traffic.json / _sq_counters_4stream.json: the counter passes of THIS round's kernels
 
 
 def build_modules(device):
@@ -580,6 +581,7 @@ def main():
 
     steps_fn, samples, t_out = [], None, None
     slot_cond = []   # per in-flight slot: the filter's conditioning words on that slot's coefficient tracks
+    slot_inp = []    # per in-flight slot: its input tensors (views of slot_flat[i] where packed)
     for i in range(S):
         if i > 0 and args.shared_inputs:
             steps_fn.append(steps_fn[0])
@@ -587,6 +589,7 @@ def main():
             continue
         inp_i, flat_i = slot_inputs(i)
         slot_flat.append(flat_i)
+        slot_inp.append(inp_i)
         fn, samples, t_out = make_step(args.workload, inp_i, osc, ss, ff, fast=not args.fp64_transitions,
                                        overlap=args.overlap_transitions, mode=args.lpc_mode)
         steps_fn.append(fn)
@@ -863,6 +866,55 @@ def main():
         timed_regions(1)
         ms_h2d = median_ms(timed_regions(3))
         refresh_pool[0] = None
+        # ---- the zero-copy route: an on-device PRODUCER writes the slot's inputs inside the slot's graph -- what
+        # the decoder's control stage does with the encoder's output (models/filters.py:90-97, models/synth.py:320-332): logits ->
+        # tanh -> step-up recursion -> a (golf_rc2lpc_fwd), log-gain -> exp -> gain, f0 track -> upsampled phase increments,
+        # table-selection logits -> sigmoid, a fresh N(0,1) noise draw -- each written straight into the slot's static inputs
+        # (views of the packed buffer), then the synthesis step.  No copy of a finished batch anywhere.
+        ms_prod = None
+        if args.workload == "golf-ss-synth" and len(slot_inp) == S:
+            from golf_amd import functional as GFp
+
+            enc, pgraphs, pouts = [], [], []
+            for i in range(S):
+                d = slot_inp[i]
+                hop_i = int(d["hop"])
+                enc.append({"logits": d["logits"].clone(), "log_gain": d["log_gain"].clone(),
+                            "f0": d["phase"][:, ::hop_i].clone(), "wlogit": torch.logit(d["wsel"].clamp(1e-6, 1 - 1e-6))})
+
+            def produce(i):
+                d, e = slot_inp[i], enc[i]
+                d["a"].copy_(GFp.rc2lpc_logits(e["logits"]))
+                torch.exp(e["log_gain"], out=d["gain"])
+                torch.sigmoid(e["wlogit"], out=d["wsel"])
+                up = GFp.linear_upsample(e["f0"], int(d["hop"]))
+                n = min(up.shape[1], d["phase"].shape[1])
+                d["phase"][:, :n].copy_(up[:, :n])
+                d["noise"].normal_()
+
+            for i in range(S):
+                warm = torch.cuda.Stream(device=device)
+                warm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(warm):
+                    for _ in range(2):
+                        produce(i)
+                        steps_fn[i]()
+                torch.cuda.current_stream().wait_stream(warm)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    produce(i)
+                    yp = steps_fn[i]()
+                pgraphs.append(g)
+                pouts.append(yp)
+            torch.cuda.synchronize()
+            held, held_outs = list(graphs), list(outs)
+            graphs[:], outs[:] = pgraphs, pouts
+            timed_regions(2)
+            ms_prod = median_ms(timed_regions(args.repeats))
+            torch.cuda.synchronize()
+            ok_prod = all(bool(torch.isfinite(o).all()) for o in pouts) and not torch.equal(pouts[0], held_outs[0])
+            assert ok_prod, "producer mode: non-finite output, or the produced batch equals the fixed one"
+            graphs[:], outs[:] = held, held_outs
         for f, k in zip(slot_flat, keep):
             f.copy_(k)
         torch.cuda.synchronize()
@@ -873,6 +925,10 @@ def main():
                      # what the copy cannot go below: its own HBM traffic (read + write) at the achievable ~5 TB/s
                      "hbm_floor_us_per_step": round(2 * nbytes / 5e12 * 1e6, 2),
                      "ms_per_step_h2d_pinned": round(ms_h2d, 5), "h2d_GBps": round(nbytes / (ms_h2d * 1e-3) / 1e9, 2),
+                     # no copy at all: the slot's graph holds an on-device producer (control transforms + noise draw) that writes
+                     # the static inputs in place, then the synthesis step; the producer's own kernels are inside the figure
+                     "ms_per_step_produced": None if ms_prod is None else round(ms_prod, 5),
+                     "produced_vs_fixed_inputs": None if ms_prod is None else round(ms_per_step / ms_prod, 4),
                      "note": "each step: one device-to-device copy (hipMemcpyDtoDAsync) of the packed batch (phase, wsel, noise, gain, a) into the slot's "
                              "static inputs on the slot's stream, then the graph replay; outputs asserted equal to eager runs on the "
                              "refreshed inputs.  golf_amd.pipeline.ReplayPipeline.submit(batch) is this mode."}
@@ -963,16 +1019,19 @@ def main():
             lat_step_us = event_time_us(step)
             _GFm.THROUGHPUT_MODE = throughput_chain
         # HBM bytes per launch and issued VALU instructions per step come from separate rocprofv3 --pmc passes (counters
-        # cannot be read in this run): the committed round-5 summaries only -- no fallback to an older round's file
-        traffic, valu = None, None
+        # cannot be read in this run): this round's committed summaries only -- no fallback to an older round's file
+        traffic, valu, step_total = None, None, None
         try:
-            fn = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
+            fn = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_hbm_traffic.json")
             if os.path.exists(fn):
                 tr = json.load(open(fn))
                 for kname, v in tr.get("kernels", {}).items():
                     if kname in dom and tr.get("batch") == B:
                         traffic = v["hbm_bytes_per_launch"]
-            fn = os.path.join(ROOT, "profiles", "r05_sq_counters_4stream.json")
+                if tr.get("batch") == B and args.workload == "golf-ss-synth":
+                    # counted HBM bytes of ONE step, summed over its kernels, for the chain this line ran
+                    step_total = (tr.get("step_total_bytes") or {}).get("throughput_chain" if throughput_chain else "latency_chain")
+            fn = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_sq_counters_4stream.json")
             if os.path.exists(fn):
                 sq = json.load(open(fn))
                 if sq.get("batch") == B and sq.get("workload") == args.workload:
@@ -987,7 +1046,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom.split("(")[0][-60:], "kernel_us": round(dom_us, 2),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/r05_hbm_traffic.json (separate rocprofv3 --pmc passes, not measured in this run)",
+                    "traffic_source": None if traffic is None else "profiles/" + PROFILE_ROUND + "_hbm_traffic.json (separate rocprofv3 --pmc passes, not measured in this run)",
+                    "step_total_bytes": step_total,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "stage_frac": round(alg_bytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "stage_us": round(stage_us, 2),
@@ -1011,7 +1071,7 @@ def main():
                 pk = float(valu["packed_insts_per_step"])
                 roofline["valu_pipe_frac"] = round((pk * 4.0 + (insts - pk) * 2.0) / (n_simd * clk * step_s), 4)
             roofline["valu_insts_per_step"] = int(insts)
-            roofline["valu_source"] = "profiles/r05_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
+            roofline["valu_source"] = "profiles/" + PROFILE_ROUND + "_sq_counters_4stream.json (rocprofv3 --pmc SQ_INSTS_VALU over the %d-stream run)" % valu.get("streams", S)
         stages = {k.split("(")[0].replace("void ", "")[-48:]: round(v, 2) for k, v in sorted(ours.items(), key=lambda kv: -kv[1])}
         single_us = lat_graph_us if lat_graph_us is not None else lat_step_us
         result = {

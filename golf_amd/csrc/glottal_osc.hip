@@ -2099,6 +2099,8 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
                                         const float* addend, int64_t addend_stride, int Tadd, const void* tap_frags) {
     if (int rc = osc_check(B, Tp, phase_hop, Fw, w_hop, n_tab, L, os, K, taps)) return rc;
     if (!phase || !wsel || !table || !out) return fail(GOLF_EINVAL, "glottal_osc_fwd: null pointer");
+    const bool throughput = (equal_energy & GOLF_OSC_THROUGHPUT) != 0;   // the caller keeps batches in flight (see the header)
+    equal_energy &= 1;
     OscGeom g;
     osc_geom(B, Tp, phase_hop, Fw, w_hop, os, &g);
     const int tout = os > 1 ? (g.N - 1) / os + 1 : g.N;
@@ -2126,7 +2128,14 @@ extern "C" int golf_glottal_osc_fwd_f32(const float* phase, int64_t phase_stride
         OscLook look;
         look.gen = (unsigned*)((char*)ws + g.off_look);
         look.ent = (unsigned long long*)((char*)ws + g.off_look + 256 * ceil_div((size_t)B * 4, 256));
-        static const bool two_launch = [] { const char* e = getenv("GOLF_OSC_TWO_LAUNCH"); return e && atoi(e) != 0; }();   // A/B knob
+        // One launch or two.  The single-pass scan saves a launch and the second read of the phase (+3 % at B = 16 384: 112.0 vs
+        // 109.0 G samples/s) and is what lets the oscillator share a grid with the transition maps; for one B = 32 batch alone the
+        // two forms are equal (122.8 vs 122.5 us for the step).  With FOUR such batches in flight every oscillator launch is a
+        // "first round" -- the tiles of an utterance enter together and wave 0 of every workgroup polls twice -- and the two
+        // launches are cheaper: 69.4 - 69.9 against 70.7 - 70.8 us/step on one box, three alternations (profiles/r06_ab_r05_vs_r06.txt).
+        // GOLF_OSC_THROUGHPUT asks for them below a device-filling batch; GOLF_OSC_TWO_LAUNCH=0/1 forces either (A/B knob).
+        static const int tl_env = [] { const char* e = getenv("GOLF_OSC_TWO_LAUNCH"); return e ? atoi(e) : -1; }();
+        const bool two_launch = tl_env >= 0 ? tl_env != 0 : (throughput && (int64_t)B * f2.ntile_f < 8192);
         if (two_launch) {   // round 5's form: the tile totals by a launch of their own (the phase is read twice)
             hipLaunchKernelGGL(osc_tile_totals_kernel<OSCF_TO>, dim3(f2.ntile2, B), dim3(osct_threads(OSCF_TO)), 0, st, phase, phase_stride,
                                Ttot, Tp, g.P, os, f2.ntile2, taps, K, f2.dmin, f2.KS, (float*)nullptr, f2.dmax, (float*)nullptr, (u64*)nullptr);
@@ -2249,8 +2258,8 @@ extern "C" int golf_source_transitions_f32(const float* phase, int64_t phase_str
                         hipGetErrorString(lds_attr));                                                                 \
         hipLaunchKernelGGL((source_maps_kernel<EE, KSV, 24, 22>), dim3(grid), dim3(512), f2.lds, st, o, m, nblk_f);   \
     } while (0)
-    if (f2.KS == 12) { if (equal_energy) GOLF_SRC_MAPS(1, 12); else GOLF_SRC_MAPS(0, 12); }
-    else             { if (equal_energy) GOLF_SRC_MAPS(1, 16); else GOLF_SRC_MAPS(0, 16); }
+    if (f2.KS == 12) { if (equal_energy & 1) GOLF_SRC_MAPS(1, 12); else GOLF_SRC_MAPS(0, 12); }
+    else             { if (equal_energy & 1) GOLF_SRC_MAPS(1, 16); else GOLF_SRC_MAPS(0, 16); }
 #undef GOLF_SRC_MAPS
     GOLF_LAUNCH_CHECK();
     return GOLF_OK;

@@ -976,10 +976,12 @@ struct UttTier { bool t2, t3; unsigned nhot; };
 __device__ __forceinline__ UttTier utterance_tier(const float* __restrict__ pm, int NP, int lane, float g1, float g2,
                                                   float g3, int accurate, float glog, int hot16, int hotn) {
     unsigned umax = 0u;
+    unsigned n = 0u;       // chunks beyond G2 (counted in the same pass over the maxima: every wave that derives a tier pays for it)
     bool ovf = false;
     for (int c0 = 0; c0 < NP; c0 += 64) {
         const int c = c0 + lane;
         const float v = c < NP ? fabsf(pm[c]) : 0.f;
+        n += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c < NP && !(v <= g2)));
         umax = max(umax, __float_as_uint(v));   // bit patterns: a NaN ranks above +inf and cannot hide
         // the product of a composite group's 16 maps must stay far from the fp32 range (sum of log2 of the maxima over the
         // group: c0 is a multiple of 64, so 16-lane rows are the groups of lpc_group_prepass_kernel)
@@ -994,14 +996,8 @@ __device__ __forceinline__ UttTier utterance_tier(const float* __restrict__ pm, 
     d.t3 = g3 > 0.f && (!(__uint_as_float(umax) <= g3) || __builtin_amdgcn_ballot_w64(ovf) != 0ull);
     bool beyond_g1 = g1 > 0.f && !(__uint_as_float(umax) <= g1);   // some chunk beyond G1: chunks beyond G2 are hot
     d.nhot = 0u;
-    unsigned n = 0u;
-    if (!d.t3 && g1 > 0.f && !(__uint_as_float(umax) <= g2)) {
-        for (int c0 = 0; c0 < NP; c0 += 64)
-            n += (unsigned)__builtin_popcountll(
-                __builtin_amdgcn_ballot_w64(c0 + lane < NP && !(fabsf(pm[c0 + lane < NP ? c0 + lane : 0]) <= g2)));
-        // (round 6) ... or a long run of them: an utterance none of whose maps passes G1 but most of which pass G2 (see hot_count)
-        beyond_g1 = beyond_g1 || (hotn > 0 && n >= (unsigned)hotn);
-    }
+    // (round 6) ... or a long run of them: an utterance none of whose maps passes G1 but most of which pass G2 (see hot_count)
+    if (!d.t3 && g1 > 0.f) beyond_g1 = beyond_g1 || (hotn > 0 && n >= (unsigned)hotn);
     d.t2 = !accurate && beyond_g1;
     if (!d.t3 && beyond_g1) {
         // (round 6) hot from end to end: with (nearly) every map recomputed anyway, the fp64 boundary scan is what is left of

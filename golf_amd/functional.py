@@ -23,6 +23,7 @@ TRAINING = 64            # GOLF_SS_TRAINING
 MAPS_ONLY = 128          # GOLF_SS_MAPS_ONLY (ABI 4)
 THROUGHPUT = 256         # GOLF_SS_THROUGHPUT (ABI 4)
 ZERO_TAIL = 512          # GOLF_SS_ZERO_TAIL (ABI 5): the backward zeroes g_ex beyond the output length itself
+OSC_THROUGHPUT = 4       # GOLF_OSC_THROUGHPUT (ABI 6): batches in flight -> the oscillator's phase scan as a launch of its own
 OSC_WS_KEPT = 2          # GOLF_OSC_WS_KEPT (ABI 5): the oscillator's backward reuses the totals in the forward's saved workspace
 FORK_TRANSITIONS = False
 SPLIT_P1 = False   # diagnostic: bench.py --split-p1  # set True to run the transition kernel beside the zero-state pass (streams)
@@ -538,7 +539,8 @@ class _GlottalOsc(torch.autograd.Function):
         ws = _workspace(lib.golf_glottal_osc_workspace_bytes(B, Tp, phase_hop, Fw, w_hop, L, os), phase.device)
         frags = osc_tap_fragments(taps, os) if (os > 1 and not want_pre) else None
         rc = lib.golf_glottal_osc_fwd_f32(phase.data_ptr(), phase.stride(0), Tp, phase_hop, wsel.data_ptr(), Fw, w_hop,
-                                          table.data_ptr(), n_tab, L, os, int(bool(equal_energy)), _lib.ptr(taps), K,
+                                          table.data_ptr(), n_tab, L, os,
+                                          int(bool(equal_energy)) | (OSC_THROUGHPUT if THROUGHPUT_MODE else 0), _lib.ptr(taps), K,
                                           _lib.ptr(pre), out.data_ptr(), out.stride(0), B, Tout, ws.data_ptr(),
                                           ws.numel(), _lib.stream_ptr(), _lib.ptr(add),
                                           0 if add is None else add.stride(0), 0 if add is None else add.shape[1],

@@ -282,6 +282,11 @@ size_t golf_glottal_osc_workspace_bytes(int B, int Tp, int phase_hop, int Fw, in
 size_t golf_glottal_osc_tap_fragments_bytes(int K, int os);
 int golf_glottal_osc_tap_fragments_f32(const float* taps, int K, int os, void* frags, size_t frags_bytes, void* stream);
 
+/* equal_energy | GOLF_OSC_THROUGHPUT (ABI 6, forward only): the caller keeps SEVERAL batches in flight on the device (cf.
+ * GOLF_SS_THROUGHPUT): below a device-filling batch the phase scan then runs as a small launch of its own in front of the
+ * fused kernel instead of inside it -- measured cheaper by ~1.3 us per B = 32 step with four batches in flight, equal for a
+ * lone batch, 3 % dearer at B = 16 384 (where the flag changes nothing).  Results are bit-identical either way. */
+#define GOLF_OSC_THROUGHPUT 4
 /* Round 6: ONE launch for the fused configuration.  The running phase is a single-pass scan inside the kernel (decoupled
  * look-back over tagged entries in `ws`; no totals launch, the phase is read once) -- the workspace may hold anything on entry
  * (no zero-fill is required, stale entries of earlier launches never validate) but must not be shared by launches in flight

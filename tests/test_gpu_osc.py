@@ -561,3 +561,21 @@ def test_prepared_tap_fragments_equal_the_inline_layout():
     assert torch.equal(cached[:k], frags[:k]) and torch.equal(cached[half:half + k], frags[half:half + k])
     y = GF.glottal_osc(phase, wt, table, taps, 1, w_hop, 4, eq, add=add)
     assert torch.equal(y, a)
+
+
+def test_throughput_flag_two_launches_are_bit_identical(monkeypatch):
+    """GOLF_OSC_THROUGHPUT (ABI 6): with batches in flight the phase scan runs as a launch of its own in front of the fused kernel
+    (round 5's form) instead of inside it.  Integer phase arithmetic either way: the same bits, B = 32 full size."""
+    from golf_amd import functional as GF
+    from golf_amd.synth import DownsampledIndexedGlottalFlowTable
+    from golf_amd.synthetic import make_inputs
+
+    inp = make_inputs(B=32, device="cuda", seed=2436)
+    osc = DownsampledIndexedGlottalFlowTable(hop_rate=10, in_channels=64, oversampling=4, equal_energy=True, lf_v2=True, points=2048).cuda()
+    run = lambda: GF.glottal_osc(inp["phase"], inp["wsel"], osc.table, osc.decimater.taps, 1, inp["w_hop"], 4, True, add=inp["noise"])
+    monkeypatch.setattr(GF, "THROUGHPUT_MODE", False)
+    a = run()
+    monkeypatch.setattr(GF, "THROUGHPUT_MODE", True)
+    b = run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -3,7 +3,7 @@ usage: python tools/collect_profiles.py [r02]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): every bench line, rocprofv3 kernel traces and the
 # separate HBM-counter passes that profiles/ is built from (tools/collect_profiles.py turns the output into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RND=${ROUND_TAG:-r05}
+RND=${ROUND_TAG:-r06}
 O=$R/gpurun_out/$RND
 rm -rf $O; mkdir -p $O
 cd $R
