@@ -983,35 +983,48 @@ __device__ __forceinline__ void oscf2_body(
     };
     u64 excl;
     {
-        u64 tsum = 0;
+        // One pass over the thread's CPT segments gives its total AND its partial sums up to the two positions the tile's own span
+        // cuts a thread at (uniform: a wave starts at a multiple of CPT samples): r_lo = (-dmin) % CPT -- the tile's first output --
+        // and r_hi = (-dmin + TO) % CPT -- one past its last.  (Until round 6 the prefix at -dmin re-evaluated the segments, and the
+        // wave's share of the tile's own advance was a third evaluation plus a second wave scan: ~110 VALU instructions per wave.)
+        const int r_lo = (-dmin) % CPT, r_hi = (-dmin + TO) % CPT;   // (uniform)
+        u64 tsum = 0, p_lo = 0, p_hi = 0;
 #pragma unroll
-        for (int r = 0; r < CPT; ++r) tsum += seg_of(r);
+        for (int r = 0; r < CPT; ++r) {
+            tsum += seg_of(r);
+            p_lo = r + 1 == r_lo ? tsum : p_lo;
+            p_hi = r + 1 == r_hi ? tsum : p_hi;
+        }
         const u64 incl = wave_incl_scan(tsum, lane);
         excl = incl - tsum;
         if (lane == 63) wtot[wv] = incl;
-        // in-wave prefix at -dmin (the tile's first output, whose phase the totals give): a thread of wave 0
-        const int th = (-dmin) / CPT, rh = (-dmin) % CPT;         // (uniform)
-        u64 r2 = excl;
-#pragma unroll
-        for (int r = 0; r + 1 < CPT; ++r) r2 += r < rh ? seg_of(r) : 0;
-        if (tid == th) *halo_p = r2;
-    }
-    {   // ---- 2b. publish this wave's share of the tile's OWN advance (segments o0 .. o0 + TO - 1 = indices -dmin .. -dmin + TO - 1)
-        u64 own = 0;
-#pragma unroll
-        for (int r = 0; r < CPT; ++r) {
-            const int i = i0t + r;
-            own += (i >= -dmin && i < -dmin + TO) ? seg_of(r) : 0;
-        }
-        if (lookback) own = wave_incl_scan(own, lane);
-        if (lane == 63 && lookback) {
-            wown[wv] = own;
-            const unsigned idx = (unsigned)((b * ntile + tile) * NW + wv);
-            u64* e = look.ent + 2 * (size_t)idx;
-            const u64 w0 = (own & 0xffffffffull) | ((u64)osc_look_tag(gnow, idx, 0) << 32);
-            const u64 w1 = (own >> 32) | ((u64)osc_look_tag(gnow, idx, 1) << 32);
-            __hip_atomic_store(e, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // in-wave prefix at -dmin (the tile's first output, whose phase the look-back gives): a thread of wave 0
+        const int th = (-dmin) / CPT;                             // (uniform)
+        const u64 at_lo = excl + p_lo, at_hi = excl + p_hi;      // this wave's prefix at a cut that falls into this thread
+        if (tid == th) *halo_p = at_lo;
+        // ---- 2b. publish this wave's share of the tile's OWN advance (segments o0 .. o0 + TO - 1 = indices -dmin .. -dmin + TO - 1):
+        //          (wave prefix at min(hi cut, wave end)) - (wave prefix at max(lo cut, wave start)), from the scan that exists
+        if (lookback) {
+            auto lane_u64 = [](u64 v, int l) -> u64 {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+                return ((u64)hi << 32) | lo;
+            };
+            const int wstart = wv * 64 * CPT, wend = wstart + 64 * CPT;   // sample indices of this wave (uniform)
+            const int x_lo = -dmin, x_hi = -dmin + TO;
+            const u64 wtotal = lane_u64(incl, 63);
+            const u64 up = x_hi >= wend ? wtotal : (x_hi <= wstart ? 0 : lane_u64(at_hi, (x_hi - wstart) / CPT));
+            const u64 dn = x_lo <= wstart ? 0 : (x_lo >= wend ? wtotal : lane_u64(at_lo, (x_lo - wstart) / CPT));
+            const u64 own = x_hi <= wstart || x_lo >= wend ? 0 : up - dn;
+            if (lane == 63) {
+                wown[wv] = own;
+                const unsigned idx = (unsigned)((b * ntile + tile) * NW + wv);
+                u64* e = look.ent + 2 * (size_t)idx;
+                const u64 w0 = (own & 0xffffffffull) | ((u64)osc_look_tag(gnow, idx, 0) << 32);
+                const u64 w1 = (own >> 32) | ((u64)osc_look_tag(gnow, idx, 1) << 32);
+                __hip_atomic_store(e, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // A workgroup whose neighbours in front started with it (a lone batch: 512 of its 768 workgroups enter within a microsecond)

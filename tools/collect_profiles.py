@@ -33,8 +33,12 @@ if os.path.exists(os.path.join(SRC, "train_step_profile.json")):
 for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):   # summarised on the GPU box by refresh_profiles.sh
     shutil.copy(f, os.path.join(DST, RND + "_" + os.path.basename(f)))
 
-def counters(tag):
+def counters(tag, per_step_only=False):
+    """per_step_only: only the kernels every step launches (dispatch count >= half the most frequent kernel's): a pass also sees
+    kernels that ran once -- the conditioning probe's transition launch, the tap-fragment layout -- and round 5's step totals
+    counted those in."""
     out = collections.defaultdict(dict)
+    ndisp = collections.defaultdict(int)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(os.path.join(SRC, f"pmc_{c}_{tag}", "**", "*counter_collection.csv"), recursive=True):
             acc = collections.defaultdict(list)
@@ -42,8 +46,12 @@ def counters(tag):
                 if "golf::" in r["Kernel_Name"]:
                     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
                     acc[k].append(float(r["Counter_Value"]))
+                    ndisp[k] = max(ndisp[k], int(float(r.get("Dispatches") or 1)))
             for k, v in acc.items():
                 out[k][c + "_KB"] = round(sum(v) / len(v))
+    if per_step_only and ndisp:
+        top = max(ndisp.values())
+        out = {k: d for k, d in out.items() if ndisp[k] * 2 >= top}
     for k, d in out.items():
         if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
@@ -60,8 +68,9 @@ json.dump({"batch": 32, "workload": "golf-ss-synth (headline), golf-ss-decoder (
            "kernels": kern,
            # one step = one launch of each of its kernels: the two launch chains of the sample-wise filter, summed
            "step_total_bytes": {
-               "latency_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synth").items()),
-               "throughput_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synthtp").items())}},
+               "latency_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synth", True).items()),
+               "throughput_chain": sum(v.get("hbm_bytes_per_launch", 0) for k, v in counters("synthtp", True).items()),
+               "latency_chain_kernels": sorted(counters("synth", True)), "throughput_chain_kernels": sorted(counters("synthtp", True))}},
           open(os.path.join(DST, RND + "_hbm_traffic.json"), "w"), indent=1)
 
 # ---- SQ counters -> per-kernel utilisation figures
