@@ -194,6 +194,10 @@ def make_step(workload, inp, osc, ss, ff, fast=True, overlap=False, mode=None):
             nz = GF.zero_phase_fir_filter(noise, lm, fir_win, hop)
             # source + filtered noise, the common length taken by the filter itself (`length=`): as `src[:, :n]` the slice's
             # backward was a 6 MB fill + a 6 MB copy in front of the oscillator's backward
+            if not train and prep is None and (FUSE_SOURCE_MAPS == "on" or (FUSE_SOURCE_MAPS == "auto" and not GF.THROUGHPUT_MODE)):
+                # the lone-batch chain: oscillator and transition maps as one launch (what SourceFilterSynth does in inference)
+                y = GF.source_filter_ss(phase, wsel_g, table, taps, 1, w_hop, 4, True, gain, a, hop, add=nz, length=nz.shape[1])
+                return GF.lti_fir(y, room_taps, K)
             src = GF.glottal_osc(phase, wsel_g, table, taps, 1, w_hop, 4, True, add=nz)
             y = GF.ltv_allpole_ss(src, gain, a, hop, prepared=prep, length=nz.shape[1])
             if not train:

@@ -88,8 +88,9 @@ class SourceFilterSynth(Synth):
         ts = [t.as_tensor() for t in (phase, w, nz, gain, a)] + [osc.table]
         if not all(t.is_cuda for t in ts) or (torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
             return None
-        if w.dim() != 2 or a.dim() != 3 or gain.dim() != 2 or int(gain.hop_length) != int(a.hop_length):
-            return None
+        if (w.dim() != 2 or a.dim() != 3 or gain.dim() != 2 or int(gain.hop_length) != int(a.hop_length)
+                or a.shape[1] != gain.shape[1] or a.shape[0] != phase.shape[0] or gain.shape[0] != phase.shape[0]):
+            return None   # (the modules' own asserts speak for malformed inputs)
         n_osc = osc.output_length(phase)
         y = GF.source_filter_ss(ts[0], ts[1], osc.table, osc.decimater.taps, int(phase.hop_length), int(w.hop_length),
                                 osc.oversampling, osc.equal_energy, ts[3], ts[4], int(a.hop_length), add=ts[2],
