@@ -800,11 +800,15 @@ def main():
         ms_no_gather = median_ms(timed_regions(args.repeats))
         gather_on[0] = True
 
-    # ---- N > 1: the same regions under every exchange this package has, so that ONE scaling lease yields the comparison DESIGN.md
-    # section 7 predicts: an RCCL all-gather per step, the staged all-gather (GE steps per collective), and
-    # peer-to-peer stores over xGMI.  Setup failures and timeouts are agreed on by all ranks (a mode that fails is reported, not fatal).
-    gather_modes = None
-    if do_gather and not args.no_compare_gather_modes:
+    gather_modes = None   # (N > 1: filled by compare_gather_modes() at the very end, under a watchdog -- see there)
+
+    def compare_gather_modes(modes):
+        """N > 1: the same regions under every exchange this package has, so that ONE scaling lease yields the comparison DESIGN.md
+        section 7 predicts: an RCCL all-gather per step, the staged all-gather (GE steps per collective), and
+        peer-to-peer stores over xGMI.  Setup failures and timeouts are agreed on by all ranks (a mode that fails is reported,
+        not fatal).  Runs LAST, after rank 0 has everything else of the line, and under a watchdog: peer-to-peer stores have never
+        run across real GPUs, and a hang there must not cost the scaling run its line."""
+        nonlocal stagers, pipelined
         import torch.distributed as dist
         from golf_amd.dist import PeerStoreGather, StagedGather
 
@@ -813,7 +817,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
 
-        gather_modes = {}
         headline_stagers, headline_pipelined = stagers, pipelined
         ge_staged = max(1, min(8, args.steps // S))
         for name, make in (("rccl_all_gather_per_step", lambda: [StagedGather(B, t_out, 1, device, world=world) for _ in range(S)]),
@@ -825,7 +828,7 @@ def main():
             except Exception as e:   # noqa: BLE001 -- reported in the line
                 err = repr(e)
             if not all_ok(err is None):
-                gather_modes[name] = {"error": err or "failed on another rank"}
+                modes[name] = {"error": err or "failed on another rank"}
                 continue
             stagers, pipelined = made, True
             try:
@@ -835,10 +838,10 @@ def main():
                 err, ms = repr(e), None
             if all_ok(err is None):
                 inb = (world - 1) * B * t_out * 4
-                gather_modes[name] = {"ms_per_step": round(ms, 5), "value": world * samples / (ms * 1e-3),
-                                      "inbound_GBps_per_rank": round(inb / (ms * 1e-3) / 1e9, 1)}
+                modes[name] = {"ms_per_step": round(ms, 5), "value": world * samples / (ms * 1e-3),
+                               "inbound_GBps_per_rank": round(inb / (ms * 1e-3) / 1e9, 1)}
             else:
-                gather_modes[name] = {"error": err or "failed on another rank"}
+                modes[name] = {"error": err or "failed on another rank"}
             if name == "peer_store":
                 try:
                     for st_ in made:
@@ -1158,11 +1161,33 @@ def main():
                 result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
             except Exception as e:  # the checker is optional for the measurement itself
                 result["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(result), flush=True)
+        if not (do_gather and not args.no_compare_gather_modes):
+            print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
 
-        dist.barrier()  # ranks > 0 wait for rank 0's profiling pass before tearing the communicator down
+        dist.barrier()  # ranks > 0 wait for rank 0's profiling pass before going on
+        if do_gather and not args.no_compare_gather_modes:
+            import threading
+
+            gather_modes = {}
+            limit = float(os.environ.get("GOLF_BENCH_COMPARE_LIMIT_S", "180"))
+
+            def give_up():   # the comparison hung: the line goes out with what was measured, and the job ends
+                if rank == 0:
+                    gather_modes["aborted"] = "comparison passes exceeded %.0f s (a mode hung); modes listed so far are complete" % limit
+                    result["exchange"]["modes"] = gather_modes
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+
+            dog = threading.Timer(limit if rank == 0 else limit + 10.0, give_up)
+            dog.daemon = True
+            dog.start()
+            compare_gather_modes(gather_modes)
+            dog.cancel()
+            if rank == 0:
+                result["exchange"]["modes"] = gather_modes
+                print(json.dumps(result), flush=True)
         if peer_store:
             for st in stagers:
                 st.close()
