@@ -3384,11 +3384,17 @@ static FixArgs fix_args(const SsPlan& p, const float* a, int F, int M, int hop, 
 }
 // fix-up workgroups (4 waves of 16 units) per utterance: KF1 lead the grid (the guarantee), KF2 trail it (the speed);
 // together at most one pass over all units of an utterance
-static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2, bool own_launch = false) {
+static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2, bool own_launch = false, bool lone_batch = false) {
     static const int e1 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF1"); return e ? atoi(e) : 0; }();   // dev knobs
     static const int e2 = [] { const char* e = getenv("GOLF_SS_FIXUP_KF2"); return e ? atoi(e) : -1; }();
     const int64_t all = ceil_div((int64_t)p.NP * NT, 64);   // workgroups that cover every unit in one pass
-    int k1 = e1 > 0 ? e1 : 6;
+    // Round 6 (G2 = 8: a hot utterance of the recipe now has 50 - 150 hot chunks, not 5 - 20): a caller WITHOUT batches in flight
+    // (no GOLF_SS_THROUGHPUT, two-level path) gets (10, 38) -- trailing workgroups cost a lone batch nothing, leading ones cost its
+    // cold utterances.  One batch alone over 32 recipe seeds, mean / cold / hot / tier 3, us: (6, 10) 140.4 / 123.2 / 147.6 / 170.3;
+    // (10, 22) 137.3 / 122.4 / 142.9 / 164.1; (10, 38) 136.2 / 121.8 / 142.2 / 161.1; (8, 48) 136.8; (10, 59) 137.3; (6, 63) 137.8;
+    // (16, 32) 139.0 / 128.8 / ..; (32, 0) 140.1 / 131.1.  With four batches in flight the same settings LOSE (headline 68.7 ->
+    // 70.2 - 72.6 us/step): there every idle workgroup is dispatch cost, and (6, 10) stays.
+    int k1 = e1 > 0 ? e1 : (lone_batch ? 10 : 6);
     if (k1 > all) k1 = (int)(all < 1 ? 1 : all);
     // Every fix-up workgroup that finds nothing to do is dispatch cost, and with several batches in flight that is what
     // counts.  Measured, (KF1, KF2) -> us/step pipelined: B = 256, launch of its own (18 hot utterances + one tier 3 in the
@@ -3397,7 +3403,7 @@ static void fixup_kf(const SsPlan& p, int NT, int* kf1, int* kf2, bool own_launc
     // (6, 26) 74.9 / 83.5 / 78.4, (6, 42) 75.8 / 86.4 / 80.9.  16 workgroups = 1024 units per pass: one pass for up to 46 hot
     // chunks of an utterance (typical: 5 - 20); a tier-3 utterance (all 199) takes five.
     (void)own_launch;
-    int64_t k2 = e2 >= 0 ? e2 : 10;
+    int64_t k2 = e2 >= 0 ? e2 : (lone_batch ? 38 : 10);
     if (k1 + k2 > all) k2 = all - k1 > 0 ? all - k1 : 0;
     *kf1 = k1;
     *kf2 = (int)k2;
@@ -3428,7 +3434,7 @@ static int launch_composites(const SsPlan& p, const float* a, int B, int F, int 
             FixArgs fa = fix_args(p, a, F, M, hop, ws, accurate, training);
             fa.B = B;
             int k1, k2;
-            fixup_kf(p, NT, &k1, &k2);
+            fixup_kf(p, NT, &k1, &k2, false, !(flags & GOLF_SS_THROUGHPUT));
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B;
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)(nf + nu)), dim3(256), 0, st,
                                (const float*)(ws + p.off_phiT), (float*)nullptr, (float*)(ws + p.off_mt),
@@ -3615,7 +3621,7 @@ static int launch_fwd(const SsPlan& p, const float* ex, int64_t ex_stride, const
             FixArgs fa = fix_args(p, a, F, M, hop, ws, fast ? 0 : 1, training);
             fa.B = B;
             int k1, k2;
-            fixup_kf(p, NT, &k1, &k2);
+            fixup_kf(p, NT, &k1, &k2, false, !(flags & GOLF_SS_THROUGHPUT));
             const int nf = fa.pmax ? B * (k1 + k2) : 0, nu = p.NG * B, nz = (int)ceil_div(nu, 4);
             const int parts = (fused_p1 ? 3 : 2) | (zin ? 4 : 0), count = (fused_p1 ? nf + nu : 0) + nz;   // in workgroups
             hipLaunchKernelGGL((lpc_group_prepass_kernel<W, NT>), dim3((unsigned)count), dim3(256), 0, st,
