@@ -52,6 +52,14 @@ def test_argument_checks_without_gpu():
     rc = lib.golf_glottal_osc_fwd_f32(None, 0, 10, 1, None, 2, 8, None, 1, 16, 1, 0, None, 0, None, None, 0, 1, 10,
                                       None, 0, None, None, 0, 0, None)
     assert rc == -1
+    # ABI 6: the source + transition-maps entry refuses what its two calls refuse (no launch), the fragment helpers are pure host logic
+    rc = lib.golf_source_transitions_f32(None, 0, 10, 1, None, 2, 8, None, 1, 16, 4, 1, None, 129, None, 0, 1, 10, None, 0, None, 0, 0,
+                                         None, None, 10, 2, 22, 240, None, 0, 2 | 128, None)
+    assert rc == -1
+    assert lib.golf_glottal_osc_tap_fragments_bytes(129, 4) == 2 * 4 * 16 * 64 * 4
+    assert lib.golf_glottal_osc_tap_fragments_bytes(129, 2) == 0 and lib.golf_glottal_osc_tap_fragments_bytes(128, 4) == 0
+    assert lib.golf_glottal_osc_tap_fragments_f32(None, 129, 4, None, 0, None) == -1
+    assert lib.golf_glottal_osc_tap_fragments_f32(None, 129, 3, None, 0, None) == -3
     # peer-exchange entry points: null pointers / too many destinations are refused before anything touches a device
     assert lib.golf_peer_store_f32(None, 0, 1, 1, None, 0, 1, None) == -1 and b"null" in lib.golf_last_error()
     import ctypes
