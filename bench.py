@@ -93,6 +93,12 @@ def parse():
                          "(rounds 2-3) the five timed regions sat on that ramp.  Reported in timing.prereplay_per_graph.")
     ap.add_argument("--lpc-mode", default="auto", choices=["auto", "serial", "chunked", "flat-scan"],
                     help="LPC-ss algorithm: time-chunked scan, batch-parallel serial recursion, or by batch size (default)")
+    ap.add_argument("--issue", default="round-robin", choices=["round-robin", "idle-first"],
+                    help="which slot takes the next step: round-robin (default, the headline's), or the first slot whose previous step "
+                         "has finished (work-conserving; for slots of unequal speed, see --serial-slots)")
+    ap.add_argument("--serial-slots", type=int, default=0,
+                    help="diagnostic (VERDICT r5 #9): the LAST this-many of the in-flight slots run the sample-wise filter on the "
+                         "batch-parallel serial kernels whatever --lpc-mode says -- a hybrid of chunked and serial batches in flight")
     ap.add_argument("--lpc-chain", default="auto", choices=["auto", "latency", "throughput"],
                     help="launch structure of the sample-wise filter (GOLF_SS_THROUGHPUT, include/golf_amd.h): 'throughput' "
                          "costs the least chip time with several batches in flight, 'latency' finishes a lone batch soonest; "
@@ -595,7 +601,8 @@ def main():
         slot_flat.append(flat_i)
         slot_inp.append(inp_i)
         fn, samples, t_out = make_step(args.workload, inp_i, osc, ss, ff, fast=not args.fp64_transitions,
-                                       overlap=args.overlap_transitions, mode=args.lpc_mode)
+                                       overlap=args.overlap_transitions,
+                                       mode="serial" if i >= S - args.serial_slots else args.lpc_mode)
         steps_fn.append(fn)
         slot_cond.append(conditioning_of(args.workload, inp_i, device))
     step = steps_fn[0]
@@ -702,8 +709,21 @@ def main():
     refresh_pool = [None]   # --refresh-inputs: packed batches (device or pinned host) copied into the slot before every replay
     gather_on = [True]      # N > 1: the same regions once more without the exchange (exchange.ms_per_step_no_gather)
 
+    slot_done = [None] * S   # --issue idle-first: an event behind each slot's last step
+
     def full_step():
-        i = step_no[0] % S
+        if args.issue == "idle-first":
+            # work-conserving: the next batch goes to a slot whose previous step has finished (round-robin from the last one used);
+            # with slots of unequal speed -- chunked and serial plans in flight together -- round-robin makes every slot wait for
+            # the slowest
+            i, spins = step_no[0] % S, 0
+            while slot_done[i] is not None and not slot_done[i].query():
+                i = (i + 1) % S
+                spins += 1
+                if spins % S == 0:
+                    time.sleep(0)
+        else:
+            i = step_no[0] % S
         step_no[0] += 1
         with torch.cuda.stream(streams[i]):
             if refresh_pool[0] is not None:   # ordered on the slot's stream: after its previous replay, before this one
@@ -717,6 +737,10 @@ def main():
                 handle = stagers[i].push(y.detach())
                 if handle is not None and not pipelined:
                     handle.wait()
+            if args.issue == "idle-first":
+                if slot_done[i] is None:
+                    slot_done[i] = torch.cuda.Event()
+                slot_done[i].record(streams[i])
         return y
 
     def drain():
@@ -1093,7 +1117,7 @@ def main():
                        "samples_out_per_utterance": t_out,
                        "parallelism": f"dp{world}" + (f"+allgather({args.gather_mode}, every {GE} step(s))" if do_gather else ""),
                        "lpc_mode": args.lpc_mode, "lpc_chain": "throughput" if throughput_chain else "latency",
-                       "fuse_source_maps": args.fuse_source_maps,
+                       "fuse_source_maps": args.fuse_source_maps, "serial_slots": args.serial_slots, "issue": args.issue,
                        "batches_in_flight": S, "slot_inputs": "shared" if args.shared_inputs else "distinct per slot",
                        "hipgraph_replay": bool(use_graphs)},
             "rtf": (elapsed / args.steps) / (B * 2.0),

@@ -109,8 +109,12 @@ class ReplayPipeline:
 
     def __init__(self, fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  make_inputs: Callable[[], Dict[str, torch.Tensor]], n_slots: int = 4, check: bool = True,
-                 use_graphs: bool = True, packed: bool = False, throughput: Optional[bool] = None):
-        self.fn, self.use_graphs, self.packed = fn, use_graphs, packed
+                 use_graphs: bool = True, packed: bool = False, throughput: Optional[bool] = None,
+                 issue: str = "round-robin"):
+        """``issue``: "round-robin" (default) or "idle-first" -- ``submit`` then takes the first slot whose previous step has
+        finished (work-conserving: what slots of unequal speed need; the slot's output stays valid until THAT slot is taken again)."""
+        assert issue in ("round-robin", "idle-first")
+        self.fn, self.use_graphs, self.packed, self.issue = fn, use_graphs, packed, issue
         self.slots: List[Slot] = [Slot(make_inputs()) for _ in range(max(1, n_slots))]
         if packed:
             for slot in self.slots:
@@ -195,6 +199,11 @@ class ReplayPipeline:
         drop them right after the call; pinned host tensors must stay alive until the slot's stream has passed the copy.
         A flat batch for a slot that also has tensor inputs outside the flat buffer (non-fp32) raises unless ``partial_ok``:
         those would silently keep their old values."""
+        if self.issue == "idle-first":
+            n, i = len(self.slots), self._next
+            while getattr(self.slots[i], "done", None) is not None and not self.slots[i].done.query():
+                i = (i + 1) % n
+            self._next = i
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         if batch is not None:
@@ -216,6 +225,10 @@ class ReplayPipeline:
                     slot.output = self.fn(slot.inputs)
                 finally:
                     _GF.THROUGHPUT_MODE = prev_mode
+        if self.issue == "idle-first":
+            if getattr(slot, "done", None) is None:
+                slot.done = torch.cuda.Event()
+            slot.done.record(slot.stream)
         return slot
 
     def synchronize(self) -> None:

@@ -347,7 +347,9 @@ def test_replay_pipeline_submit_refreshes_inputs_vs_oracle():
 
     refs = [oracle(bt) for bt in batches]
     for packed in (False, True):
-        pipe = ReplayPipeline(fn, lambda: {k: batches[0][k].clone() for k in keys}, n_slots=2, packed=packed)
+        # (the packed round also takes its slots idle-first: whichever slot has finished gets the next batch)
+        pipe = ReplayPipeline(fn, lambda: {k: batches[0][k].clone() for k in keys}, n_slots=2, packed=packed,
+                              issue="idle-first" if packed else "round-robin")
         got = []
         for bt in batches:
             s = pipe.submit(pipe.pack(bt) if packed else {k: bt[k] for k in keys})
