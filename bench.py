@@ -902,9 +902,8 @@ def main():
         # tanh -> step-up recursion -> a (golf_rc2lpc_fwd), log-gain -> exp -> gain, f0 track -> upsampled phase increments,
         # table-selection logits -> sigmoid, a fresh N(0,1) noise draw -- each written straight into the slot's static inputs
         # (views of the packed buffer), then the synthesis step.  No copy of a finished batch anywhere.
-        ms_prod, prod_err = None, None
-        if args.workload == "golf-ss-synth" and len(slot_inp) == S:
-          try:   # (a side figure: whatever goes wrong here is reported in the line, it must not cost the run its headline)
+        def measure_producer():
+            """(ms per step, error): the slots' graphs with an on-device producer in front of the synthesis step"""
             from golf_amd import functional as GFp
 
             enc, pgraphs, pouts = [], [], []
@@ -947,11 +946,17 @@ def main():
             ok_prod = all(bool(torch.isfinite(o).all()) for o in pouts) and not torch.equal(pouts[0], held_outs[0])
             graphs[:], outs[:] = held, held_outs
             if not ok_prod:
-                ms_prod, prod_err = None, "producer mode: non-finite output, or the produced batch equals the fixed one"
-          except Exception as e:   # noqa: BLE001
-            ms_prod, prod_err = None, repr(e)
-            if "held" in locals():
-                graphs[:], outs[:] = held, held_outs
+                return None, "producer mode: non-finite output, or the produced batch equals the fixed one"
+            return ms_prod, None
+
+        ms_prod, prod_err = None, None
+        if args.workload == "golf-ss-synth" and len(slot_inp) == S:
+            held_graphs, held_outputs = list(graphs), list(outs)
+            try:   # (a side figure: whatever goes wrong here is reported in the line, it must not cost the run its headline)
+                ms_prod, prod_err = measure_producer()
+            except Exception as e:   # noqa: BLE001
+                ms_prod, prod_err = None, repr(e)
+                graphs[:], outs[:] = held_graphs, held_outputs
         for f, k in zip(slot_flat, keep):
             f.copy_(k)
         torch.cuda.synchronize()
